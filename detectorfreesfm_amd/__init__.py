@@ -1,0 +1,13 @@
+"""detectorfreesfm_amd -- MI355X (gfx950) native dense-matching hot path of Detector-Free SfM.
+
+Two drop-in plugins behind the reference's own Python surfaces, with the hot kernels in
+hand-written HIP (``csrc/`` -> ``libdfsfm_hip.so``, C ABI in ``include/dfsfm_hip.h``):
+
+* ``HipLoFTR``             coarse matcher (LoFTR coarse_only)
+* ``HipMultiviewMatcher``  multiview refinement head
+"""
+from .coarse import HipLoFTR
+from .refine import HipMultiviewMatcher
+from .config import loftr_coarse_only_config, multiview_refinement_config
+
+__all__ = ["HipLoFTR", "HipMultiviewMatcher", "loftr_coarse_only_config", "multiview_refinement_config"]

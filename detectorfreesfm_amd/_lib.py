@@ -1,0 +1,71 @@
+"""ctypes binding of ``libdfsfm_hip.so`` (C ABI declared in ``include/dfsfm_hip.h``).
+
+The library is the product: there is NO fallback.  If the shared object is missing or an entry
+point is absent, importing this module's ``lib()`` raises, and every op built on it fails loudly.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, c_char_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdfsfm_hip.so")
+
+DFSFM_OK = 0
+_ERRORS = {-1: "DFSFM_E_BADARG", -2: "DFSFM_E_UNSUPPORTED", -3: "DFSFM_E_WORKSPACE", -4: "DFSFM_E_LAUNCH"}
+
+# (name, restype, argtypes) -- must list every symbol declared in include/dfsfm_hip.h
+SIGNATURES = [
+    ("dfsfm_version", c_int, []),
+    ("dfsfm_last_error_string", c_char_p, []),
+    ("dfsfm_linear_attention_workspace", c_size_t, [c_int, c_int, c_int, c_int]),
+    ("dfsfm_linear_attention_f32", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+      c_void_p, c_size_t, c_void_p]),
+    ("dfsfm_coarse_match_workspace", c_size_t, [c_int, c_int, c_int]),
+    ("dfsfm_coarse_match_f32", c_int,
+     [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_size_t, c_void_p]),
+    ("dfsfm_coarse_conf_matrix_f32", c_int,
+     [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("dfsfm_roi_align_f32", c_int,
+     [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+      c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("dfsfm_fine_match_f32", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+]
+
+_lib = None
+
+
+class DfsfmError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfsfmError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C detectorfreesfm_amd/csrc`). There is no CPU/PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in SIGNATURES:
+            fn = getattr(handle, name)          # AttributeError if the symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != DFSFM_OK:
+        extra = ""
+        if rc == -4:
+            extra = ": " + (lib().dfsfm_last_error_string() or b"").decode()
+        raise DfsfmError(f"{what} failed with {_ERRORS.get(rc, rc)}{extra}")

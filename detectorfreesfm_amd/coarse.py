@@ -1,0 +1,228 @@
+"""MI355X coarse matcher behind the reference's ``NEUSFM_coarse_matcher`` plugin surface.
+
+``HipLoFTR`` is a drop-in for the reference's ``LoFTR`` module in coarse_only mode
+(third_party/LoFTR/src/loftr/loftr.py:12-87): same constructor argument (the lower-cased config
+dict), same ``state_dict`` layout (``load_state_dict(strict=True)`` of the official checkpoints,
+``matcher.`` prefix stripped), same in-place ``forward(data)`` contract
+(src/coarse_match/coarse_match_worker.py:83-99 reads ``m_bids, mkpts0_f, mkpts1_f, mconf``).
+
+Hot kernels are hand-written HIP (``libdfsfm_hip.so``): linear attention (K1) inside every
+encoder layer and the fused correlation / dual-softmax / mutual-NN / keypoint stage (K3-K5).
+The dense convolutions and ``nn.Linear`` GEMMs go to MIOpen / hipBLASLt through PyTorch-ROCm in
+fp32.  Output-identical work the reference wastes is skipped:
+the FPN top-down branch (dead when fine.enable=False, resnet_fpn.py:110-116) and the dense
+``conf_matrix`` (never read by an inference caller).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .params import ParamModule, loftr_param_spec
+
+
+def position_encoding_sine(d_model: int, max_shape=(256, 256), temp_bug_fix: bool = False) -> torch.Tensor:
+    """2-D sinusoidal encoding buffer [1,d_model,H,W] with the semantics of PositionEncodingSine
+    (third_party/LoFTR/src/loftr/utils/position_encoding.py:22-35).  With temp_bug_fix=False the
+    exponent uses ``-ln(1e4) / d_model // 2`` (floor division binds last), which the released
+    weights were trained with and the plugin builder selects (coarse_match_worker.py:35)."""
+    ys = torch.arange(1, max_shape[0] + 1, dtype=torch.float32)[:, None].expand(*max_shape)
+    xs = torch.arange(1, max_shape[1] + 1, dtype=torch.float32)[None, :].expand(*max_shape)
+    k = torch.arange(0, d_model // 2, 2, dtype=torch.float32)
+    rate = (-math.log(10000.0) / (d_model // 2)) if temp_bug_fix else (-math.log(10000.0) / d_model // 2)
+    div = torch.exp(k * rate)[:, None, None]
+    pe = torch.zeros((d_model, *max_shape))
+    pe[0::4] = torch.sin(xs * div)
+    pe[1::4] = torch.cos(xs * div)
+    pe[2::4] = torch.sin(ys * div)
+    pe[3::4] = torch.cos(ys * div)
+    return pe[None]
+
+
+def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
+    """conv -> eval BatchNorm == conv with scaled weights + bias."""
+    s = bn_w / torch.sqrt(var + eps)
+    return (w * s[:, None, None, None]).contiguous(), (bn_b - mean * s).contiguous()
+
+
+class EncoderLayerWeights:
+    """Packed weights of one LoFTREncoderLayer (transformer.py:7-33)."""
+
+    def __init__(self, get, prefix):
+        wq, wk, wv = get(prefix + "q_proj.weight"), get(prefix + "k_proj.weight"), get(prefix + "v_proj.weight")
+        self.wq = wq.contiguous()
+        self.wkv = torch.cat([wk, wv], 0).contiguous()
+        self.wqkv = torch.cat([wq, wk, wv], 0).contiguous()
+        self.merge = get(prefix + "merge.weight").contiguous()
+        self.w1 = get(prefix + "mlp.0.weight").contiguous()
+        self.w2 = get(prefix + "mlp.2.weight").contiguous()
+        self.n1 = (get(prefix + "norm1.weight"), get(prefix + "norm1.bias"))
+        self.n2 = (get(prefix + "norm2.weight"), get(prefix + "norm2.bias"))
+
+
+def encoder_layer(w: EncoderLayerWeights, x, source, nhead, x_mask=None, source_mask=None,
+                  q_group=1, kv_group=1, is_self=False):
+    """LoFTREncoderLayer.forward (LoFTR transformer.py:35-58; multiview copy
+    src/MultiviewMatcher/matcher_module/transformer.py:66-95) with K1 as the attention core.
+    Projections of the same input share one GEMM (q|k|v for self, k|v for cross)."""
+    N, L, C = x.shape
+    S = source.shape[1]
+    D = C // nhead
+    if is_self:
+        qkv = F.linear(x, w.wqkv)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    else:
+        q = F.linear(x, w.wq)
+        kv = F.linear(source, w.wkv)
+        k, v = kv[..., :C], kv[..., C:]
+    msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
+                               v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group)
+    msg = F.linear(msg.view(N, L, C), w.merge)
+    msg = F.layer_norm(msg, (C,), w.n1[0], w.n1[1])
+    msg = F.linear(torch.cat([x, msg], dim=2), w.w1)
+    msg = F.linear(F.relu_(msg), w.w2)
+    msg = F.layer_norm(msg, (C,), w.n2[0], w.n2[1])
+    return x + msg
+
+
+class HipLoFTR(ParamModule):
+    def __init__(self, config: dict, skip_dead_fpn: bool = True):
+        super().__init__()
+        if config["match_coarse"]["match_type"] != "dual_softmax":
+            raise NotImplementedError("only the dual_softmax coarse matcher is on the hot path")
+        if config["fine"]["enable"]:
+            raise NotImplementedError("HipLoFTR implements the coarse_only configuration "
+                                      "(loftr_ds_coarse_only.py: LOFTR.FINE.ENABLE=False)")
+        if config["coarse"]["attention"] != "linear":
+            raise NotImplementedError("only linear attention")
+        self.config = config
+        self.skip_dead_fpn = skip_dead_fpn
+        self.register_spec(loftr_param_spec(config))
+        self.register_buffer("pe", position_encoding_sine(config["coarse"]["d_model"],
+                                                          temp_bug_fix=config["coarse"]["temp_bug_fix"]),
+                             persistent=False)
+        self._packed = None
+
+    # -- checkpoint compatibility (loftr.py:83-87) -------------------------------------------
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        sd = {}
+        for k, v in state_dict.items():
+            sd[k.replace("matcher.", "", 1) if k.startswith("matcher.") else k] = v
+        self._packed = None
+        return super().load_state_dict(sd, *args, **kwargs)
+
+    def _apply(self, fn, *a, **kw):
+        self._packed = None
+        return super()._apply(fn, *a, **kw)
+
+    # -- weight packing -----------------------------------------------------------------------
+    def _pack(self):
+        g = self.p
+        P = {}
+
+        def conv_bn(conv, bn):
+            return _fold_bn(g(conv + ".weight"), g(bn + ".weight"), g(bn + ".bias"),
+                            g(bn + ".running_mean"), g(bn + ".running_var"))
+        P["stem"] = conv_bn("backbone.conv1", "backbone.bn1")
+        for li in (1, 2, 3):
+            for bi in (0, 1):
+                q = f"backbone.layer{li}.{bi}"
+                blk = {"c1": conv_bn(q + ".conv1", q + ".bn1"), "c2": conv_bn(q + ".conv2", q + ".bn2"),
+                       "stride": 2 if (li > 1 and bi == 0) else 1}
+                if blk["stride"] != 1:
+                    blk["down"] = conv_bn(q + ".downsample.0", q + ".downsample.1")
+                P[f"l{li}b{bi}"] = blk
+        P["l3out"] = g("backbone.layer3_outconv.weight")
+        if not self.skip_dead_fpn:
+            P["l2out"] = g("backbone.layer2_outconv.weight")
+            P["l1out"] = g("backbone.layer1_outconv.weight")
+            for nm in ("layer2_outconv2", "layer1_outconv2"):
+                P[nm] = (conv_bn(f"backbone.{nm}.0", f"backbone.{nm}.1"), g(f"backbone.{nm}.3.weight"))
+        n_layers = len(self.config["coarse"]["layer_names"])
+        P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.") for i in range(n_layers)]
+        self._packed = P
+        return P
+
+    # -- K6: local-feature CNN (ResNetFPN_8_2.forward, resnet_fpn.py:100-118) -------------------
+    def _backbone(self, x, P):
+        def block(t, b):
+            y = F.relu_(F.conv2d(t, b["c1"][0], b["c1"][1], b["stride"], 1))
+            y = F.conv2d(y, b["c2"][0], b["c2"][1], 1, 1)
+            if "down" in b:
+                t = F.conv2d(t, b["down"][0], b["down"][1], b["stride"], 0)
+            return F.relu_(y.add_(t))
+        x0 = F.relu_(F.conv2d(x, P["stem"][0], P["stem"][1], 2, 3))
+        x1 = block(block(x0, P["l1b0"]), P["l1b1"])
+        x2 = block(block(x1, P["l2b0"]), P["l2b1"])
+        x3 = block(block(x2, P["l3b0"]), P["l3b1"])
+        x3_out = F.conv2d(x3, P["l3out"])
+        if self.skip_dead_fpn:
+            return x3_out, None
+
+        def outconv2(q, t):
+            (w0, b0), w3 = P[q]
+            return F.conv2d(F.leaky_relu_(F.conv2d(t, w0, b0, 1, 1), 0.01), w3, None, 1, 1)
+        x3_2x = F.interpolate(x3_out, scale_factor=2.0, mode="bilinear", align_corners=True)
+        x2_out = outconv2("layer2_outconv2", F.conv2d(x2, P["l2out"]) + x3_2x)
+        x2_2x = F.interpolate(x2_out, scale_factor=2.0, mode="bilinear", align_corners=True)
+        x1_out = outconv2("layer1_outconv2", F.conv2d(x1, P["l1out"]) + x2_2x)
+        return x3_out, x1_out
+
+    # -- K2/K1: LocalFeatureTransformer.forward (transformer.py:80-101) -------------------------
+    def _transformer(self, f0, f1, P):
+        nhead = self.config["coarse"]["nhead"]
+        same = f0.shape == f1.shape
+        N = f0.shape[0]
+        for w, name in zip(P["enc"], self.config["coarse"]["layer_names"]):
+            if name == "self":
+                if same:   # both images through one batched call
+                    xs = torch.cat([f0, f1], 0)
+                    xs = encoder_layer(w, xs, xs, nhead, is_self=True)
+                    f0, f1 = xs[:N], xs[N:]
+                else:
+                    f0 = encoder_layer(w, f0, f0, nhead, is_self=True)
+                    f1 = encoder_layer(w, f1, f1, nhead, is_self=True)
+            elif name == "cross":
+                f0 = encoder_layer(w, f0, f1, nhead)
+                f1 = encoder_layer(w, f1, f0, nhead)      # sees the UPDATED feat0 (:96-97)
+            else:
+                raise KeyError(name)
+        return f0, f1
+
+    def coarse_features(self, image0, image1):
+        """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c)."""
+        P = self._packed or self._pack()
+        bs = image0.size(0)
+        if image0.shape[2:] == image1.shape[2:]:
+            c, _ = self._backbone(torch.cat([image0, image1], 0), P)
+            c0, c1 = c[:bs], c[bs:]
+        else:
+            c0, _ = self._backbone(image0, P)
+            c1, _ = self._backbone(image1, P)
+        hw0_c, hw1_c = tuple(c0.shape[2:]), tuple(c1.shape[2:])
+        f0 = (c0 + self.pe[:, :, :hw0_c[0], :hw0_c[1]]).flatten(2).transpose(1, 2).contiguous()
+        f1 = (c1 + self.pe[:, :, :hw1_c[0], :hw1_c[1]]).flatten(2).transpose(1, 2).contiguous()
+        f0, f1 = self._transformer(f0, f1, P)
+        return f0, f1, hw0_c, hw1_c
+
+    @torch.no_grad()
+    def forward(self, data: dict):
+        """Updates ``data`` in place like LoFTR.forward (loftr.py:29-73, fine.enable=False)."""
+        img0, img1 = data["image0"], data["image1"]
+        if "mask0" in data:
+            raise NotImplementedError("padding masks (training-time feature) are not on the inference path")
+        data.update({"bs": img0.size(0), "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
+        f0, f1, hw0_c, hw1_c = self.coarse_features(img0, img1)
+        data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
+                     "hw0_f": torch.Size((img0.shape[2] // 2, img0.shape[3] // 2)),
+                     "hw1_f": torch.Size((img1.shape[2] // 2, img1.shape[3] // 2))})
+        mc = self.config["match_coarse"]
+        scale = data["hw0_i"][0] / hw0_c[0]
+        m = ops.coarse_match(f0, f1, hw0_c, hw1_c, mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
+                             data.get("scale0"), data.get("scale1"), scale)
+        data.update({"b_ids": m["b_ids"], "i_ids": m["i_ids"], "j_ids": m["j_ids"],
+                     "gt_mask": m["mconf"] == 0, "m_bids": m["b_ids"], "mkpts0_c": m["mkpts0_c"],
+                     "mkpts1_c": m["mkpts1_c"], "mconf": m["mconf"],
+                     "mkpts0_f": m["mkpts0_c"], "mkpts1_f": m["mkpts1_c"]})
+        return None

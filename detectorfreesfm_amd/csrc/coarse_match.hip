@@ -1,0 +1,507 @@
+// K3+K4+K5 -- all-pairs coarse correlation, dual-softmax, mutual-nearest-neighbour selection and
+// keypoint epilogue for gfx950 (MI355X).  The L x S similarity / confidence matrices are never
+// written to HBM.
+//
+// Replaces CoarseMatching.forward + get_coarse_match (eval, dual_softmax) of the reference
+//   third_party/LoFTR/src/loftr/utils/coarse_matching.py:84-145, 148-258 (mask_border :8-22)
+//
+// Launch sequence (all on the caller's stream, batch index in blockIdx.z / blockIdx.y):
+//   1. cm_gemm<STATS>  : 128x128 tiles of sim = (f0/sqrt(C)).(f1/sqrt(C))^T / temperature on the
+//                        fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32, 157 TF peak);
+//                        epilogue leaves per-tile (max, sum exp) partials for rows and columns.
+//   2. cm_reduce_stats : merges the partials into the softmax statistics of every row/column
+//                        and clears the best-candidate words.
+//   3. cm_gemm<SELECT> : recomputes each sim tile (cheaper than a 92 MB round trip per matrix
+//                        at fp32 MFMA rate would be to keep resident at batch 8), forms
+//                        conf = softmax_col * softmax_row exactly as the reference does
+//                        (exp(s-max)/sum per axis, then the product) and pushes, for entries
+//                        with conf > thr only, the row-best (conf, smallest j) and column-best
+//                        conf with order-independent integer atomicMax -> deterministic.
+//   4. cm_select       : per row i: j* = row-best; keep iff conf>thr, conf == column-best[j*]
+//                        (mutual), and (i, j*) is outside the low-side border; counts per pair.
+//   5. cm_compact      : ordered compaction (ascending (b,i), as torch.where) + K5 epilogue.
+//
+// GEMM tile: 4 waves, each a 64x64 quadrant = 2x2 MFMA tiles; BK=32 staged through LDS with a
+// 16-byte XOR swizzle (slot ^= (row>>1)&7) that makes every ds_read_b128 fragment read
+// conflict-free; next k-slab is prefetched into registers while the MFMAs run.
+#include "common.h"
+
+namespace {
+
+using namespace dfsfm;
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_LD = BN + 1;                               // padded epilogue tile
+constexpr int SMEM_STAGE = 2 * (BM + BN) * BK * 4;           // 65536 B, double buffered A|B
+constexpr int SMEM_TILE = BM * TILE_LD * 4;                  // 66048 B
+constexpr int SMEM_STATS = (BM + BN) * 8;                    // row/col (max,sum) for SELECT
+constexpr int SMEM_BYTES = SMEM_TILE + SMEM_STATS;           // 68096 B -> 2 workgroups / CU
+
+enum { MODE_STATS = 0, MODE_SELECT = 1, MODE_CONF = 2 };
+
+struct GemmArgs {
+    const float* f0;
+    const float* f1;
+    int L, S, C;
+    int ntm, ntn;            // tiles along L, S
+    float op_div;            // operand divisor (sqrt(C)) when not folded, else 1
+    float acc_mul;           // accumulator multiplier (1/C) when folded, else 1
+    float temperature;
+    float thr;
+    float2* row_part;        // [N][ntn][L]  (max, sumexp)
+    float2* col_part;        // [N][ntm][S]
+    const float2* row_stat;  // [N][L]
+    const float2* col_stat;  // [N][S]
+    unsigned long long* row_best;   // [N][L]  conf bits << 32 | ~j
+    unsigned int* col_best;         // [N][S]  conf bits
+    float* conf_out;         // [N][L][S] (MODE_CONF)
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+// Bijective XCD-aware remap (MI355X guide T1): consecutive logical tiles -> same XCD L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <int MODE, bool PRESCALE>
+__global__ __launch_bounds__(256, 2) void cm_gemm(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);                       // [2][BM][BK]
+    float* sB = sA + 2 * BM * BK;                                     // [2][BN][BK]
+    float* tile = reinterpret_cast<float*>(smem);                     // [BM][TILE_LD] (aliases)
+    float2* s_rstat = reinterpret_cast<float2*>(smem + SMEM_TILE);    // [BM]
+    float2* s_cstat = s_rstat + BM;                                   // [BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n = blockIdx.y;
+    const int t_id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = t_id / g.ntn, tn = t_id % g.ntn;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const float* A = g.f0 + (int64_t)n * g.L * g.C;
+    const float* B = g.f1 + (int64_t)n * g.S * g.C;
+
+    if (MODE != MODE_STATS) {
+        if (tid < BM) {
+            const int i = row0 + tid;
+            s_rstat[tid] = i < g.L ? g.row_stat[(int64_t)n * g.L + i] : make_float2(0.f, 1.f);
+        } else {
+            const int j = col0 + tid - BM;
+            s_cstat[tid - BM] = j < g.S ? g.col_stat[(int64_t)n * g.S + j] : make_float2(0.f, 1.f);
+        }
+    }
+
+    // ---- staging: each thread moves 4 float4 of A and 4 of B per k-slab --------------------
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 3, c = idx & 7;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[j] = (row0 + r < g.L)
+                        ? *reinterpret_cast<const f32x4*>(A + (int64_t)(row0 + r) * g.C + k0 + c * 4) : z;
+            rb[j] = (col0 + r < g.S)
+                        ? *reinterpret_cast<const f32x4*>(B + (int64_t)(col0 + r) * g.C + k0 + c * 4) : z;
+            if (PRESCALE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ra[j][e] = ra[j][e] / g.op_div; rb[j][e] = rb[j][e] / g.op_div; }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 3, c = idx & 7;
+            *reinterpret_cast<f32x4*>(sA + buf * BM * BK + r * BK + swz(r, c) * 4) = ra[j];
+            *reinterpret_cast<f32x4*>(sB + buf * BN * BK + r * BK + swz(r, c) * 4) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+
+    const int nk = g.C / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const float* a_base = sA + buf * BM * BK;
+        const float* b_base = sB + buf * BN * BK;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {        // lane half h owns k in [16h, 16h+16) of the slab
+            f32x4 av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int r = wr * 64 + a * 32 + col;
+                av[a] = *reinterpret_cast<const f32x4*>(a_base + r * BK + swz(r, half * 4 + qd) * 4);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int r = wc * 64 + b * 32 + col;
+                bv[b] = *reinterpret_cast<const f32x4*>(b_base + r * BK + swz(r, half * 4 + qd) * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][t], bv[b][t], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    // lane holds sim[row = wr*64 + a*32 + mfma32_row(r,half)][col = wc*64 + b*32 + (lane&31)]
+    bool any_above = false;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + a * 32 + mfma32_row(r, half);
+                const int lc = wc * 64 + b * 32 + col;
+                float s = (acc[a][b][r] * g.acc_mul) / g.temperature;
+                if (MODE != MODE_STATS) {
+                    const float2 rs = s_rstat[lr], cs = s_cstat[lc];
+                    // softmax over dim 1 (column j normalised over i) * softmax over dim 2
+                    const float p_col = expf(s - cs.x) / cs.y;
+                    const float p_row = expf(s - rs.x) / rs.y;
+                    s = p_col * p_row;
+                    if (MODE == MODE_SELECT)
+                        any_above |= (s > g.thr) && (row0 + lr < g.L) && (col0 + lc < g.S);
+                }
+                acc[a][b][r] = s;
+            }
+
+    if (MODE == MODE_SELECT) {
+        // The overwhelmingly common tile has no entry above thr: nothing to record.
+        if (!__syncthreads_or(any_above)) return;
+    } else {
+        __syncthreads();   // staging buffers are dead, the tile aliases them
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + a * 32 + mfma32_row(r, half);
+                const int lc = wc * 64 + b * 32 + col;
+                tile[lr * TILE_LD + lc] = acc[a][b][r];
+            }
+    __syncthreads();
+
+    const int nrow = min(BM, g.L - row0), ncol = min(BN, g.S - col0);
+    if (MODE == MODE_STATS) {
+        if (tid < BM) {
+            if (tid < nrow) {
+                float m = -INFINITY;
+                for (int j = 0; j < ncol; ++j) m = fmaxf(m, tile[tid * TILE_LD + j]);
+                float sum = 0.f;
+                for (int j = 0; j < ncol; ++j) sum += expf(tile[tid * TILE_LD + j] - m);
+                g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = make_float2(m, sum);
+            }
+        } else {
+            const int c = tid - BM;
+            if (c < ncol) {
+                float m = -INFINITY;
+                for (int i = 0; i < nrow; ++i) m = fmaxf(m, tile[i * TILE_LD + c]);
+                float sum = 0.f;
+                for (int i = 0; i < nrow; ++i) sum += expf(tile[i * TILE_LD + c] - m);
+                g.col_part[((int64_t)n * g.ntm + tm) * g.S + col0 + c] = make_float2(m, sum);
+            }
+        }
+    } else if (MODE == MODE_SELECT) {
+        if (tid < BM) {
+            if (tid < nrow) {
+                float best = g.thr;
+                int bj = -1;
+                for (int j = 0; j < ncol; ++j) {
+                    const float v = tile[tid * TILE_LD + j];
+                    if (v > best) { best = v; bj = j; }      // strict > keeps the smallest j on ties
+                }
+                if (bj >= 0) {
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(~(unsigned)(col0 + bj));
+                    atomicMax(&g.row_best[(int64_t)n * g.L + row0 + tid], key);
+                }
+            }
+        } else {
+            const int c = tid - BM;
+            if (c < ncol) {
+                float best = g.thr;
+                bool found = false;
+                for (int i = 0; i < nrow; ++i) {
+                    const float v = tile[i * TILE_LD + c];
+                    if (v > best) { best = v; found = true; }
+                }
+                if (found) atomicMax(&g.col_best[(int64_t)n * g.S + col0 + c], __float_as_uint(best));
+            }
+        }
+    } else {   // MODE_CONF: dump the confidence tile, coalesced
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int r = e / BN, c = e % BN;
+            if (r < nrow && c < ncol)
+                g.conf_out[((int64_t)n * g.L + row0 + r) * g.S + col0 + c] = tile[r * TILE_LD + c];
+        }
+    }
+}
+
+// Merge per-tile (max, sumexp) partials; clear row_best / col_best.
+__global__ __launch_bounds__(256) void cm_reduce_stats(const float2* __restrict__ row_part,
+                                                       const float2* __restrict__ col_part,
+                                                       float2* __restrict__ row_stat,
+                                                       float2* __restrict__ col_stat,
+                                                       unsigned long long* __restrict__ row_best,
+                                                       unsigned int* __restrict__ col_best, int L, int S,
+                                                       int ntm, int ntn) {
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < L) {
+        float m = -INFINITY;
+        for (int t = 0; t < ntn; ++t) m = fmaxf(m, row_part[((int64_t)n * ntn + t) * L + e].x);
+        float sum = 0.f;
+        for (int t = 0; t < ntn; ++t) {
+            const float2 p = row_part[((int64_t)n * ntn + t) * L + e];
+            sum += p.y * expf(p.x - m);
+        }
+        row_stat[(int64_t)n * L + e] = make_float2(m, sum);
+        row_best[(int64_t)n * L + e] = 0ull;
+    } else if (e < L + S) {
+        const int j = e - L;
+        float m = -INFINITY;
+        for (int t = 0; t < ntm; ++t) m = fmaxf(m, col_part[((int64_t)n * ntm + t) * S + j].x);
+        float sum = 0.f;
+        for (int t = 0; t < ntm; ++t) {
+            const float2 p = col_part[((int64_t)n * ntm + t) * S + j];
+            sum += p.y * expf(p.x - m);
+        }
+        col_stat[(int64_t)n * S + j] = make_float2(m, sum);
+        col_best[(int64_t)n * S + j] = 0u;
+    }
+}
+
+// Per-row decision; one workgroup per pair.  flags[n][i] = 1 iff row i yields a match.
+__global__ __launch_bounds__(1024) void cm_select(const unsigned long long* __restrict__ row_best,
+                                                  const unsigned int* __restrict__ col_best,
+                                                  uint8_t* __restrict__ flags, int32_t* __restrict__ counts,
+                                                  int L, int S, float thr, int border, int w0c, int w1c) {
+    const int n = blockIdx.x;
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const unsigned long long key = row_best[(int64_t)n * L + i];
+        bool ok = false;
+        if (key != 0ull) {
+            const unsigned bits = (unsigned)(key >> 32);
+            const int j = (int)(~(unsigned)(key & 0xffffffffull));
+            const float v = __uint_as_float(bits);
+            ok = v > thr && col_best[(int64_t)n * S + j] == bits;
+            // mask_border: only the LOW side of each grid axis is removed (reference quirk).
+            ok = ok && (i / w0c >= border) && (i % w0c >= border) && (j / w1c >= border) && (j % w1c >= border);
+        }
+        flags[(int64_t)n * L + i] = ok ? 1 : 0;
+        local += ok ? 1 : 0;
+    }
+    atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[n] = s_cnt;
+}
+
+// Ordered compaction + keypoint epilogue; one workgroup per pair.
+__global__ __launch_bounds__(1024) void cm_compact(const unsigned long long* __restrict__ row_best,
+                                                   const uint8_t* __restrict__ flags,
+                                                   const int32_t* __restrict__ counts, int N, int L, int w0c,
+                                                   int w1c, const float* __restrict__ scale0,
+                                                   const float* __restrict__ scale1, float coarse_scale,
+                                                   int64_t* __restrict__ b_ids, int64_t* __restrict__ i_ids,
+                                                   int64_t* __restrict__ j_ids, float* __restrict__ mconf,
+                                                   float* __restrict__ mkpts0, float* __restrict__ mkpts1,
+                                                   int32_t* __restrict__ total) {
+    const int n = blockIdx.x;
+    __shared__ int s_wave[16];
+    int base = 0;
+    for (int b = 0; b < n; ++b) base += counts[b];
+    if (n == N - 1 && threadIdx.x == 0) *total = base + counts[n];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (x, y) scale = coarse_scale * scale[b][{1,0}]   (coarse_matching.py:239-247)
+    const float s0x = scale0 ? coarse_scale * scale0[n * 2 + 1] : coarse_scale;
+    const float s0y = scale0 ? coarse_scale * scale0[n * 2 + 0] : coarse_scale;
+    const float s1x = scale1 ? coarse_scale * scale1[n * 2 + 1] : coarse_scale;
+    const float s1y = scale1 ? coarse_scale * scale1[n * 2 + 0] : coarse_scale;
+    for (int i0 = 0; i0 < L; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool f = i < L && flags[(int64_t)n * L + i];
+        const unsigned long long bal = __ballot(f);
+        const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            const int c = s_wave[w];
+            if (w < wave) off += c;
+            tot += c;
+        }
+        if (f) {
+            const int pos = base + off + in_wave;
+            const unsigned long long key = row_best[(int64_t)n * L + i];
+            const int j = (int)(~(unsigned)(key & 0xffffffffull));
+            b_ids[pos] = n;
+            i_ids[pos] = i;
+            j_ids[pos] = j;
+            mconf[pos] = __uint_as_float((unsigned)(key >> 32));
+            mkpts0[pos * 2 + 0] = (float)(i % w0c) * s0x;
+            mkpts0[pos * 2 + 1] = (float)(i / w0c) * s0y;
+            mkpts1[pos * 2 + 0] = (float)(j % w1c) * s1x;
+            mkpts1[pos * 2 + 1] = (float)(j / w1c) * s1y;
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+struct Workspace {
+    float2 *row_part, *col_part, *row_stat, *col_stat;
+    unsigned long long* row_best;
+    unsigned int* col_best;
+    uint8_t* flags;
+    int32_t* counts;
+    size_t bytes;
+};
+
+Workspace carve(void* base, int N, int L, int S) {
+    const int ntm = (L + BM - 1) / BM, ntn = (S + BN - 1) / BN;
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(base) + off);
+        off += align_up(bytes, 256);
+        return p;
+    };
+    w.row_part = reinterpret_cast<float2*>(take((size_t)N * ntn * L * sizeof(float2)));
+    w.col_part = reinterpret_cast<float2*>(take((size_t)N * ntm * S * sizeof(float2)));
+    w.row_stat = reinterpret_cast<float2*>(take((size_t)N * L * sizeof(float2)));
+    w.col_stat = reinterpret_cast<float2*>(take((size_t)N * S * sizeof(float2)));
+    w.row_best = reinterpret_cast<unsigned long long*>(take((size_t)N * L * 8));
+    w.col_best = reinterpret_cast<unsigned int*>(take((size_t)N * S * 4));
+    w.flags = reinterpret_cast<uint8_t*>(take((size_t)N * L));
+    w.counts = reinterpret_cast<int32_t*>(take((size_t)N * 4));
+    w.bytes = off;
+    return w;
+}
+
+bool is_pow4(int c) { return c > 0 && (c & (c - 1)) == 0 && (__builtin_ctz(c) % 2 == 0); }
+
+template <int MODE>
+void launch_gemm(const GemmArgs& g, int N, bool prescale, hipStream_t stream) {
+    dim3 grid(g.ntm * g.ntn, N), blk(256);
+    // > 64 KiB of dynamic LDS needs the opt-in attribute (set once per kernel instance).
+    static bool attr_set[2] = {false, false};
+    if (prescale) {
+        if (!attr_set[1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_gemm<MODE, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL((cm_gemm<MODE, true>), grid, blk, SMEM_BYTES, stream, g);
+    } else {
+        if (!attr_set[0]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_gemm<MODE, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL((cm_gemm<MODE, false>), grid, blk, SMEM_BYTES, stream, g);
+    }
+}
+
+int check_common(const float* f0, const float* f1, int N, int L, int S, int C, float temperature,
+                 void* ws, size_t ws_bytes) {
+    if (!f0 || !f1 || !ws) return DFSFM_E_BADARG;
+    if (N <= 0 || L <= 0 || S <= 0 || C <= 0 || !(temperature > 0.f)) return DFSFM_E_BADARG;
+    if (C % BK != 0 || N > 65535) return DFSFM_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(f0) & 15) || (reinterpret_cast<uintptr_t>(f1) & 15)) return DFSFM_E_UNSUPPORTED;
+    if (ws_bytes < dfsfm_coarse_match_workspace(N, L, S)) return DFSFM_E_WORKSPACE;
+    return DFSFM_OK;
+}
+
+GemmArgs make_args(const float* f0, const float* f1, int L, int S, int C, float temperature, float thr,
+                   const Workspace& w, bool* prescale) {
+    GemmArgs g{};
+    g.f0 = f0; g.f1 = f1; g.L = L; g.S = S; g.C = C;
+    g.ntm = (L + BM - 1) / BM; g.ntn = (S + BN - 1) / BN;
+    // feat / sqrt(C) on both operands (coarse_matching.py:103-104).  For C a power of 4 the
+    // division is exact and commutes with the dot product, so it is folded into one multiply.
+    *prescale = !is_pow4(C);
+    g.op_div = *prescale ? sqrtf((float)C) : 1.f;
+    g.acc_mul = *prescale ? 1.f : 1.f / (float)C;
+    g.temperature = temperature; g.thr = thr;
+    g.row_part = w.row_part; g.col_part = w.col_part; g.row_stat = w.row_stat; g.col_stat = w.col_stat;
+    g.row_best = w.row_best; g.col_best = w.col_best; g.conf_out = nullptr;
+    return g;
+}
+
+}  // namespace
+
+extern "C" size_t dfsfm_coarse_match_workspace(int N, int L, int S) {
+    if (N <= 0 || L <= 0 || S <= 0) return 0;
+    return carve(nullptr, N, L, S).bytes;
+}
+
+extern "C" int dfsfm_coarse_match_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,
+                                      float temperature, float thr, int border, int h0c, int w0c, int h1c,
+                                      int w1c, const float* scale0, const float* scale1, float coarse_scale,
+                                      int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                                      float* mkpts0, float* mkpts1, int32_t* count, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+    int rc = check_common(feat0, feat1, N, L, S, C, temperature, workspace, workspace_bytes);
+    if (rc != DFSFM_OK) return rc;
+    if (!b_ids || !i_ids || !j_ids || !mconf || !mkpts0 || !mkpts1 || !count) return DFSFM_E_BADARG;
+    if (h0c * w0c != L || h1c * w1c != S || border < 0) return DFSFM_E_BADARG;
+    if (!(thr >= 0.f)) return DFSFM_E_UNSUPPORTED;   // best-candidate words use 0 as "none"
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Workspace w = carve(workspace, N, L, S);
+    bool prescale;
+    GemmArgs g = make_args(feat0, feat1, L, S, C, temperature, thr, w, &prescale);
+
+    launch_gemm<MODE_STATS>(g, N, prescale, stream);
+    hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
+                       w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, g.ntm, g.ntn);
+    launch_gemm<MODE_SELECT>(g, N, prescale, stream);
+    hipLaunchKernelGGL(cm_select, dim3(N), dim3(1024), 0, stream, w.row_best, w.col_best, w.flags, w.counts, L,
+                       S, thr, border, w0c, w1c);
+    hipLaunchKernelGGL(cm_compact, dim3(N), dim3(1024), 0, stream, w.row_best, w.flags, w.counts, N, L, w0c,
+                       w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0, mkpts1, count);
+    return check_launch("dfsfm_coarse_match_f32");
+}
+
+extern "C" int dfsfm_coarse_conf_matrix_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,
+                                            float temperature, float* conf, void* workspace,
+                                            size_t workspace_bytes, void* stream_) {
+    int rc = check_common(feat0, feat1, N, L, S, C, temperature, workspace, workspace_bytes);
+    if (rc != DFSFM_OK) return rc;
+    if (!conf) return DFSFM_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Workspace w = carve(workspace, N, L, S);
+    bool prescale;
+    GemmArgs g = make_args(feat0, feat1, L, S, C, temperature, 0.f, w, &prescale);
+    g.conf_out = conf;
+    launch_gemm<MODE_STATS>(g, N, prescale, stream);
+    hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
+                       w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, g.ntm, g.ntn);
+    launch_gemm<MODE_CONF>(g, N, prescale, stream);
+    return check_launch("dfsfm_coarse_conf_matrix_f32");
+}

@@ -1,0 +1,315 @@
+// K1 -- linear attention  out = phi(Q) (phi(K)^T V) Z   for gfx950 (MI355X).
+//
+// Replaces LinearAttention.forward of the reference
+//   third_party/LoFTR/src/loftr/loftr_module/linear_attention.py:20-47     (coarse: H=8, D=32)
+//   src/MultiviewMatcher/matcher_module/linear_attention.py:28-60          (refine: H=8, D=16)
+//
+// HBM-bound op (AI ~ 8 flop/B): q,k,v are read once, out written once, nothing else of size
+// O(L) touches memory.  Three launches:
+//   1. kv_partial : every workgroup reduces a chunk of S rows into per-head  KV = K^T (v/S)
+//                   (DxD) and Ksum (D) with fp32 MFMA; the K/V operands are loaded straight
+//                   from global in MFMA fragment order (128-B row segments), no LDS.
+//   2. kv_finalize: sums the chunk partials in fixed order (deterministic; skipped when one
+//                   chunk covers S, the refinement case).
+//   3. apply      : out^T = KV^T Q^T per head with MFMA, Z = 1/(Q.Ksum+eps) from the same
+//                   registers (one cross-half shuffle), scaled and stored as float4.
+// MFMA k-index permutation: the hardware pairs lane halves (32x32x2: 2 halves, 16x16x4: 4
+// quarter-groups) as the k index; we give half g the k-range [g*KH, (g+1)*KH) for BOTH
+// operands, which keeps every lane's loads contiguous.  Summation order is fixed -> results are
+// run-to-run deterministic.
+#include "common.h"
+
+namespace {
+
+using namespace dfsfm;
+
+__device__ __forceinline__ float mask_at(const uint8_t* m, int group, int64_t base, int idx) {
+    return m ? (float)m[base + idx / group] : 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// D = 32  (v_mfma_f32_32x32x2_f32)
+// ---------------------------------------------------------------------------------------------
+constexpr int KV32 = 32 * 32 + 32;   // floats per (n,h): KV[d][v] then Ksum[d]
+
+__global__ __launch_bounds__(256) void la_kv_partial_d32(
+    const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+    int kv_group, float* __restrict__ part, int S, int H, int ldk, int ldv, int rows_per_chunk,
+    int nchunks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int s_begin = chunk * rows_per_chunk;
+    const int s_end = min(S, s_begin + rows_per_chunk);
+    const float Sf = (float)S;
+    const int64_t mbase = kv_mask ? (int64_t)n * ((S + kv_group - 1) / kv_group) : 0;
+    const float* kn = k + (int64_t)n * S * ldk;
+    const float* vn = v + (int64_t)n * S * ldv;
+
+    for (int h = wave; h < H; h += 4) {
+        f32x16 acc = {0};
+        float ksum = 0.f;
+        for (int s0 = s_begin; s0 < s_end; s0 += 32) {
+            float kk[16], vv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int s = s0 + half * 16 + t;
+                float kx = 0.f, vx = 0.f;
+                if (s < s_end) {
+                    const float m = mask_at(kv_mask, kv_group, mbase, s);
+                    kx = elu_plus_one(kn[(int64_t)s * ldk + h * 32 + col]) * m;
+                    vx = (vn[(int64_t)s * ldv + h * 32 + col] * m) / Sf;
+                }
+                kk[t] = kx;
+                vv[t] = vx;
+                ksum += kx;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t)   // A[i=d][k=s] = K[s][d], B[k=s][j=v] = V[s][v]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[t], vv[t], acc, 0, 0, 0);
+        }
+        ksum += __shfl_xor(ksum, 32);
+        float* p = part + (((int64_t)n * nchunks + chunk) * H + h) * KV32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[mfma32_row(r, half) * 32 + col] = acc[r];
+        if (half == 0) p[1024 + col] = ksum;
+    }
+}
+
+__global__ __launch_bounds__(256) void la_apply_d32(
+    const float* __restrict__ q, const uint8_t* __restrict__ q_mask, int q_group,
+    const float* __restrict__ kvf, float* __restrict__ out, int L, int S, int H, int ldq, int ldo,
+    float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y;
+    const int l = blockIdx.x * 32 + col;
+    const bool valid = l < L;
+    const float Sf = (float)S;
+    const int64_t mbase = q_mask ? (int64_t)n * ((L + q_group - 1) / q_group) : 0;
+    const float qm = valid ? mask_at(q_mask, q_group, mbase, l) : 0.f;
+    const float* qrow = q + ((int64_t)n * L + (valid ? l : 0)) * ldq;
+    float* orow = out + ((int64_t)n * L + (valid ? l : 0)) * ldo;
+
+    for (int h = wave; h < H; h += 4) {
+        const float* kv = kvf + ((int64_t)n * H + h) * KV32;
+        float a[16], ks[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = kv[(half * 16 + t) * 32 + col];     // A[i=v][k=d] = KV[d][v]
+            ks[t] = kv[1024 + half * 16 + t];
+        }
+        float Q[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (valid) x = *reinterpret_cast<const f32x4*>(qrow + h * 32 + half * 16 + j * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Q[j * 4 + e] = valid ? elu_plus_one(x[e]) * qm : 0.f;
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) z += Q[t] * ks[t];
+        z += __shfl_xor(z, 32);
+        const float Z = 1.f / (z + eps);
+        f32x16 acc = {0};
+#pragma unroll
+        for (int t = 0; t < 16; ++t)   // B[k=d][j=l] = Q[l][d]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], Q[t], acc, 0, 0, 0);
+        if (valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // regs 4g..4g+3 -> v = 8g + 4*half + (0..3)
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (acc[g * 4 + e] * Z) * Sf;
+                *reinterpret_cast<f32x4*>(orow + h * 32 + g * 8 + half * 4) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// D = 16  (v_mfma_f32_16x16x4_f32)
+// ---------------------------------------------------------------------------------------------
+constexpr int KV16 = 16 * 16 + 16;
+
+__global__ __launch_bounds__(256) void la_kv_partial_d16(
+    const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+    int kv_group, float* __restrict__ part, int S, int H, int ldk, int ldv, int rows_per_chunk,
+    int nchunks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, grp = lane >> 4;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int s_begin = chunk * rows_per_chunk;
+    const int s_end = min(S, s_begin + rows_per_chunk);
+    const float Sf = (float)S;
+    const int64_t mbase = kv_mask ? (int64_t)n * ((S + kv_group - 1) / kv_group) : 0;
+    const float* kn = k + (int64_t)n * S * ldk;
+    const float* vn = v + (int64_t)n * S * ldv;
+
+    for (int h = wave; h < H; h += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float ksum = 0.f;
+        for (int s0 = s_begin; s0 < s_end; s0 += 32) {
+            float kk[8], vv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int s = s0 + grp * 8 + t;
+                float kx = 0.f, vx = 0.f;
+                if (s < s_end) {
+                    const float m = mask_at(kv_mask, kv_group, mbase, s);
+                    kx = elu_plus_one(kn[(int64_t)s * ldk + h * 16 + col]) * m;
+                    vx = (vn[(int64_t)s * ldv + h * 16 + col] * m) / Sf;
+                }
+                kk[t] = kx;
+                vv[t] = vx;
+                ksum += kx;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t], vv[t], acc, 0, 0, 0);
+        }
+        ksum += __shfl_xor(ksum, 16);
+        ksum += __shfl_xor(ksum, 32);
+        float* p = part + (((int64_t)n * nchunks + chunk) * H + h) * KV16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[(grp * 4 + r) * 16 + col] = acc[r];   // row d = 4*grp + r
+        if (grp == 0) p[256 + col] = ksum;
+    }
+}
+
+// Each workgroup covers 64 rows x all heads: wave w owns heads w, w+4, ...; 4 sub-blocks of 16 rows.
+__global__ __launch_bounds__(256) void la_apply_d16(
+    const float* __restrict__ q, const uint8_t* __restrict__ q_mask, int q_group,
+    const float* __restrict__ kvf, float* __restrict__ out, int L, int S, int H, int ldq, int ldo,
+    float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, grp = lane >> 4;
+    const int n = blockIdx.y;
+    const float Sf = (float)S;
+    const int64_t mbase = q_mask ? (int64_t)n * ((L + q_group - 1) / q_group) : 0;
+
+    for (int h = wave; h < H; h += 4) {
+        const float* kv = kvf + ((int64_t)n * H + h) * KV16;
+        float a[4], ks[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = kv[(grp * 4 + t) * 16 + col];       // A[i=v][k=d] = KV[d][v]
+            ks[t] = kv[256 + grp * 4 + t];
+        }
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const int l = blockIdx.x * 64 + sb * 16 + col;
+            const bool valid = l < L;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            float qm = 0.f;
+            if (valid) {
+                x = *reinterpret_cast<const f32x4*>(q + ((int64_t)n * L + l) * ldq + h * 16 + grp * 4);
+                qm = mask_at(q_mask, q_group, mbase, l);
+            }
+            float Q[4];
+            float z = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Q[e] = valid ? elu_plus_one(x[e]) * qm : 0.f;
+                z += Q[e] * ks[e];
+            }
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 32);
+            const float Z = 1.f / (z + eps);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Q[t], acc, 0, 0, 0);
+            if (valid) {   // C: col = lane&15 = row l, row v = 4*grp + reg
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (acc[e] * Z) * Sf;
+                *reinterpret_cast<f32x4*>(out + ((int64_t)n * L + l) * ldo + h * 16 + grp * 4) = o;
+            }
+        }
+    }
+}
+
+// Sum the chunk partials in chunk order: kvf[n][h][:] = sum_c part[n][c][h][:].
+__global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ part,
+                                                      float* __restrict__ kvf, int H, int nchunks,
+                                                      int kvsz) {
+    const int nh = blockIdx.x;   // n*H + h
+    const int n = nh / H, h = nh % H;
+    for (int e = threadIdx.x; e < kvsz; e += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c)
+            s += part[(((int64_t)n * nchunks + c) * H + h) * kvsz + e];
+        kvf[(int64_t)nh * kvsz + e] = s;
+    }
+}
+
+// Rows per kv_partial workgroup: aim for ~1024 workgroups, at least 64 rows each.
+int chunk_rows(int N, int S) {
+    int64_t want = ((int64_t)S * N + 1023) / 1024;
+    int rows = (int)((want + 31) / 32 * 32);
+    if (rows < 64) rows = 64;
+    const int smax = (S + 31) / 32 * 32;
+    if (rows > smax) rows = smax;
+    return rows;
+}
+
+}  // namespace
+
+extern "C" size_t dfsfm_linear_attention_workspace(int N, int S, int H, int D) {
+    if (N <= 0 || S <= 0 || H <= 0 || (D != 16 && D != 32)) return 0;
+    const int rows = chunk_rows(N, S);
+    const int nchunks = (S + rows - 1) / rows;
+    const size_t kvsz = (size_t)D * D + D;
+    size_t fin = (size_t)N * H * kvsz * sizeof(float);
+    size_t part = nchunks > 1 ? (size_t)N * nchunks * H * kvsz * sizeof(float) : 0;
+    return dfsfm::align_up(fin, 256) + dfsfm::align_up(part, 256);
+}
+
+extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const float* v,
+                                          const uint8_t* q_mask, int q_group,
+                                          const uint8_t* kv_mask, int kv_group, float* out, int N,
+                                          int L, int S, int H, int D, int ldq, int ldk, int ldv,
+                                          int ldo, float eps, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    if (!q || !k || !v || !out || !workspace) return DFSFM_E_BADARG;
+    if (N <= 0 || L <= 0 || S <= 0 || H <= 0) return DFSFM_E_BADARG;
+    if (D != 16 && D != 32) return DFSFM_E_UNSUPPORTED;
+    if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return DFSFM_E_BADARG;
+    if ((ldq & 3) || (ldo & 3)) return DFSFM_E_UNSUPPORTED;   // float4 row access
+    if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return DFSFM_E_UNSUPPORTED;
+    if (q_mask && (q_group <= 0)) return DFSFM_E_BADARG;
+    if (kv_mask && (kv_group <= 0)) return DFSFM_E_BADARG;
+    if (N > 65535) return DFSFM_E_UNSUPPORTED;
+    if (workspace_bytes < dfsfm_linear_attention_workspace(N, S, H, D)) return DFSFM_E_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    const int rows = chunk_rows(N, S);
+    const int nchunks = (S + rows - 1) / rows;
+    const int kvsz = D * D + D;
+    float* kvf = static_cast<float*>(workspace);
+    float* part = nchunks > 1
+                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) +
+                                                 dfsfm::align_up((size_t)N * H * kvsz * sizeof(float), 256))
+                      : kvf;
+    dim3 gA(nchunks, N), blk(256);
+    if (D == 32) {
+        hipLaunchKernelGGL(la_kv_partial_d32, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, H,
+                           ldk, ldv, rows, nchunks);
+    } else {
+        hipLaunchKernelGGL(la_kv_partial_d16, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, H,
+                           ldk, ldv, rows, nchunks);
+    }
+    if (nchunks > 1)
+        hipLaunchKernelGGL(la_kv_finalize, dim3(N * H), blk, 0, stream, part, kvf, H, nchunks, kvsz);
+    if (D == 32) {
+        hipLaunchKernelGGL(la_apply_d32, dim3((L + 31) / 32, N), blk, 0, stream, q, q_mask, q_group, kvf,
+                           out, L, S, H, ldq, ldo, eps);
+    } else {
+        hipLaunchKernelGGL(la_apply_d16, dim3((L + 63) / 64, N), blk, 0, stream, q, q_mask, q_group, kvf,
+                           out, L, S, H, ldq, ldo, eps);
+    }
+    return dfsfm::check_launch("dfsfm_linear_attention_f32");
+}

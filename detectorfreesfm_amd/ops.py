@@ -1,0 +1,162 @@
+"""Torch-tensor front ends of the HIP kernels (raw pointers + current stream -> C ABI).
+
+PyTorch is plumbing here: it owns the device memory and the stream.  Every function launches
+hand-written gfx950 kernels from ``libdfsfm_hip.so``; none has a PyTorch/CPU fallback.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _as_u8(m: Optional[torch.Tensor]):
+    if m is None:
+        return None
+    if m.dtype == torch.bool:
+        return m.contiguous().view(torch.uint8)
+    return (m != 0).contiguous().view(torch.uint8)
+
+
+def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None):
+    """K1.  q [N,L,H,D]; k,v [N,S,H,D] fp32 (row-strided views allowed: stride(-1)=1,
+    stride(-2)=D); q_mask [N,L/q_group], kv_mask [N,S/kv_group] bool/uint8 or None."""
+    _require_cuda(q, k, v)
+    N, L, H, D = q.shape
+    S = k.shape[1]
+    for t, n_rows in ((q, L), (k, S), (v, S)):
+        if t.dtype != torch.float32 or t.stride(3) != 1 or t.stride(2) != D or (N > 1 and t.stride(0) != n_rows * t.stride(1)):
+            raise _lib.DfsfmError("linear_attention: need fp32 [N,rows,H,D] with dense (H,D) and batch stride rows*ld")
+    if out is None:
+        out = torch.empty((N, L, H, D), dtype=torch.float32, device=q.device)
+    qm, km = _as_u8(q_mask), _as_u8(kv_mask)
+    lib = _lib.lib()
+    ws_bytes = lib.dfsfm_linear_attention_workspace(N, S, H, D)
+    if ws_bytes == 0:
+        raise _lib.DfsfmError(f"linear_attention: unsupported shape N={N} S={S} H={H} D={D}")
+    ws = _workspace(ws_bytes, q.device)
+    rc = lib.dfsfm_linear_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(qm), q_group, _ptr(km), kv_group,
+                                        _ptr(out), N, L, S, H, D, q.stride(1), k.stride(1), v.stride(1),
+                                        out.stride(1), eps, _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "dfsfm_linear_attention_f32")
+    return out
+
+
+def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None,
+                 coarse_scale=8.0):
+    """K3+K4+K5.  feat0 [N,L,C], feat1 [N,S,C] fp32 contiguous.  Returns a dict with
+    b_ids,i_ids,j_ids (int64 [M]), mconf [M], mkpts0_c, mkpts1_c [M,2] in ascending (b,i) order."""
+    _require_cuda(feat0, feat1)
+    feat0, feat1 = feat0.contiguous(), feat1.contiguous()
+    N, L, C = feat0.shape
+    S = feat1.shape[1]
+    dev = feat0.device
+    lib = _lib.lib()
+    ws = _workspace(lib.dfsfm_coarse_match_workspace(N, L, S), dev)
+    cap = N * L
+    ids = torch.empty((3, cap), dtype=torch.int64, device=dev)
+    mconf = torch.empty((cap,), dtype=torch.float32, device=dev)
+    mk = torch.empty((2, cap, 2), dtype=torch.float32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    s0 = None if scale0 is None else scale0.to(device=dev, dtype=torch.float32).contiguous()
+    s1 = None if scale1 is None else scale1.to(device=dev, dtype=torch.float32).contiguous()
+    rc = lib.dfsfm_coarse_match_f32(_ptr(feat0), _ptr(feat1), N, L, S, C, float(temperature), float(thr),
+                                    int(border), hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1], _ptr(s0), _ptr(s1),
+                                    float(coarse_scale), _ptr(ids[0]), _ptr(ids[1]), _ptr(ids[2]), _ptr(mconf),
+                                    _ptr(mk[0]), _ptr(mk[1]), _ptr(count), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "dfsfm_coarse_match_f32")
+    M = int(count.item())          # data-dependent size, like torch.where in the reference
+    return {"b_ids": ids[0, :M], "i_ids": ids[1, :M], "j_ids": ids[2, :M], "mconf": mconf[:M],
+            "mkpts0_c": mk[0, :M], "mkpts1_c": mk[1, :M]}
+
+
+def coarse_conf_matrix(feat0, feat1, temperature):
+    """Dense dual-softmax confidence matrix [N,L,S] (parity/debug aid)."""
+    _require_cuda(feat0, feat1)
+    feat0, feat1 = feat0.contiguous(), feat1.contiguous()
+    N, L, C = feat0.shape
+    S = feat1.shape[1]
+    lib = _lib.lib()
+    ws = _workspace(lib.dfsfm_coarse_match_workspace(N, L, S), feat0.device)
+    conf = torch.empty((N, L, S), dtype=torch.float32, device=feat0.device)
+    rc = lib.dfsfm_coarse_conf_matrix_f32(_ptr(feat0), _ptr(feat1), N, L, S, C, float(temperature), _ptr(conf),
+                                          _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "dfsfm_coarse_conf_matrix_f32")
+    return conf
+
+
+def roi_align(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapolation_value=0.0,
+              mean=None, std=None, out=None):
+    """K8.  feat [Nimg,C,H,W]; boxes [M,4] (x1,y1,x2,y2); returns / fills out [*,C,crop_h,crop_w]."""
+    _require_cuda(feat, boxes)
+    feat = feat.contiguous()
+    boxes = boxes.to(torch.float32).contiguous()
+    Nimg, C, H, W = feat.shape
+    M = boxes.shape[0]
+    if out is None:
+        if out_slot is not None:
+            raise _lib.DfsfmError("roi_align: out_slot needs a preallocated `out`")
+        out = torch.empty((M, C, crop_h, crop_w), dtype=torch.float32, device=feat.device)
+    bi = None if box_ind is None else box_ind.to(torch.int32).contiguous()
+    sl = None if out_slot is None else out_slot.to(torch.int64).contiguous()
+    rc = _lib.lib().dfsfm_roi_align_f32(_ptr(feat), Nimg, C, H, W, _ptr(boxes), _ptr(bi), _ptr(sl), M, crop_h,
+                                        crop_w, float(extrapolation_value), _ptr(mean), _ptr(std), _ptr(out),
+                                        _stream())
+    _lib.check(rc, "dfsfm_roi_align_f32")
+    return out
+
+
+def fine_match(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, ref_pts=None,
+               scale_r=None, rs_t=0, rs_n=0):
+    """K11+K12.  ref [T,WW,C], qry [T,Vq,WW,C]; track_mask [T,Vq]; movable [T] or None.
+    Returns dict(best_index, left_norm, coords, std[, query_refined, ref_refined])."""
+    _require_cuda(ref, qry)
+    ref, qry = ref.contiguous(), qry.contiguous()
+    T, Vq, WW, C = qry.shape
+    dev = ref.device
+    tm = _as_u8(track_mask)
+    mv = _as_u8(movable)
+    best = torch.empty((T,), dtype=torch.int32, device=dev)
+    left_norm = torch.empty((T, 2), dtype=torch.float32, device=dev)
+    coords = torch.empty((T, Vq, 2), dtype=torch.float32, device=dev)
+    std = torch.empty((T, Vq), dtype=torch.float32, device=dev)
+    qref = torch.empty((T, 2), dtype=torch.float32, device=dev) if query_pts is not None else None
+    rref = torch.empty((T, Vq, 2), dtype=torch.float32, device=dev) if ref_pts is not None else None
+    rc = _lib.lib().dfsfm_fine_match_f32(_ptr(ref), _ptr(qry), _ptr(tm), _ptr(mv), T, Vq, W, left, C,
+                                         _ptr(query_pts), _ptr(scale_q), _ptr(ref_pts), _ptr(scale_r),
+                                         rs_t, rs_n, _ptr(best), _ptr(left_norm), _ptr(coords), _ptr(std),
+                                         _ptr(qref), _ptr(rref), _stream())
+    _lib.check(rc, "dfsfm_fine_match_f32")
+    out = {"best_index": best, "left_norm": left_norm, "coords": coords, "std": std}
+    if qref is not None:
+        out["query_refined"] = qref
+    if rref is not None:
+        out["ref_refined"] = rref
+    return out

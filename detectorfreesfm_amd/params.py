@@ -1,0 +1,170 @@
+"""Parameter layouts of the two hot-path models, identical (names, shapes) to the reference's
+``state_dict`` so real checkpoints load with ``strict=True``:
+
+* LoFTR (211 tensors): third_party/LoFTR/src/loftr/loftr.py:12-27 and its sub-modules; the
+  ``matcher.`` key prefix is stripped like loftr.py:83-87.
+* MultiviewMatcher (72 tensors): src/MultiviewMatcher/MultiviewMatcher.py:17-42; checkpoint
+  keys ``matcher.*`` -> strip, ``loftr_fine`` -> ``fine_transformer``, ``loftr_coarse`` dropped
+  (src/post_optimization/matcher_model/multiview_match_worker.py:40-53).
+
+Also: seeded synthetic weights (no checkpoints are available offline).  The distributions follow
+the reference's initialisers (kaiming_normal fan_out for ResNet convs, xavier_uniform for
+transformer matrices, torch defaults for VGG / adaptation convs) with randomised BatchNorm
+running statistics so that eval-mode BN is exercised.  The generator is deterministic for a
+given seed on any machine (torch CPU generator), so fixtures only need to store the seed.
+"""
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+Spec = List[Tuple[str, Tuple[int, ...], str]]   # (name, shape, kind)
+
+
+def _bn(spec: Spec, p: str, c: int):
+    spec += [(p + "weight", (c,), "bn_w"), (p + "bias", (c,), "bn_b"),
+             (p + "running_mean", (c,), "bn_mean"), (p + "running_var", (c,), "bn_var"),
+             (p + "num_batches_tracked", (), "counter")]
+
+
+def _encoder_layers(spec: Spec, p: str, n_layers: int, d: int):
+    for i in range(n_layers):
+        q = f"{p}layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "merge"):
+            spec.append((q + nm + ".weight", (d, d), "xavier"))
+        spec.append((q + "mlp.0.weight", (2 * d, 2 * d), "xavier"))
+        spec.append((q + "mlp.2.weight", (d, 2 * d), "xavier"))
+        for nm in ("norm1", "norm2"):
+            spec += [(q + nm + ".weight", (d,), "ones"), (q + nm + ".bias", (d,), "zeros")]
+
+
+def loftr_param_spec(cfg: dict) -> Spec:
+    s: Spec = []
+    d0 = cfg["resnetfpn"]["initial_dim"]
+    b1, b2, b3 = cfg["resnetfpn"]["block_dims"]
+    p = "backbone."
+    s.append((p + "conv1.weight", (d0, 1, 7, 7), "kaiming_out"))
+    _bn(s, p + "bn1.", d0)
+    cin = d0
+    for li, (dim, stride) in enumerate(((b1, 1), (b2, 2), (b3, 2)), start=1):
+        for bi in range(2):
+            q = f"{p}layer{li}.{bi}."
+            st = stride if bi == 0 else 1
+            s.append((q + "conv1.weight", (dim, cin, 3, 3), "kaiming_out"))
+            s.append((q + "conv2.weight", (dim, dim, 3, 3), "kaiming_out"))
+            _bn(s, q + "bn1.", dim)
+            _bn(s, q + "bn2.", dim)
+            if st != 1:
+                s.append((q + "downsample.0.weight", (dim, cin, 1, 1), "kaiming_out"))
+                _bn(s, q + "downsample.1.", dim)
+            cin = dim
+    s.append((p + "layer3_outconv.weight", (b3, b3, 1, 1), "kaiming_out"))
+    s.append((p + "layer2_outconv.weight", (b3, b2, 1, 1), "kaiming_out"))
+    s.append((p + "layer2_outconv2.0.weight", (b3, b3, 3, 3), "kaiming_out"))
+    _bn(s, p + "layer2_outconv2.1.", b3)
+    s.append((p + "layer2_outconv2.3.weight", (b2, b3, 3, 3), "kaiming_out"))
+    s.append((p + "layer1_outconv.weight", (b2, b1, 1, 1), "kaiming_out"))
+    s.append((p + "layer1_outconv2.0.weight", (b2, b2, 3, 3), "kaiming_out"))
+    _bn(s, p + "layer1_outconv2.1.", b2)
+    s.append((p + "layer1_outconv2.3.weight", (b1, b2, 3, 3), "kaiming_out"))
+    dc, df = cfg["coarse"]["d_model"], cfg["fine"]["d_model"]
+    _encoder_layers(s, "loftr_coarse.", len(cfg["coarse"]["layer_names"]), dc)
+    # fine-level modules: present in every LoFTR checkpoint, unused when fine.enable=False
+    s += [("fine_preprocess.down_proj.weight", (df, dc), "kaiming_out"),
+          ("fine_preprocess.down_proj.bias", (df,), "zeros"),
+          ("fine_preprocess.merge_feat.weight", (df, 2 * df), "kaiming_out"),
+          ("fine_preprocess.merge_feat.bias", (df,), "zeros")]
+    _encoder_layers(s, "loftr_fine.", len(cfg["fine"]["layer_names"]), df)
+    return s
+
+
+_VGG_CONVS = ((0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256))
+_ADAP_IN = (64, 256)   # channels of relu1_2 / relu3_3 (vgg16_layers, backbone/S2DNet/vggnet.py:12-44)
+
+
+def multiview_param_spec(cfg: dict) -> Spec:
+    s: Spec = []
+    od = cfg["backbone"]["s2dnet"]["output_dim"]
+    for idx, cin, cout in _VGG_CONVS:
+        s += [(f"backbone.encoder.{idx}.weight", (cout, cin, 3, 3), "torch_conv_w"),
+              (f"backbone.encoder.{idx}.bias", (cout,), "torch_conv_b:%d" % (cin * 9))]
+    for i in range(cfg["backbone"]["s2dnet"]["num_layers"]):
+        q = f"backbone.adaptation_layers.adap_layer_{i}."
+        s += [(q + "0.weight", (64, _ADAP_IN[i], 1, 1), "torch_conv_w"),
+              (q + "0.bias", (64,), "torch_conv_b:%d" % _ADAP_IN[i]),
+              (q + "2.weight", (od, 64, 5, 5), "torch_conv_w"),
+              (q + "2.bias", (od,), "torch_conv_b:%d" % (64 * 25))]
+        _bn(s, q + "3.", od)
+    mt = cfg["multiview_transform"]
+    _encoder_layers(s, "fine_transformer.", len(mt["layer_names"]) * mt["layer_iter_n"], mt["d_model"])
+    return s
+
+
+def random_state_dict(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape, kind in spec:
+        if kind == "kaiming_out":          # nn.init.kaiming_normal_(mode='fan_out', relu)
+            fan_out = shape[0] * (shape[2] * shape[3] if len(shape) == 4 else 1)
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
+        elif kind == "xavier":             # nn.init.xavier_uniform_
+            bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind == "torch_conv_w":       # kaiming_uniform_(a=sqrt(5)) -> U(-1/sqrt(fan_in), ..)
+            bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind.startswith("torch_conv_b"):
+            bound = 1.0 / math.sqrt(int(kind.split(":")[1]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind in ("ones",):
+            t = torch.ones(shape)
+        elif kind in ("zeros",):
+            t = torch.zeros(shape)
+        elif kind == "bn_w":
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif kind == "bn_b":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif kind == "bn_mean":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif kind == "bn_var":
+            t = torch.rand(shape, generator=g) + 0.5
+        elif kind == "counter":
+            t = torch.zeros((), dtype=torch.long)
+        else:
+            raise ValueError(kind)
+        sd[name] = t
+    return sd
+
+
+class ParamModule(nn.Module):
+    """nn.Module whose parameters/buffers carry the reference's dotted names.
+
+    ``register_spec`` builds the nested container modules so that ``state_dict()`` /
+    ``load_state_dict(strict=True)`` / ``.cuda()`` behave exactly like the reference model's.
+    ``p(name)`` fetches a tensor by its dotted name."""
+
+    def register_spec(self, spec: Spec):
+        self._names = []
+        for name, shape, kind in spec:
+            parts = name.split(".")
+            mod = self
+            for part in parts[:-1]:
+                if not hasattr(mod, part):
+                    mod.add_module(part, nn.Module())
+                mod = getattr(mod, part)
+            if kind in ("bn_mean", "bn_var", "counter"):
+                init = torch.zeros(shape, dtype=torch.long if kind == "counter" else torch.float32)
+                if kind == "bn_var":
+                    init = torch.ones(shape)
+                mod.register_buffer(parts[-1], init)
+            else:
+                init = torch.ones(shape) if kind in ("ones", "bn_w") else torch.zeros(shape)
+                mod.register_parameter(parts[-1], nn.Parameter(init, requires_grad=False))
+            self._names.append(name)
+
+    def p(self, name: str) -> torch.Tensor:
+        obj = self
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        return obj

@@ -1,0 +1,129 @@
+"""Reference-shaped plugin builders (same names, argument meaning and error behaviour).
+
+coarse   ``build_model(args) -> (detector, matcher)``, ``extract_preds``, ``extract_matches``
+         mirror src/coarse_match/coarse_match_worker.py:21-99; selected with the NEW matcher name
+         ``args['matcher'] == 'loftr_hip'`` (``neuralsfm.NEUSFM_coarse_matcher``), so the
+         reference's own 'loftr_official' / 'aspanformer' / 'matchformer' branches stay intact.
+refine   ``build_refine_model(args, rewindow_size_factor, model_idx) -> matcher`` and
+         ``extract_results`` mirror src/post_optimization/matcher_model/multiview_match_worker.py:16-82.
+
+INTEGRATION.md shows the few lines a maintainer adds to the reference to route to these.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .coarse import HipLoFTR
+from .config import loftr_coarse_only_config, multiview_refinement_config
+from .refine import HipMultiviewMatcher
+
+
+class DetectorWrapper(nn.Module):
+    """No-op 'OnGrid' detector (src/coarse_match/utils/detector_wrapper.py:4-22)."""
+
+    def __init__(self, detector=None, detector_type="OnGrid", fullcfg=None):
+        super().__init__()
+        if detector_type != "OnGrid" or detector is not None:
+            raise NotImplementedError(detector_type)
+        self.detector_type = detector_type
+
+    @torch.no_grad()
+    def forward(self, batch):
+        return None
+
+
+def build_model(args: dict):
+    """args: {'matcher': 'loftr_hip', 'type': 'coarse_only', 'match_thr': float, 'seed': int,
+    'loftr_hip': {'weight_path': path-or-None, 'cfg': optional lower-cased LoFTR config}}."""
+    if "seed" in args:
+        torch.manual_seed(args["seed"])
+    if args["matcher"] != "loftr_hip":
+        raise NotImplementedError(args["matcher"])
+    if args.get("type", "coarse_only") != "coarse_only":
+        raise NotImplementedError("loftr_hip provides the coarse_only matcher")
+    margs = args.get("loftr_hip", {})
+    cfg = margs.get("cfg") or loftr_coarse_only_config(args["match_thr"])
+    cfg["match_coarse"]["thr"] = args["match_thr"]
+    cfg["coarse"]["temp_bug_fix"] = False
+    matcher = HipLoFTR(config=cfg)
+    weight_path = margs.get("weight_path")
+    if weight_path is not None:
+        state_dict = torch.load(weight_path, map_location="cpu")["state_dict"]
+        matcher.load_state_dict(state_dict, strict=True)
+    detector = DetectorWrapper()
+    detector.eval()
+    matcher.eval()
+    return detector, matcher
+
+
+def extract_preds(data):
+    """extract predictions assuming bs==1 (coarse_match_worker.py:83-91)."""
+    m_bids = data["m_bids"].cpu().numpy()
+    assert (np.unique(m_bids) == 0).all()
+    return data["mkpts0_f"].cpu().numpy(), data["mkpts1_f"].cpu().numpy(), data["mconf"].cpu().numpy()
+
+
+@torch.no_grad()
+def extract_matches(data, detector=None, matcher=None):
+    detector(data)
+    matcher(data)
+    return extract_preds(data)
+
+
+def match_table(data):
+    """(M,5) rows [x0,y0,x1,y1,conf] as stored per pair (coarse_match_worker.py:139-141)."""
+    mk0, mk1, mc = extract_preds(data)
+    return np.concatenate([mk0, mk1, mc[:, None]], -1)
+
+
+def build_refine_model(args: dict, rewindow_size_factor=None, model_idx=None):
+    """args: {'cfg': optional model.multiview_refinement dict, 'weight_path': [path-or-None], 'seed': int}."""
+    if "seed" in args:
+        torch.manual_seed(args["seed"])
+    cfg = multiview_refinement_config() if args.get("cfg") is None else copy.deepcopy(args["cfg"])
+    if rewindow_size_factor is not None:     # window shrink per refinement iteration (:20-34)
+        w = max(7, ((cfg["multiview_transform"]["window_size"] // 2) - rewindow_size_factor) * 2 + 1)
+        cfg["backbone"]["s2dnet"]["window_size"] = w
+        cfg["multiview_transform"]["window_size"] = w
+        cfg["multiview_matching_test"]["window_size"] = w
+        lw = cfg["multiview_matching_test"]["left_point_movement_window_size"]
+        if lw is not None:
+            cfg["multiview_matching_test"]["left_point_movement_window_size"] = max(
+                3, ((lw // 2) - rewindow_size_factor) * 2 + 1)
+    matcher = HipMultiviewMatcher(config=cfg, test=True).eval()
+    paths = args.get("weight_path", [None])
+    model_path = paths[model_idx] if model_idx is not None else paths[0]
+    if model_path is not None:
+        state_dict = torch.load(model_path, map_location="cpu")["state_dict"]
+        for k in list(state_dict.keys()):          # multiview_match_worker.py:42-52
+            if "matcher." in k:
+                state_dict[k.replace("matcher.", "")] = state_dict.pop(k)
+            else:
+                state_dict.pop(k)
+        for k in list(state_dict.keys()):
+            if "loftr_coarse" in k:
+                state_dict.pop(k)
+            if "loftr_fine" in k:
+                state_dict[k.replace("loftr_fine", "fine_transformer")] = state_dict.pop(k)
+        matcher.load_state_dict(state_dict, strict=True)
+    return matcher
+
+
+@torch.no_grad()
+def extract_results(data, matcher=None):
+    """multiview_match_worker.py:59-82."""
+    matcher(data)
+    reference_points_refined = data["query_points_refined"].cpu().numpy()
+    reference_img_ids = data["query_img_ids"].cpu().numpy()
+    reference_pt2D_idxs = data["query_pt2d_idxs"].cpu().numpy()
+    ref_movable_mask = data["query_movable_mask"].cpu().numpy()
+    query_points_refined = data["reference_points_refined"][-1].cpu().numpy()
+    query_img_ids = data["reference_img_ids"].cpu().numpy()
+    query_pt2D_idxs = data["reference_pt2d_idxs"].cpu().numpy()
+    mask = data["track_valid_mask"].cpu().numpy()
+    assert query_points_refined.shape[0] == 1
+    return ([query_points_refined[mask], query_img_ids[mask], query_pt2D_idxs[mask]],
+            [reference_points_refined[ref_movable_mask], reference_img_ids[ref_movable_mask],
+             reference_pt2D_idxs[ref_movable_mask]], data.get("time"))

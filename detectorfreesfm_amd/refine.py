@@ -1,0 +1,241 @@
+"""MI355X multiview refinement head behind the reference's ``refinement_models`` /
+``MultiviewMatcher`` plugin surface.
+
+``HipMultiviewMatcher`` is a drop-in for ``MultiviewMatcher(config, test=True).eval()``
+(src/MultiviewMatcher/MultiviewMatcher.py:17-405) as built by
+src/post_optimization/matcher_model/multiview_match_worker.py:16-56: same config dict
+(``model.multiview_refinement``), same 72-tensor ``state_dict`` layout (``backbone.*``,
+``fine_transformer.*``), same in-place ``forward(data)`` contract (``query_points_refined``,
+``reference_points_refined``, ``std`` -- read by ``extract_results`` :59-82).
+
+Hand-written HIP: RoIAlign patch extraction (K8, with the ImageNet normalisation fused),
+linear attention (K1, D=16) in the four multiview encoder layers (K10), and the fused fine
+correlation / softmax expectation / candidate argmin / refined keypoints (K11+K12).  The S2DNet
+patch CNN (K9) and the nn.Linear GEMMs run on MIOpen / hipBLASLt through PyTorch-ROCm in fp32.
+
+Output-identical work the reference wastes is skipped ("dead work"):
+* only the centre (W+4)^2 of relu1_2 feeds adaptation layer 0 (the reference convolves the full
+  35x35 map and crops to WxW afterwards, s2dnet.py:164-193);
+* the bicubic align_corners upsample of adaptation layer 1 is evaluated only at the WxW centre,
+  as two small matmuls with PyTorch's own interpolation coefficients;
+* padded view slots (image index -1) are never cropped or convolved: they are masked everywhere
+  downstream, the reference feeds them a copy of the last patch (MultiviewMatcher.py:253-266).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .coarse import EncoderLayerWeights, encoder_layer, _fold_bn
+from .params import ParamModule, multiview_param_spec
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # S2DNet.mean / .std, backbone/S2DNet/s2dnet.py:66-67
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _bicubic_rows(n_in: int, n_out: int, lo: int, hi: int) -> torch.Tensor:
+    """Rows [lo,hi) of the (n_out x n_in) matrix of nn.Upsample(mode='bicubic', align_corners=True)
+    along one axis, obtained from PyTorch's own kernel applied to the identity."""
+    eye = torch.eye(n_in, dtype=torch.float32).view(1, n_in, n_in, 1)          # [1, k, in, 1]
+    up = F.interpolate(eye, size=(n_out, 1), mode="bicubic", align_corners=True)  # [1, k, out, 1]
+    return up[0, :, lo:hi, 0].t().contiguous()                                    # [hi-lo, k]
+
+
+class HipMultiviewMatcher(ParamModule):
+    def __init__(self, config: dict, test: bool = True, max_backbone_patches: int = 16384, **_unused):
+        super().__init__()
+        if not test:
+            raise NotImplementedError("training path is out of scope; build with test=True")
+        bb = config["backbone"]
+        s2d = bb["s2dnet"]
+        mt = config["multiview_transform"]
+        ok = (bb["type"] == "S2DNet" and s2d["num_layers"] == 2 and s2d["combine"] and
+              s2d["substitute_pooling_layers"] and s2d["zoomin_strategy"] == "post" and
+              config["n_matching_steps"] == 1 and not config["enable_multiview_scale_align"] and
+              mt["sparse"] and not mt["enable_rescaled_crop"] and mt["attention"] == "linear" and
+              mt["attention_type"] == "multiview" and mt["norm_method"] == "layernorm" and
+              mt["rezero"] is None and not mt["final_proj"] and mt["type"] == "LoFTR")
+        if not ok:
+            raise NotImplementedError("HipMultiviewMatcher implements the shipped refinement configuration "
+                                      "(hydra_training_configs/experiment/multiview_refinement_matching.yaml)")
+        self.config = config
+        self.max_backbone_patches = max_backbone_patches
+        self.register_spec(multiview_param_spec(config))
+        self.register_buffer("_mean", torch.tensor(IMAGENET_MEAN), persistent=False)
+        self.register_buffer("_std", torch.tensor(IMAGENET_STD), persistent=False)
+        self._packed = None
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        self._packed = None
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+    def _apply(self, fn, *a, **kw):
+        self._packed = None
+        return super()._apply(fn, *a, **kw)
+
+    # -- weight packing -----------------------------------------------------------------------
+    def _pack(self):
+        g = self.p
+        P = {"enc": {i: (g(f"backbone.encoder.{i}.weight"), g(f"backbone.encoder.{i}.bias"))
+                     for i in (0, 2, 5, 7, 10, 12, 14)}}
+        for i in (0, 1):
+            q = f"backbone.adaptation_layers.adap_layer_{i}."
+            w5, b5 = g(q + "2.weight"), g(q + "2.bias")
+            s = g(q + "3.weight") / torch.sqrt(g(q + "3.running_var") + 1e-5)
+            # conv(+bias) -> eval BN folded: w*s, (b - mean)*s + beta
+            P[f"adap{i}"] = (g(q + "0.weight"), g(q + "0.bias"), (w5 * s[:, None, None, None]).contiguous(),
+                             ((b5 - g(q + "3.running_mean")) * s + g(q + "3.bias")).contiguous())
+        mt = self.config["multiview_transform"]
+        n_layers = len(mt["layer_names"]) * mt["layer_iter_n"]
+        P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.") for i in range(n_layers)]
+        self._packed = P
+        return P
+
+    # -- K9: S2DNet._forward on normalised patches (s2dnet.py:127-193) ----------------------------
+    def _s2dnet(self, x, P, W):
+        crop = x.shape[-1]
+
+        def conv(i, t):
+            return F.relu_(F.conv2d(t, P["enc"][i][0], P["enc"][i][1], 1, 1))
+        x = conv(2, conv(0, x))
+        c, r = crop // 2, W // 2
+        f0 = x[..., c - r - 2:c + r + 3, c - r - 2:c + r + 3]      # centre (W+4)^2 of relu1_2
+        x = F.max_pool2d(x, 3, 2, 1)
+        x = conv(7, conv(5, x))
+        x = F.max_pool2d(x, 3, 2, 1)
+        f1 = conv(14, conv(12, conv(10, x)))                        # relu3_3, 1/4 resolution
+
+        a0 = P["adap0"]
+        y0 = F.conv2d(F.relu_(F.conv2d(f0, a0[0], a0[1])), a0[2], a0[3], 1, 0)      # [M,od,W,W]
+        a1 = P["adap1"]
+        y1 = F.conv2d(F.relu_(F.conv2d(f1, a1[0], a1[1])), a1[2], a1[3], 1, 2)      # [M,od,h4,w4]
+        key = (y1.shape[-1], crop, W)
+        if P.get("bicubic_key") != key:
+            B = _bicubic_rows(y1.shape[-1], crop, c - r, c + r + 1)
+            P["bicubic"] = torch.kron(B, B).contiguous().to(y1.device)   # separable -> one [WW, h4*w4] map
+            P["bicubic_key"] = key
+        K = P["bicubic"]                                             # [W*W, h4*w4]
+        up = torch.matmul(y1.flatten(2), K.t()).view(y0.shape)      # one GEMM for the whole batch
+        return y0 + up
+
+    @torch.no_grad()
+    def forward(self, data: dict, chunk_track: int = 1000, chunk_backbone_img: bool = True):
+        """Updates ``data`` in place like MultiviewMatcher.forward(test) (MultiviewMatcher.py:59-405)."""
+        P = self._packed or self._pack()
+        cfg = self.config
+        mt = cfg["multiview_transform"]
+        W, crop = mt["window_size"], mt["crop_size"]
+        left = cfg["multiview_matching_test"]["left_point_movement_window_size"]
+        if left is None:
+            raise NotImplementedError("left_point_movement_window_size=None (training config)")
+        WW = W * W
+        C = mt["d_model"]
+        images = data["images"]
+        if isinstance(images, torch.Tensor):
+            images = [images[:, i] for i in range(images.shape[1])]
+        n_img = len(images)
+        dev = images[0].device
+        if images[0].shape[0] != 1:
+            raise NotImplementedError("batch size 1 only (as the reference, fine_preprocess.py:40)")
+        data["W"] = W
+
+        fine_res = float(cfg["backbone"]["resolution"][-1])
+        scales = torch.full((1, n_img, 2), fine_res, device=dev)
+        if "scales" in data:
+            scales = scales * data["scales"][:, :, [1, 0]]
+        ref_coarse = data["reference_points_coarse"].contiguous()                     # [1,V-1,T,2]
+        pts = torch.cat([data["query_points"][:, None], ref_coarse], dim=1)          # [1,V,T,2]
+        img_idxs = torch.cat([data["query_img_idxs"][:, None], data["reference_img_idxs"]], dim=1)
+        _, V, T = img_idxs.shape
+        pt_scales = scales.view(-1, 2)[img_idxs.view(-1)].view(1, V, T, 2).contiguous()   # -1 -> last image (:103)
+        pts = pts / pt_scales
+
+        # ---- view-count grouping (MultiviewMatcher.py:117-133); one host sync ---------------------
+        tvm = data["track_valid_mask"]                                                 # [1,V-1,T]
+        keys, counts = torch.unique(tvm.sum(-2).max(0)[0], sorted=True, return_counts=True)
+        keys, counts = keys.flip(0).tolist(), counts.flip(0).tolist()
+        max_view_tracks = 16 * chunk_track
+        groups, i = [], 0
+        while i < len(keys):
+            vv = int(keys[i]) + 1
+            if vv * counts[i] <= max_view_tracks:
+                groups.append((vv, counts[i]))
+                i += 1
+            else:
+                groups.append((vv, max_view_tracks // vv))
+                counts[i] -= max_view_tracks // vv
+
+        # ---- K8 crop + K9 backbone, valid view slots only; features land in [T,V,WW,C] -------------
+        flat_idx = img_idxs.reshape(-1)                                                # (v t) order
+        flat_pts = pts.reshape(-1, 2)
+        order = torch.argsort(flat_idx, stable=True)
+        per_img = torch.bincount(flat_idx.clamp(min=-1) + 1, minlength=n_img + 1).tolist()   # one sync
+        n_pad, per_img = per_img[0], per_img[1:]
+        order = order[n_pad:]
+        M = order.numel()
+        r = crop // 2
+        boxes = torch.cat([flat_pts - r, flat_pts + r], dim=-1)[order].contiguous()     # fine_preprocess.py:101-104
+        slot = (order % T) * V + order // T                                            # (v t) -> (t v)
+        feats = torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
+        patches = torch.empty((M, 3, crop, crop), dtype=torch.float32, device=dev)
+        start = 0
+        for ii in range(n_img):
+            n = per_img[ii]
+            if n == 0:
+                continue
+            ops.roi_align(images[ii], boxes[start:start + n], crop, crop, mean=self._mean, std=self._std,
+                          out=patches[start:start + n])
+            start += n
+        for s in range(0, M, self.max_backbone_patches):
+            e = min(M, s + self.max_backbone_patches)
+            f = self._s2dnet(patches[s:e], P, W)                                        # [m,C,W,W]
+            feats.index_copy_(0, slot[s:e], f.flatten(2).transpose(1, 2))
+        del patches
+        feats = feats.view(T, V, WW, C)
+
+        # ---- K10 transformer + K11/K12 fine matching per view-count group ---------------------------
+        movable = data["query_movable_mask"][0].contiguous() if "query_movable_mask" in data else None
+        qpts = data["query_points"][0].contiguous()                                    # original scale
+        tmask = tvm[0].transpose(0, 1).contiguous()                                    # [T,V-1]
+        q_out = torch.empty((T, 2), dtype=torch.float32, device=dev)
+        r_out = torch.zeros((1, V - 1, T, 2), dtype=torch.float32, device=dev)
+        s_out = torch.zeros((1, V - 1, T), dtype=torch.float32, device=dev)
+        names = list(mt["layer_names"]) * mt["layer_iter_n"]
+        nhead = mt["nhead"]
+        i = 0
+        for cv, nt in groups:
+            sl = slice(i, i + nt)
+            Vq = cv - 1
+            if Vq == 0:      # tracks without any valid reference view: nothing to refine
+                q_out[sl] = qpts[sl]
+                i += nt
+                continue
+            ref = feats[sl, 0].contiguous()                                            # [nt,WW,C]
+            qry = feats[sl, 1:cv].reshape(nt, Vq * WW, C)
+            qm = tmask[sl, :Vq].contiguous()
+            if mt["enable"]:
+                for w, name in zip(P["layers"], names):   # matcher_module/transformer.py:158-172
+                    if name == "self":
+                        ref, qry = (encoder_layer(w, ref, ref, nhead, is_self=True),
+                                    encoder_layer(w, qry, qry, nhead, qm, qm, WW, WW, is_self=True))
+                    elif name == "cross":                 # both sides from the PRE-update tensors
+                        qry, ref = (encoder_layer(w, qry, ref, nhead, qm, None, WW, 1),
+                                    encoder_layer(w, ref, qry, nhead, None, qm, 1, WW))
+                    else:
+                        raise NotImplementedError(name)
+            m = ops.fine_match(ref, qry.view(nt, Vq, WW, C), qm, None if movable is None else movable[sl],
+                               W, left, qpts[sl], pt_scales[0, 0, sl], ref_coarse[0, :, i:],
+                               pt_scales[0, 1:, i:], 1, T)
+            q_out[sl] = m["query_refined"]
+            r_out[0, :Vq, sl] = m["ref_refined"].transpose(0, 1)
+            s_out[0, :Vq, sl] = m["std"].transpose(0, 1)
+            i += nt
+
+        data["query_points_refined"] = q_out[None]
+        data["fine_local_heatmap_pred"] = None     # the heat-map is never materialised
+        if "reference_points_refined" in data:
+            data["reference_points_refined"].append(r_out)
+            data["std"].append(s_out)
+        else:
+            data["reference_points_refined"] = [r_out]
+            data["std"] = [s_out]
+        return None

@@ -1,0 +1,75 @@
+"""Seeded synthetic inputs for the two hot-path halves.
+
+No datasets or checkpoints are reachable offline, so benchmarks and parity tests use synthetic
+frames of the reference's shapes and seeded random weights (``params.random_state_dict``).
+Everything is generated on the CPU with explicit generators -> identical on every machine.
+"""
+import torch
+
+
+def coarse_pair_batch(n_pairs: int, H: int = 480, W: int = 640, seed: int = 1000, shift=(1, 2)):
+    """Config 2 input: image0 ~ U[0,1); image1 = image0 rolled by (8*dy, 8*dx) px + 0.02 N(0,1).
+    Returns the plugin's ``data`` dict (image0/1 [N,1,H,W], scale0/1 [N,2])."""
+    im0, im1 = [], []
+    for p in range(n_pairs):
+        g = torch.Generator().manual_seed(seed + p)
+        a = torch.rand((1, 1, H, W), generator=g)
+        b = torch.roll(a, shifts=(8 * shift[0], 8 * shift[1]), dims=(2, 3)) + 0.02 * torch.randn((1, 1, H, W), generator=g)
+        im0.append(a)
+        im1.append(b)
+    return {"image0": torch.cat(im0), "image1": torch.cat(im1),
+            "scale0": torch.ones(n_pairs, 2), "scale1": torch.ones(n_pairs, 2)}
+
+
+def correlated_features(N: int, L: int, S: int, C: int = 256, seed: int = 7, noise: float = 0.1):
+    """Kernel-level K3/K4 input: f0 ~ N(0,1), f1 = f0[perm] + noise*N(0,1) (random weights give
+    ~0 matches at thr 0.2, so matching tests feed correlated features directly)."""
+    g = torch.Generator().manual_seed(seed)
+    f0 = torch.randn((N, L, C), generator=g)
+    f1 = torch.empty((N, S, C))
+    for n in range(N):
+        perm = torch.randperm(max(L, S), generator=g)[:S] % L
+        f1[n] = f0[n, perm] + noise * torch.randn((S, C), generator=g)
+    return f0, f1
+
+
+def refine_bag(T: int = 2000, V: int = 5, H: int = 480, W: int = 640, seed: int = 2000,
+               variable_lengths: bool = False, scales=None):
+    """Config 3 input: V RGB images U[0,1), T tracks; query ~ U([30,W-30]x[30,H-30]),
+    reference = query + N(0, 2 px); view v of every track lives in image v.
+    ``variable_lengths`` draws track lengths from {2..V} (sorted descending, padded with -1)."""
+    g = torch.Generator().manual_seed(seed)
+    images = [torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(seed + v)) for v in range(V)]
+    q = torch.stack([torch.rand(T, generator=g) * (W - 60) + 30, torch.rand(T, generator=g) * (H - 60) + 30], -1)
+    ref = q[None] + 2.0 * torch.randn((V - 1, T, 2), generator=g)
+    if variable_lengths:
+        lens = torch.randint(2, V + 1, (T,), generator=g).sort(descending=True)[0]
+    else:
+        lens = torch.full((T,), V)
+    valid = torch.arange(1, V)[:, None] < lens[None]                                  # [V-1,T]
+    ref_idx = torch.where(valid, torch.arange(1, V)[:, None].expand(V - 1, T), torch.full((V - 1, T), -1))
+    data = {
+        "images": images,
+        "scales": (torch.ones(1, V, 2) if scales is None else scales),
+        "query_points": q[None].float(),
+        "reference_points_coarse": ref[None].float(),
+        "query_img_idxs": torch.zeros(1, T, dtype=torch.long),
+        "reference_img_idxs": ref_idx[None],
+        "track_valid_mask": valid[None],
+        "scales_relative": torch.ones(1, V, T),
+        "view_point_vector": torch.zeros(1, V, T, 3),
+        "query_movable_mask": torch.ones(1, T, dtype=torch.bool),
+    }
+    return data
+
+
+def to_device(data: dict, device):
+    out = {}
+    for k, v in data.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(device)
+        elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+            out[k] = [t.to(device) for t in v]
+        else:
+            out[k] = v
+    return out

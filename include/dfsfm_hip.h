@@ -1,0 +1,137 @@
+/*
+ * dfsfm_hip.h -- C ABI of libdfsfm_hip.so: the MI355X (gfx950) hot kernels of the
+ * DetectorFreeSfM dense-matching path.
+ *
+ * The reference (zju3dv/DetectorFreeSfM) has no FFI of its own for this path: the boundary is
+ * a duck-typed Python nn.Module contract.  This library sits UNDER that
+ * contract: `detectorfreesfm_amd` keeps the reference's Python plugin surface and calls these
+ * entry points through ctypes on raw device pointers.  Every entry point cites the reference
+ * code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`
+ *   - all tensors are dense row-major fp32 unless stated; indices are int64 like torch's
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); every call is
+ *     asynchronous on that stream and re-entrant across streams (no global state, no
+ *     allocation: scratch comes from the caller through `workspace`)
+ *   - return value: 0 on success, a negative DFSFM_E_* code otherwise; nothing is launched
+ *     when an argument check fails
+ */
+#ifndef DFSFM_HIP_H
+#define DFSFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFSFM_OK 0
+#define DFSFM_E_BADARG (-1)      /* null pointer / non-positive size                       */
+#define DFSFM_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for           */
+#define DFSFM_E_WORKSPACE (-3)   /* workspace too small (query the *_workspace function)   */
+#define DFSFM_E_LAUNCH (-4)      /* hipLaunch / runtime error; see dfsfm_last_error_string */
+
+/* Library / device introspection. */
+int dfsfm_version(void);                    /* ABI version, currently 1 */
+const char* dfsfm_last_error_string(void);  /* thread-local text for the last DFSFM_E_LAUNCH */
+
+/* ------------------------------------------------------------------------------------------
+ * K1  Linear attention  phi(Q) (phi(K)^T V)
+ * Replaces LinearAttention.forward
+ *   third_party/LoFTR/src/loftr/loftr_module/linear_attention.py:20-47   (coarse, H=8, D=32)
+ *   src/MultiviewMatcher/matcher_module/linear_attention.py:28-60        (refine, H=8, D=16)
+ * out[n,l,h,:] = (Q[n,l,h,:] . KV[n,h]) * Z[n,l,h] * S,  Q=elu(q)+1, K=elu(k)+1,
+ * KV[n,h]=sum_s K[n,s,h,:]^T (v[n,s,h,:]/S),  Z = 1/(Q . sum_s K + eps); masks multiply Q, K, v.
+ *
+ * q [N,L,H*D] with row stride ldq floats (>= H*D), k/v [N,S,H*D] with row strides ldk/ldv,
+ * out [N,L,H*D] with row stride ldo; batch strides are L*ldq, S*ldk, S*ldv, L*ldo.
+ * q_mask [N, L/q_group], kv_mask [N, S/kv_group] are uint8 (0/1) or NULL; a mask entry covers
+ * `group` consecutive tokens (the refinement head repeats a per-view mask over W*W tokens,
+ * matcher_module/transformer.py:151).  D must be 16 or 32.
+ * ---------------------------------------------------------------------------------------- */
+size_t dfsfm_linear_attention_workspace(int N, int S, int H, int D);
+int dfsfm_linear_attention_f32(const float* q, const float* k, const float* v,
+                               const uint8_t* q_mask, int q_group,
+                               const uint8_t* kv_mask, int kv_group,
+                               float* out, int N, int L, int S, int H, int D,
+                               int ldq, int ldk, int ldv, int ldo, float eps,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3+K4+K5  Coarse correlation + dual-softmax + mutual-NN selection + keypoint epilogue
+ * Replaces CoarseMatching.forward / get_coarse_match (eval, dual_softmax, no padding masks)
+ *   third_party/LoFTR/src/loftr/utils/coarse_matching.py:84-145, 148-258, mask_border :8-22
+ * feat0 [N,L,C], feat1 [N,S,C] (L=h0c*w0c, S=h1c*w1c); the L x S matrices are never written.
+ * A match (b,i,j) is kept iff conf>thr, conf is the max of its row AND of its column, and
+ * neither cell lies in the first `border` rows/cols of its grid (the reference's high-side
+ * slices are empty, coarse_matching.py:19-22 -- reproduced).  Output rows are in ascending
+ * (b,i) order like torch.where.
+ *   mkpts0[m] = (i % w0c, i / w0c) * (coarse_scale * scale0[b][{1,0}])   (:239-247)
+ * scale0/scale1 [N,2] = (h_scale, w_scale) or NULL (treated as 1).
+ * Outputs must hold N*L rows; *count (device int32) receives M.
+ * ---------------------------------------------------------------------------------------- */
+size_t dfsfm_coarse_match_workspace(int N, int L, int S);
+int dfsfm_coarse_match_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,
+                           float temperature, float thr, int border,
+                           int h0c, int w0c, int h1c, int w1c,
+                           const float* scale0, const float* scale1, float coarse_scale,
+                           int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                           float* mkpts0, float* mkpts1, int32_t* count,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Dense confidence matrix conf[N,L,S] = softmax(sim,1)*softmax(sim,2) (coarse_matching.py:103-116).
+ * Debug / parity aid only ("conf_matrix" is stored by the reference but no inference caller
+ * reads it, src/coarse_match/coarse_match_worker.py:83-91). Same workspace as above. */
+int dfsfm_coarse_conf_matrix_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,
+                                 float temperature, float* conf,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8  RoIAlign patch extraction (TensorFlow crop_and_resize semantics, extrapolation value)
+ * Replaces roi_align.RoIAlign(crop, crop, transform_fpcoor=False) as called from
+ *   src/MultiviewMatcher/matcher_module/fine_preprocess.py:92-106 (un-vendored
+ *   third_party/RoIAlign.pytorch; semantics in oracle/restate.py:roi_align_crop)
+ * feat [Nimg,C,H,W]; boxes [M,4]=(x1,y1,x2,y2) pixels; box_ind [M] int32 or NULL (=0).
+ * out_slot [M] int64 or NULL: patch m is written to out[out_slot[m]] (lets the caller scatter
+ * one image's patches straight into (view,track) order, MultiviewMatcher.py:253-266).
+ * mean/std [C] or NULL: when given, (value-mean[c])/std[c] is applied to every output
+ * (fuses the ImageNet normalisation of S2DNet._forward, backbone/S2DNet/s2dnet.py:132-133).
+ * out [*,C,crop_h,crop_w].
+ * ---------------------------------------------------------------------------------------- */
+int dfsfm_roi_align_f32(const float* feat, int Nimg, int C, int H, int W,
+                        const float* boxes, const int32_t* box_ind, const int64_t* out_slot, int M,
+                        int crop_h, int crop_w, float extrapolation_value,
+                        const float* mean, const float* std, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11+K12  Fine-window correlation, softmax expectation, best-candidate selection, keypoints
+ * Replaces FineMatching.forward (test config: s2d heatmap + argsoftmax,
+ * left_point_movement, best_left_strategy='smallest_mean_std')
+ *   src/MultiviewMatcher/utils/fine_matching.py:36-98, 100-119, 129-179, 195-252, 258-285
+ * ref [T,W*W,C], qry [T,Vq,W*W,C]; track_mask [T,Vq] uint8; movable [T] uint8 or NULL (=1).
+ * For every track: the centre left x left window of `ref` gives L candidates; for each
+ * candidate and view: heat = softmax_r(<ref_l, qry_r>/sqrt(C)); (ex,ey)=E[grid], std =
+ * sqrt(max(var_x,1e-10))+sqrt(max(var_y,1e-10)); score_l = masked mean over views of std;
+ * best = argmin_l (first minimum), or the centre candidate when not movable.
+ * Outputs (any may be NULL):
+ *   best_index [T] int32, left_norm [T,2], coords [T,Vq,2], std [T,Vq]
+ *   query_refined [T,2]   = query_pts[t]  + left_norm * (left/2) * scale_q[t]
+ *   ref_refined [T,Vq,2]  = ref_pts[t,n]  + coords    * (W/2)    * scale_r[t,n]
+ * query_pts [T,2], scale_q [T,2], ref_pts / scale_r addressed as base[(t*rs_t + n*rs_n)*2]
+ * so the caller can pass the reference's [V-1,T,2] tensors without a transpose
+ * (rs_t=1, rs_n=T) or a [T,Vq,2] tensor (rs_t=Vq, rs_n=1).  C must be a multiple of 4,
+ * W*W <= 256, left <= W, left*left <= 64.
+ * ---------------------------------------------------------------------------------------- */
+int dfsfm_fine_match_f32(const float* ref, const float* qry, const uint8_t* track_mask,
+                         const uint8_t* movable, int T, int Vq, int W, int left, int C,
+                         const float* query_pts, const float* scale_q,
+                         const float* ref_pts, const float* scale_r, int64_t rs_t, int64_t rs_n,
+                         int32_t* best_index, float* left_norm, float* coords, float* std,
+                         float* query_refined, float* ref_refined, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFSFM_HIP_H */

@@ -1,0 +1,150 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the REAL reference.
+
+Run in the build container (needs /root/reference):  ``python -m oracle.make_golden``
+
+The reference ships no golden vectors for this path, so the fixtures are
+outputs of the reference's own Python modules (imported unchanged through oracle/ref_import.py)
+on seeded inputs.  Inputs/weights are regenerated from seeds by ``detectorfreesfm_amd.synth`` /
+``params.random_state_dict`` (deterministic torch CPU generators), so the fixtures stay small.
+The ``roi_align`` stage inside the refinement fixture is the restated stand-in (parity unpinned
+for that stage; see oracle/restate.py header).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from detectorfreesfm_amd import synth  # noqa: E402
+from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config  # noqa: E402
+from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# Case parameters are shared with the tests through these dicts (stored inside the npz too).
+CASES = {
+    "linear_attention": dict(seed=11, N=2, L=70, S=90, H=8, D=32),
+    "linear_attention_d16": dict(seed=12, N=3, L=45, S=225, H=8, D=16, kv_group=45),
+    "coarse_matching": dict(seed=7, N=2, h0=12, w0=20, h1=15, w1=16, C=256, noise=0.1, thr=0.2, border=2),
+    "fine_matching": dict(seed=21, T=6, Vq=3, W=15, left=7, C=128),
+    "loftr_e2e": dict(weight_seed=0, data_seed=1000, n_pairs=1, H=96, W=128, thr=1e-3),
+    "multiview_e2e": dict(weight_seed=1, data_seed=2000, T=40, V=4, H=120, W=160),
+}
+
+
+def la_inputs(c):
+    g = torch.Generator().manual_seed(c["seed"])
+    q = torch.randn((c["N"], c["L"], c["H"], c["D"]), generator=g)
+    k = torch.randn((c["N"], c["S"], c["H"], c["D"]), generator=g)
+    v = torch.randn((c["N"], c["S"], c["H"], c["D"]), generator=g)
+    grp = c.get("kv_group", 1)
+    kv_mask = torch.rand((c["N"], c["S"] // grp), generator=g) > 0.3
+    q_mask = torch.rand((c["N"], c["L"]), generator=g) > 0.2
+    return q, k, v, q_mask, kv_mask
+
+
+def fine_inputs(c):
+    g = torch.Generator().manual_seed(c["seed"])
+    ref = torch.randn((c["T"], c["W"] ** 2, c["C"]), generator=g)
+    qry = ref[:, None] * 0.5 + torch.randn((c["T"], c["Vq"], c["W"] ** 2, c["C"]), generator=g)
+    mask = torch.rand((c["T"], c["Vq"]), generator=g) > 0.25
+    mask[:, 0] = True
+    movable = torch.rand((c["T"],), generator=g) > 0.3
+    return ref, qry, mask, movable
+
+
+def main():
+    assert ref_import.reference_available(), "needs /root/reference"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    LoFTR, _ = ref_import.import_loftr()
+    from third_party.LoFTR.src.loftr.loftr_module.linear_attention import LinearAttention
+    from third_party.LoFTR.src.loftr.utils.coarse_matching import CoarseMatching
+    MultiviewMatcher = ref_import.import_multiview_matcher()
+    from src.MultiviewMatcher.matcher_module.linear_attention import LinearAttention as LinearAttentionMV
+    from src.MultiviewMatcher.utils.fine_matching import FineMatching
+
+    with torch.no_grad():
+        # K1, coarse flavour (D=32), full masks
+        c = CASES["linear_attention"]
+        q, k, v, qm, km = la_inputs(c)
+        out = LinearAttention()(q, k, v, qm, km)
+        out_nomask = LinearAttention()(q, k, v)
+        np.savez(os.path.join(OUT, "linear_attention.npz"), out=out.numpy(), out_nomask=out_nomask.numpy(), **c)
+
+        # K1, refinement flavour (D=16), per-view kv mask repeated over tokens
+        c = CASES["linear_attention_d16"]
+        q, k, v, qm, km = la_inputs(c)
+        km_full = km.repeat_interleave(c["kv_group"], dim=1)
+        out = LinearAttentionMV(c["D"], kernel_fn="elu + 1")(q, k, v, None, km_full)
+        np.savez(os.path.join(OUT, "linear_attention_d16.npz"), out=out.numpy(), **c)
+
+        # K3+K4+K5: CoarseMatching on correlated features
+        c = CASES["coarse_matching"]
+        f0, f1 = synth.correlated_features(c["N"], c["h0"] * c["w0"], c["h1"] * c["w1"], c["C"], c["seed"], c["noise"])
+        mcfg = loftr_coarse_only_config(c["thr"])["match_coarse"]
+        mcfg["border_rm"] = c["border"]
+        cm = CoarseMatching(mcfg).eval()
+        scale0 = torch.tensor([[1.5, 2.0], [1.0, 0.75]])
+        scale1 = torch.tensor([[1.0, 1.25], [2.0, 1.0]])
+        data = {"hw0_i": (c["h0"] * 8, c["w0"] * 8), "hw1_i": (c["h1"] * 8, c["w1"] * 8),
+                "hw0_c": (c["h0"], c["w0"]), "hw1_c": (c["h1"], c["w1"]), "scale0": scale0, "scale1": scale1}
+        cm(f0, f1, data)
+        np.savez(os.path.join(OUT, "coarse_matching.npz"), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(),
+                 j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_c=data["mkpts0_c"].numpy(),
+                 mkpts1_c=data["mkpts1_c"].numpy(), conf_rowmax=data["conf_matrix"].max(2)[0].numpy(),
+                 conf_colmax=data["conf_matrix"].max(1)[0].numpy(), scale0=scale0.numpy(), scale1=scale1.numpy(), **c)
+
+        # K11+K12: FineMatching (test config)
+        c = CASES["fine_matching"]
+        ref, qry, mask, movable = fine_inputs(c)
+        rcfg = multiview_refinement_config()
+        fm = FineMatching(rcfg["multiview_matching_test"]).eval()
+        T, Vq = c["T"], c["Vq"]
+        g = torch.Generator().manual_seed(c["seed"] + 1)
+        qpts = torch.rand((1, T, 2), generator=g) * 100
+        rpts = torch.rand((1, T, Vq, 2), generator=g) * 100
+        sq = torch.rand((1, T, 2), generator=g) + 0.5
+        sr = torch.rand((1, Vq, T, 2), generator=g) + 0.5
+        d = {"W": c["W"], "scales_origin_to_fine_query": sq, "scales_origin_to_fine_reference": sr}
+        qr, rr, std, _ = fm(ref[None], qry[None], qpts, rpts, d, track_mask=mask[None], query_movable_mask=movable[None])
+        np.savez(os.path.join(OUT, "fine_matching.npz"), query_refined=qr.numpy(), ref_refined=rr.numpy(),
+                 std=std.numpy(), qpts=qpts.numpy(), rpts=rpts.numpy(), sq=sq.numpy(), sr=sr.numpy(), **c)
+
+        # coarse end-to-end: the real LoFTR module with seeded weights
+        c = CASES["loftr_e2e"]
+        cfg = loftr_coarse_only_config(c["thr"])
+        sd = random_state_dict(loftr_param_spec(cfg), c["weight_seed"])
+        m = LoFTR(cfg).eval()
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+        data["scale0"] = torch.tensor([[1.5, 2.0]])
+        data["scale1"] = torch.tensor([[1.0, 1.25]])
+        m(data)
+        np.savez(os.path.join(OUT, "loftr_e2e.npz"), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(),
+                 j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_f=data["mkpts0_f"].numpy(),
+                 mkpts1_f=data["mkpts1_f"].numpy(), conf_rowmax=data["conf_matrix"].max(2)[0].numpy(),
+                 scale0=data["scale0"].numpy(), scale1=data["scale1"].numpy(), **c)
+
+        # refinement end-to-end: the real MultiviewMatcher with seeded weights (RoIAlign = stand-in)
+        c = CASES["multiview_e2e"]
+        rcfg = multiview_refinement_config()
+        rsd = random_state_dict(multiview_param_spec(rcfg), c["weight_seed"])
+        mm = MultiviewMatcher(rcfg, test=True).eval()
+        mm.load_state_dict({k: v.clone() for k, v in rsd.items()}, strict=True)
+        rdata = synth.refine_bag(c["T"], c["V"], c["H"], c["W"], c["data_seed"], variable_lengths=True)
+        rdata["scales"] = torch.tensor([[[1.0, 1.0], [1.25, 1.5], [1.0, 2.0], [0.5, 0.75]]])
+        mm(rdata)
+        np.savez(os.path.join(OUT, "multiview_e2e.npz"), query_points_refined=rdata["query_points_refined"].numpy(),
+                 reference_points_refined=rdata["reference_points_refined"][-1].numpy(), std=rdata["std"][-1].numpy(),
+                 scales=rdata["scales"].numpy(), **c)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,253 @@
+"""TEST INFRASTRUCTURE ONLY -- loader for the *real* reference (zju3dv/DetectorFreeSfM).
+
+This module imports the reference's own Python modules from ``/root/reference``
+UNCHANGED, so that (a) ``oracle/restate.py`` can be validated against the code it
+restates and (b) ``oracle/make_golden.py`` can generate the fixtures committed under
+``tests/golden/``.  ``/root/reference`` only exists in the build container, never on the
+GPU box, so nothing here may be imported by ``-m gpu`` tests, ``smoke()`` or ``bench.py``.
+
+The reference depends on packages that are not installed here.
+None of their arithmetic is on the coarse path; on the refinement path two kornia
+helpers and the un-vendored ``roi_align`` extension are executed.  We register minimal
+stand-ins in ``sys.modules`` *before* importing the reference:
+
+* ``yacs.config.CfgNode``          -- attribute dict (third_party/LoFTR/src/config/default.py:1)
+* ``kornia...dsnt.spatial_expectation2d``, ``kornia.utils.grid.create_meshgrid``
+                                   -- executed at src/MultiviewMatcher/utils/fine_matching.py:274-275
+* ``loguru.logger``                -- no-op logger
+* ``omegaconf.OmegaConf``          -- merge/set_struct/set_readonly on plain dicts
+                                      (src/MultiviewMatcher/backbone/S2DNet/base_model.py:21-26)
+* ``torchvision.models.vgg16``     -- architecture only (s2dnet.py:86-87)
+* ``timm.models.registry.register_model`` -- identity decorator (backbone/resnet.py:7)
+* ``roi_align.roi_align.RoIAlign`` -- NOT the reference's code: the un-vendored
+                                      longcw/RoIAlign.pytorch submodule; stand-in =
+                                      ``oracle.restate.roi_align_crop`` (PARITY UNPINNED for
+                                      this stage, see oracle/restate.py header)
+* ``src`` package shim             -- bypasses src/__init__.py (imports ray/hloc/natsort)
+"""
+import importlib
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("DFSFM_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "third_party", "LoFTR", "src", "loftr"))
+
+
+class _AttrDict(dict):
+    """yacs.CfgNode stand-in: dict with attribute access (enough for default.py)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        import copy
+        return copy.deepcopy(self)
+
+
+class _DictConf(dict):
+    """omegaconf node stand-in: nested attribute dict."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = _DictConf(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _mod(name):
+    m = types.ModuleType(name)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    import torch
+    import torch.nn as nn
+    import PIL.Image  # noqa: F401  (base_model.py:39 annotates with PIL.Image)
+
+    if "yacs" not in sys.modules:
+        yacs = _mod("yacs")
+        yc = _mod("yacs.config")
+        yc.CfgNode = _AttrDict
+        yacs.config = yc
+
+    if "loguru" not in sys.modules:
+        lg = _mod("loguru")
+
+        class _L:
+            def __getattr__(self, _):
+                return lambda *a, **k: None
+        lg.logger = _L()
+
+    if "kornia" not in sys.modules:
+        k = _mod("kornia")
+        kg = _mod("kornia.geometry")
+        ks = _mod("kornia.geometry.subpix")
+        kd = _mod("kornia.geometry.subpix.dsnt")
+        ku = _mod("kornia.utils")
+        kug = _mod("kornia.utils.grid")
+
+        def create_meshgrid(h, w, normalized_coordinates=True, device=None):
+            # kornia 0.4.1 semantics: [1,h,w,2], last dim (x,y), linspace(-1,1) when normalised
+            xs = torch.linspace(0, w - 1, w, device=device)
+            ys = torch.linspace(0, h - 1, h, device=device)
+            if normalized_coordinates:
+                xs = (xs / (w - 1) - 0.5) * 2
+                ys = (ys / (h - 1) - 0.5) * 2
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            return torch.stack([gx, gy], dim=-1)[None]
+
+        def spatial_expectation2d(heatmap, normalized_coordinates=True):
+            b, n, h, w = heatmap.shape
+            grid = create_meshgrid(h, w, normalized_coordinates, heatmap.device).to(heatmap.dtype)
+            px = grid[..., 0].reshape(-1)
+            py = grid[..., 1].reshape(-1)
+            flat = heatmap.reshape(b, n, -1)
+            ex = torch.sum(px * flat, -1, keepdim=True)
+            ey = torch.sum(py * flat, -1, keepdim=True)
+            return torch.cat([ex, ey], -1)
+
+        kd.spatial_expectation2d = spatial_expectation2d
+        ks.dsnt = kd
+        kg.subpix = ks
+        k.geometry = kg
+        kug.create_meshgrid = create_meshgrid
+        ku.grid = kug
+        ku.create_meshgrid = create_meshgrid
+        k.utils = ku
+
+    if "omegaconf" not in sys.modules:
+        oc = _mod("omegaconf")
+
+        class OmegaConf:
+            @staticmethod
+            def merge(*cfgs):
+                out = {}
+                for c in cfgs:
+                    out.update(dict(c))
+                return _DictConf(out)
+
+            @staticmethod
+            def set_struct(c, v):
+                return None
+
+            @staticmethod
+            def set_readonly(c, v):
+                return None
+
+            @staticmethod
+            def create(d):
+                return _DictConf(d)
+        oc.OmegaConf = OmegaConf
+
+    if "torchvision" not in sys.modules:
+        tv = _mod("torchvision")
+        tvm = _mod("torchvision.models")
+        tvt = _mod("torchvision.transforms")
+        tvf = _mod("torchvision.transforms.functional")
+        tv.transforms = tvt
+        tvt.functional = tvf
+
+        def vgg16(pretrained=False, **kw):
+            cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+            layers, c_in = [], 3
+            for v in cfg:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                else:
+                    layers += [nn.Conv2d(c_in, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                    c_in = v
+            m = nn.Module()
+            m.features = nn.Sequential(*layers)
+            return m
+        tvm.vgg16 = vgg16
+        tv.models = tvm
+
+    if "timm" not in sys.modules:
+        t = _mod("timm")
+        tm = _mod("timm.models")
+        tr = _mod("timm.models.registry")
+        tr.register_model = lambda f: f
+        tm.registry = tr
+        t.models = tm
+
+    if "roi_align" not in sys.modules:
+        ra = _mod("roi_align")
+        rr = _mod("roi_align.roi_align")
+        from oracle.restate import roi_align_crop
+
+        class RoIAlign(nn.Module):
+            def __init__(self, crop_height, crop_width, extrapolation_value=0, transform_fpcoor=True):
+                super().__init__()
+                self.crop_height, self.crop_width = crop_height, crop_width
+                self.extrapolation_value = extrapolation_value
+                self.transform_fpcoor = transform_fpcoor
+
+            def forward(self, featuremap, boxes, box_ind):
+                assert not self.transform_fpcoor
+                return roi_align_crop(featuremap, boxes, box_ind.reshape(-1), self.crop_height,
+                                      self.crop_width, self.extrapolation_value)
+        rr.RoIAlign = RoIAlign
+        ra.roi_align = rr
+
+    # `src` package shim: real src/__init__.py pulls ray/hloc/natsort
+    if "src" not in sys.modules or not hasattr(sys.modules["src"], "__path__"):
+        src = _mod("src")
+        src.__path__ = [os.path.join(REFERENCE_ROOT, "src")]
+        su = _mod("src.utils")
+        su.__path__ = [os.path.join(REFERENCE_ROOT, "src", "utils")]
+        sp = _mod("src.utils.profiler")
+
+        class PassThroughProfiler:
+            def record_function(self, name):
+                import contextlib
+                return contextlib.nullcontext()
+            profile = record_function
+        sp.PassThroughProfiler = PassThroughProfiler
+        su.profiler = sp
+        src.utils = su
+
+
+def _ensure_path():
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+def import_loftr():
+    """Return the reference's ``LoFTR`` class and its lower-cased default config dict."""
+    _ensure_path()
+    install_stubs()
+    from third_party.LoFTR.src.loftr.loftr import LoFTR
+    default = importlib.import_module("third_party.LoFTR.src.config.default")
+
+    def lower(c):
+        if not isinstance(c, dict):
+            return list(c) if isinstance(c, tuple) else c
+        return {k.lower(): lower(v) for k, v in c.items()}
+    cfg = lower(default._CN)["loftr"]
+    return LoFTR, cfg
+
+
+def import_multiview_matcher():
+    """Return the reference's ``MultiviewMatcher`` class."""
+    _ensure_path()
+    install_stubs()
+    from src.MultiviewMatcher.MultiviewMatcher import MultiviewMatcher
+    return MultiviewMatcher

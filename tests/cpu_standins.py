@@ -1,0 +1,61 @@
+"""Test-only stand-ins: the oracle's CPU restatements behind the ``ops`` signatures, so that the
+HOST logic of the plugins (weight packing, BN folding, grouping, scatter order, dead-work
+skipping) can be exercised by ``-m "not gpu"`` tests.  The product never uses these."""
+import contextlib
+
+import torch
+
+from oracle import restate
+
+
+def _la(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None):
+    qm = None if q_mask is None else q_mask.repeat_interleave(q_group, dim=1)[:, :q.shape[1]]
+    km = None if kv_mask is None else kv_mask.repeat_interleave(kv_group, dim=1)[:, :k.shape[1]]
+    return restate.linear_attention(q, k, v, qm, km, eps)
+
+
+def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None, coarse_scale=8.0):
+    hw0_i = (hw0_c[0] * coarse_scale, hw0_c[1] * coarse_scale)
+    return restate.coarse_matching(feat0, feat1, hw0_c, hw1_c, hw0_i, thr, border, temperature, scale0, scale1)
+
+
+def _roi(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapolation_value=0.0, mean=None,
+         std=None, out=None):
+    bi = torch.zeros(boxes.shape[0], dtype=torch.int32) if box_ind is None else box_ind
+    p = restate.roi_align_crop(feat, boxes, bi, crop_h, crop_w, extrapolation_value)
+    if mean is not None:
+        p = (p - mean[:, None, None]) / std[:, None, None]
+    if out is None:
+        return p
+    if out_slot is None:
+        out.copy_(p)
+    else:
+        out[out_slot] = p
+    return out
+
+
+def _fm(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, ref_pts=None, scale_r=None,
+        rs_t=0, rs_n=0):
+    T, Vq = qry.shape[:2]
+    mv = torch.ones(T, dtype=torch.bool) if movable is None else movable.bool()
+    left_norm, coords, std, best = restate.fine_matching(ref, qry, W, left, track_mask.bool(), mv)
+    out = {"best_index": best.int(), "left_norm": left_norm, "coords": coords, "std": std}
+    if query_pts is not None:
+        out["query_refined"] = query_pts + left_norm * (left // 2) * scale_q
+    if ref_pts is not None:   # strided [Vq(+), T(+), 2] views, (rs_t, rs_n) = (1, Tfull)
+        rp = ref_pts[:Vq, :T].transpose(0, 1)
+        sr = scale_r[:Vq, :T].transpose(0, 1)
+        out["ref_refined"] = rp + coords * (W // 2) * sr
+    return out
+
+
+@contextlib.contextmanager
+def cpu_ops():
+    from detectorfreesfm_amd import ops
+    saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match")}
+    ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
+    try:
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)
