@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=2000, help="tracks per refinement bag (configs[2]: 2000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="only time the hand-written kernels at the bench shapes (compact rocprofv3 target)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,6 +164,11 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.kernels_only:
+        rl = kernel_rooflines(dev, args.batch)
+        print(json.dumps({"rooflines": rl}))
+        return
 
     # ---- coarse matcher: configs[1] ---------------------------------------------------------------
     cfg = loftr_coarse_only_config(0.2)
