@@ -37,6 +37,9 @@ SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("dfsfm_layernorm_f32", c_int,
+     [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    ("dfsfm_add_scatter_tokens_f32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 ]
 
 _lib = None

@@ -55,35 +55,46 @@ class EncoderLayerWeights:
         self.wkv = torch.cat([wk, wv], 0).contiguous()
         self.wqkv = torch.cat([wq, wk, wv], 0).contiguous()
         self.merge = get(prefix + "merge.weight").contiguous()
-        self.w1 = get(prefix + "mlp.0.weight").contiguous()
+        self.w1t = get(prefix + "mlp.0.weight").t()          # [2C_in, 2C_out] view for addmm
+        self.b1 = torch.zeros(self.w1t.shape[1], dtype=wq.dtype, device=wq.device)
         self.w2 = get(prefix + "mlp.2.weight").contiguous()
-        self.n1 = (get(prefix + "norm1.weight"), get(prefix + "norm1.bias"))
-        self.n2 = (get(prefix + "norm2.weight"), get(prefix + "norm2.bias"))
+        self.n1 = (get(prefix + "norm1.weight").contiguous(), get(prefix + "norm1.bias").contiguous())
+        self.n2 = (get(prefix + "norm2.weight").contiguous(), get(prefix + "norm2.bias").contiguous())
 
 
-def encoder_layer(w: EncoderLayerWeights, x, source, nhead, x_mask=None, source_mask=None,
+def encoder_layer(w: EncoderLayerWeights, xm, source, out, nhead, x_mask=None, source_mask=None,
                   q_group=1, kv_group=1, is_self=False):
     """LoFTREncoderLayer.forward (LoFTR transformer.py:35-58; multiview copy
-    src/MultiviewMatcher/matcher_module/transformer.py:66-95) with K1 as the attention core.
-    Projections of the same input share one GEMM (q|k|v for self, k|v for cross)."""
-    N, L, C = x.shape
-    S = source.shape[1]
+    src/MultiviewMatcher/matcher_module/transformer.py:66-95), concat-free:
+
+    ``xm`` [N,L,2C] holds x in ``xm[..., :C]``; its second half is where norm1(message) lands, so
+    ``torch.cat([x, message])`` never happens -- the MLP GEMM reads ``xm`` as is.  ``source``
+    [N,S,C] and ``out`` [N,L,C] may be row-strided views (e.g. the first half of another
+    [.., 2C] buffer); ``out`` receives ``x + norm2(mlp(...))``.
+
+    GEMMs: hipBLASLt fp32 through torch (q|k|v fused for self, k|v for cross; ReLU as GEMM
+    epilogue).  K1, both LayerNorms and the residual add are hand-written HIP."""
+    N, L, C2 = xm.shape
+    C = C2 // 2
     D = C // nhead
+    S = source.shape[1]
+    xm2 = xm.view(N * L, C2)
+    x2 = xm2[:, :C]                                        # [rows, C] view, row stride 2C: no copy
     if is_self:
-        qkv = F.linear(x, w.wqkv)
+        qkv = F.linear(x2, w.wqkv).view(N, L, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     else:
-        q = F.linear(x, w.wq)
-        kv = F.linear(source, w.wkv)
+        q = F.linear(x2, w.wq).view(N, L, C)
+        kv = F.linear(source.reshape(N * S, C), w.wkv).view(N, S, 2 * C)
         k, v = kv[..., :C], kv[..., C:]
     msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
                                v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group)
-    msg = F.linear(msg.view(N, L, C), w.merge)
-    msg = F.layer_norm(msg, (C,), w.n1[0], w.n1[1])
-    msg = F.linear(torch.cat([x, msg], dim=2), w.w1)
-    msg = F.linear(F.relu_(msg), w.w2)
-    msg = F.layer_norm(msg, (C,), w.n2[0], w.n2[1])
-    return x + msg
+    merged = F.linear(msg.view(N * L, C), w.merge)
+    ops.layernorm(merged, w.n1[0], w.n1[1], out=xm2[:, C:])                   # norm1 -> [x | message]
+    h = torch._addmm_activation(w.b1, xm2, w.w1t)                             # relu(mlp.0([x|message]))
+    o = F.linear(h, w.w2)
+    ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=xm[..., :C], out=out)   # x + norm2(.)
+    return out
 
 
 class HipLoFTR(ParamModule):
@@ -171,24 +182,44 @@ class HipLoFTR(ParamModule):
 
     # -- K2/K1: LocalFeatureTransformer.forward (transformer.py:80-101) -------------------------
     def _transformer(self, f0, f1, P):
+        """f0 [N,L,C], f1 [N,S,C] -> updated features (contiguous).  Activations ping-pong between
+        two [.,.,2C] buffers (see encoder_layer); when both images have the same grid they share
+        one buffer so that self layers run as ONE batch of 2N sequences."""
         nhead = self.config["coarse"]["nhead"]
-        same = f0.shape == f1.shape
-        N = f0.shape[0]
-        for w, name in zip(P["enc"], self.config["coarse"]["layer_names"]):
+        names = self.config["coarse"]["layer_names"]
+        N, L, C = f0.shape
+        S = f1.shape[1]
+        same = L == S
+        dev = f0.device
+
+        def new_buffers(width):
+            if same:
+                big = torch.empty((2 * N, L, width), dtype=torch.float32, device=dev)
+                return big, big[:N], big[N:]
+            return None, torch.empty((N, L, width), dtype=torch.float32, device=dev), \
+                torch.empty((N, S, width), dtype=torch.float32, device=dev)
+        cur = new_buffers(2 * C)
+        nxt = new_buffers(2 * C)
+        cur[1][..., :C] = f0
+        cur[2][..., :C] = f1
+        for li, (w, name) in enumerate(zip(P["enc"], names)):
+            last = li == len(names) - 1
+            dst = new_buffers(C) if last else tuple(None if b is None else b[..., :C] for b in nxt)
             if name == "self":
                 if same:   # both images through one batched call
-                    xs = torch.cat([f0, f1], 0)
-                    xs = encoder_layer(w, xs, xs, nhead, is_self=True)
-                    f0, f1 = xs[:N], xs[N:]
+                    encoder_layer(w, cur[0], cur[0][..., :C], dst[0], nhead, is_self=True)
                 else:
-                    f0 = encoder_layer(w, f0, f0, nhead, is_self=True)
-                    f1 = encoder_layer(w, f1, f1, nhead, is_self=True)
+                    encoder_layer(w, cur[1], cur[1][..., :C], dst[1], nhead, is_self=True)
+                    encoder_layer(w, cur[2], cur[2][..., :C], dst[2], nhead, is_self=True)
             elif name == "cross":
-                f0 = encoder_layer(w, f0, f1, nhead)
-                f1 = encoder_layer(w, f1, f0, nhead)      # sees the UPDATED feat0 (:96-97)
+                encoder_layer(w, cur[1], cur[2][..., :C], dst[1], nhead)
+                encoder_layer(w, cur[2], dst[1], dst[2], nhead)       # sees the UPDATED feat0 (:96-97)
             else:
                 raise KeyError(name)
-        return f0, f1
+            if last:
+                return dst[1], dst[2]
+            cur, nxt = nxt, cur
+        return cur[1][..., :C].contiguous(), cur[2][..., :C].contiguous()
 
     def coarse_features(self, image0, image1):
         """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c)."""

@@ -34,7 +34,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_LD = BN + 1;                               // padded epilogue tile
 constexpr int SMEM_STAGE = 2 * (BM + BN) * BK * 4;           // 65536 B, double buffered A|B
 constexpr int SMEM_TILE = BM * TILE_LD * 4;                  // 66048 B
-constexpr int SMEM_STATS = (BM + BN) * 8;                    // row/col (max,sum) for SELECT
+constexpr int SMEM_STATS = (BM + BN) * (8 + 4);              // row/col (max,sum) + candidate gates
 constexpr int SMEM_BYTES = SMEM_TILE + SMEM_STATS;           // 68096 B -> 2 workgroups / CU
 
 enum { MODE_STATS = 0, MODE_SELECT = 1, MODE_CONF = 2 };
@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256, 2) void cm_gemm(GemmArgs g) {
     float* tile = reinterpret_cast<float*>(smem);                     // [BM][TILE_LD] (aliases)
     float2* s_rstat = reinterpret_cast<float2*>(smem + SMEM_TILE);    // [BM]
     float2* s_cstat = s_rstat + BM;                                   // [BN]
+    float* s_rgate = reinterpret_cast<float*>(s_cstat + BN);          // [BM] SELECT: sim needed for p_row > thr
+    float* s_cgate = s_rgate + BM;                                    // [BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -86,12 +88,19 @@ __global__ __launch_bounds__(256, 2) void cm_gemm(GemmArgs g) {
     const float* B = g.f1 + (int64_t)n * g.S * g.C;
 
     if (MODE != MODE_STATS) {
+        // conf = p_row * p_col > thr needs p_row > thr and p_col > thr, i.e.
+        // sim > max + log(thr * sum) on both axes: a cheap gate (1e-3 slack covers exp/log rounding)
+        // that keeps the two expf + two divisions off all but the rare candidate entries.
         if (tid < BM) {
             const int i = row0 + tid;
-            s_rstat[tid] = i < g.L ? g.row_stat[(int64_t)n * g.L + i] : make_float2(0.f, 1.f);
+            const float2 st = i < g.L ? g.row_stat[(int64_t)n * g.L + i] : make_float2(0.f, 1.f);
+            s_rstat[tid] = st;
+            s_rgate[tid] = i < g.L ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
         } else {
             const int j = col0 + tid - BM;
-            s_cstat[tid - BM] = j < g.S ? g.col_stat[(int64_t)n * g.S + j] : make_float2(0.f, 1.f);
+            const float2 st = j < g.S ? g.col_stat[(int64_t)n * g.S + j] : make_float2(0.f, 1.f);
+            s_cstat[tid - BM] = st;
+            s_cgate[tid - BM] = j < g.S ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
         }
     }
 
@@ -101,11 +110,9 @@ __global__ __launch_bounds__(256, 2) void cm_gemm(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = tid + 256 * j, r = idx >> 3, c = idx & 7;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[j] = (row0 + r < g.L)
-                        ? *reinterpret_cast<const f32x4*>(A + (int64_t)(row0 + r) * g.C + k0 + c * 4) : z;
-            rb[j] = (col0 + r < g.S)
-                        ? *reinterpret_cast<const f32x4*>(B + (int64_t)(col0 + r) * g.C + k0 + c * 4) : z;
+            // rows past the end are clamped (branch-free); the epilogue never looks at them
+            ra[j] = *reinterpret_cast<const f32x4*>(A + (int64_t)min(row0 + r, g.L - 1) * g.C + k0 + c * 4);
+            rb[j] = *reinterpret_cast<const f32x4*>(B + (int64_t)min(col0 + r, g.S - 1) * g.C + k0 + c * 4);
             if (PRESCALE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ra[j][e] = ra[j][e] / g.op_div; rb[j][e] = rb[j][e] / g.op_div; }
@@ -173,14 +180,15 @@ __global__ __launch_bounds__(256, 2) void cm_gemm(GemmArgs g) {
                 const int lr = wr * 64 + a * 32 + mfma32_row(r, half);
                 const int lc = wc * 64 + b * 32 + col;
                 float s = (acc[a][b][r] * g.acc_mul) / g.temperature;
-                if (MODE != MODE_STATS) {
+                if (MODE == MODE_CONF || (MODE == MODE_SELECT && s > s_rgate[lr] && s > s_cgate[lc])) {
                     const float2 rs = s_rstat[lr], cs = s_cstat[lc];
                     // softmax over dim 1 (column j normalised over i) * softmax over dim 2
                     const float p_col = expf(s - cs.x) / cs.y;
                     const float p_row = expf(s - rs.x) / rs.y;
                     s = p_col * p_row;
-                    if (MODE == MODE_SELECT)
-                        any_above |= (s > g.thr) && (row0 + lr < g.L) && (col0 + lc < g.S);
+                    if (MODE == MODE_SELECT) any_above |= s > g.thr;
+                } else if (MODE == MODE_SELECT) {
+                    s = 0.f;                    // cannot exceed thr; value is never used
                 }
                 acc[a][b][r] = s;
             }

@@ -1,0 +1,133 @@
+// Fused row-wise epilogue kernels for the encoder layers (K2 / K10) and the patch-feature
+// hand-off (K9 -> K10) on gfx950 (MI355X).  All HBM-bound: every element is read once and written
+// once, with row strides so results land directly where the next GEMM reads them.
+//
+//  * layernorm (+ residual, strided in/out) replaces
+//        message = self.norm1(message)                      LoFTR transformer.py:50  / multiview :82
+//        message = self.mlp(torch.cat([x, message], dim=2)) :55 / :87   (the concat: LN1 writes
+//                                                            straight into the [x|message] buffer)
+//        return x + self.norm2(message)                     :56-58 / :88-95
+//  * add_scatter_tokens replaces the feature sum, 'm c h w -> m (h w) c' rearrange and the
+//    original-order gather of MultiviewMatcher.py:240-270 / s2dnet.py:164-171 (fmap += upsample).
+#include "common.h"
+
+namespace {
+
+// One wave per row, VEC = C/64 contiguous floats per lane (C = 64*VEC).
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ residual, int64_t ldr,
+                                                        float* __restrict__ out, int64_t ldo, int64_t rows) {
+    constexpr int C = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[VEC];
+    const float* xr = x + row * ldx + lane * VEC;
+    if (VEC == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xr);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = t[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = xr[e];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += v[e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) q += (v[e] - mean) * (v[e] - mean);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.f / sqrtf(q / (float)C + eps);
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        o[e] = (v[e] - mean) * rstd * gamma[lane * VEC + e] + beta[lane * VEC + e];
+    if (residual) {
+        const float* rr = residual + row * ldr + lane * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = rr[e] + o[e];
+    }
+    float* orow = out + row * ldo + lane * VEC;
+    if (VEC == 4) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] = o[e];
+        *reinterpret_cast<f32x4*>(orow) = t;
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) orow[e] = o[e];
+    }
+}
+
+// dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p]);  one workgroup per patch, 32-channel slabs
+// transposed through LDS so both the reads (p fastest) and the writes (c fastest) are coalesced.
+__global__ __launch_bounds__(256) void add_scatter_tokens_kernel(const float* __restrict__ a,
+                                                                 const float* __restrict__ b,
+                                                                 const int64_t* __restrict__ slot,
+                                                                 float* __restrict__ dst, int C, int P) {
+    extern __shared__ float tile[];   // [32][P + 1]
+    const int m = blockIdx.x;
+    const int64_t s = slot ? slot[m] : (int64_t)m;
+    const float* am = a + (int64_t)m * C * P;
+    const float* bm = b ? b + (int64_t)m * C * P : nullptr;
+    float* dm = dst + s * P * C;
+    const int ld = P + 1;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int nc = min(32, C - c0);
+        for (int e = threadIdx.x; e < nc * P; e += blockDim.x) {
+            const int cy = e / P, p = e - cy * P;
+            float v = am[(int64_t)(c0 + cy) * P + p];
+            if (bm) v += bm[(int64_t)(c0 + cy) * P + p];
+            tile[cy * ld + p] = v;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < P * 32; e += blockDim.x) {
+            const int p = e >> 5, cx = e & 31;
+            if (cx < nc) dm[(int64_t)p * C + c0 + cx] = tile[cx * ld + p];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                   const float* residual, int64_t ldr, float* out, int64_t ldo, int64_t rows,
+                                   int C, void* stream_) {
+    if (rows == 0) return DFSFM_OK;
+    if (!x || !gamma || !beta || !out || rows < 0 || C <= 0) return DFSFM_E_BADARG;
+    if (ldx < C || ldo < C || (residual && ldr < C)) return DFSFM_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+    if (C == 256) {
+        if ((ldx & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+            return DFSFM_E_UNSUPPORTED;
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows);
+    } else if (C == 128) {
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows);
+    } else if (C == 64) {
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows);
+    } else {
+        return DFSFM_E_UNSUPPORTED;
+    }
+    return dfsfm::check_launch("dfsfm_layernorm_f32");
+}
+
+extern "C" int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, const int64_t* slot, float* dst,
+                                            int M, int C, int P, void* stream_) {
+    if (M == 0) return DFSFM_OK;
+    if (!a || !dst || M < 0 || C <= 0 || P <= 0) return DFSFM_E_BADARG;
+    if ((size_t)32 * (P + 1) * 4 > 64 * 1024) return DFSFM_E_UNSUPPORTED;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(add_scatter_tokens_kernel, dim3(M), dim3(256), (size_t)32 * (P + 1) * 4, stream, a, b, slot,
+                       dst, C, P);
+    return dfsfm::check_launch("dfsfm_add_scatter_tokens_f32");
+}

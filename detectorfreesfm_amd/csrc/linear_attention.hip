@@ -7,21 +7,32 @@
 // HBM-bound op (AI ~ 8 flop/B): q,k,v are read once, out written once, nothing else of size
 // O(L) touches memory.  Three launches:
 //   1. kv_partial : every workgroup reduces a chunk of S rows into per-head  KV = K^T (v/S)
-//                   (DxD) and Ksum (D) with fp32 MFMA; the K/V operands are loaded straight
-//                   from global in MFMA fragment order (128-B row segments), no LDS.
-//   2. kv_finalize: sums the chunk partials in fixed order (deterministic; skipped when one
-//                   chunk covers S, the refinement case).
+//                   (DxD) and Ksum (D) with fp32 MFMA.  H=8 fast path (`*_staged`): whole rows are
+//                   loaded with 16-byte coalesced loads, phi/mask/(1/S) applied once per element,
+//                   staged through LDS and read back in MFMA fragment order; the next 32-row
+//                   block is prefetched into registers.  Generic path: fragment-order global loads.
+//   2. kv_finalize: sums the chunk partials, one thread per element, fixed order (deterministic;
+//                   skipped when one chunk covers S, the refinement case).
 //   3. apply      : out^T = KV^T Q^T per head with MFMA, Z = 1/(Q.Ksum+eps) from the same
-//                   registers (one cross-half shuffle), scaled and stored as float4.
+//                   registers (one cross-half shuffle).  D=32/H=8: q rows and results go through
+//                   one LDS tile so loads and stores are whole 1-KB rows; KV fragments stay in
+//                   registers across up to 4 row blocks.
 // MFMA k-index permutation: the hardware pairs lane halves (32x32x2: 2 halves, 16x16x4: 4
-// quarter-groups) as the k index; we give half g the k-range [g*KH, (g+1)*KH) for BOTH
-// operands, which keeps every lane's loads contiguous.  Summation order is fixed -> results are
-// run-to-run deterministic.
+// quarter-groups) as the k index; we give each group its own k-range on BOTH operands, which
+// keeps every lane's accesses contiguous.  Summation order is fixed -> results are run-to-run
+// deterministic.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 using namespace dfsfm;
+
+template <int D, typename Acc>
+__device__ __forceinline__ Acc mfma_step(float a, float b, Acc acc) {
+    if constexpr (D == 32) return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
 
 __device__ __forceinline__ float mask_at(const uint8_t* m, int group, int64_t base, int idx) {
     return m ? (float)m[base + idx / group] : 1.f;
@@ -231,23 +242,245 @@ __global__ __launch_bounds__(256) void la_apply_d16(
     }
 }
 
-// Sum the chunk partials in chunk order: kvf[n][h][:] = sum_c part[n][c][h][:].
+
+// ---------------------------------------------------------------------------------------------
+// H = 8 fast path: whole rows (all heads) are staged through LDS with 16-byte coalesced loads,
+// phi / mask / (1/S) applied once per element on the way in, MFMA fragments read back with
+// conflict-free ds_read_b32.  Next 32-row block is prefetched into registers during the MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void la_kv_partial_staged(
+    const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+    int kv_group, float* __restrict__ part, int S, int ldk, int ldv, int rows_per_chunk, int nchunks) {
+    constexpr int H = 8, C = H * D;
+    constexpr int LD = (D == 16) ? C + 16 : C;          // D=16: rows t*4+g differ by 1 -> +16 banks
+    constexpr int NV = (32 * C / 4) / 256;              // float4 per thread per matrix per block
+    constexpr int KVSZ = D * D + D;
+    __shared__ __attribute__((aligned(16))) float sK[32 * LD];
+    __shared__ __attribute__((aligned(16))) float sV[32 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int s_begin = chunk * rows_per_chunk;
+    const int s_end = min(S, s_begin + rows_per_chunk);
+    const float Sf = (float)S;
+    const int64_t mbase = kv_mask ? (int64_t)n * ((S + kv_group - 1) / kv_group) : 0;
+    const float* kn = k + (int64_t)n * S * ldk;
+    const float* vn = v + (int64_t)n * S * ldv;
+
+    f32x4 rk[NV], rv[NV];
+    auto gload = [&](int s0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = tid + 256 * j, r = idx / (C / 4), c4 = idx % (C / 4);
+            const int srow = s0 + r;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (srow < s_end) {
+                a = *reinterpret_cast<const f32x4*>(kn + (int64_t)srow * ldk + c4 * 4);
+                b = *reinterpret_cast<const f32x4*>(vn + (int64_t)srow * ldv + c4 * 4);
+                const float m = mask_at(kv_mask, kv_group, mbase, srow);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = elu_plus_one(a[e]) * m;
+                    b[e] = (b[e] * m) / Sf;
+                }
+            }
+            rk[j] = a;
+            rv[j] = b;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = tid + 256 * j, r = idx / (C / 4), c4 = idx % (C / 4);
+            *reinterpret_cast<f32x4*>(sK + r * LD + c4 * 4) = rk[j];
+            *reinterpret_cast<f32x4*>(sV + r * LD + c4 * 4) = rv[j];
+        }
+    };
+
+    using acc_t = typename std::conditional<D == 32, f32x16, f32x4>::type;
+    acc_t acc[2];
+    float ksum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) acc[hh] = acc_t{0};
+
+    gload(s_begin);
+    for (int s0 = s_begin; s0 < s_end; s0 += 32) {
+        __syncthreads();               // previous block's fragment reads are done
+        lstore();
+        __syncthreads();
+        if (s0 + 32 < s_end) gload(s0 + 32);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = wave + 4 * hh;
+            if (D == 32) {
+                const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float a = sK[(half * 16 + t) * LD + h * 32 + col];
+                    const float b = sV[(half * 16 + t) * LD + h * 32 + col];
+                    ksum[hh] += a;
+                    acc[hh] = mfma_step<D>(a, b, acc[hh]);
+                }
+            } else {
+                const int col = lane & 15, grp = lane >> 4;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float a = sK[(t * 4 + grp) * LD + h * 16 + col];
+                    const float b = sV[(t * 4 + grp) * LD + h * 16 + col];
+                    ksum[hh] += a;
+                    acc[hh] = mfma_step<D>(a, b, acc[hh]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = wave + 4 * hh;
+        float* p = part + (((int64_t)n * nchunks + chunk) * H + h) * KVSZ;
+        float ks = ksum[hh];
+        if (D == 32) {
+            const int col = lane & 31, half = lane >> 5;
+            ks += __shfl_xor(ks, 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[mfma32_row(r, half) * 32 + col] = acc[hh][r];
+            if (half == 0) p[1024 + col] = ks;
+        } else {
+            const int col = lane & 15, grp = lane >> 4;
+            ks += __shfl_xor(ks, 16);
+            ks += __shfl_xor(ks, 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[(grp * 4 + r) * 16 + col] = acc[hh][r];
+            if (grp == 0) p[256 + col] = ks;
+        }
+    }
+}
+
+// out for H=8, D=32: a workgroup walks up to 4 blocks of 32 rows; wave w keeps KV^T / Ksum of
+// heads w and w+4 in registers; q rows are staged through LDS (coalesced 1-KB row loads),
+// results go back through the same LDS tile so that stores are whole rows too.
+__global__ __launch_bounds__(256, 2) void la_apply_staged_d32(
+    const float* __restrict__ q, const uint8_t* __restrict__ q_mask, int q_group,
+    const float* __restrict__ kvf, float* __restrict__ out, int L, int S, int ldq, int ldo, float eps,
+    int blocks_per_wg) {
+    constexpr int H = 8, C = 256, LD = C + 4;          // +4 floats: conflict-free b128 row reads
+    __shared__ __attribute__((aligned(16))) float sQ[32 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y;
+    const float Sf = (float)S;
+    const int64_t mbase = q_mask ? (int64_t)n * ((L + q_group - 1) / q_group) : 0;
+    const float* qn = q + (int64_t)n * L * ldq;
+    float* on = out + (int64_t)n * L * ldo;
+
+    float a[2][16], ks[2][16];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const float* kv = kvf + ((int64_t)n * H + wave + 4 * hh) * KV32;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[hh][t] = kv[(half * 16 + t) * 32 + col];
+            ks[hh][t] = kv[1024 + half * 16 + t];
+        }
+    }
+    f32x4 rq[8];
+    auto gload = [&](int l0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 6, c4 = idx & 63;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (l0 + r < L) {
+                x = *reinterpret_cast<const f32x4*>(qn + (int64_t)(l0 + r) * ldq + c4 * 4);
+                const float m = mask_at(q_mask, q_group, mbase, l0 + r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = elu_plus_one(x[e]) * m;
+            }
+            rq[j] = x;
+        }
+    };
+    const int l_first = blockIdx.x * blocks_per_wg * 32;
+    const int l_last = min(L, l_first + blocks_per_wg * 32);
+    gload(l_first);
+    for (int l0 = l_first; l0 < l_last; l0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 6, c4 = idx & 63;
+            *reinterpret_cast<f32x4*>(sQ + r * LD + c4 * 4) = rq[j];
+        }
+        __syncthreads();
+        if (l0 + 32 < l_last) gload(l0 + 32);
+        f32x16 acc[2];
+        float Z[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = wave + 4 * hh;
+            float Q[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(sQ + col * LD + h * 32 + half * 16 + j * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Q[j * 4 + e] = x[e];
+            }
+            float z = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) z += Q[t] * ks[hh][t];
+            z += __shfl_xor(z, 32);
+            Z[hh] = 1.f / (z + eps);
+            acc[hh] = f32x16{0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                acc[hh] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[hh][t], Q[t], acc[hh], 0, 0, 0);
+        }
+        __syncthreads();               // every wave has its Q fragments; the tile becomes the output stage
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = wave + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (acc[hh][g * 4 + e] * Z[hh]) * Sf;
+                *reinterpret_cast<f32x4*>(sQ + col * LD + h * 32 + g * 8 + half * 4) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 6, c4 = idx & 63;
+            if (l0 + r < L)
+                *reinterpret_cast<f32x4*>(on + (int64_t)(l0 + r) * ldo + c4 * 4) =
+                    *reinterpret_cast<const f32x4*>(sQ + r * LD + c4 * 4);
+        }
+        __syncthreads();
+    }
+}
+
+// Sum the chunk partials: one thread per element, four interleaved partial sums (fixed order ->
+// deterministic) so that the chunk loads are independent instead of one serial latency chain.
 __global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ part,
                                                       float* __restrict__ kvf, int H, int nchunks,
                                                       int kvsz) {
     const int nh = blockIdx.x;   // n*H + h
     const int n = nh / H, h = nh % H;
-    for (int e = threadIdx.x; e < kvsz; e += blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < nchunks; ++c)
-            s += part[(((int64_t)n * nchunks + c) * H + h) * kvsz + e];
-        kvf[(int64_t)nh * kvsz + e] = s;
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;
+    if (e >= kvsz) return;
+    const float* p = part + ((int64_t)n * nchunks * H + h) * kvsz + e;
+    const int64_t stride = (int64_t)H * kvsz;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= nchunks; c += 4) {
+        s0 += p[(c + 0) * stride];
+        s1 += p[(c + 1) * stride];
+        s2 += p[(c + 2) * stride];
+        s3 += p[(c + 3) * stride];
     }
+    for (; c < nchunks; ++c) s0 += p[c * stride];
+    kvf[(int64_t)nh * kvsz + e] = (s0 + s1) + (s2 + s3);
 }
 
-// Rows per kv_partial workgroup: aim for ~1024 workgroups, at least 64 rows each.
+// Rows per kv_partial workgroup: aim for ~512 workgroups (one resident wave of 2 per CU), at least
+// 64 rows each.
 int chunk_rows(int N, int S) {
-    int64_t want = ((int64_t)S * N + 1023) / 1024;
+    int64_t want = ((int64_t)S * N + 511) / 512;
     int rows = (int)((want + 31) / 32 * 32);
     if (rows < 64) rows = 64;
     const int smax = (S + 31) / 32 * 32;
@@ -295,21 +528,40 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
                                                  dfsfm::align_up((size_t)N * H * kvsz * sizeof(float), 256))
                       : kvf;
     dim3 gA(nchunks, N), blk(256);
+    const bool k_aligned = !(ldk & 3) && !(ldv & 3) && !(reinterpret_cast<uintptr_t>(k) & 15) &&
+                           !(reinterpret_cast<uintptr_t>(v) & 15);
+    const bool staged = (H == 8) && k_aligned;          // whole-row LDS staging (coalesced 16-B loads)
     if (D == 32) {
-        hipLaunchKernelGGL(la_kv_partial_d32, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, H,
-                           ldk, ldv, rows, nchunks);
+        if (staged)
+            hipLaunchKernelGGL(la_kv_partial_staged<32>, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, ldk,
+                               ldv, rows, nchunks);
+        else
+            hipLaunchKernelGGL(la_kv_partial_d32, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, H, ldk,
+                               ldv, rows, nchunks);
     } else {
-        hipLaunchKernelGGL(la_kv_partial_d16, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, H,
-                           ldk, ldv, rows, nchunks);
+        if (staged)
+            hipLaunchKernelGGL(la_kv_partial_staged<16>, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, ldk,
+                               ldv, rows, nchunks);
+        else
+            hipLaunchKernelGGL(la_kv_partial_d16, gA, blk, 0, stream, k, v, kv_mask, kv_group, part, S, H, ldk,
+                               ldv, rows, nchunks);
     }
     if (nchunks > 1)
-        hipLaunchKernelGGL(la_kv_finalize, dim3(N * H), blk, 0, stream, part, kvf, H, nchunks, kvsz);
+        hipLaunchKernelGGL(la_kv_finalize, dim3(N * H, (kvsz + 255) / 256), blk, 0, stream, part, kvf, H, nchunks,
+                           kvsz);
     if (D == 32) {
-        hipLaunchKernelGGL(la_apply_d32, dim3((L + 31) / 32, N), blk, 0, stream, q, q_mask, q_group, kvf,
-                           out, L, S, H, ldq, ldo, eps);
+        if (H == 8) {
+            const int nblk = (L + 31) / 32;
+            const int bpw = (int64_t)nblk * N >= 4096 ? 4 : ((int64_t)nblk * N >= 1024 ? 2 : 1);
+            hipLaunchKernelGGL(la_apply_staged_d32, dim3((nblk + bpw - 1) / bpw, N), blk, 0, stream, q, q_mask,
+                               q_group, kvf, out, L, S, ldq, ldo, eps, bpw);
+        } else {
+            hipLaunchKernelGGL(la_apply_d32, dim3((L + 31) / 32, N), blk, 0, stream, q, q_mask, q_group, kvf, out,
+                               L, S, H, ldq, ldo, eps);
+        }
     } else {
-        hipLaunchKernelGGL(la_apply_d16, dim3((L + 63) / 64, N), blk, 0, stream, q, q_mask, q_group, kvf,
-                           out, L, S, H, ldq, ldo, eps);
+        hipLaunchKernelGGL(la_apply_d16, dim3((L + 63) / 64, N), blk, 0, stream, q, q_mask, q_group, kvf, out, L, S,
+                           H, ldq, ldo, eps);
     }
     return dfsfm::check_launch("dfsfm_linear_attention_f32");
 }

@@ -160,3 +160,53 @@ def fine_match(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=N
     if rref is not None:
         out["ref_refined"] = rref
     return out
+
+
+def _rows_ld(t: torch.Tensor):
+    """(rows, row stride) of a tensor whose last dim is dense and whose leading dims flatten
+    uniformly (e.g. a column slice of a contiguous [..., 2C] buffer)."""
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        raise _lib.DfsfmError("need fp32 rows with unit inner stride")
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    for i in range(t.dim() - 2):
+        if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+            raise _lib.DfsfmError("leading dims do not flatten to uniformly strided rows")
+    rows = 1
+    for s in t.shape[:-1]:
+        rows *= s
+    return rows, ld
+
+
+def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None):
+    """out = (residual or 0) + LayerNorm(x) * gamma + beta over the last dim (row-strided views OK)."""
+    _require_cuda(x, gamma, beta)
+    rows, ldx = _rows_ld(x)
+    C = x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    rows_o, ldo = _rows_ld(out)
+    ldr = 0
+    if residual is not None:
+        rows_r, ldr = _rows_ld(residual)
+        if rows_r != rows:
+            raise _lib.DfsfmError("layernorm: residual shape mismatch")
+    if rows_o != rows or out.shape[-1] != C:
+        raise _lib.DfsfmError("layernorm: out shape mismatch")
+    rc = _lib.lib().dfsfm_layernorm_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), ldr,
+                                        _ptr(out), ldo, rows, C, _stream())
+    _lib.check(rc, "dfsfm_layernorm_f32")
+    return out
+
+
+def add_scatter_tokens(a, b, slot, dst):
+    """dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p]);  a,b [M,C,P] contiguous, dst [*,P,C] contiguous."""
+    _require_cuda(a, dst)
+    a = a.contiguous()
+    b = None if b is None else b.contiguous()
+    M, C, P = a.shape
+    if not dst.is_contiguous() or dst.shape[-2:] != (P, C):
+        raise _lib.DfsfmError("add_scatter_tokens: dst must be contiguous [*, P, C]")
+    sl = None if slot is None else slot.to(torch.int64).contiguous()
+    rc = _lib.lib().dfsfm_add_scatter_tokens_f32(_ptr(a), _ptr(b), _ptr(sl), _ptr(dst), M, C, P, _stream())
+    _lib.check(rc, "dfsfm_add_scatter_tokens_f32")
+    return dst

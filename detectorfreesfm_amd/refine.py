@@ -17,7 +17,7 @@ Output-identical work the reference wastes is skipped ("dea
 * only the centre (W+4)^2 of relu1_2 feeds adaptation layer 0 (the reference convolves the full
   35x35 map and crops to WxW afterwards, s2dnet.py:164-193);
 * the bicubic align_corners upsample of adaptation layer 1 is evaluated only at the WxW centre,
-  as two small matmuls with PyTorch's own interpolation coefficients;
+  as one GEMM with PyTorch's own interpolation coefficients;
 * padded view slots (image index -1) are never cropped or convolved: they are masked everywhere
   downstream, the reference feeds them a copy of the last patch (MultiviewMatcher.py:253-266).
 """
@@ -114,8 +114,8 @@ class HipMultiviewMatcher(ParamModule):
             P["bicubic"] = torch.kron(B, B).contiguous().to(y1.device)   # separable -> one [WW, h4*w4] map
             P["bicubic_key"] = key
         K = P["bicubic"]                                             # [W*W, h4*w4]
-        up = torch.matmul(y1.flatten(2), K.t()).view(y0.shape)      # one GEMM for the whole batch
-        return y0 + up
+        up = torch.matmul(y1.flatten(2), K.t())                     # one GEMM for the whole batch: [M,od,W*W]
+        return y0.flatten(2), up                                    # summed by the scatter kernel
 
     @torch.no_grad()
     def forward(self, data: dict, chunk_track: int = 1000, chunk_backbone_img: bool = True):
@@ -187,8 +187,9 @@ class HipMultiviewMatcher(ParamModule):
             start += n
         for s in range(0, M, self.max_backbone_patches):
             e = min(M, s + self.max_backbone_patches)
-            f = self._s2dnet(patches[s:e], P, W)                                        # [m,C,W,W]
-            feats.index_copy_(0, slot[s:e], f.flatten(2).transpose(1, 2))
+            y0, up = self._s2dnet(patches[s:e], P, W)                                   # 2 x [m,C,WW]
+            ops.add_scatter_tokens(y0, up, slot[s:e], feats)          # (y0+up) 'm c p -> slot p c'
+
         del patches
         feats = feats.view(T, V, WW, C)
 
@@ -209,19 +210,35 @@ class HipMultiviewMatcher(ParamModule):
                 q_out[sl] = qpts[sl]
                 i += nt
                 continue
-            ref = feats[sl, 0].contiguous()                                            # [nt,WW,C]
-            qry = feats[sl, 1:cv].reshape(nt, Vq * WW, C)
             qm = tmask[sl, :Vq].contiguous()
             if mt["enable"]:
-                for w, name in zip(P["layers"], names):   # matcher_module/transformer.py:158-172
+                # activations ping-pong between [., ., 2C] buffers (x | norm1(message)), see encoder_layer
+                rb = [torch.empty((nt, WW, 2 * C), dtype=torch.float32, device=dev) for _ in range(2)]
+                qb = [torch.empty((nt, Vq * WW, 2 * C), dtype=torch.float32, device=dev) for _ in range(2)]
+                rb[0][..., :C] = feats[sl, 0]
+                qb[0].view(nt, Vq, WW, 2 * C)[..., :C] = feats[sl, 1:cv]
+                ref = qry = None
+                for li, (w, name) in enumerate(zip(P["layers"], names)):   # matcher_module/transformer.py:158-172
+                    last = li == len(names) - 1
+                    if last:
+                        ref = torch.empty((nt, WW, C), dtype=torch.float32, device=dev)
+                        qry = torch.empty((nt, Vq * WW, C), dtype=torch.float32, device=dev)
+                        dr, dq = ref, qry
+                    else:
+                        dr, dq = rb[1][..., :C], qb[1][..., :C]
                     if name == "self":
-                        ref, qry = (encoder_layer(w, ref, ref, nhead, is_self=True),
-                                    encoder_layer(w, qry, qry, nhead, qm, qm, WW, WW, is_self=True))
-                    elif name == "cross":                 # both sides from the PRE-update tensors
-                        qry, ref = (encoder_layer(w, qry, ref, nhead, qm, None, WW, 1),
-                                    encoder_layer(w, ref, qry, nhead, None, qm, 1, WW))
+                        encoder_layer(w, rb[0], rb[0][..., :C], dr, nhead, is_self=True)
+                        encoder_layer(w, qb[0], qb[0][..., :C], dq, nhead, qm, qm, WW, WW, is_self=True)
+                    elif name == "cross":                 # both sides from the PRE-update tensors (:163)
+                        encoder_layer(w, qb[0], rb[0][..., :C], dq, nhead, qm, None, WW, 1)
+                        encoder_layer(w, rb[0], qb[0][..., :C], dr, nhead, None, qm, 1, WW)
                     else:
                         raise NotImplementedError(name)
+                    rb.reverse()
+                    qb.reverse()
+            else:
+                ref = feats[sl, 0].contiguous()
+                qry = feats[sl, 1:cv].reshape(nt, Vq * WW, C)
             m = ops.fine_match(ref, qry.view(nt, Vq, WW, C), qm, None if movable is None else movable[sl],
                                W, left, qpts[sl], pt_scales[0, 0, sl], ref_coarse[0, :, i:],
                                pt_scales[0, 1:, i:], 1, T)

@@ -131,6 +131,29 @@ int dfsfm_fine_match_f32(const float* ref, const float* qry, const uint8_t* trac
                          int32_t* best_index, float* left_norm, float* coords, float* std,
                          float* query_refined, float* ref_refined, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K2/K10 epilogues  LayerNorm (+ residual) with row strides
+ * out[r, 0:C] = (residual ? residual[r, 0:C] : 0) + LayerNorm(x[r, 0:C]) * gamma + beta
+ * Replaces norm1 / norm2 / the residual add of LoFTREncoderLayer.forward
+ *   third_party/LoFTR/src/loftr/loftr_module/transformer.py:50,56-58
+ *   src/MultiviewMatcher/matcher_module/transformer.py:82,88-95
+ * and, through `ldo`, the torch.cat([x, message]) of :55 / :87: norm1 writes straight into the
+ * second half of a [rows, 2C] buffer whose first half holds x.  ldx/ldr/ldo are row strides in
+ * floats.  C must be 64, 128 or 256.
+ * ---------------------------------------------------------------------------------------- */
+int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                        const float* residual, int64_t ldr, float* out, int64_t ldo, int64_t rows, int C,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9 -> K10 hand-off  dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p])
+ * a, b [M, C, P] (NCHW patch features, P = W*W), slot [M] int64 or NULL (identity), dst [*, P, C].
+ * Replaces the hypercolumn sum (backbone/S2DNet/s2dnet.py:164-171), the 'm c h w -> m (h w) c'
+ * rearrange and the original-order gather of src/MultiviewMatcher/MultiviewMatcher.py:240-270.
+ * ---------------------------------------------------------------------------------------- */
+int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, const int64_t* slot, float* dst,
+                                 int M, int C, int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

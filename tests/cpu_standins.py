@@ -49,11 +49,33 @@ def _fm(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, re
     return out
 
 
+def _ln(x, gamma, beta, eps=1e-5, residual=None, out=None):
+    y = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
+    if residual is not None:
+        y = residual.reshape(y.shape) + y
+    if out is None:
+        return y
+    out.copy_(y.reshape(out.shape))
+    return out
+
+
+def _scatter(a, b, slot, dst):
+    v = a if b is None else a + b
+    v = v.transpose(1, 2)
+    if slot is None:
+        dst[:v.shape[0]] = v
+    else:
+        dst[slot] = v
+    return dst
+
+
 @contextlib.contextmanager
 def cpu_ops():
     from detectorfreesfm_amd import ops
-    saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match")}
+    saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
+                                          "layernorm", "add_scatter_tokens")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
+    ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     try:
         yield
     finally:
