@@ -49,8 +49,9 @@ def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
 class EncoderLayerWeights:
     """Packed weights of one LoFTREncoderLayer (transformer.py:7-33)."""
 
-    def __init__(self, get, prefix):
+    def __init__(self, get, prefix, backend="hip"):
         wq, wk, wv = get(prefix + "q_proj.weight"), get(prefix + "k_proj.weight"), get(prefix + "v_proj.weight")
+        self.backend = backend
         self.wq = wq.contiguous()
         self.wkv = torch.cat([wk, wv], 0).contiguous()
         self.wqkv = torch.cat([wq, wk, wv], 0).contiguous()
@@ -60,6 +61,10 @@ class EncoderLayerWeights:
         self.w2 = get(prefix + "mlp.2.weight").contiguous()
         self.n1 = (get(prefix + "norm1.weight").contiguous(), get(prefix + "norm1.bias").contiguous())
         self.n2 = (get(prefix + "norm2.weight").contiguous(), get(prefix + "norm2.bias").contiguous())
+        if backend == "hip":     # fp16x2-split packed weights for dfsfm_conv2d_nhwc_f32 (1x1 case)
+            self.pq, self.pkv, self.pqkv = ops.PackedDense(self.wq), ops.PackedDense(self.wkv), ops.PackedDense(self.wqkv)
+            self.pmerge, self.p2 = ops.PackedDense(self.merge), ops.PackedDense(self.w2)
+            self.p1 = ops.PackedDense(get(prefix + "mlp.0.weight"))
 
 
 def encoder_layer(w: EncoderLayerWeights, xm, source, out, nhead, x_mask=None, source_mask=None,
@@ -72,34 +77,49 @@ def encoder_layer(w: EncoderLayerWeights, xm, source, out, nhead, x_mask=None, s
     [N,S,C] and ``out`` [N,L,C] may be row-strided views (e.g. the first half of another
     [.., 2C] buffer); ``out`` receives ``x + norm2(mlp(...))``.
 
-    GEMMs: hipBLASLt fp32 through torch (q|k|v fused for self, k|v for cross; ReLU as GEMM
-    epilogue).  K1, both LayerNorms and the residual add are hand-written HIP."""
+    GEMMs (q|k|v fused for self, k|v for cross; ReLU as GEMM epilogue): backend "hip" = the
+    hand-written fp16x2-split MFMA kernel (dfsfm_conv2d_nhwc_f32, 1x1 case); backend "library" =
+    hipBLASLt fp32 through torch (measurement control).  K1, both LayerNorms and the residual add
+    are hand-written HIP either way."""
     N, L, C2 = xm.shape
     C = C2 // 2
     D = C // nhead
     S = source.shape[1]
     xm2 = xm.view(N * L, C2)
     x2 = xm2[:, :C]                                        # [rows, C] view, row stride 2C: no copy
+    hip = w.backend == "hip"
     if is_self:
-        qkv = F.linear(x2, w.wqkv).view(N, L, 3 * C)
+        qkv = (ops.linear(x2, w.pqkv) if hip else F.linear(x2, w.wqkv)).view(N, L, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     else:
-        q = F.linear(x2, w.wq).view(N, L, C)
-        kv = F.linear(source.reshape(N * S, C), w.wkv).view(N, S, 2 * C)
+        src2 = source.reshape(N * S, C)
+        q = (ops.linear(x2, w.pq) if hip else F.linear(x2, w.wq)).view(N, L, C)
+        kv = (ops.linear(src2, w.pkv) if hip else F.linear(src2, w.wkv)).view(N, S, 2 * C)
         k, v = kv[..., :C], kv[..., C:]
     msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
                                v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group)
-    merged = F.linear(msg.view(N * L, C), w.merge)
+    msg2 = msg.view(N * L, C)
+    merged = ops.linear(msg2, w.pmerge) if hip else F.linear(msg2, w.merge)
     ops.layernorm(merged, w.n1[0], w.n1[1], out=xm2[:, C:])                   # norm1 -> [x | message]
-    h = torch._addmm_activation(w.b1, xm2, w.w1t)                             # relu(mlp.0([x|message]))
-    o = F.linear(h, w.w2)
+    if hip:
+        h = ops.linear(xm2, w.p1, relu=True)                                  # relu(mlp.0([x|message]))
+        o = ops.linear(h, w.p2)
+    else:
+        h = torch._addmm_activation(w.b1, xm2, w.w1t)
+        o = F.linear(h, w.w2)
     ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=xm[..., :C], out=out)   # x + norm2(.)
     return out
 
 
 class HipLoFTR(ParamModule):
-    def __init__(self, config: dict, skip_dead_fpn: bool = True):
+    def __init__(self, config: dict, skip_dead_fpn: bool = True, dense_backend: str = "hip"):
+        """dense_backend: "hip" (default) runs every convolution and linear layer on the hand-written
+        fp16x2-split MFMA kernel; "library" routes them to MIOpen / hipBLASLt fp32 through PyTorch and
+        exists as an explicit measurement control, never as a silent fallback."""
         super().__init__()
+        if dense_backend not in ("hip", "library"):
+            raise ValueError(dense_backend)
+        self.dense_backend = dense_backend
         if config["match_coarse"]["match_type"] != "dual_softmax":
             raise NotImplementedError("only the dual_softmax coarse matcher is on the hot path")
         if config["fine"]["enable"]:
@@ -151,9 +171,34 @@ class HipLoFTR(ParamModule):
             for nm in ("layer2_outconv2", "layer1_outconv2"):
                 P[nm] = (conv_bn(f"backbone.{nm}.0", f"backbone.{nm}.1"), g(f"backbone.{nm}.3.weight"))
         n_layers = len(self.config["coarse"]["layer_names"])
-        P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.") for i in range(n_layers)]
+        P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.", self.dense_backend) for i in range(n_layers)]
+        if self.dense_backend == "hip":
+            H = {"stem": ops.PackedDense(*P["stem"]), "l3out": ops.PackedDense(P["l3out"])}
+            for li in (1, 2, 3):
+                for bi in (0, 1):
+                    b = P[f"l{li}b{bi}"]
+                    hb = {"c1": ops.PackedDense(*b["c1"]), "c2": ops.PackedDense(*b["c2"]), "stride": b["stride"]}
+                    if "down" in b:
+                        hb["down"] = ops.PackedDense(*b["down"])
+                    H[f"l{li}b{bi}"] = hb
+            P["hip"] = H
         self._packed = P
         return P
+
+    # -- K6 on the hand-written NHWC implicit-GEMM kernel (conv + folded BN + ReLU + residual fused) --
+    def _backbone_hip(self, x, P):
+        """x [N,1,H,W] -> coarse feature map as tokens [N, H/8*W/8, C] (NHWC == token-major)."""
+        H = P["hip"]
+        t = x.permute(0, 2, 3, 1)                       # C=1: NCHW memory is already NHWC
+        t = ops.conv2d_nhwc(t, H["stem"], 2, 3, relu=True)
+        for li in (1, 2, 3):
+            for bi in (0, 1):
+                b = H[f"l{li}b{bi}"]
+                y = ops.conv2d_nhwc(t, b["c1"], b["stride"], 1, relu=True)
+                sc = ops.conv2d_nhwc(t, b["down"], b["stride"], 0) if "down" in b else t
+                t = ops.conv2d_nhwc(y, b["c2"], 1, 1, residual=sc, relu=True)
+        t = ops.conv2d_nhwc(t, H["l3out"], 1, 0)
+        return t
 
     # -- K6: local-feature CNN (ResNetFPN_8_2.forward, resnet_fpn.py:100-118) -------------------
     def _backbone(self, x, P):
@@ -225,17 +270,38 @@ class HipLoFTR(ParamModule):
         """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c)."""
         P = self._packed or self._pack()
         bs = image0.size(0)
-        if image0.shape[2:] == image1.shape[2:]:
-            c, _ = self._backbone(torch.cat([image0, image1], 0), P)
-            c0, c1 = c[:bs], c[bs:]
+        same = image0.shape[2:] == image1.shape[2:]
+        if self.dense_backend == "hip":
+            if not self.skip_dead_fpn:
+                raise NotImplementedError("the dead FPN branch is only available with dense_backend='library'")
+            if same:
+                c = self._backbone_hip(torch.cat([image0, image1], 0), P)
+                c0, c1 = c[:bs], c[bs:]
+            else:
+                c0, c1 = self._backbone_hip(image0, P), self._backbone_hip(image1, P)
+            hw0_c, hw1_c = tuple(c0.shape[1:3]), tuple(c1.shape[1:3])
+            f0 = c0.flatten(1, 2) + self._pe_tokens(hw0_c)
+            f1 = c1.flatten(1, 2) + self._pe_tokens(hw1_c)
         else:
-            c0, _ = self._backbone(image0, P)
-            c1, _ = self._backbone(image1, P)
-        hw0_c, hw1_c = tuple(c0.shape[2:]), tuple(c1.shape[2:])
-        f0 = (c0 + self.pe[:, :, :hw0_c[0], :hw0_c[1]]).flatten(2).transpose(1, 2).contiguous()
-        f1 = (c1 + self.pe[:, :, :hw1_c[0], :hw1_c[1]]).flatten(2).transpose(1, 2).contiguous()
+            if same:
+                c, _ = self._backbone(torch.cat([image0, image1], 0), P)
+                c0, c1 = c[:bs], c[bs:]
+            else:
+                c0, _ = self._backbone(image0, P)
+                c1, _ = self._backbone(image1, P)
+            hw0_c, hw1_c = tuple(c0.shape[2:]), tuple(c1.shape[2:])
+            f0 = (c0 + self.pe[:, :, :hw0_c[0], :hw0_c[1]]).flatten(2).transpose(1, 2).contiguous()
+            f1 = (c1 + self.pe[:, :, :hw1_c[0], :hw1_c[1]]).flatten(2).transpose(1, 2).contiguous()
         f0, f1 = self._transformer(f0, f1, P)
         return f0, f1, hw0_c, hw1_c
+
+    def _pe_tokens(self, hw):
+        """Positional encoding in token-major layout [h*w, C] (cached per grid size)."""
+        cache = self.__dict__.setdefault("_pe_cache", {})
+        key = (hw, self.pe.device)
+        if key not in cache:
+            cache[key] = self.pe[0, :, :hw[0], :hw[1]].permute(1, 2, 0).reshape(hw[0] * hw[1], -1).contiguous()
+        return cache[key]
 
     @torch.no_grad()
     def forward(self, data: dict):

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(
     const float* __restrict__ feat, int C, int H, int W, const float* __restrict__ boxes,
     const int32_t* __restrict__ box_ind, const int64_t* __restrict__ out_slot, int crop_h, int crop_w,
     float extrapolation, const float* __restrict__ mean, const float* __restrict__ stdv,
-    float* __restrict__ out) {
+    float* __restrict__ out, int out_nhwc) {
     __shared__ float s_y[MAX_CROP], s_x[MAX_CROP];
     const int m = blockIdx.x;
     const float bx1 = boxes[m * 4 + 0], by1 = boxes[m * 4 + 1];
@@ -61,7 +61,14 @@ __global__ __launch_bounds__(256) void roi_align_kernel(
     float* o = out + slot * C * crop_h * crop_w;
     const int plane = crop_h * crop_w, total = C * plane;
     for (int idx = tid; idx < total; idx += blockDim.x) {
-        const int c = idx / plane, rem = idx - c * plane;
+        int c, rem;
+        if (out_nhwc) {            // [crop_h, crop_w, C]: channel fastest (feeds the NHWC conv kernels)
+            rem = idx / C;
+            c = idx - rem * C;
+        } else {                   // [C, crop_h, crop_w]
+            c = idx / plane;
+            rem = idx - c * plane;
+        }
         const int iy = rem / crop_w, ix = rem - iy * crop_w;
         const float in_y = s_y[iy], in_x = s_x[ix];
         float val = extrapolation;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(
 extern "C" int dfsfm_roi_align_f32(const float* feat, int Nimg, int C, int H, int W, const float* boxes,
                                    const int32_t* box_ind, const int64_t* out_slot, int M, int crop_h,
                                    int crop_w, float extrapolation_value, const float* mean,
-                                   const float* std, float* out, void* stream_) {
+                                   const float* std, float* out, int out_channels_last, void* stream_) {
     if (M == 0) return DFSFM_OK;
     if (!feat || !boxes || !out) return DFSFM_E_BADARG;
     if (Nimg <= 0 || C <= 0 || H <= 1 || W <= 1 || M < 0 || crop_h <= 0 || crop_w <= 0) return DFSFM_E_BADARG;
@@ -93,6 +100,6 @@ extern "C" int dfsfm_roi_align_f32(const float* feat, int Nimg, int C, int H, in
     if (crop_h > MAX_CROP || crop_w > MAX_CROP) return DFSFM_E_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(roi_align_kernel, dim3(M), dim3(256), 0, stream, feat, C, H, W, boxes, box_ind,
-                       out_slot, crop_h, crop_w, extrapolation_value, mean, std, out);
+                       out_slot, crop_h, crop_w, extrapolation_value, mean, std, out, out_channels_last);
     return dfsfm::check_launch("dfsfm_roi_align_f32");
 }

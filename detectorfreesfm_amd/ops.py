@@ -113,8 +113,9 @@ def coarse_conf_matrix(feat0, feat1, temperature):
 
 
 def roi_align(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapolation_value=0.0,
-              mean=None, std=None, out=None):
-    """K8.  feat [Nimg,C,H,W]; boxes [M,4] (x1,y1,x2,y2); returns / fills out [*,C,crop_h,crop_w]."""
+              mean=None, std=None, out=None, channels_last=False):
+    """K8.  feat [Nimg,C,H,W]; boxes [M,4] (x1,y1,x2,y2); returns / fills out [*,C,crop_h,crop_w]
+    (or [*,crop_h,crop_w,C] with channels_last=True)."""
     _require_cuda(feat, boxes)
     feat = feat.contiguous()
     boxes = boxes.to(torch.float32).contiguous()
@@ -123,12 +124,13 @@ def roi_align(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapol
     if out is None:
         if out_slot is not None:
             raise _lib.DfsfmError("roi_align: out_slot needs a preallocated `out`")
-        out = torch.empty((M, C, crop_h, crop_w), dtype=torch.float32, device=feat.device)
+        shape = (M, crop_h, crop_w, C) if channels_last else (M, C, crop_h, crop_w)
+        out = torch.empty(shape, dtype=torch.float32, device=feat.device)
     bi = None if box_ind is None else box_ind.to(torch.int32).contiguous()
     sl = None if out_slot is None else out_slot.to(torch.int64).contiguous()
     rc = _lib.lib().dfsfm_roi_align_f32(_ptr(feat), Nimg, C, H, W, _ptr(boxes), _ptr(bi), _ptr(sl), M, crop_h,
                                         crop_w, float(extrapolation_value), _ptr(mean), _ptr(std), _ptr(out),
-                                        _stream())
+                                        1 if channels_last else 0, _stream())
     _lib.check(rc, "dfsfm_roi_align_f32")
     return out
 
@@ -210,3 +212,71 @@ def add_scatter_tokens(a, b, slot, dst):
     rc = _lib.lib().dfsfm_add_scatter_tokens_f32(_ptr(a), _ptr(b), _ptr(sl), _ptr(dst), M, C, P, _stream())
     _lib.check(rc, "dfsfm_add_scatter_tokens_f32")
     return dst
+
+
+class PackedDense:
+    """Weights of one conv / linear layer in the layout dfsfm_conv2d_nhwc_f32 consumes:
+    fp16 hi / lo [ceil128(Cout), Kpad], K = kh*kw*Cin in (ky,kx,ci) order, w = hi + lo/2048."""
+
+    def __init__(self, w: torch.Tensor, bias=None):
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        Cout, Cin, kh, kw = w.shape
+        K = kh * kw * Cin
+        self.Cout, self.Cin, self.kh, self.kw = Cout, Cin, kh, kw
+        self.Kpad = (K + 31) // 32 * 32
+        npad = (Cout + 127) // 128 * 128
+        full = torch.zeros((npad, self.Kpad), dtype=torch.float32, device=w.device)
+        full[:Cout, :K] = w.detach().float().permute(0, 2, 3, 1).reshape(Cout, K)
+        hi = torch.where(full.abs() >= 2.0 ** -14, full, torch.zeros_like(full)).half()
+        self.hi = hi.contiguous()
+        self.lo = ((full - hi.float()) * 2048.0).half().contiguous()
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+
+def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, out=None):
+    """K6/K9.  x [N,H,W,Cin] fp32 NHWC (any view with unit channel stride); returns [N,Ho,Wo,Cout].
+    out/residual may be row-strided [.., Cout] views whose leading dims flatten uniformly."""
+    _require_cuda(x)
+    N, H, W, Cin = x.shape
+    if Cin != pw.Cin or x.dtype != torch.float32 or (Cin > 1 and x.stride(3) != 1):
+        raise _lib.DfsfmError("conv2d_nhwc: bad input")
+    Ho = (H + 2 * pad - pw.kh) // stride + 1
+    Wo = (W + 2 * pad - pw.kw) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, pw.Cout), dtype=torch.float32, device=x.device)
+    rows_o, ldo = _rows_ld(out)
+    if rows_o != N * Ho * Wo or out.shape[-1] != pw.Cout:
+        raise _lib.DfsfmError("conv2d_nhwc: out shape mismatch")
+    ldr = 0
+    if residual is not None:
+        rows_r, ldr = _rows_ld(residual)
+        if rows_r != rows_o or residual.shape[-1] != pw.Cout:
+            raise _lib.DfsfmError("conv2d_nhwc: residual shape mismatch")
+    sxn = x.stride(0) if N > 1 else H * x.stride(1)
+    rc = _lib.lib().dfsfm_conv2d_nhwc_f32(_ptr(x), sxn, x.stride(1), x.stride(2), N, H, W, Cin, _ptr(pw.hi),
+                                          _ptr(pw.lo), pw.Cout, pw.Kpad, pw.kh, pw.kw, stride, pad, _ptr(pw.bias),
+                                          _ptr(residual), ldr, 1 if relu else 0, _ptr(out), ldo, _stream())
+    _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
+    return out
+
+
+def linear(x, pw: PackedDense, residual=None, relu=False, out=None):
+    """K2.  x [rows, K] (row-strided view OK) @ W^T (+bias, +residual, relu) -> [rows, Cout]."""
+    rows, ld = _rows_ld(x)
+    x4 = x.as_strided((1, 1, rows, x.shape[-1]), (0, 0, ld, 1))
+    if out is None:
+        out = torch.empty((rows, pw.Cout), dtype=torch.float32, device=x.device)
+    conv2d_nhwc(x4, pw, 1, 0, residual, relu, out.view(-1, pw.Cout) if out.is_contiguous() else out)
+    return out
+
+
+def maxpool3x3s2_nhwc(x):
+    """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor."""
+    _require_cuda(x)
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dfsfm_maxpool3x3s2_nhwc_f32(_ptr(x), N, H, W, C, _ptr(out), _stream())
+    _lib.check(rc, "dfsfm_maxpool3x3s2_nhwc_f32")
+    return out

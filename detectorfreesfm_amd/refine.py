@@ -8,10 +8,12 @@ src/post_optimization/matcher_model/multiview_match_worker.py:16-56: same config
 ``fine_transformer.*``), same in-place ``forward(data)`` contract (``query_points_refined``,
 ``reference_points_refined``, ``std`` -- read by ``extract_results`` :59-82).
 
-Hand-written HIP: RoIAlign patch extraction (K8, with the ImageNet normalisation fused),
-linear attention (K1, D=16) in the four multiview encoder layers (K10), and the fused fine
-correlation / softmax expectation / candidate argmin / refined keypoints (K11+K12).  The S2DNet
-patch CNN (K9) and the nn.Linear GEMMs run on MIOpen / hipBLASLt through PyTorch-ROCm in fp32.
+Hand-written HIP: RoIAlign patch extraction (K8, with the ImageNet normalisation fused, NHWC
+output in (track, view) order), the S2DNet patch CNN (K9) and every nn.Linear (K10) on the
+fp16x2-split MFMA implicit-GEMM kernel with fused bias/BN/ReLU/residual, max pooling, linear
+attention (K1, D=16), LayerNorm + residual, and the fused fine correlation / softmax expectation /
+candidate argmin / refined keypoints (K11+K12).  ``dense_backend="library"`` keeps an explicit
+MIOpen / hipBLASLt fp32 control path for measurement.
 
 Output-identical work the reference wastes is skipped ("dead work"):
 * only the centre (W+4)^2 of relu1_2 feeds adaptation layer 0 (the reference convolves the full
@@ -41,8 +43,14 @@ def _bicubic_rows(n_in: int, n_out: int, lo: int, hi: int) -> torch.Tensor:
 
 
 class HipMultiviewMatcher(ParamModule):
-    def __init__(self, config: dict, test: bool = True, max_backbone_patches: int = 16384, **_unused):
+    def __init__(self, config: dict, test: bool = True, max_backbone_patches: int = 16384,
+                 dense_backend: str = "hip", **_unused):
+        """dense_backend: "hip" (default) = hand-written fp16x2-split MFMA conv / linear kernels on NHWC
+        patches; "library" = MIOpen / hipBLASLt fp32 through PyTorch (explicit measurement control)."""
         super().__init__()
+        if dense_backend not in ("hip", "library"):
+            raise ValueError(dense_backend)
+        self.dense_backend = dense_backend
         if not test:
             raise NotImplementedError("training path is out of scope; build with test=True")
         bb = config["backbone"]
@@ -86,9 +94,42 @@ class HipMultiviewMatcher(ParamModule):
                              ((b5 - g(q + "3.running_mean")) * s + g(q + "3.bias")).contiguous())
         mt = self.config["multiview_transform"]
         n_layers = len(mt["layer_names"]) * mt["layer_iter_n"]
-        P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.") for i in range(n_layers)]
+        P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.", self.dense_backend)
+                       for i in range(n_layers)]
+        if self.dense_backend == "hip":
+            H = {"enc": {i: ops.PackedDense(*P["enc"][i]) for i in P["enc"]}}
+            for i in (0, 1):
+                a = P[f"adap{i}"]
+                H[f"adap{i}"] = (ops.PackedDense(a[0], a[1]), ops.PackedDense(a[2], a[3]))
+            P["hip"] = H
         self._packed = P
         return P
+
+    # -- K9 on the hand-written NHWC kernels: out [m, W*W, C] tokens written straight into `dst` ------
+    def _s2dnet_hip(self, x, P, W, dst):
+        """x [m,crop,crop,3] normalised NHWC patches; dst [m, W*W, od] receives adap0 + bicubic(adap1)."""
+        H = P["hip"]
+        m, crop = x.shape[0], x.shape[1]
+        c, r = crop // 2, W // 2
+        x = ops.conv2d_nhwc(x, H["enc"][0], 1, 1, relu=True)
+        x = ops.conv2d_nhwc(x, H["enc"][2], 1, 1, relu=True)                      # relu1_2 [m,35,35,64]
+        f0 = x[:, c - r - 2:c + r + 3, c - r - 2:c + r + 3, :]                      # centre (W+4)^2 view
+        t = ops.maxpool3x3s2_nhwc(x)
+        t = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["enc"][5], 1, 1, relu=True), H["enc"][7], 1, 1, relu=True)
+        t = ops.maxpool3x3s2_nhwc(t)
+        for i in (10, 12, 14):
+            t = ops.conv2d_nhwc(t, H["enc"][i], 1, 1, relu=True)                   # relu3_3 [m,9,9,256]
+        y1 = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["adap1"][0], 1, 0, relu=True), H["adap1"][1], 1, 2)
+        h4 = y1.shape[1]
+        key = (h4, crop, W)
+        if P.get("bicubic_key") != key:
+            B = _bicubic_rows(h4, crop, c - r, c + r + 1)
+            P["bicubic"] = torch.kron(B, B).contiguous().to(y1.device)           # [W*W, h4*h4]
+            P["bicubic_key"] = key
+        up = torch.bmm(P["bicubic"].expand(m, -1, -1), y1.view(m, h4 * h4, -1))   # [m, W*W, od]
+        a0 = ops.conv2d_nhwc(f0, H["adap0"][0], 1, 0, relu=True)                  # [m,W+4,W+4,64]
+        ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out=dst)           # + hypercolumn sum, fused
+        return dst
 
     # -- K9: S2DNet._forward on normalised patches (s2dnet.py:127-193) ----------------------------
     def _s2dnet(self, x, P, W):
@@ -170,26 +211,51 @@ class HipMultiviewMatcher(ParamModule):
         order = torch.argsort(flat_idx, stable=True)
         per_img = torch.bincount(flat_idx.clamp(min=-1) + 1, minlength=n_img + 1).tolist()   # one sync
         n_pad, per_img = per_img[0], per_img[1:]
-        order = order[n_pad:]
+        order = order[n_pad:]                                                          # valid, grouped by image
         M = order.numel()
         r = crop // 2
         boxes = torch.cat([flat_pts - r, flat_pts + r], dim=-1)[order].contiguous()     # fine_preprocess.py:101-104
         slot = (order % T) * V + order // T                                            # (v t) -> (t v)
-        feats = torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
-        patches = torch.empty((M, 3, crop, crop), dtype=torch.float32, device=dev)
+        hip = self.dense_backend == "hip"
+        if hip:
+            # patch m of the compact list goes to position rank(slot): the CNN then emits features
+            # already in (track, view) order -- no gather afterwards (MultiviewMatcher.py:264-270)
+            by_slot = torch.argsort(slot)
+            pos = torch.empty_like(by_slot)
+            pos[by_slot] = torch.arange(M, device=dev)
+            patches = torch.empty((M, crop, crop, 3), dtype=torch.float32, device=dev)
+        else:
+            pos = None
+            patches = torch.empty((M, 3, crop, crop), dtype=torch.float32, device=dev)
         start = 0
         for ii in range(n_img):
             n = per_img[ii]
             if n == 0:
                 continue
-            ops.roi_align(images[ii], boxes[start:start + n], crop, crop, mean=self._mean, std=self._std,
-                          out=patches[start:start + n])
+            if hip:
+                ops.roi_align(images[ii], boxes[start:start + n], crop, crop, out_slot=pos[start:start + n],
+                              mean=self._mean, std=self._std, out=patches, channels_last=True)
+            else:
+                ops.roi_align(images[ii], boxes[start:start + n], crop, crop, mean=self._mean, std=self._std,
+                              out=patches[start:start + n])
             start += n
-        for s in range(0, M, self.max_backbone_patches):
-            e = min(M, s + self.max_backbone_patches)
-            y0, up = self._s2dnet(patches[s:e], P, W)                                   # 2 x [m,C,WW]
-            ops.add_scatter_tokens(y0, up, slot[s:e], feats)          # (y0+up) 'm c p -> slot p c'
-
+        if hip:
+            dense = n_pad == 0                      # every (track, view) slot is valid: write in place
+            feats = torch.empty((T * V, WW, C), dtype=torch.float32, device=dev) if dense else \
+                torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
+            comp = feats if dense else torch.empty((M, WW, C), dtype=torch.float32, device=dev)
+            for s in range(0, M, self.max_backbone_patches):
+                e = min(M, s + self.max_backbone_patches)
+                self._s2dnet_hip(patches[s:e], P, W, comp[s:e])
+            if not dense:
+                feats.index_copy_(0, slot[by_slot], comp)
+                del comp
+        else:
+            feats = torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
+            for s in range(0, M, self.max_backbone_patches):
+                e = min(M, s + self.max_backbone_patches)
+                y0, up = self._s2dnet(patches[s:e], P, W)                               # 2 x [m,C,WW]
+                ops.add_scatter_tokens(y0, up, slot[s:e], feats)      # (y0+up) 'm c p -> slot p c'
         del patches
         feats = feats.view(T, V, WW, C)
 

@@ -98,12 +98,14 @@ int dfsfm_coarse_conf_matrix_f32(const float* feat0, const float* feat1, int N, 
  * one image's patches straight into (view,track) order, MultiviewMatcher.py:253-266).
  * mean/std [C] or NULL: when given, (value-mean[c])/std[c] is applied to every output
  * (fuses the ImageNet normalisation of S2DNet._forward, backbone/S2DNet/s2dnet.py:132-133).
- * out [*,C,crop_h,crop_w].
+ * out [*,C,crop_h,crop_w], or [*,crop_h,crop_w,C] when out_channels_last != 0 (the layout the
+ * NHWC convolution kernels below consume).
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_roi_align_f32(const float* feat, int Nimg, int C, int H, int W,
                         const float* boxes, const int32_t* box_ind, const int64_t* out_slot, int M,
                         int crop_h, int crop_w, float extrapolation_value,
-                        const float* mean, const float* std, float* out, void* stream);
+                        const float* mean, const float* std, float* out, int out_channels_last,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K11+K12  Fine-window correlation, softmax expectation, best-candidate selection, keypoints
@@ -153,6 +155,30 @@ int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const f
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, const int64_t* slot, float* dst,
                                  int M, int C, int P, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2/K6/K9  Convolution / linear layer, NHWC, implicit GEMM on the fp16 matrix cores with an
+ * fp16x2 operand split (fp32-class accuracy, see csrc/conv_gemm.hip), fused epilogue:
+ *   out[m, co] = act( sum_{ky,kx,ci} x[n, oy*stride+ky-pad, ox*stride+kx-pad, ci] * w[co,ky,kx,ci]
+ *                     + bias[co] + residual[m, co] ),   m = (n*Ho + oy)*Wo + ox
+ * Replaces nn.Conv2d (+ folded eval BatchNorm, ReLU, residual add) of
+ *   third_party/LoFTR/src/loftr/backbone/resnet_fpn.py:15-40,100-118
+ *   src/MultiviewMatcher/backbone/S2DNet/s2dnet.py:24-52,127-175
+ * and, as the 1x1 case with Nimg=1,H=1,W=rows, nn.Linear of the encoder layers
+ *   third_party/LoFTR/src/loftr/loftr_module/transformer.py:21-31,42-55.
+ * x element (n,y,x,c) at x[n*sxn + y*sxh + x*ldx + c] (any NHWC view, e.g. a centre crop or a
+ * column slice); w_hi/w_lo: fp16 [ceil128(Cout)][Kpad] with K = kh*kw*Cin in (ky,kx,ci) order,
+ * zero padded, Kpad % 32 == 0, w = w_hi + w_lo/2048 (hi = 0 where |w| < 2^-14);
+ * bias [Cout] or NULL; residual [M, Cout] with row stride ldr or NULL; out row stride ldo.
+ * ---------------------------------------------------------------------------------------- */
+int dfsfm_conv2d_nhwc_f32(const float* x, int64_t sxn, int64_t sxh, int64_t ldx, int Nimg, int H, int W,
+                          int Cin, const void* w_hi, const void* w_lo, int Cout, int Kpad, int kh, int kw,
+                          int stride, int pad, const float* bias, const float* residual, int64_t ldr,
+                          int relu, float* out, int64_t ldo, void* stream);
+
+/* nn.MaxPool2d(3, stride=2, padding=1) on a dense NHWC tensor (S2DNet with
+ * substitute_pooling_layers, backbone/S2DNet/s2dnet.py:89-92).  C % 4 == 0. */
+int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, int Nimg, int H, int W, int C, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,11 +20,13 @@ def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale
 
 
 def _roi(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapolation_value=0.0, mean=None,
-         std=None, out=None):
+         std=None, out=None, channels_last=False):
     bi = torch.zeros(boxes.shape[0], dtype=torch.int32) if box_ind is None else box_ind
     p = restate.roi_align_crop(feat, boxes, bi, crop_h, crop_w, extrapolation_value)
     if mean is not None:
         p = (p - mean[:, None, None]) / std[:, None, None]
+    if channels_last:
+        p = p.permute(0, 2, 3, 1).contiguous()
     if out is None:
         return p
     if out_slot is None:
@@ -69,13 +71,58 @@ def _scatter(a, b, slot, dst):
     return dst
 
 
+def _split(x):
+    hi = torch.where(x.abs() >= 2.0 ** -14, x, torch.zeros_like(x)).half().float()
+    return hi, ((x - hi) * 2048.0).half().float()
+
+
+def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None):
+    """Exact algebra of dfsfm_conv2d_nhwc_f32: fp16x2 split of both operands, three products."""
+    import torch.nn.functional as F
+    K = pw.kh * pw.kw * pw.Cin
+
+    def unpack(t):
+        return t[:pw.Cout, :K].float().reshape(pw.Cout, pw.kh, pw.kw, pw.Cin).permute(0, 3, 1, 2).contiguous()
+    wh, wl = unpack(pw.hi), unpack(pw.lo)
+    xh, xl = _split(x.permute(0, 3, 1, 2))
+    y = F.conv2d(xh, wh, None, stride, pad) + (F.conv2d(xh, wl, None, stride, pad) + F.conv2d(xl, wh, None, stride, pad)) / 2048.0
+    y = y.permute(0, 2, 3, 1)
+    if pw.bias is not None:
+        y = y + pw.bias
+    if residual is not None:
+        y = y + residual.reshape(y.shape)
+    if relu:
+        y = torch.relu(y)
+    if out is None:
+        return y.contiguous()
+    out.copy_(y.reshape(out.shape))
+    return out
+
+
+def _linear(x, pw, residual=None, relu=False, out=None):
+    rows = x.reshape(-1, x.shape[-1])
+    y = _conv(rows[None, None], pw, 1, 0, None if residual is None else residual.reshape(1, 1, rows.shape[0], -1), relu)
+    y = y.reshape(rows.shape[0], pw.Cout)
+    if out is None:
+        return y
+    out.copy_(y.reshape(out.shape))
+    return out
+
+
+def _maxpool(x):
+    import torch.nn.functional as F
+    return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+
+
 @contextlib.contextmanager
 def cpu_ops():
     from detectorfreesfm_amd import ops
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
-                                          "layernorm", "add_scatter_tokens")}
+                                          "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
+                                          "maxpool3x3s2_nhwc")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
+    ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
     try:
         yield
     finally:
