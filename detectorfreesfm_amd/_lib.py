@@ -41,9 +41,11 @@ SIGNATURES = [
      [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     ("dfsfm_add_scatter_tokens_f32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("dfsfm_conv2d_nhwc_f32", c_int,
-     [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-      c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
-    ("dfsfm_maxpool3x3s2_nhwc_f32", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+     [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+      c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    ("dfsfm_maxpool3x3s2_nhwc_f32", c_int,
+     [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 ]
 
 _lib = None

@@ -173,13 +173,16 @@ class HipLoFTR(ParamModule):
         n_layers = len(self.config["coarse"]["layer_names"])
         P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.", self.dense_backend) for i in range(n_layers)]
         if self.dense_backend == "hip":
-            H = {"stem": ops.PackedDense(*P["stem"]), "l3out": ops.PackedDense(P["l3out"])}
+            def pk(wb, split_in=True):    # weights for a conv whose input arrives as a SplitAct
+                w, b = wb if isinstance(wb, tuple) else (wb, None)
+                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None)
+            H = {"stem": pk(P["stem"], split_in=False), "l3out": pk(P["l3out"])}
             for li in (1, 2, 3):
                 for bi in (0, 1):
                     b = P[f"l{li}b{bi}"]
-                    hb = {"c1": ops.PackedDense(*b["c1"]), "c2": ops.PackedDense(*b["c2"]), "stride": b["stride"]}
+                    hb = {"c1": pk(b["c1"]), "c2": pk(b["c2"]), "stride": b["stride"]}
                     if "down" in b:
-                        hb["down"] = ops.PackedDense(*b["down"])
+                        hb["down"] = pk(b["down"])
                     H[f"l{li}b{bi}"] = hb
             P["hip"] = H
         self._packed = P
@@ -187,20 +190,21 @@ class HipLoFTR(ParamModule):
 
     # -- K6 on the hand-written NHWC implicit-GEMM kernel (conv + folded BN + ReLU + residual fused) --
     def _backbone_hip(self, x, P):
-        """x [N,1,H,W] -> coarse feature map as tokens [N, H/8*W/8, C] (NHWC == token-major)."""
+        """x [N,1,H,W] -> coarse feature map as tokens [N, H/8, W/8, C] (NHWC == token-major).
+        Activations between convolutions travel as split fp16 planes (ops.SplitAct): the producer's
+        epilogue splits once, consumers DMA the planes straight into LDS."""
         H = P["hip"]
         t = x.permute(0, 2, 3, 1)                       # C=1: NCHW memory is already NHWC
-        t = ops.conv2d_nhwc(t, H["stem"], 2, 3, relu=True)
+        t = ops.conv2d_nhwc(t, H["stem"], 2, 3, relu=True, out_split=True)
         for li in (1, 2, 3):
             for bi in (0, 1):
                 b = H[f"l{li}b{bi}"]
-                y = ops.conv2d_nhwc(t, b["c1"], b["stride"], 1, relu=True)
-                sc = ops.conv2d_nhwc(t, b["down"], b["stride"], 0) if "down" in b else t
-                t = ops.conv2d_nhwc(y, b["c2"], 1, 1, residual=sc, relu=True)
-        t = ops.conv2d_nhwc(t, H["l3out"], 1, 0)
-        return t
+                y = ops.conv2d_nhwc(t, b["c1"], b["stride"], 1, relu=True, out_split=True)
+                sc = ops.conv2d_nhwc(t, b["down"], b["stride"], 0, out_split=True) if "down" in b else t
+                t = ops.conv2d_nhwc(y, b["c2"], 1, 1, residual=sc, relu=True, out_split=True)
+        return ops.conv2d_nhwc(t, H["l3out"], 1, 0)     # fp32 tokens for the transformer
 
-    # -- K6: local-feature CNN (ResNetFPN_8_2.forward, resnet_fpn.py:100-118) -------------------
+    # -- K6, library control path: MIOpen fp32 convs (ResNetFPN_8_2.forward, resnet_fpn.py:100-118) ----
     def _backbone(self, x, P):
         def block(t, b):
             y = F.relu_(F.conv2d(t, b["c1"][0], b["c1"][1], b["stride"], 1))

@@ -37,15 +37,29 @@ constexpr int STAGE_B = 4 * TILE_B;                 // A_hi, A_lo, B_hi, B_lo
 constexpr int SMEM_BYTES = 2 * STAGE_B;             // double buffered: 64 KB
 
 struct ConvArgs {
-    const float* x;          // NHWC input: element (n,y,x,c) at n*sxn + y*sxh + x*ldx + c (floats)
+    const float* x;          // fp32 NHWC input: element (n,y,x,c) at n*sxn + y*sxh + x*ldx + c
+    const _Float16* xh;      // ... or the same tensor pre-split into fp16 hi / lo planes (same strides,
+    const _Float16* xl;      //     in elements); x = xh + xl / 2048
     const _Float16* wh;      // [Npad][Kpad]
     const _Float16* wl;
     const float* bias;       // [Cout] or null
-    const float* res;        // [M][ldr] or null
-    float* out;              // [M][ldo]
-    int64_t ldx, sxh, sxn, ldr, ldo, M;
-    int H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, K, Kpad, relu;
+    const float* res;        // residual [M][ldr] fp32, or split planes resh/resl, or none
+    const _Float16* resh;
+    const _Float16* resl;
+    float* out;              // [M][ldo] fp32 and/or split planes outh/outl [M][ldo_s] (Cout_s channels,
+    _Float16* outh;          //     channels >= Cout written as zeros)
+    _Float16* outl;
+    int64_t ldx, sxh, sxn, ldr, ldo, ldo_s, M;
+    int H, W, Cin, Ho, Wo, Cout, Cout_s, kh, kw, stride, pad, K, Kpad, relu;
+    unsigned xbytes;         // byte size of one input plane (buffer-descriptor bound, v2 kernel)
+    unsigned wbytes;
 };
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)x : (_Float16)0.f;
+    hi = h;
+    lo = (_Float16)((x - (float)h) * 2048.f);
+}
 
 __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
 #pragma unroll
@@ -223,19 +237,248 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wc * 64 + j * 32 + col;
-            if (n >= g.Cout) continue;
-            const float b = g.bias ? g.bias[n] : 0.f;
+            const float b = (g.bias && n < g.Cout) ? g.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, kgrp);
-                if (m < g.M) {
-                    float v = accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f) + b;
+                if (m >= g.M) continue;
+                float v = 0.f;
+                if (n < g.Cout) {
+                    v = accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f) + b;
                     if (g.res) v += g.res[m * g.ldr + n];
+                    if (g.resh) v += (float)g.resh[m * g.ldr + n] + (float)g.resl[m * g.ldr + n] * (1.f / 2048.f);
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.out[m * g.ldo + n] = v;
+                    if (g.out) g.out[m * g.ldo + n] = v;
+                }
+                if (g.outh && n < g.Cout_s) {
+                    _Float16 h, l;
+                    split1(v, h, l);
+                    g.outh[m * g.ldo_s + n] = h;
+                    g.outl[m * g.ldo_s + n] = l;
                 }
             }
         }
+}
+
+// =================================================================================================
+// v2: pre-split activations, LDS-DMA pipeline.  256 x BN tile, 8 waves (4 x 2, 64 x BN/2 each),
+// BK=32, THREE LDS stages filled by buffer_load ... lds (16 B/lane, no VGPR round trip, no VALU):
+// slab kt+2 is in flight while slab kt is multiplied; counted s_waitcnt vmcnt + raw s_barrier keep
+// the DMA queue alive across barriers (MI355X guide: T3/T4, "pipelining across barriers").
+// Out-of-image taps / rows past M use an out-of-range buffer offset, which the hardware
+// zero-fills.  The epilogue stages the tile through LDS so every store is 16-32 bytes per lane.
+// =================================================================================================
+constexpr int BM2 = 256, NST = 3;
+
+template <int BN_>
+struct V2 {
+    static constexpr int A_PLANE = BM2 * 64;                 // bytes: 256 rows x 32 halves
+    static constexpr int B_PLANE = BN_ * 64;
+    static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    static constexpr int RING = NST * STAGE;
+    static constexpr int B_INSTR = (BN_ / 16) * 2 / 8;       // B LDS-DMA instructions per wave per slab
+    static constexpr int G = 4 + B_INSTR;                    // LDS-DMA instructions per wave per slab
+    static constexpr int TILE_LD = BN_ + 4;                  // fp32 epilogue tile row (floats)
+    static constexpr int SMEM = (RING > BM2 * TILE_LD * 4) ? RING : BM2 * TILE_LD * 4;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BN_>
+__global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
+    using T = V2<BN_>;
+    constexpr int NJ = BN_ / 64;                              // 32-wide column tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kgrp = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM2;
+    const int n0 = blockIdx.y * BN_;
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.wh, 0, g.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
+
+    // lane -> (row within a 16-row group, 16-byte k-slot); XOR swizzle applied on the SOURCE side
+    const int lrow = lane >> 2;
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);        // logical slot of this lane (all groups)
+    // two activation rows per lane: groups `wave` and `wave + 8`
+    int iy0[2], ix0[2];
+    unsigned abase[2];
+    bool aok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t m = m0 + (wave + 8 * q) * 16 + lrow;
+        aok[q] = m < g.M;
+        const int64_t mm = aok[q] ? m : 0;
+        const int ox = (int)(mm % g.Wo);
+        const int64_t t = mm / g.Wo;
+        const int oy = (int)(t % g.Ho);
+        const int64_t n = t / g.Ho;
+        iy0[q] = oy * g.stride - g.pad;
+        ix0[q] = ox * g.stride - g.pad;
+        abase[q] = (unsigned)(n * g.sxn);
+    }
+    // running decomposition of this lane's k index (advances by BK per slab)
+    int ci = lslot * 8, ky = 0, kx = 0, kcur = lslot * 8;
+    while (ci >= g.Cin) { ci -= g.Cin; if (++kx == g.kw) { kx = 0; ++ky; } }
+    unsigned boff = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);   // + group*16 rows, + k0
+
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        char* st = smem + stage * T::STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+            const bool ok = aok[q] && kcur < g.K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const unsigned off = ok ? (abase[q] + (unsigned)iy * (unsigned)g.sxh + (unsigned)ix * (unsigned)g.ldx + (unsigned)ci) * 2u
+                                    : g.xbytes;             // out of range -> hardware writes zeros
+            const int grp = wave + 8 * q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(st + grp * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(st + T::A_PLANE + grp * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < T::B_INSTR; ++j) {
+            const int ib = wave + 8 * j;
+            const int plane = ib / (BN_ / 16), grp = ib % (BN_ / 16);
+            const unsigned off = boff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane ? rwl : rwh,
+                                                     (lds_void*)(st + 2 * T::A_PLANE + plane * T::B_PLANE + grp * 1024),
+                                                     16, off, 0, 0, 0);
+        }
+        // advance this lane's k bookkeeping to the next slab
+        kcur += BK;
+        boff += BK * 2;
+        ci += BK;
+        while (ci >= g.Cin) { ci -= g.Cin; if (++kx == g.kw) { kx = 0; ++ky; } }
+    };
+
+    f32x16 accm[2][NJ], accx[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            accm[i][j] = f32x16{0};
+            accx[i][j] = f32x16{0};
+        }
+
+    const int nk = g.Kpad / BK;
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<T::G>(); else wait_vmcnt<0>();   // slab kt has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                                 // ... and everybody else's
+        if (kt + 2 < nk) issue((kt + 2) % NST);
+        const char* st = smem + (kt % NST) * T::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = tile_off(wr * 64 + i * 32 + col, ks * 2 + kgrp);
+                ah[i] = *reinterpret_cast<const half8*>(st + off);
+                al[i] = *reinterpret_cast<const half8*>(st + T::A_PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
+                bh[j] = *reinterpret_cast<const half8*>(st + 2 * T::A_PLANE + off);
+                bl[j] = *reinterpret_cast<const half8*>(st + 2 * T::A_PLANE + T::B_PLANE + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue through LDS: tile[row][col] fp32, then 8 channels per thread ---------------------
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * T::TILE_LD + wc * (BN_ / 2) + j * 32 + col] =
+                    accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
+    __syncthreads();
+    constexpr int CH = BN_ / 8;                               // 8-channel chunks per row
+    for (int e = tid; e < BM2 * CH; e += 512) {
+        const int r = e / CH, c8 = (e % CH) * 8;
+        const int64_t m = m0 + r;
+        const int n = n0 + c8;
+        if (m >= g.M || (n >= g.Cout && n >= g.Cout_s)) continue;
+        float v[8];
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8 + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = t0[q]; v[4 + q] = t1[q]; }
+        const bool full = n + 8 <= g.Cout;
+        if (full) {
+            if (g.bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += g.bias[n + q];
+            }
+            if (g.res) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+            }
+            if (g.resh) {
+                const half8 rh = *reinterpret_cast<const half8*>(g.resh + m * g.ldr + n);
+                const half8 rl = *reinterpret_cast<const half8*>(g.resl + m * g.ldr + n);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += (float)rh[q] + (float)rl[q] * (1.f / 2048.f);
+            }
+        } else {   // chunk straddles Cout (e.g. 196 = 24*8 + 4): per-channel guards
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (n + q < g.Cout) {
+                    if (g.bias) v[q] += g.bias[n + q];
+                    if (g.res) v[q] += g.res[m * g.ldr + n + q];
+                    if (g.resh) v[q] += (float)g.resh[m * g.ldr + n + q] + (float)g.resl[m * g.ldr + n + q] * (1.f / 2048.f);
+                } else {
+                    v[q] = 0.f;
+                }
+            }
+        }
+        if (g.relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (g.out) {
+            if (full) {
+                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (n + q < g.Cout) g.out[m * g.ldo + n + q] = v[q];
+            }
+        }
+        if (g.outh && n < g.Cout_s) {          // Cout_s % 8 == 0: whole chunk, padded channels are zeros
+            half8 h, l;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                _Float16 a, b;
+                split1(v[q], a, b);
+                h[q] = a;
+                l[q] = b;
+            }
+            *reinterpret_cast<half8*>(g.outh + m * g.ldo_s + n) = h;
+            *reinterpret_cast<half8*>(g.outl + m * g.ldo_s + n) = l;
+        }
+    }
 }
 
 // 3x3 / stride 2 / pad 1 max pooling, NHWC (nn.MaxPool2d(3, 2, 1), s2dnet.py:89-92)
@@ -266,29 +509,121 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
     *reinterpret_cast<f32x4*>(y + ((n * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
 }
 
+// max pooling on split activations: reconstruct hi + lo/2048, take the max, split again
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_sf_kernel(const _Float16* __restrict__ xh,
+                                                                   const _Float16* __restrict__ xl,
+                                                                   _Float16* __restrict__ yh, _Float16* __restrict__ yl,
+                                                                   int H, int W, int C, int Ho, int Wo, int64_t total8) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total8) return;
+    const int c8 = (int)(e % (C / 8));
+    int64_t t = e / (C / 8);
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int64_t n = t / Ho;
+    float m[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const int64_t o = ((n * H + iy) * W + ix) * C + c8 * 8;
+            const half8 h = *reinterpret_cast<const half8*>(xh + o);
+            const half8 l = *reinterpret_cast<const half8*>(xl + o);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)h[q] + (float)l[q] * (1.f / 2048.f));
+        }
+    }
+    half8 oh, ol;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        _Float16 a, b;
+        split1(m[q], a, b);
+        oh[q] = a;
+        ol[q] = b;
+    }
+    const int64_t o = ((n * Ho + oy) * Wo + ox) * C + c8 * 8;
+    *reinterpret_cast<half8*>(yh + o) = oh;
+    *reinterpret_cast<half8*>(yl + o) = ol;
+}
+
+template <int BN_>
+void launch_v2(const ConvArgs& g, hipStream_t stream) {
+    using T = V2<BN_>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_sf_kernel<BN_>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((g.M + BM2 - 1) / BM2), (unsigned)((g.Cout + BN_ - 1) / BN_));
+    hipLaunchKernelGGL(conv_gemm_sf_kernel<BN_>, grid, dim3(512), T::SMEM, stream, g);
+}
+
 }  // namespace
 
-extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, int64_t sxn, int64_t sxh, int64_t ldx, int Nimg, int H, int W,
-                                     int Cin,
-                                     const void* w_hi, const void* w_lo, int Cout, int Kpad, int kh, int kw,
-                                     int stride, int pad, const float* bias, const float* residual, int64_t ldr,
-                                     int relu, float* out, int64_t ldo, void* stream_) {
-    if (!x || !w_hi || !w_lo || !out) return DFSFM_E_BADARG;
+extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
+                                     int64_t ldx, int Nimg, int H, int W, int Cin, const void* w_hi,
+                                     const void* w_lo, int Cout, int Kpad, int kh, int kw, int stride, int pad,
+                                     const float* bias, const float* residual, const void* res_hi,
+                                     const void* res_lo, int64_t ldr, int relu, float* out, int64_t ldo,
+                                     void* out_hi, void* out_lo, int64_t ldo_s, int Cout_s, void* stream_) {
+    const bool split_in = x_hi != nullptr;
+    if ((!x && !split_in) || (x && split_in) || (split_in && !x_lo) || !w_hi || !w_lo) return DFSFM_E_BADARG;
+    if (!out && !out_hi) return DFSFM_E_BADARG;
+    if ((out_hi == nullptr) != (out_lo == nullptr) || (res_hi == nullptr) != (res_lo == nullptr)) return DFSFM_E_BADARG;
+    if (residual && res_hi) return DFSFM_E_BADARG;
     if (Nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
         return DFSFM_E_BADARG;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return DFSFM_E_BADARG;
     const int K = kh * kw * Cin;
-    if (Kpad < K || Kpad % BK != 0 || ldx < Cin || ldo < Cout || (residual && ldr < Cout)) return DFSFM_E_BADARG;
-    const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && (sxh % 4 == 0) && (sxn % 4 == 0) &&
-                     !(reinterpret_cast<uintptr_t>(x) & 15);
+    if (Kpad < K || Kpad % BK != 0 || ldx < Cin || (out && ldo < Cout) || ((residual || res_hi) && ldr < Cout))
+        return DFSFM_E_BADARG;
+    if (out_hi && (Cout_s < Cout || Cout_s % 8 != 0 || ldo_s < Cout_s || Cout_s > (Cout + 127) / 128 * 128))
+        return DFSFM_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(w_hi) & 15) || (reinterpret_cast<uintptr_t>(w_lo) & 15)) return DFSFM_E_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    ConvArgs g;
-    g.x = x; g.wh = static_cast<const _Float16*>(w_hi); g.wl = static_cast<const _Float16*>(w_lo);
-    g.bias = bias; g.res = residual; g.out = out; g.ldx = ldx; g.sxh = sxh; g.sxn = sxn; g.ldr = ldr; g.ldo = ldo;
+    ConvArgs g{};
+    g.x = x; g.xh = static_cast<const _Float16*>(x_hi); g.xl = static_cast<const _Float16*>(x_lo);
+    g.wh = static_cast<const _Float16*>(w_hi); g.wl = static_cast<const _Float16*>(w_lo);
+    g.bias = bias; g.res = residual; g.resh = static_cast<const _Float16*>(res_hi);
+    g.resl = static_cast<const _Float16*>(res_lo);
+    g.out = out; g.outh = static_cast<_Float16*>(out_hi); g.outl = static_cast<_Float16*>(out_lo);
+    g.ldx = ldx; g.sxh = sxh; g.sxn = sxn; g.ldr = ldr; g.ldo = ldo; g.ldo_s = ldo_s;
     g.M = (int64_t)Nimg * Ho * Wo; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout;
+    g.Cout_s = out_hi ? Cout_s : 0;
     g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad; g.K = K; g.Kpad = Kpad; g.relu = relu;
+
+    if (split_in) {
+        // v2: LDS-DMA pipeline.  Needs 8-channel granularity and < 4 GiB planes (32-bit buffer offsets).
+        const int64_t span = ((int64_t)(Nimg - 1) * sxn + (int64_t)(H - 1) * sxh + (int64_t)(W - 1) * ldx + Cin) * 2;
+        const int npad = (Cout + 127) / 128 * 128;
+        const int64_t wspan = (int64_t)npad * Kpad * 2;
+        if (Cin % 8 || ldx % 8 || sxh % 8 || sxn % 8 || span >= (int64_t)0xFFFFFFF0 || wspan >= (int64_t)0xFFFFFFF0)
+            return DFSFM_E_UNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(x_hi) & 15) || (reinterpret_cast<uintptr_t>(x_lo) & 15)) return DFSFM_E_UNSUPPORTED;
+        if (out && ((ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))) return DFSFM_E_UNSUPPORTED;
+        if (residual && ((ldr & 3) || (reinterpret_cast<uintptr_t>(residual) & 15))) return DFSFM_E_UNSUPPORTED;
+        if (res_hi && ((ldr & 7) || (reinterpret_cast<uintptr_t>(res_hi) & 15) || (reinterpret_cast<uintptr_t>(res_lo) & 15)))
+            return DFSFM_E_UNSUPPORTED;
+        if (out_hi && ((ldo_s & 7) || (reinterpret_cast<uintptr_t>(out_hi) & 15) || (reinterpret_cast<uintptr_t>(out_lo) & 15)))
+            return DFSFM_E_UNSUPPORTED;
+        g.xbytes = (unsigned)span;
+        g.wbytes = (unsigned)wspan;
+        if (Cout <= 64) launch_v2<64>(g, stream);
+        else launch_v2<128>(g, stream);
+        return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(v2)");
+    }
+
+    const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && (sxh % 4 == 0) && (sxn % 4 == 0) &&
+                     !(reinterpret_cast<uintptr_t>(x) & 15);
     const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((Cout + BN - 1) / BN)), blk(256);
     static bool attr_set[2] = {false, false};
     if (vec) {
@@ -309,13 +644,25 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, int64_t sxn, int64_t sxh, i
     return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32");
 }
 
-extern "C" int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, int Nimg, int H, int W, int C, float* out, void* stream_) {
-    if (!x || !out || Nimg <= 0 || H <= 0 || W <= 0 || C <= 0) return DFSFM_E_BADARG;
+extern "C" int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int Nimg, int H, int W,
+                                           int C, float* out, void* out_hi, void* out_lo, void* stream_) {
+    if (Nimg <= 0 || H <= 0 || W <= 0 || C <= 0) return DFSFM_E_BADARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (x_hi) {
+        if (!x_lo || !out_hi || !out_lo) return DFSFM_E_BADARG;
+        if (C % 8 != 0) return DFSFM_E_UNSUPPORTED;
+        const int64_t total8 = (int64_t)Nimg * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL(maxpool3x3s2_nhwc_sf_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
+                           static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), H, W, C, Ho, Wo, total8);
+        return dfsfm::check_launch("dfsfm_maxpool3x3s2_nhwc_f32(split)");
+    }
+    if (!x || !out) return DFSFM_E_BADARG;
     if (C % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
         return DFSFM_E_UNSUPPORTED;
-    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total4 = (int64_t)Nimg * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), x, out, H, W, C, Ho, Wo, total4);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x, out,
+                       H, W, C, Ho, Wo, total4);
     return dfsfm::check_launch("dfsfm_maxpool3x3s2_nhwc_f32");
 }

@@ -214,51 +214,104 @@ def add_scatter_tokens(a, b, slot, dst):
     return dst
 
 
+class SplitAct:
+    """Activation tensor in the split form the conv kernel DMAs straight into LDS:
+    value = hi + lo/2048 with fp16 planes hi, lo of shape [N,H,W,Cpad]; channels >= C are zeros."""
+
+    def __init__(self, hi, lo, C):
+        self.hi, self.lo, self.C = hi, lo, C
+
+    @property
+    def shape(self):
+        return (*self.hi.shape[:3], self.C)
+
+    @staticmethod
+    def empty(N, H, W, C, device):
+        cpad = (C + 7) // 8 * 8
+        return SplitAct(torch.empty((N, H, W, cpad), dtype=torch.float16, device=device),
+                        torch.empty((N, H, W, cpad), dtype=torch.float16, device=device), C)
+
+    def crop(self, y0, y1, x0, x1):
+        return SplitAct(self.hi[:, y0:y1, x0:x1], self.lo[:, y0:y1, x0:x1], self.C)
+
+    def float(self):
+        """Exact fp32 value (test/debug aid)."""
+        return (self.hi.float() + self.lo.float() / 2048.0)[..., :self.C]
+
+
 class PackedDense:
     """Weights of one conv / linear layer in the layout dfsfm_conv2d_nhwc_f32 consumes:
-    fp16 hi / lo [ceil128(Cout), Kpad], K = kh*kw*Cin in (ky,kx,ci) order, w = hi + lo/2048."""
+    fp16 hi / lo [ceil128(Cout), Kpad], K = kh*kw*Cin_pad in (ky,kx,ci) order, w = hi + lo/2048.
+    ``cin_pad`` (>= Cin, multiple of 8) matches the channel padding of a SplitAct input."""
 
-    def __init__(self, w: torch.Tensor, bias=None):
+    def __init__(self, w: torch.Tensor, bias=None, cin_pad=None):
         if w.dim() == 2:
             w = w[:, :, None, None]
         Cout, Cin, kh, kw = w.shape
-        K = kh * kw * Cin
-        self.Cout, self.Cin, self.kh, self.kw = Cout, Cin, kh, kw
+        cp = Cin if cin_pad is None else cin_pad
+        K = kh * kw * cp
+        self.Cout, self.Cin, self.kh, self.kw = Cout, cp, kh, kw
         self.Kpad = (K + 31) // 32 * 32
         npad = (Cout + 127) // 128 * 128
+        wk = torch.zeros((Cout, kh, kw, cp), dtype=torch.float32, device=w.device)
+        wk[..., :Cin] = w.detach().float().permute(0, 2, 3, 1)
         full = torch.zeros((npad, self.Kpad), dtype=torch.float32, device=w.device)
-        full[:Cout, :K] = w.detach().float().permute(0, 2, 3, 1).reshape(Cout, K)
+        full[:Cout, :K] = wk.reshape(Cout, K)
         hi = torch.where(full.abs() >= 2.0 ** -14, full, torch.zeros_like(full)).half()
         self.hi = hi.contiguous()
         self.lo = ((full - hi.float()) * 2048.0).half().contiguous()
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 
-def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, out=None):
-    """K6/K9.  x [N,H,W,Cin] fp32 NHWC (any view with unit channel stride); returns [N,Ho,Wo,Cout].
-    out/residual may be row-strided [.., Cout] views whose leading dims flatten uniformly."""
-    _require_cuda(x)
-    N, H, W, Cin = x.shape
-    if Cin != pw.Cin or x.dtype != torch.float32 or (Cin > 1 and x.stride(3) != 1):
+def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, out=None, out_split=False):
+    """K6/K9.  x: fp32 [N,H,W,Cin] NHWC view, or a SplitAct.  residual: fp32 [.., Cout] view or SplitAct.
+    Returns fp32 [N,Ho,Wo,Cout] (or fills ``out``), or a SplitAct when ``out_split``."""
+    split_in = isinstance(x, SplitAct)
+    xt = x.hi if split_in else x
+    _require_cuda(xt)
+    N, H, W, Cin = xt.shape
+    want = torch.float16 if split_in else torch.float32
+    if Cin != pw.Cin or xt.dtype != want or (Cin > 1 and xt.stride(3) != 1):
         raise _lib.DfsfmError("conv2d_nhwc: bad input")
+    if split_in and (x.lo.shape != x.hi.shape or x.lo.stride() != x.hi.stride()):
+        raise _lib.DfsfmError("conv2d_nhwc: hi/lo planes differ")
     Ho = (H + 2 * pad - pw.kh) // stride + 1
     Wo = (W + 2 * pad - pw.kw) // stride + 1
-    if out is None:
-        out = torch.empty((N, Ho, Wo, pw.Cout), dtype=torch.float32, device=x.device)
-    rows_o, ldo = _rows_ld(out)
-    if rows_o != N * Ho * Wo or out.shape[-1] != pw.Cout:
-        raise _lib.DfsfmError("conv2d_nhwc: out shape mismatch")
+    dev = xt.device
+    o32 = oh = ol = None
+    ldo = ldo_s = cout_s = 0
+    result = None
+    if out_split:
+        result = SplitAct.empty(N, Ho, Wo, pw.Cout, dev)
+        oh, ol, cout_s, ldo_s = result.hi, result.lo, result.hi.shape[-1], result.hi.shape[-1]
+    else:
+        if out is None:
+            out = torch.empty((N, Ho, Wo, pw.Cout), dtype=torch.float32, device=dev)
+        rows_o, ldo = _rows_ld(out)
+        if rows_o != N * Ho * Wo or out.shape[-1] != pw.Cout:
+            raise _lib.DfsfmError("conv2d_nhwc: out shape mismatch")
+        o32, result = out, out
+    r32 = rh = rl = None
     ldr = 0
     if residual is not None:
-        rows_r, ldr = _rows_ld(residual)
-        if rows_r != rows_o or residual.shape[-1] != pw.Cout:
-            raise _lib.DfsfmError("conv2d_nhwc: residual shape mismatch")
-    sxn = x.stride(0) if N > 1 else H * x.stride(1)
-    rc = _lib.lib().dfsfm_conv2d_nhwc_f32(_ptr(x), sxn, x.stride(1), x.stride(2), N, H, W, Cin, _ptr(pw.hi),
-                                          _ptr(pw.lo), pw.Cout, pw.Kpad, pw.kh, pw.kw, stride, pad, _ptr(pw.bias),
-                                          _ptr(residual), ldr, 1 if relu else 0, _ptr(out), ldo, _stream())
+        if isinstance(residual, SplitAct):
+            rh, rl = residual.hi, residual.lo
+            if not rh.is_contiguous() or rh.numel() != N * Ho * Wo * rh.shape[-1] or residual.C != pw.Cout:
+                raise _lib.DfsfmError("conv2d_nhwc: split residual mismatch")
+            ldr = rh.shape[-1]
+        else:
+            rows_r, ldr = _rows_ld(residual)
+            if rows_r != N * Ho * Wo or residual.shape[-1] != pw.Cout:
+                raise _lib.DfsfmError("conv2d_nhwc: residual shape mismatch")
+            r32 = residual
+    sxn = xt.stride(0) if N > 1 else H * xt.stride(1)
+    rc = _lib.lib().dfsfm_conv2d_nhwc_f32(
+        None if split_in else _ptr(x), _ptr(x.hi) if split_in else None, _ptr(x.lo) if split_in else None,
+        sxn, xt.stride(1), xt.stride(2), N, H, W, Cin, _ptr(pw.hi), _ptr(pw.lo), pw.Cout, pw.Kpad, pw.kh, pw.kw,
+        stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 1 if relu else 0,
+        _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
-    return out
+    return result
 
 
 def linear(x, pw: PackedDense, residual=None, relu=False, out=None):
@@ -267,16 +320,27 @@ def linear(x, pw: PackedDense, residual=None, relu=False, out=None):
     x4 = x.as_strided((1, 1, rows, x.shape[-1]), (0, 0, ld, 1))
     if out is None:
         out = torch.empty((rows, pw.Cout), dtype=torch.float32, device=x.device)
-    conv2d_nhwc(x4, pw, 1, 0, residual, relu, out.view(-1, pw.Cout) if out.is_contiguous() else out)
+    conv2d_nhwc(x4, pw, 1, 0, residual, relu, out)
     return out
 
 
 def maxpool3x3s2_nhwc(x):
-    """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor."""
+    """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor (fp32) or SplitAct."""
+    if isinstance(x, SplitAct):
+        _require_cuda(x.hi)
+        if not (x.hi.is_contiguous() and x.lo.is_contiguous()):
+            raise _lib.DfsfmError("maxpool: split input must be dense")
+        N, H, W, Cp = x.hi.shape
+        y = SplitAct(torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cp), dtype=torch.float16, device=x.hi.device),
+                     torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cp), dtype=torch.float16, device=x.hi.device), x.C)
+        rc = _lib.lib().dfsfm_maxpool3x3s2_nhwc_f32(None, _ptr(x.hi), _ptr(x.lo), N, H, W, Cp, None, _ptr(y.hi),
+                                                    _ptr(y.lo), _stream())
+        _lib.check(rc, "dfsfm_maxpool3x3s2_nhwc_f32")
+        return y
     _require_cuda(x)
     x = x.contiguous()
     N, H, W, C = x.shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
-    rc = _lib.lib().dfsfm_maxpool3x3s2_nhwc_f32(_ptr(x), N, H, W, C, _ptr(out), _stream())
+    rc = _lib.lib().dfsfm_maxpool3x3s2_nhwc_f32(_ptr(x), None, None, N, H, W, C, _ptr(out), None, None, _stream())
     _lib.check(rc, "dfsfm_maxpool3x3s2_nhwc_f32")
     return out

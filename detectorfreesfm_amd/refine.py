@@ -97,10 +97,12 @@ class HipMultiviewMatcher(ParamModule):
         P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.", self.dense_backend)
                        for i in range(n_layers)]
         if self.dense_backend == "hip":
-            H = {"enc": {i: ops.PackedDense(*P["enc"][i]) for i in P["enc"]}}
+            def pk(w, b, split_in=True):
+                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None)
+            H = {"enc": {i: pk(*P["enc"][i], split_in=(i != 0)) for i in P["enc"]}}   # conv1_1 reads fp32 patches
             for i in (0, 1):
                 a = P[f"adap{i}"]
-                H[f"adap{i}"] = (ops.PackedDense(a[0], a[1]), ops.PackedDense(a[2], a[3]))
+                H[f"adap{i}"] = (pk(a[0], a[1]), pk(a[2], a[3]))
             P["hip"] = H
         self._packed = P
         return P
@@ -111,15 +113,16 @@ class HipMultiviewMatcher(ParamModule):
         H = P["hip"]
         m, crop = x.shape[0], x.shape[1]
         c, r = crop // 2, W // 2
-        x = ops.conv2d_nhwc(x, H["enc"][0], 1, 1, relu=True)
-        x = ops.conv2d_nhwc(x, H["enc"][2], 1, 1, relu=True)                      # relu1_2 [m,35,35,64]
-        f0 = x[:, c - r - 2:c + r + 3, c - r - 2:c + r + 3, :]                      # centre (W+4)^2 view
+        S = dict(relu=True, out_split=True)             # conv -> ReLU -> split planes for the next conv
+        x = ops.conv2d_nhwc(x, H["enc"][0], 1, 1, **S)
+        x = ops.conv2d_nhwc(x, H["enc"][2], 1, 1, **S)                            # relu1_2 [m,35,35,64]
+        f0 = x.crop(c - r - 2, c + r + 3, c - r - 2, c + r + 3)                     # centre (W+4)^2 view
         t = ops.maxpool3x3s2_nhwc(x)
-        t = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["enc"][5], 1, 1, relu=True), H["enc"][7], 1, 1, relu=True)
+        t = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["enc"][5], 1, 1, **S), H["enc"][7], 1, 1, **S)
         t = ops.maxpool3x3s2_nhwc(t)
         for i in (10, 12, 14):
-            t = ops.conv2d_nhwc(t, H["enc"][i], 1, 1, relu=True)                   # relu3_3 [m,9,9,256]
-        y1 = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["adap1"][0], 1, 0, relu=True), H["adap1"][1], 1, 2)
+            t = ops.conv2d_nhwc(t, H["enc"][i], 1, 1, **S)                         # relu3_3 [m,9,9,256]
+        y1 = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["adap1"][0], 1, 0, **S), H["adap1"][1], 1, 2)
         h4 = y1.shape[1]
         key = (h4, crop, W)
         if P.get("bicubic_key") != key:
@@ -127,7 +130,7 @@ class HipMultiviewMatcher(ParamModule):
             P["bicubic"] = torch.kron(B, B).contiguous().to(y1.device)           # [W*W, h4*h4]
             P["bicubic_key"] = key
         up = torch.bmm(P["bicubic"].expand(m, -1, -1), y1.view(m, h4 * h4, -1))   # [m, W*W, od]
-        a0 = ops.conv2d_nhwc(f0, H["adap0"][0], 1, 0, relu=True)                  # [m,W+4,W+4,64]
+        a0 = ops.conv2d_nhwc(f0, H["adap0"][0], 1, 0, **S)                        # [m,W+4,W+4,64]
         ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out=dst)           # + hypercolumn sum, fused
         return dst
 

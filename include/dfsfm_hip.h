@@ -166,19 +166,33 @@ int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, const int64_t* 
  *   src/MultiviewMatcher/backbone/S2DNet/s2dnet.py:24-52,127-175
  * and, as the 1x1 case with Nimg=1,H=1,W=rows, nn.Linear of the encoder layers
  *   third_party/LoFTR/src/loftr/loftr_module/transformer.py:21-31,42-55.
- * x element (n,y,x,c) at x[n*sxn + y*sxh + x*ldx + c] (any NHWC view, e.g. a centre crop or a
- * column slice); w_hi/w_lo: fp16 [ceil128(Cout)][Kpad] with K = kh*kw*Cin in (ky,kx,ci) order,
- * zero padded, Kpad % 32 == 0, w = w_hi + w_lo/2048 (hi = 0 where |w| < 2^-14);
- * bias [Cout] or NULL; residual [M, Cout] with row stride ldr or NULL; out row stride ldo.
+ *
+ * "Split" tensors: a value v is stored as two fp16 planes, v = hi + lo/2048, with
+ * hi = (|v| >= 2^-14 ? fp16(v) : 0) and lo = fp16((v - hi) * 2048) (22 significant bits, same
+ * 4 bytes per element as fp32).  Activations between convolutions travel in this form so the
+ * kernel can DMA them straight into LDS.
+ *
+ * Input : either x (fp32) or x_hi/x_lo (split planes, fp16); element (n,y,x,c) at
+ *         [n*sxn + y*sxh + x*ldx + c] (element strides; any NHWC view, e.g. a centre crop).
+ *         Split input needs Cin, ldx, sxh, sxn multiples of 8 and planes < 4 GiB.
+ * Weights: w_hi/w_lo fp16 [ceil128(Cout)][Kpad], K = kh*kw*Cin in (ky,kx,ci) order, zero padded,
+ *         Kpad % 32 == 0, same hi/lo split.  bias [Cout] or NULL.
+ * Residual: fp32 [M, Cout] (row stride ldr) or split planes res_hi/res_lo (row stride ldr), or none.
+ * Output: fp32 `out` (row stride ldo) and/or split planes out_hi/out_lo (row stride ldo_s, Cout_s >=
+ *         Cout channels, Cout_s % 8 == 0; channels >= Cout are written as zeros).
  * ---------------------------------------------------------------------------------------- */
-int dfsfm_conv2d_nhwc_f32(const float* x, int64_t sxn, int64_t sxh, int64_t ldx, int Nimg, int H, int W,
-                          int Cin, const void* w_hi, const void* w_lo, int Cout, int Kpad, int kh, int kw,
-                          int stride, int pad, const float* bias, const float* residual, int64_t ldr,
-                          int relu, float* out, int64_t ldo, void* stream);
+int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
+                          int64_t ldx, int Nimg, int H, int W, int Cin, const void* w_hi, const void* w_lo,
+                          int Cout, int Kpad, int kh, int kw, int stride, int pad, const float* bias,
+                          const float* residual, const void* res_hi, const void* res_lo, int64_t ldr,
+                          int relu, float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s,
+                          int Cout_s, void* stream);
 
-/* nn.MaxPool2d(3, stride=2, padding=1) on a dense NHWC tensor (S2DNet with
- * substitute_pooling_layers, backbone/S2DNet/s2dnet.py:89-92).  C % 4 == 0. */
-int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, int Nimg, int H, int W, int C, float* out, void* stream);
+/* nn.MaxPool2d(3, stride=2, padding=1) on a dense NHWC tensor, fp32 (x -> out, C % 4 == 0) or split
+ * planes (x_hi/x_lo -> out_hi/out_lo, C % 8 == 0)  (S2DNet with substitute_pooling_layers,
+ * backbone/S2DNet/s2dnet.py:89-92). */
+int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int Nimg, int H, int W,
+                                int C, float* out, void* out_hi, void* out_lo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,23 +76,40 @@ def _split(x):
     return hi, ((x - hi) * 2048.0).half().float()
 
 
-def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None):
+def _to_split(y):
+    from detectorfreesfm_amd.ops import SplitAct
+    C = y.shape[-1]
+    cp = (C + 7) // 8 * 8
+    hi, lo = _split(y)
+    H = torch.zeros((*y.shape[:3], cp), dtype=torch.float16)
+    L = torch.zeros((*y.shape[:3], cp), dtype=torch.float16)
+    H[..., :C], L[..., :C] = hi.half(), lo.half()
+    return SplitAct(H, L, C)
+
+
+def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None, out_split=False):
     """Exact algebra of dfsfm_conv2d_nhwc_f32: fp16x2 split of both operands, three products."""
     import torch.nn.functional as F
+    from detectorfreesfm_amd.ops import SplitAct
     K = pw.kh * pw.kw * pw.Cin
 
     def unpack(t):
         return t[:pw.Cout, :K].float().reshape(pw.Cout, pw.kh, pw.kw, pw.Cin).permute(0, 3, 1, 2).contiguous()
     wh, wl = unpack(pw.hi), unpack(pw.lo)
-    xh, xl = _split(x.permute(0, 3, 1, 2))
+    if isinstance(x, SplitAct):
+        xh, xl = x.hi.float().permute(0, 3, 1, 2), x.lo.float().permute(0, 3, 1, 2)
+    else:
+        xh, xl = _split(x.permute(0, 3, 1, 2))
     y = F.conv2d(xh, wh, None, stride, pad) + (F.conv2d(xh, wl, None, stride, pad) + F.conv2d(xl, wh, None, stride, pad)) / 2048.0
     y = y.permute(0, 2, 3, 1)
     if pw.bias is not None:
         y = y + pw.bias
     if residual is not None:
-        y = y + residual.reshape(y.shape)
+        y = y + (residual.float() if isinstance(residual, SplitAct) else residual).reshape(y.shape)
     if relu:
         y = torch.relu(y)
+    if out_split:
+        return _to_split(y)
     if out is None:
         return y.contiguous()
     out.copy_(y.reshape(out.shape))
@@ -111,6 +128,9 @@ def _linear(x, pw, residual=None, relu=False, out=None):
 
 def _maxpool(x):
     import torch.nn.functional as F
+    from detectorfreesfm_amd.ops import SplitAct
+    if isinstance(x, SplitAct):
+        return _to_split(F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))
     return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
 
 
