@@ -30,6 +30,7 @@ from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, r
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
+MFMA_F16_PEAK_TF = 2500.0    # fp16/bf16 dense MFMA peak (spec; 2178-2382 TF measured micro-benchmarks)
 
 
 def event_time_ms(fn, iters=10, warmup=2):
@@ -69,6 +70,22 @@ def kernel_rooflines(dev, batch):
     """Hand-written kernels at the bench shapes, inputs resident, events on the launch stream."""
     out = []
     g = torch.Generator().manual_seed(0)
+    # K6/K9/K2 conv_gemm_sf (fp16x2-split implicit GEMM on the fp16 matrix cores): the layer that dominates the
+    # coarse step -- BasicBlock 3x3, 128->128 channels at 240x320, 2*batch images.  Algorithmic flops =
+    # 2*M*Cout*kh*kw*Cin (counted once; the kernel issues 3 fp16 MFMAs per product for fp32-class accuracy).
+    nimg = 2 * batch
+    x = torch.randn((nimg, 240, 320, 128), generator=g).to(dev)
+    xs = ops.SplitAct.empty(nimg, 240, 320, 128, dev)
+    ops.split_rows(x, None, out_split=xs)
+    pw = ops.PackedDense(torch.randn((128, 128, 3, 3), generator=g).to(dev) * 0.03, torch.zeros(128, device=dev), cin_pad=128)
+    ms = event_time_ms(lambda: ops.conv2d_nhwc(xs, pw, 1, 1, relu=True, out_split=True))
+    flops = 2.0 * nimg * 240 * 320 * 128 * 9 * 128
+    out.append({"kernel": "conv_gemm_sf_kernel<128> (3x3, 128->128 @240x320)", "bound": "mfma",
+                "achieved": flops / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": flops / ms / 1e9 / MFMA_F16_PEAK_TF, "traffic": None, "ms": ms, "units": f"{nimg} images",
+                "mfma_flops_executed_frac": 3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
+                "step_share": "75% of the coarse step, 69% of the refinement step (profiles/r01_*_step_kernel_stats.csv)"})
+    del x, xs, pw
     # K3+K4+K5 at batch x (4800 x 4800 x 256): algorithmic flops 2*L*S*C per pair (SURVEY 8d)
     L = S = 4800
     f0, f1 = synth.correlated_features(batch, L, S, 256, 7, 0.1)
@@ -94,6 +111,7 @@ def kernel_rooflines(dev, batch):
     boxes = torch.cat([pts - 17, pts + 17], -1)
     buf = torch.empty((M, 3, 35, 35), device=dev)
     ms = event_time_ms(lambda: ops.roi_align(img, boxes, 35, 35, out=buf))
+    del buf
     byts = M * (3 * 35 * 35 * 4 + 3 * 36 * 36 * 4)
     out.append({"kernel": "roi_align 3x35x35", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "ms": ms,
@@ -197,14 +215,15 @@ def main():
         P = matcher._packed or matcher._pack()
         imgs = torch.cat([data["image0"], data["image1"]], 0)
         with torch.no_grad():
-            breakdown["backbone_ms"] = event_time_ms(lambda: matcher._backbone(imgs, P), 5, 1)
-            c, _ = matcher._backbone(imgs, P)
-            f = (c + matcher.pe[:, :, :60, :80]).flatten(2).transpose(1, 2).contiguous()
-            f0, f1 = f[:args.batch], f[args.batch:]
-            breakdown["transformer_ms"] = event_time_ms(lambda: matcher._transformer(f0, f1, P), 5, 1)
+            breakdown["backbone_ms"] = event_time_ms(lambda: matcher._backbone_hip(imgs, P), 5, 1)
+            c = matcher._backbone_hip(imgs, P).flatten(1, 2)
+            pe = matcher._pe_tokens((60, 80))
+            f0, f1 = c[:args.batch], c[args.batch:]
+            breakdown["transformer_ms"] = event_time_ms(lambda: matcher._transformer(f0, f1, P, pe, pe), 5, 1)
+            g0, g1 = matcher._transformer(f0, f1, P, pe, pe)
             breakdown["coarse_match_ms"] = event_time_ms(
-                lambda: ops.coarse_match(f0, f1, (60, 80), (60, 80), 0.2, 2, 0.1), 5, 1)
-        del imgs, c, f, f0, f1
+                lambda: ops.coarse_match(g0, g1, (60, 80), (60, 80), 0.2, 2, 0.1), 5, 1)
+        del imgs, c, f0, f1, g0, g1
 
     # ---- refinement head: configs[2] --------------------------------------------------------------
     rcfg = multiview_refinement_config()
@@ -228,7 +247,7 @@ def main():
         "metric": "coarse_image_pairs_per_sec", "value": pairs_per_s, "unit": "image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"configs[1]: LoFTR coarse_only, 640x480, batch {args.batch} pairs per GPU per step, "
                                "seeded random weights, inputs resident in HBM; match-table all-gather per step when N>1",
                    "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
@@ -241,9 +260,10 @@ def main():
     if rank == 0 and not args.no_rooflines:
         rl = kernel_rooflines(dev, args.batch)
         result["rooflines"] = rl
-        dom = max(rl, key=lambda r: r["ms"])
+        dom = rl[0]     # conv_gemm_sf: by far the largest share of both steps (profiles/r01_*_step_kernel_stats.csv)
         result["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
         result["roofline"]["kernel"] = dom["kernel"]
+        result["roofline"]["mfma_flops_executed_frac"] = dom["mfma_flops_executed_frac"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

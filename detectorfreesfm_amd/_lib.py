@@ -8,7 +8,8 @@ import os
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdfsfm_hip.so")
+# DFSFM_LIB_PATH lets kernel A/B experiments point at an alternative build of the same ABI.
+LIB_PATH = os.environ.get("DFSFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libdfsfm_hip.so")
 
 DFSFM_OK = 0
 _ERRORS = {-1: "DFSFM_E_BADARG", -2: "DFSFM_E_UNSUPPORTED", -3: "DFSFM_E_WORKSPACE", -4: "DFSFM_E_LAUNCH"}
@@ -21,7 +22,7 @@ SIGNATURES = [
     ("dfsfm_linear_attention_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-      c_void_p, c_size_t, c_void_p]),
+      c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     ("dfsfm_coarse_match_workspace", c_size_t, [c_int, c_int, c_int]),
     ("dfsfm_coarse_match_f32", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
@@ -38,7 +39,11 @@ SIGNATURES = [
       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("dfsfm_layernorm_f32", c_int,
-     [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+     [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+      c_int64, c_int64, c_int, c_void_p]),
+    ("dfsfm_split_rows_f32", c_int,
+     [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
+      c_void_p]),
     ("dfsfm_add_scatter_tokens_f32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("dfsfm_conv2d_nhwc_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -111,6 +111,38 @@ def encoder_layer(w: EncoderLayerWeights, xm, source, out, nhead, x_mask=None, s
     return out
 
 
+def encoder_layer_split(w: EncoderLayerWeights, x, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
+                        q_group=1, kv_group=1, is_self=False):
+    """The same layer with every GEMM on the LDS-DMA (v2) kernel: activations that feed a GEMM are
+    kept as split fp16 planes (ops.SplitAct), produced by the epilogue of whichever kernel computes
+    them (LayerNorm, attention apply, GEMM) -- no conversion pass, no concat.
+
+    x   fp32 [N,L,C]            residual input (row-strided view OK)
+    xs  SplitAct [N,L,2C]       first half = split(x); second half receives split(norm1(message))
+    src SplitAct [N,S,C] view   split source tokens (== xs.cols(0,C) for self-attention)
+    out_x  fp32 [N,L,C] view    receives x + norm2(mlp(...))
+    out_xs SplitAct [N,L,C] view or None: the same values as split planes for the next layer"""
+    N, L, C = x.shape
+    D = C // nhead
+    S = src.hi.shape[1]
+    xs_x = xs.cols(0, C)
+    if is_self:
+        qkv = ops.linear(xs_x, w.pqkv).view(N, L, 3 * C)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    else:
+        q = ops.linear(xs_x, w.pq).view(N, L, C)
+        kv = ops.linear(src, w.pkv).view(N, S, 2 * C)
+        k, v = kv[..., :C], kv[..., C:]
+    msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
+                               v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group, out_split=True)
+    merged = ops.linear(msg, w.pmerge)
+    ops.layernorm(merged, w.n1[0], w.n1[1], out_split=xs.cols(C, 2 * C), want_f32=False)   # norm1 -> [x | message]
+    h = ops.linear(xs, w.p1, relu=True, out_split=True)                                   # relu(mlp.0([x|message]))
+    o = ops.linear(h, w.p2)
+    ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=x, out=out_x, out_split=out_xs)
+    return out_x
+
+
 class HipLoFTR(ParamModule):
     def __init__(self, config: dict, skip_dead_fpn: bool = True, dense_backend: str = "hip"):
         """dense_backend: "hip" (default) runs every convolution and linear layer on the hand-written
@@ -230,32 +262,67 @@ class HipLoFTR(ParamModule):
         return x3_out, x1_out
 
     # -- K2/K1: LocalFeatureTransformer.forward (transformer.py:80-101) -------------------------
-    def _transformer(self, f0, f1, P):
-        """f0 [N,L,C], f1 [N,S,C] -> updated features (contiguous).  Activations ping-pong between
-        two [.,.,2C] buffers (see encoder_layer); when both images have the same grid they share
-        one buffer so that self layers run as ONE batch of 2N sequences."""
+    def _transformer(self, f0, f1, P, pe0=None, pe1=None):
+        """f0 [N,L,C], f1 [N,S,C] (+ optional positional-encoding tables added on the way in) -> updated
+        features (contiguous fp32).  When both images have the same grid they share buffers so that
+        self layers run as ONE batch of 2N sequences.
+        backend "hip": fp32 x (residual chain) + split planes [.,.,2C] = [x | norm1(message)] ping-pong
+        (encoder_layer_split); backend "library": fp32 [.,.,2C] buffers (encoder_layer)."""
         nhead = self.config["coarse"]["nhead"]
         names = self.config["coarse"]["layer_names"]
         N, L, C = f0.shape
         S = f1.shape[1]
         same = L == S
         dev = f0.device
+        hip = self.dense_backend == "hip"
 
-        def new_buffers(width):
+        def new_f32(width):
             if same:
                 big = torch.empty((2 * N, L, width), dtype=torch.float32, device=dev)
                 return big, big[:N], big[N:]
             return None, torch.empty((N, L, width), dtype=torch.float32, device=dev), \
                 torch.empty((N, S, width), dtype=torch.float32, device=dev)
-        cur = new_buffers(2 * C)
-        nxt = new_buffers(2 * C)
-        cur[1][..., :C] = f0
-        cur[2][..., :C] = f1
+
+        def new_split(width):
+            if same:
+                big = ops.SplitAct.empty_rows((2 * N, L), width, dev)
+                return big, big[:N], big[N:]
+            return None, ops.SplitAct.empty_rows((N, L), width, dev), ops.SplitAct.empty_rows((N, S), width, dev)
+
+        if hip:
+            X, Xn = new_f32(C), new_f32(C)
+            XS, XSn = new_split(2 * C), new_split(2 * C)
+            ops.split_rows(f0, pe0, out=X[1], out_split=XS[1].cols(0, C))
+            ops.split_rows(f1, pe1, out=X[2], out_split=XS[2].cols(0, C))
+            for li, (w, name) in enumerate(zip(P["enc"], names)):
+                last = li == len(names) - 1
+                oxs = (None, None, None) if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
+                if name == "self":
+                    if same:   # both images through one batched call
+                        encoder_layer_split(w, X[0], XS[0], XS[0].cols(0, C), Xn[0], oxs[0], nhead, is_self=True)
+                    else:
+                        for i in (1, 2):
+                            encoder_layer_split(w, X[i], XS[i], XS[i].cols(0, C), Xn[i], oxs[i], nhead, is_self=True)
+                elif name == "cross":
+                    # feat1's cross-attention needs the UPDATED feat0 as split planes even in the last layer
+                    ox1 = oxs[1] if oxs[1] is not None else ops.SplitAct.empty_rows((N, L), C, dev)
+                    encoder_layer_split(w, X[1], XS[1], XS[2].cols(0, C), Xn[1], ox1, nhead)
+                    encoder_layer_split(w, X[2], XS[2], ox1, Xn[2], oxs[2], nhead)       # sees the updated feat0 (:96-97)
+                else:
+                    raise KeyError(name)
+                X, Xn = Xn, X
+                XS, XSn = XSn, XS
+            return X[1], X[2]
+
+        cur = new_f32(2 * C)
+        nxt = new_f32(2 * C)
+        cur[1][..., :C] = f0 if pe0 is None else f0 + pe0
+        cur[2][..., :C] = f1 if pe1 is None else f1 + pe1
         for li, (w, name) in enumerate(zip(P["enc"], names)):
             last = li == len(names) - 1
-            dst = new_buffers(C) if last else tuple(None if b is None else b[..., :C] for b in nxt)
+            dst = new_f32(C) if last else tuple(None if b is None else b[..., :C] for b in nxt)
             if name == "self":
-                if same:   # both images through one batched call
+                if same:
                     encoder_layer(w, cur[0], cur[0][..., :C], dst[0], nhead, is_self=True)
                 else:
                     encoder_layer(w, cur[1], cur[1][..., :C], dst[1], nhead, is_self=True)
@@ -284,8 +351,9 @@ class HipLoFTR(ParamModule):
             else:
                 c0, c1 = self._backbone_hip(image0, P), self._backbone_hip(image1, P)
             hw0_c, hw1_c = tuple(c0.shape[1:3]), tuple(c1.shape[1:3])
-            f0 = c0.flatten(1, 2) + self._pe_tokens(hw0_c)
-            f1 = c1.flatten(1, 2) + self._pe_tokens(hw1_c)
+            f0, f1 = self._transformer(c0.flatten(1, 2), c1.flatten(1, 2), P, self._pe_tokens(hw0_c),
+                                       self._pe_tokens(hw1_c))     # pos-enc added while splitting
+            return f0, f1, hw0_c, hw1_c
         else:
             if same:
                 c, _ = self._backbone(torch.cat([image0, image1], 0), P)

@@ -36,4 +36,32 @@ __device__ __forceinline__ float elu_plus_one(float x) {
     return (x > 0.f ? x : expm1f(x)) + 1.f;
 }
 
+// fp16x2 split of an fp32 value: v = hi + lo/2048 (22 significant bits); values below the fp16 normal
+// range go entirely to lo so the matrix cores never see an fp16 subnormal (csrc/conv_gemm.hip).
+__device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
+    const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)x : (_Float16)0.f;
+    hi = h;
+    lo = (_Float16)((x - (float)h) * 2048.f);
+}
+
+typedef _Float16 dfsfm_half4 __attribute__((ext_vector_type(4)));
+
+// Store 4 consecutive values as fp32 (if out) and/or as split fp16 planes (if outh).
+__device__ __forceinline__ void store4(float* out, _Float16* outh, _Float16* outl, int64_t o32, int64_t o16,
+                                       const f32x4 v) {
+    if (out) *reinterpret_cast<f32x4*>(out + o32) = v;
+    if (outh) {
+        dfsfm_half4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, b;
+            split_f32(v[e], a, b);
+            h[e] = a;
+            l[e] = b;
+        }
+        *reinterpret_cast<dfsfm_half4*>(outh + o16) = h;
+        *reinterpret_cast<dfsfm_half4*>(outl + o16) = l;
+    }
+}
+
 }  // namespace dfsfm

@@ -35,6 +35,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_B = BM * BK * 2;                 // bytes of one fp16 tile (8 KB)
 constexpr int STAGE_B = 4 * TILE_B;                 // A_hi, A_lo, B_hi, B_lo
 constexpr int SMEM_BYTES = 2 * STAGE_B;             // double buffered: 64 KB
+constexpr int LUT_MAX = 256;                        // scalar-gather path: k -> (ky,kx,ci) table entries
 
 struct ConvArgs {
     const float* x;          // fp32 NHWC input: element (n,y,x,c) at n*sxn + y*sxh + x*ldx + c
@@ -55,11 +56,7 @@ struct ConvArgs {
     unsigned wbytes;
 };
 
-__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
-    const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)x : (_Float16)0.f;
-    hi = h;
-    lo = (_Float16)((x - (float)h) * 2048.f);
-}
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) { split_f32(x, hi, lo); }
 
 __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
 #pragma unroll
@@ -82,7 +79,7 @@ struct RowGeom {           // one activation row handled by this thread
 };
 
 template <bool VEC_A>
-__device__ __forceinline__ void load_slab(const ConvArgs& g, int k0, int c4, int tid, int n0, const RowGeom& r0,
+__device__ __forceinline__ void load_slab(const ConvArgs& g, const int* lut, int k0, int c4, int tid, int n0, const RowGeom& r0,
                                           const RowGeom& r1, const RowGeom& r2, const RowGeom& r3, f32x4& a0,
                                           f32x4& a1, f32x4& a2, f32x4& a3, uint4& bh0, uint4& bh1, uint4& bl0,
                                           uint4& bl1) {
@@ -103,8 +100,16 @@ __device__ __forceinline__ void load_slab(const ConvArgs& g, int k0, int c4, int
             for (int e = 0; e < 4; ++e) {
                 const int ke = k + e;
                 if (ke < g.K && rg.ok) {
-                    const int tap = ke / g.Cin, ci = ke - tap * g.Cin;
-                    const int ky = tap / g.kw, kx = tap - ky * g.kw;
+                    int ky, kx, ci;
+                    if (lut) {                      // (ky, kx, ci) of every k, tabulated once per workgroup
+                        const int t = lut[ke];
+                        ky = t & 255; kx = (t >> 8) & 255; ci = t >> 16;
+                    } else {
+                        const int tap = ke / g.Cin;
+                        ci = ke - tap * g.Cin;
+                        ky = tap / g.kw;
+                        kx = tap - ky * g.kw;
+                    }
                     const int iy = rg.iy0 + ky, ix = rg.ix0 + kx;
                     if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
                         t[e] = g.x[rg.base + (int64_t)iy * g.sxh + (int64_t)ix * g.ldx + ci];
@@ -179,7 +184,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g) {
     const RowGeom g0 = geom(0), g1 = geom(1), g2 = geom(2), g3 = geom(3);
     f32x4 a0, a1, a2, a3;
     uint4 bh0, bh1, bl0, bl1;
-#define GLOAD(k0) load_slab<VEC_A>(g, (k0), c4, tid, n0, g0, g1, g2, g3, a0, a1, a2, a3, bh0, bh1, bl0, bl1)
+    // scalar-gather path (Cin = 1 or 3): k -> (ky, kx, ci) table in LDS instead of two divisions per element
+    const int* lut = nullptr;
+    if (!VEC_A && g.Kpad <= LUT_MAX && g.kh < 256 && g.kw < 256) {
+        int* l = reinterpret_cast<int*>(smem + SMEM_BYTES);
+        for (int k = tid; k < g.K; k += 256) {
+            const int tap = k / g.Cin, ci = k - tap * g.Cin;
+            const int ky = tap / g.kw, kx = tap - ky * g.kw;
+            l[k] = ky | (kx << 8) | (ci << 16);
+        }
+        __syncthreads();
+        lut = l;
+    }
+#define GLOAD(k0) load_slab<VEC_A>(g, lut, (k0), c4, tid, n0, g0, g1, g2, g3, a0, a1, a2, a3, bh0, bh1, bl0, bl1)
 #define LSTORE(buf) store_slab(smem + (buf) * STAGE_B, tid, c4, a0, a1, a2, a3, bh0, bh1, bl0, bl1)
 
     f32x16 accm[2][2], accx[2][2];
@@ -295,8 +312,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kgrp = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.x * BM2;
-    const int n0 = blockIdx.y * BN_;
+    // N tiles of one M tile are adjacent in dispatch order: they share the activation tile in L2 / MALL
+    const int ntn = (g.Cout + BN_ - 1) / BN_;
+    const int64_t m0 = (int64_t)(blockIdx.x / ntn) * BM2;
+    const int n0 = (blockIdx.x % ntn) * BN_;
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
@@ -562,7 +581,7 @@ void launch_v2(const ConvArgs& g, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         attr_set = true;
     }
-    const dim3 grid((unsigned)((g.M + BM2 - 1) / BM2), (unsigned)((g.Cout + BN_ - 1) / BN_));
+    const dim3 grid((unsigned)((g.M + BM2 - 1) / BM2) * (unsigned)((g.Cout + BN_ - 1) / BN_));
     hipLaunchKernelGGL(conv_gemm_sf_kernel<BN_>, grid, dim3(512), T::SMEM, stream, g);
 }
 
@@ -636,10 +655,10 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
     } else {
         if (!attr_set[1]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES + LUT_MAX * 4);
             attr_set[1] = true;
         }
-        hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, blk, SMEM_BYTES, stream, g);
+        hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, blk, SMEM_BYTES + LUT_MAX * 4, stream, g);
     }
     return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32");
 }

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ residual, int64_t ldr,
-                                                        float* __restrict__ out, int64_t ldo, int64_t rows) {
+                                                        float* __restrict__ out, int64_t ldo, int64_t rows,
+                                                        _Float16* __restrict__ outh, _Float16* __restrict__ outl,
+                                                        int64_t ldos) {
     constexpr int C = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -55,16 +57,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = rr[e] + o[e];
     }
-    float* orow = out + row * ldo + lane * VEC;
-    if (VEC == 4) {
-        f32x4 t;
+    if (out) {
+        float* orow = out + row * ldo + lane * VEC;
+        if (VEC == 4) {
+            f32x4 t;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) t[e] = o[e];
-        *reinterpret_cast<f32x4*>(orow) = t;
-    } else {
+            for (int e = 0; e < VEC; ++e) t[e] = o[e];
+            *reinterpret_cast<f32x4*>(orow) = t;
+        } else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) orow[e] = o[e];
+            for (int e = 0; e < VEC; ++e) orow[e] = o[e];
+        }
     }
+    if (outh) {   // the same values as split fp16 planes, for the LDS-DMA GEMM kernel
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            _Float16 a, b;
+            dfsfm::split_f32(o[e], a, b);
+            outh[row * ldos + lane * VEC + e] = a;
+            outl[row * ldos + lane * VEC + e] = b;
+        }
+    }
+}
+
+// out_hi/out_lo[r, c] = split(x[r, c] (+ add[r % add_rows, c]));  optional fp32 copy of the sum.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ add, int64_t add_rows,
+                                                         float* __restrict__ out, int64_t ldo,
+                                                         _Float16* __restrict__ outh, _Float16* __restrict__ outl,
+                                                         int64_t ldos, int64_t rows, int C4) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * C4) return;
+    const int64_t r = e / C4;
+    const int c = (int)(e - r * C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    if (add) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(add + (r % add_rows) * (int64_t)(C4 * 4) + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += a[q];
+    }
+    dfsfm::store4(out, outh, outl, r * ldo + c, r * ldos + c, v);
 }
 
 // dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p]);  one workgroup per patch, 32-channel slabs
@@ -100,21 +132,25 @@ __global__ __launch_bounds__(256) void add_scatter_tokens_kernel(const float* __
 }  // namespace
 
 extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                                   const float* residual, int64_t ldr, float* out, int64_t ldo, int64_t rows,
-                                   int C, void* stream_) {
+                                   const float* residual, int64_t ldr, float* out, int64_t ldo, void* out_hi,
+                                   void* out_lo, int64_t ldo_s, int64_t rows, int C, void* stream_) {
     if (rows == 0) return DFSFM_OK;
-    if (!x || !gamma || !beta || !out || rows < 0 || C <= 0) return DFSFM_E_BADARG;
-    if (ldx < C || ldo < C || (residual && ldr < C)) return DFSFM_E_BADARG;
+    if (!x || !gamma || !beta || (!out && !out_hi) || rows < 0 || C <= 0) return DFSFM_E_BADARG;
+    if ((out_hi == nullptr) != (out_lo == nullptr)) return DFSFM_E_BADARG;
+    if (ldx < C || (out && ldo < C) || (out_hi && ldo_s < C) || (residual && ldr < C)) return DFSFM_E_BADARG;
+    _Float16* oh = static_cast<_Float16*>(out_hi);
+    _Float16* ol = static_cast<_Float16*>(out_lo);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
     if (C == 256) {
-        if ((ldx & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+            (out && ((ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))))
             return DFSFM_E_UNSUPPORTED;
-        hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows);
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 128) {
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 64) {
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else {
         return DFSFM_E_UNSUPPORTED;
     }
@@ -130,4 +166,21 @@ extern "C" int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, cons
     hipLaunchKernelGGL(add_scatter_tokens_kernel, dim3(M), dim3(256), (size_t)32 * (P + 1) * 4, stream, a, b, slot,
                        dst, C, P);
     return dfsfm::check_launch("dfsfm_add_scatter_tokens_f32");
+}
+
+extern "C" int dfsfm_split_rows_f32(const float* x, int64_t ldx, const float* add, int64_t add_rows, float* out,
+                                    int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, int64_t rows, int C,
+                                    void* stream_) {
+    if (rows == 0) return DFSFM_OK;
+    if (!x || (!out && !out_hi) || rows < 0 || C <= 0 || (add && add_rows <= 0)) return DFSFM_E_BADARG;
+    if ((out_hi == nullptr) != (out_lo == nullptr)) return DFSFM_E_BADARG;
+    if ((C & 3) || (ldx & 3) || (out && (ldo & 3)) || (out_hi && (ldo_s & 3))) return DFSFM_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (out && (reinterpret_cast<uintptr_t>(out) & 15)) ||
+        (add && (reinterpret_cast<uintptr_t>(add) & 15)))
+        return DFSFM_E_UNSUPPORTED;
+    const int64_t total = rows * (C / 4);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), x, ldx, add, add_rows, out, ldo,
+                       static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), ldo_s, rows, C / 4);
+    return dfsfm::check_launch("dfsfm_split_rows_f32");
 }

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void la_kv_partial_d32(
 __global__ __launch_bounds__(256) void la_apply_d32(
     const float* __restrict__ q, const uint8_t* __restrict__ q_mask, int q_group,
     const float* __restrict__ kvf, float* __restrict__ out, int L, int S, int H, int ldq, int ldo,
-    float eps) {
+    float eps, _Float16* __restrict__ outh, _Float16* __restrict__ outl, int ldos) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int n = blockIdx.y;
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void la_apply_d32(
     const int64_t mbase = q_mask ? (int64_t)n * ((L + q_group - 1) / q_group) : 0;
     const float qm = valid ? mask_at(q_mask, q_group, mbase, l) : 0.f;
     const float* qrow = q + ((int64_t)n * L + (valid ? l : 0)) * ldq;
-    float* orow = out + ((int64_t)n * L + (valid ? l : 0)) * ldo;
+    const int64_t orow = ((int64_t)n * L + (valid ? l : 0)) * ldo;
+    const int64_t srow = ((int64_t)n * L + (valid ? l : 0)) * ldos;
 
     for (int h = wave; h < H; h += 4) {
         const float* kv = kvf + ((int64_t)n * H + h) * KV32;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void la_apply_d32(
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (acc[g * 4 + e] * Z) * Sf;
-                *reinterpret_cast<f32x4*>(orow + h * 32 + g * 8 + half * 4) = o;
+                store4(out, outh, outl, orow + h * 32 + g * 8 + half * 4, srow + h * 32 + g * 8 + half * 4, o);
             }
         }
     }
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void la_kv_partial_d16(
 __global__ __launch_bounds__(256) void la_apply_d16(
     const float* __restrict__ q, const uint8_t* __restrict__ q_mask, int q_group,
     const float* __restrict__ kvf, float* __restrict__ out, int L, int S, int H, int ldq, int ldo,
-    float eps) {
+    float eps, _Float16* __restrict__ outh, _Float16* __restrict__ outl, int ldos) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, grp = lane >> 4;
     const int n = blockIdx.y;
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256) void la_apply_d16(
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (acc[e] * Z) * Sf;
-                *reinterpret_cast<f32x4*>(out + ((int64_t)n * L + l) * ldo + h * 16 + grp * 4) = o;
+                store4(out, outh, outl, ((int64_t)n * L + l) * ldo + h * 16 + grp * 4,
+                       ((int64_t)n * L + l) * ldos + h * 16 + grp * 4, o);
             }
         }
     }
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void la_kv_partial_staged(
 __global__ __launch_bounds__(256, 2) void la_apply_staged_d32(
     const float* __restrict__ q, const uint8_t* __restrict__ q_mask, int q_group,
     const float* __restrict__ kvf, float* __restrict__ out, int L, int S, int ldq, int ldo, float eps,
-    int blocks_per_wg) {
+    int blocks_per_wg, _Float16* __restrict__ outh, _Float16* __restrict__ outl, int ldos) {
     constexpr int H = 8, C = 256, LD = C + 4;          // +4 floats: conflict-free b128 row reads
     __shared__ __attribute__((aligned(16))) float sQ[32 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void la_apply_staged_d32(
     const float Sf = (float)S;
     const int64_t mbase = q_mask ? (int64_t)n * ((L + q_group - 1) / q_group) : 0;
     const float* qn = q + (int64_t)n * L * ldq;
-    float* on = out + (int64_t)n * L * ldo;
+    const int64_t on = (int64_t)n * L * ldo, osn = (int64_t)n * L * ldos;
 
     float a[2][16], ks[2][16];
 #pragma unroll
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void la_apply_staged_d32(
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, r = idx >> 6, c4 = idx & 63;
             if (l0 + r < L)
-                *reinterpret_cast<f32x4*>(on + (int64_t)(l0 + r) * ldo + c4 * 4) =
-                    *reinterpret_cast<const f32x4*>(sQ + r * LD + c4 * 4);
+                store4(out, outh, outl, on + (int64_t)(l0 + r) * ldo + c4 * 4, osn + (int64_t)(l0 + r) * ldos + c4 * 4,
+                       *reinterpret_cast<const f32x4*>(sQ + r * LD + c4 * 4));
         }
         __syncthreads();
     }
@@ -504,14 +506,20 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
                                           const uint8_t* q_mask, int q_group,
                                           const uint8_t* kv_mask, int kv_group, float* out, int N,
                                           int L, int S, int H, int D, int ldq, int ldk, int ldv,
-                                          int ldo, float eps, void* workspace,
-                                          size_t workspace_bytes, void* stream_) {
-    if (!q || !k || !v || !out || !workspace) return DFSFM_E_BADARG;
+                                          int ldo, float eps, void* out_hi, void* out_lo, int ldo_s,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!q || !k || !v || (!out && !out_hi) || !workspace) return DFSFM_E_BADARG;
+    if ((out_hi == nullptr) != (out_lo == nullptr)) return DFSFM_E_BADARG;
+    if (out_hi && (ldo_s < H * D || (ldo_s & 3) || (reinterpret_cast<uintptr_t>(out_hi) & 7) ||
+                   (reinterpret_cast<uintptr_t>(out_lo) & 7)))
+        return DFSFM_E_BADARG;
+    _Float16* oh = static_cast<_Float16*>(out_hi);
+    _Float16* ol = static_cast<_Float16*>(out_lo);
     if (N <= 0 || L <= 0 || S <= 0 || H <= 0) return DFSFM_E_BADARG;
     if (D != 16 && D != 32) return DFSFM_E_UNSUPPORTED;
-    if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return DFSFM_E_BADARG;
-    if ((ldq & 3) || (ldo & 3)) return DFSFM_E_UNSUPPORTED;   // float4 row access
-    if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    if (ldq < H * D || ldk < H * D || ldv < H * D || (out && ldo < H * D)) return DFSFM_E_BADARG;
+    if ((ldq & 3) || (out && (ldo & 3))) return DFSFM_E_UNSUPPORTED;   // float4 row access
+    if ((reinterpret_cast<uintptr_t>(q) & 15) || (out && (reinterpret_cast<uintptr_t>(out) & 15)))
         return DFSFM_E_UNSUPPORTED;
     if (q_mask && (q_group <= 0)) return DFSFM_E_BADARG;
     if (kv_mask && (kv_group <= 0)) return DFSFM_E_BADARG;
@@ -554,14 +562,14 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
             const int nblk = (L + 31) / 32;
             const int bpw = (int64_t)nblk * N >= 4096 ? 4 : ((int64_t)nblk * N >= 1024 ? 2 : 1);
             hipLaunchKernelGGL(la_apply_staged_d32, dim3((nblk + bpw - 1) / bpw, N), blk, 0, stream, q, q_mask,
-                               q_group, kvf, out, L, S, ldq, ldo, eps, bpw);
+                               q_group, kvf, out, L, S, ldq, ldo, eps, bpw, oh, ol, ldo_s);
         } else {
             hipLaunchKernelGGL(la_apply_d32, dim3((L + 31) / 32, N), blk, 0, stream, q, q_mask, q_group, kvf, out,
-                               L, S, H, ldq, ldo, eps);
+                               L, S, H, ldq, ldo, eps, oh, ol, ldo_s);
         }
     } else {
         hipLaunchKernelGGL(la_apply_d16, dim3((L + 63) / 64, N), blk, 0, stream, q, q_mask, q_group, kvf, out, L, S,
-                           H, ldq, ldo, eps);
+                           H, ldq, ldo, eps, oh, ol, ldo_s);
     }
     return dfsfm::check_launch("dfsfm_linear_attention_f32");
 }

@@ -45,17 +45,27 @@ def _as_u8(m: Optional[torch.Tensor]):
     return (m != 0).contiguous().view(torch.uint8)
 
 
-def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None):
+def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None,
+                     out_split=False):
     """K1.  q [N,L,H,D]; k,v [N,S,H,D] fp32 (row-strided views allowed: stride(-1)=1,
-    stride(-2)=D); q_mask [N,L/q_group], kv_mask [N,S/kv_group] bool/uint8 or None."""
+    stride(-2)=D); q_mask [N,L/q_group], kv_mask [N,S/kv_group] bool/uint8 or None.
+    out_split=True returns the message as a SplitAct [N*L, H*D] (for the merge GEMM) instead of fp32."""
     _require_cuda(q, k, v)
     N, L, H, D = q.shape
     S = k.shape[1]
     for t, n_rows in ((q, L), (k, S), (v, S)):
         if t.dtype != torch.float32 or t.stride(3) != 1 or t.stride(2) != D or (N > 1 and t.stride(0) != n_rows * t.stride(1)):
             raise _lib.DfsfmError("linear_attention: need fp32 [N,rows,H,D] with dense (H,D) and batch stride rows*ld")
-    if out is None:
-        out = torch.empty((N, L, H, D), dtype=torch.float32, device=q.device)
+    res = oh = ol = None
+    ldo = ldos = H * D
+    if out_split:
+        res = SplitAct(torch.empty((N * L, H * D), dtype=torch.float16, device=q.device),
+                       torch.empty((N * L, H * D), dtype=torch.float16, device=q.device), H * D)
+        oh, ol, out = res.hi, res.lo, None
+    else:
+        if out is None:
+            out = torch.empty((N, L, H, D), dtype=torch.float32, device=q.device)
+        res, ldo = out, out.stride(1)
     qm, km = _as_u8(q_mask), _as_u8(kv_mask)
     lib = _lib.lib()
     ws_bytes = lib.dfsfm_linear_attention_workspace(N, S, H, D)
@@ -64,9 +74,9 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, 
     ws = _workspace(ws_bytes, q.device)
     rc = lib.dfsfm_linear_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(qm), q_group, _ptr(km), kv_group,
                                         _ptr(out), N, L, S, H, D, q.stride(1), k.stride(1), v.stride(1),
-                                        out.stride(1), eps, _ptr(ws), ws.numel(), _stream())
+                                        ldo, eps, _ptr(oh), _ptr(ol), ldos, _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "dfsfm_linear_attention_f32")
-    return out
+    return res
 
 
 def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None,
@@ -164,11 +174,11 @@ def fine_match(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=N
     return out
 
 
-def _rows_ld(t: torch.Tensor):
+def _rows_ld(t: torch.Tensor, dtype=torch.float32):
     """(rows, row stride) of a tensor whose last dim is dense and whose leading dims flatten
     uniformly (e.g. a column slice of a contiguous [..., 2C] buffer)."""
-    if t.dtype != torch.float32 or t.stride(-1) != 1:
-        raise _lib.DfsfmError("need fp32 rows with unit inner stride")
+    if t.dtype != dtype or t.stride(-1) != 1:
+        raise _lib.DfsfmError("need rows of the expected dtype with unit inner stride")
     ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
     for i in range(t.dim() - 2):
         if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
@@ -179,25 +189,57 @@ def _rows_ld(t: torch.Tensor):
     return rows, ld
 
 
-def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None):
-    """out = (residual or 0) + LayerNorm(x) * gamma + beta over the last dim (row-strided views OK)."""
+def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None, want_f32=True):
+    """(residual or 0) + LayerNorm(x)*gamma + beta over the last dim (row-strided views OK).
+    Written as fp32 into ``out`` (allocated if None and want_f32) and/or as split planes into the
+    SplitAct view ``out_split`` (e.g. a column slice of the [x | message] split buffer)."""
     _require_cuda(x, gamma, beta)
     rows, ldx = _rows_ld(x)
     C = x.shape[-1]
-    if out is None:
+    ldo = 0
+    if out is None and want_f32:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    rows_o, ldo = _rows_ld(out)
+    if out is not None:
+        rows_o, ldo = _rows_ld(out)
+        if rows_o != rows or out.shape[-1] != C:
+            raise _lib.DfsfmError("layernorm: out shape mismatch")
+    oh = ol = None
+    ldos = 0
+    if out_split is not None:
+        rows_s, ldos = _rows_ld(out_split.hi, torch.float16)
+        if rows_s != rows or out_split.hi.shape[-1] != C or out_split.lo.stride() != out_split.hi.stride():
+            raise _lib.DfsfmError("layernorm: split out shape mismatch")
+        oh, ol = out_split.hi, out_split.lo
     ldr = 0
     if residual is not None:
         rows_r, ldr = _rows_ld(residual)
         if rows_r != rows:
             raise _lib.DfsfmError("layernorm: residual shape mismatch")
-    if rows_o != rows or out.shape[-1] != C:
-        raise _lib.DfsfmError("layernorm: out shape mismatch")
     rc = _lib.lib().dfsfm_layernorm_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), ldr,
-                                        _ptr(out), ldo, rows, C, _stream())
+                                        _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
     _lib.check(rc, "dfsfm_layernorm_f32")
     return out
+
+
+def split_rows(x, add=None, out=None, out_split=None):
+    """out / out_split = x (+ add broadcast over row blocks); x [..., C] fp32 rows, add [R, C] contiguous."""
+    _require_cuda(x)
+    rows, ldx = _rows_ld(x)
+    C = x.shape[-1]
+    ldo = ldos = 0
+    if out is not None:
+        _, ldo = _rows_ld(out)
+    oh = ol = None
+    if out_split is not None:
+        _, ldos = _rows_ld(out_split.hi, torch.float16)
+        oh, ol = out_split.hi, out_split.lo
+    add_rows = 0
+    if add is not None:
+        add = add.contiguous()
+        add_rows = add.shape[0]
+    rc = _lib.lib().dfsfm_split_rows_f32(_ptr(x), ldx, _ptr(add), add_rows, _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos,
+                                         rows, C, _stream())
+    _lib.check(rc, "dfsfm_split_rows_f32")
 
 
 def add_scatter_tokens(a, b, slot, dst):
@@ -223,7 +265,20 @@ class SplitAct:
 
     @property
     def shape(self):
-        return (*self.hi.shape[:3], self.C)
+        return (*self.hi.shape[:-1], self.C)
+
+    @staticmethod
+    def empty_rows(shape, C, device):
+        """Split planes [*shape, C] for row tensors (C % 8 == 0)."""
+        return SplitAct(torch.empty((*shape, C), dtype=torch.float16, device=device),
+                        torch.empty((*shape, C), dtype=torch.float16, device=device), C)
+
+    def cols(self, a, b):
+        """Column slice view [..., a:b] (both planes)."""
+        return SplitAct(self.hi[..., a:b], self.lo[..., a:b], b - a)
+
+    def __getitem__(self, idx):
+        return SplitAct(self.hi[idx], self.lo[idx], self.C)
 
     @staticmethod
     def empty(N, H, W, C, device):
@@ -314,12 +369,23 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
     return result
 
 
-def linear(x, pw: PackedDense, residual=None, relu=False, out=None):
-    """K2.  x [rows, K] (row-strided view OK) @ W^T (+bias, +residual, relu) -> [rows, Cout]."""
-    rows, ld = _rows_ld(x)
-    x4 = x.as_strided((1, 1, rows, x.shape[-1]), (0, 0, ld, 1))
+def linear(x, pw: PackedDense, residual=None, relu=False, out=None, out_split=False):
+    """K2.  x [rows, K] fp32 (row-strided view OK) or a SplitAct of such rows; @ W^T (+bias, +residual, relu).
+    Returns fp32 [rows, Cout], or a SplitAct [rows, Cout] when out_split."""
+    if isinstance(x, SplitAct):
+        rows, ld = _rows_ld(x.hi, torch.float16)
+        K = x.hi.shape[-1]
+        x4 = SplitAct(x.hi.as_strided((1, 1, rows, K), (0, 0, ld, 1)), x.lo.as_strided((1, 1, rows, K), (0, 0, ld, 1)), K)
+        dev = x.hi.device
+    else:
+        rows, ld = _rows_ld(x)
+        x4 = x.as_strided((1, 1, rows, x.shape[-1]), (0, 0, ld, 1))
+        dev = x.device
+    if out_split:
+        y = conv2d_nhwc(x4, pw, 1, 0, residual, relu, out_split=True)
+        return SplitAct(y.hi.view(rows, -1), y.lo.view(rows, -1), pw.Cout)
     if out is None:
-        out = torch.empty((rows, pw.Cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((rows, pw.Cout), dtype=torch.float32, device=dev)
     conv2d_nhwc(x4, pw, 1, 0, residual, relu, out)
     return out
 

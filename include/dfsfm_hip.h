@@ -50,6 +50,8 @@ const char* dfsfm_last_error_string(void);  /* thread-local text for the last DF
  * q_mask [N, L/q_group], kv_mask [N, S/kv_group] are uint8 (0/1) or NULL; a mask entry covers
  * `group` consecutive tokens (the refinement head repeats a per-view mask over W*W tokens,
  * matcher_module/transformer.py:151).  D must be 16 or 32.
+ * Output: fp32 `out` (may be NULL) and/or split fp16 planes out_hi/out_lo with row stride ldo_s
+ * (value = hi + lo/2048, see dfsfm_conv2d_nhwc_f32) for the GEMM that consumes the message.
  * ---------------------------------------------------------------------------------------- */
 size_t dfsfm_linear_attention_workspace(int N, int S, int H, int D);
 int dfsfm_linear_attention_f32(const float* q, const float* k, const float* v,
@@ -57,6 +59,7 @@ int dfsfm_linear_attention_f32(const float* q, const float* k, const float* v,
                                const uint8_t* kv_mask, int kv_group,
                                float* out, int N, int L, int S, int H, int D,
                                int ldq, int ldk, int ldv, int ldo, float eps,
+                               void* out_hi, void* out_lo, int ldo_s,
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -141,11 +144,19 @@ int dfsfm_fine_match_f32(const float* ref, const float* qry, const uint8_t* trac
  *   src/MultiviewMatcher/matcher_module/transformer.py:82,88-95
  * and, through `ldo`, the torch.cat([x, message]) of :55 / :87: norm1 writes straight into the
  * second half of a [rows, 2C] buffer whose first half holds x.  ldx/ldr/ldo are row strides in
- * floats.  C must be 64, 128 or 256.
+ * floats.  C must be 64, 128 or 256.  The result is written as fp32 (`out`, may be NULL) and/or
+ * as split fp16 planes out_hi/out_lo (row stride ldo_s) for the GEMMs that consume it.
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                        const float* residual, int64_t ldr, float* out, int64_t ldo, int64_t rows, int C,
-                        void* stream);
+                        const float* residual, int64_t ldr, float* out, int64_t ldo, void* out_hi,
+                        void* out_lo, int64_t ldo_s, int64_t rows, int C, void* stream);
+
+/* out[r, :] = x[r, :] (+ add[r % add_rows, :]) as fp32 (`out`, may be NULL) and/or split planes.
+ * Used once per forward to add the positional encoding (LoFTR loftr.py:58-59: the [h*w, C] table
+ * broadcasts over the batch) and hand the tokens to the first encoder layer.  C % 4 == 0. */
+int dfsfm_split_rows_f32(const float* x, int64_t ldx, const float* add, int64_t add_rows, float* out,
+                         int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, int64_t rows, int C,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9 -> K10 hand-off  dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p])

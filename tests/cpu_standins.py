@@ -8,10 +8,27 @@ import torch
 from oracle import restate
 
 
-def _la(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None):
+def _rows_split(y):
+    """fp32 rows [..., C] -> SplitAct with planes of the same shape."""
+    from detectorfreesfm_amd.ops import SplitAct
+    hi, lo = _split(y)
+    return SplitAct(hi.half(), lo.half(), y.shape[-1])
+
+
+def _put_split(dst, y):
+    hi, lo = _split(y)
+    dst.hi.copy_(hi.half().reshape(dst.hi.shape))
+    dst.lo.copy_(lo.half().reshape(dst.lo.shape))
+
+
+def _la(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None, out_split=False):
     qm = None if q_mask is None else q_mask.repeat_interleave(q_group, dim=1)[:, :q.shape[1]]
     km = None if kv_mask is None else kv_mask.repeat_interleave(kv_group, dim=1)[:, :k.shape[1]]
-    return restate.linear_attention(q, k, v, qm, km, eps)
+    y = restate.linear_attention(q, k, v, qm, km, eps)
+    if out_split:
+        N, L, H, D = y.shape
+        return _rows_split(y.reshape(N * L, H * D))
+    return y
 
 
 def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None, coarse_scale=8.0):
@@ -51,14 +68,24 @@ def _fm(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, re
     return out
 
 
-def _ln(x, gamma, beta, eps=1e-5, residual=None, out=None):
+def _ln(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None, want_f32=True):
     y = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
     if residual is not None:
         y = residual.reshape(y.shape) + y
+    if out_split is not None:
+        _put_split(out_split, y)
     if out is None:
-        return y
+        return y if want_f32 else None
     out.copy_(y.reshape(out.shape))
     return out
+
+
+def _split_rows(x, add=None, out=None, out_split=None):
+    y = x if add is None else (x.reshape(-1, add.shape[0], x.shape[-1]) + add).reshape(x.shape)
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+    if out_split is not None:
+        _put_split(out_split, y)
 
 
 def _scatter(a, b, slot, dst):
@@ -116,10 +143,19 @@ def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None, out_split
     return out
 
 
-def _linear(x, pw, residual=None, relu=False, out=None):
-    rows = x.reshape(-1, x.shape[-1])
-    y = _conv(rows[None, None], pw, 1, 0, None if residual is None else residual.reshape(1, 1, rows.shape[0], -1), relu)
-    y = y.reshape(rows.shape[0], pw.Cout)
+def _linear(x, pw, residual=None, relu=False, out=None, out_split=False):
+    from detectorfreesfm_amd.ops import SplitAct
+    if isinstance(x, SplitAct):
+        K = x.hi.shape[-1]
+        x4 = SplitAct(x.hi.reshape(1, 1, -1, K), x.lo.reshape(1, 1, -1, K), K)
+        nrows = x4.hi.shape[2]
+    else:
+        x4 = x.reshape(1, 1, -1, x.shape[-1])
+        nrows = x4.shape[2]
+    y = _conv(x4, pw, 1, 0, None if residual is None else residual.reshape(1, 1, nrows, -1), relu)
+    y = y.reshape(nrows, pw.Cout)
+    if out_split:
+        return _rows_split(y)
     if out is None:
         return y
     out.copy_(y.reshape(out.shape))
@@ -139,10 +175,11 @@ def cpu_ops():
     from detectorfreesfm_amd import ops
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
-                                          "maxpool3x3s2_nhwc")}
+                                          "maxpool3x3s2_nhwc", "split_rows")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
+    ops.split_rows = _split_rows
     try:
         yield
     finally:

@@ -16,7 +16,7 @@ def _declared_symbols():
 def test_header_symbols_exported(built_lib):
     from detectorfreesfm_amd import _lib
     declared = _declared_symbols()
-    assert len(declared) >= 13
+    assert len(declared) >= 14
     bound = {name for name, _, _ in _lib.SIGNATURES}
     assert set(declared) == bound, (set(declared) ^ bound)
     raw = ctypes.CDLL(_lib.LIB_PATH)
@@ -29,7 +29,7 @@ def test_argument_checks_do_not_launch(built_lib):
     L = built_lib
     # null pointers -> BADARG, before any HIP call
     assert L.dfsfm_linear_attention_f32(None, None, None, None, 1, None, 1, None, 1, 8, 8, 8, 32, 256, 256, 256,
-                                        256, 1e-6, None, 0, None) == -1
+                                        256, 1e-6, None, None, 0, None, 0, None) == -1
     assert L.dfsfm_coarse_match_f32(None, None, 1, 16, 16, 256, 0.1, 0.2, 2, 4, 4, 4, 4, None, None, 8.0, None,
                                     None, None, None, None, None, None, None, 0, None) == -1
     assert L.dfsfm_roi_align_f32(None, 1, 3, 8, 8, None, None, None, 4, 35, 35, 0.0, None, None, None, 0, None) == -1

@@ -1,0 +1,20 @@
+"""One warm forward of each plugin (for rocprofv3 --kernel-trace --stats): python tools/profile_step.py [coarse|refine] [n]"""
+import sys, torch
+sys.path.insert(0, '.')
+from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, synth
+from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config
+from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict
+which = sys.argv[1] if len(sys.argv) > 1 else 'coarse'
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = 'cuda:0'
+if which == 'coarse':
+    cfg = loftr_coarse_only_config(0.2)
+    m = HipLoFTR(cfg); m.load_state_dict(random_state_dict(loftr_param_spec(cfg), 0)); m = m.eval().to(dev)
+    data = synth.to_device(synth.coarse_pair_batch(8, 480, 640, seed=1000), dev)
+else:
+    cfg = multiview_refinement_config()
+    m = HipMultiviewMatcher(cfg); m.load_state_dict(random_state_dict(multiview_param_spec(cfg), 1)); m = m.eval().to(dev)
+    data = synth.to_device(synth.refine_bag(2000, 5, 480, 640, seed=2000), dev)
+for _ in range(n):
+    m(dict(data))
+torch.cuda.synchronize()
