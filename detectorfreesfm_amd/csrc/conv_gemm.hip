@@ -23,6 +23,7 @@
 // conflict-free swizzled ds_read_b128, next slab prefetched into registers and split while the
 // MFMAs run; epilogue fuses bias (folded BN), residual, ReLU.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -342,37 +343,68 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
         ix0[q] = ox * g.stride - g.pad;
         abase[q] = (unsigned)(n * g.sxn);
     }
-    // running decomposition of this lane's k index (advances by BK per slab)
+    // running decomposition of this lane's k index (advances by BK per slab); branch-free updates so the
+    // whole main loop stays one basic block and the LDS-DMA issues can sit between MFMAs
     int ci = lslot * 8, ky = 0, kx = 0, kcur = lslot * 8;
+#pragma unroll 1
     while (ci >= g.Cin) { ci -= g.Cin; if (++kx == g.kw) { kx = 0; ++ky; } }
     unsigned boff = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);   // + group*16 rows, + k0
-
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-        char* st = smem + stage * T::STAGE;
+    unsigned offA[2], offB[2];
+    auto addr = [&]() __attribute__((always_inline)) {      // offsets of the next slab's pieces, then advance
+        const bool kin = kcur < g.K;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int iy = iy0[q] + ky, ix = ix0[q] + kx;
-            const bool ok = aok[q] && kcur < g.K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-            const unsigned off = ok ? (abase[q] + (unsigned)iy * (unsigned)g.sxh + (unsigned)ix * (unsigned)g.ldx + (unsigned)ci) * 2u
-                                    : g.xbytes;             // out of range -> hardware writes zeros
-            const int grp = wave + 8 * q;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(st + grp * 1024), 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(st + T::A_PLANE + grp * 1024), 16, off, 0, 0, 0);
+            const bool ok = aok[q] & kin & (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.W);
+            const unsigned off = (abase[q] + (unsigned)iy * (unsigned)g.sxh + (unsigned)ix * (unsigned)g.ldx + (unsigned)ci) * 2u;
+            offA[q] = ok ? off : g.xbytes;                  // out of range -> hardware writes zeros
         }
 #pragma unroll
         for (int j = 0; j < T::B_INSTR; ++j) {
-            const int ib = wave + 8 * j;
-            const int plane = ib / (BN_ / 16), grp = ib % (BN_ / 16);
-            const unsigned off = boff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane ? rwl : rwh,
-                                                     (lds_void*)(st + 2 * T::A_PLANE + plane * T::B_PLANE + grp * 1024),
-                                                     16, off, 0, 0, 0);
+            const int grp = (wave + 8 * j) % (BN_ / 16);
+            offB[j] = kcur - lslot * 8 < g.Kpad ? boff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
         }
-        // advance this lane's k bookkeeping to the next slab
         kcur += BK;
         boff += BK * 2;
         ci += BK;
-        while (ci >= g.Cin) { ci -= g.Cin; if (++kx == g.kw) { kx = 0; ++ky; } }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                       // up to 4 tap wraps per slab (Cin >= 8)
+            const bool wrap = ci >= g.Cin;
+            ci -= wrap ? g.Cin : 0;
+            kx += wrap ? 1 : 0;
+            const bool wrap2 = kx == g.kw;
+            kx = wrap2 ? 0 : kx;
+            ky += wrap2 ? 1 : 0;
+        }
+    };
+    // pieces of a slab: A rows group `wave + 8q`, plane hi/lo (4 pieces), then the weight pieces
+#ifdef DFSFM_ABL_NODMA
+#define DMA_A(q, lo, stage) ((void)0)
+#define DMA_B(j, stage) ((void)0)
+#else
+#define DMA_A(q, lo, stage)                                                                                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((lo) ? rxl : rxh,                                                \
+                                             (lds_void*)(smem + (stage) * T::STAGE + (lo) * T::A_PLANE +      \
+                                                         (wave + 8 * (q)) * 1024),                            \
+                                             16, offA[q], 0, 0, 0)
+#define DMA_B(j, stage)                                                                                       \
+    do {                                                                                                      \
+        const int ib_ = wave + 8 * (j);                                                                       \
+        const int plane_ = ib_ / (BN_ / 16), grp_ = ib_ % (BN_ / 16);                                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(plane_ ? rwl : rwh,                                          \
+                                                 (lds_void*)(smem + (stage) * T::STAGE + 2 * T::A_PLANE +     \
+                                                             plane_ * T::B_PLANE + grp_ * 1024),              \
+                                                 16, offB[j], 0, 0, 0);                                       \
+    } while (0)
+#endif
+    auto issue_all = [&](int stage) __attribute__((always_inline)) {
+        addr();
+        DMA_A(0, 0, stage);
+        DMA_A(0, 1, stage);
+        DMA_A(1, 0, stage);
+        DMA_A(1, 1, stage);
+        DMA_B(0, stage);
+        if constexpr (T::B_INSTR > 1) DMA_B(1, stage);
     };
 
     f32x16 accm[2][NJ], accx[2][NJ];
@@ -384,39 +416,115 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
             accx[i][j] = f32x16{0};
         }
 
-    const int nk = g.Kpad / BK;
-    issue(0);
-    if (nk > 1) issue(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<T::G>(); else wait_vmcnt<0>();   // slab kt has landed (this wave's part)
-        __builtin_amdgcn_s_barrier();                                 // ... and everybody else's
-        if (kt + 2 < nk) issue((kt + 2) % NST);
-        const char* st = smem + (kt % NST) * T::STAGE;
+    // Fragment sets F0 (k-step 0 of a slab) and F1 (k-step 1) are loaded one half-slab ahead of the MFMAs
+    // that use them, so LDS latency hides behind matrix work.  One barrier per slab, placed between
+    // the two k-steps: it publishes slab kt+1 (needed for the F0 prefetch) and frees stage (kt-1)%3.
+    half8 a0h[2], a0l[2], b0h[NJ], b0l[NJ], a1h[2], a1l[2], b1h[NJ], b1l[NJ];
+    auto read_frags = [&](const char* st, int ks, half8 (&ah)[2], half8 (&al)[2], half8 (&bh)[NJ],
+                          half8 (&bl)[NJ]) __attribute__((always_inline)) {
+#ifdef DFSFM_ABL_NOREAD
+        if (ks >= 0) return;
+#endif
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 ah[2], al[2], bh[NJ], bl[NJ];
+        for (int i = 0; i < 2; ++i) {
+            const int off = tile_off(wr * 64 + i * 32 + col, ks * 2 + kgrp);
+            ah[i] = *reinterpret_cast<const half8*>(st + off);
+            al[i] = *reinterpret_cast<const half8*>(st + T::A_PLANE + off);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = tile_off(wr * 64 + i * 32 + col, ks * 2 + kgrp);
-                ah[i] = *reinterpret_cast<const half8*>(st + off);
-                al[i] = *reinterpret_cast<const half8*>(st + T::A_PLANE + off);
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
+            bh[j] = *reinterpret_cast<const half8*>(st + 2 * T::A_PLANE + off);
+            bl[j] = *reinterpret_cast<const half8*>(st + 2 * T::A_PLANE + T::B_PLANE + off);
+        }
+    };
+    auto mma = [&](const half8 (&ah)[2], const half8 (&al)[2], const half8 (&bh)[NJ], const half8 (&bl)[NJ])
+                   __attribute__((always_inline)) {
+#ifdef DFSFM_ABL_NOMMA
+        asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(bh[0]), "v"(bl[0]), "v"(ah[1]), "v"(al[1]));
+        return;
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
-                bh[j] = *reinterpret_cast<const half8*>(st + 2 * T::A_PLANE + off);
-                bl[j] = *reinterpret_cast<const half8*>(st + 2 * T::A_PLANE + T::B_PLANE + off);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
-                }
+    };
+
+    // Ring schedule (3 stages): at the mid-slab point of slab kt every read of stage kt%3 has been issued
+    // (F0 one half-slab earlier, F1 at the top of this slab), so slab kt+3 is DMA'd into it right there:
+    // two slabs are always in flight while one is being multiplied.  Every slab issues exactly G pieces
+    // (past the end of K they are out-of-range = zero fill, no memory traffic), which keeps the vmcnt
+    // arithmetic constant and the loop body branch-free; the pieces are spread between MFMA groups.
+    const int nk = g.Kpad / BK;
+    issue_all(0);
+    issue_all(1);
+    issue_all(2);
+    wait_vmcnt<2 * T::G>();                                           // slab 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, 0, a0h, a0l, b0h, b0l);
+    auto mma3 = [&](const half8& ah, const half8& al, const half8& bh, const half8& bl, f32x16& m, f32x16& x)
+                    __attribute__((always_inline)) {
+#ifdef DFSFM_ABL_NOMMA
+        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+        return;
+#endif
+        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, m, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, x, 0, 0, 0);
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt % NST;
+        read_frags(smem + stage * T::STAGE, 1, a1h, a1l, b1h, b1l);  // prefetch k-step 1 of this slab
+        mma(a0h, a0l, b0h, b0l);                                      // k-step 0
+        addr();                                                       // offsets of slab kt+3 (VALU only)
+        wait_vmcnt<T::G>();                                           // slab kt+1 landed (kt+2 may still fly)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's reads of stage kt%3 are done
+        __builtin_amdgcn_s_barrier();
+        read_frags(smem + ((kt + 1) % NST) * T::STAGE, 0, a0h, a0l, b0h, b0l);   // prefetch next slab's k-step 0
+        // k-step 1, with slab kt+3's DMA pieces (-> the stage just retired) spread between the MFMA groups
+        DMA_A(0, 0, stage);
+        mma3(a1h[0], a1l[0], b1h[0], b1l[0], accm[0][0], accx[0][0]);
+        DMA_A(0, 1, stage);
+        if constexpr (NJ == 2) {
+            mma3(a1h[0], a1l[0], b1h[1], b1l[1], accm[0][1], accx[0][1]);
+            DMA_A(1, 0, stage);
+            DMA_A(1, 1, stage);
+            mma3(a1h[1], a1l[1], b1h[0], b1l[0], accm[1][0], accx[1][0]);
+            DMA_B(0, stage);
+            DMA_B(1, stage);
+            mma3(a1h[1], a1l[1], b1h[1], b1l[1], accm[1][1], accx[1][1]);
+        } else {
+            DMA_A(1, 0, stage);
+            DMA_A(1, 1, stage);
+            mma3(a1h[1], a1l[1], b1h[0], b1l[0], accm[1][0], accx[1][0]);
+            DMA_B(0, stage);
         }
+#if 1   // pinned interleave measured +5 % over the compiler's order (DMA issues hoisted in front of the MFMAs)
+        // pin the interleave: F0 prefetch reads first, then {DMA piece(s), 3 MFMAs} groups
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        if constexpr (NJ == 2) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        }
+#endif
     }
+    wait_vmcnt<0>();                                                  // the zero-fill tail pieces, before LDS is reused
+#undef DMA_A
+#undef DMA_B
 
     // ---- epilogue through LDS: tile[row][col] fp32, then 8 channels per thread ---------------------
     __syncthreads();
