@@ -15,6 +15,8 @@ the FPN top-down branch (dead when fine.enable=False, resnet_fpn.py:110-116) and
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -152,6 +154,7 @@ class HipLoFTR(ParamModule):
         if dense_backend not in ("hip", "library"):
             raise ValueError(dense_backend)
         self.dense_backend = dense_backend
+        self.same_conv = os.environ.get("DFSFM_SAME_CONV", "1") != "0"   # A/B switch for the tap-reuse conv kernel
         if config["match_coarse"]["match_type"] != "dual_softmax":
             raise NotImplementedError("only the dual_softmax coarse matcher is on the hot path")
         if config["fine"]["enable"]:
@@ -205,14 +208,15 @@ class HipLoFTR(ParamModule):
         n_layers = len(self.config["coarse"]["layer_names"])
         P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.", self.dense_backend) for i in range(n_layers)]
         if self.dense_backend == "hip":
-            def pk(wb, split_in=True):    # weights for a conv whose input arrives as a SplitAct
-                w, b = wb if isinstance(wb, tuple) else (wb, None)
-                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None)
+            def pk(wb, split_in=True, same=False):    # weights for a conv whose input arrives as a SplitAct
+                w, b = wb if isinstance(wb, tuple) else (wb, None)   # same: stride-1 3x3 -> activation-reuse kernel
+                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
+                                       tap_padded=same and self.same_conv)
             H = {"stem": pk(P["stem"], split_in=False), "l3out": pk(P["l3out"])}
             for li in (1, 2, 3):
                 for bi in (0, 1):
                     b = P[f"l{li}b{bi}"]
-                    hb = {"c1": pk(b["c1"]), "c2": pk(b["c2"]), "stride": b["stride"]}
+                    hb = {"c1": pk(b["c1"], same=b["stride"] == 1), "c2": pk(b["c2"], same=True), "stride": b["stride"]}
                     if "down" in b:
                         hb["down"] = pk(b["down"])
                     H[f"l{li}b{bi}"] = hb

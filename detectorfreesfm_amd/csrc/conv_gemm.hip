@@ -55,6 +55,7 @@ struct ConvArgs {
     int H, W, Cin, Ho, Wo, Cout, Cout_s, kh, kw, stride, pad, K, Kpad, relu;
     unsigned xbytes;         // byte size of one input plane (buffer-descriptor bound, v2 kernel)
     unsigned wbytes;
+    unsigned ntiles;         // M tiles x N tiles (v2 kernels; the grid is padded to a multiple of 8)
 };
 
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) { split_f32(x, hi, lo); }
@@ -303,6 +304,116 @@ struct V2 {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Shared epilogue of the split-input kernels: the accumulator tile goes through LDS so each thread owns 8
+// consecutive channels of one output row: bias (folded BN), fp32 / split residual, ReLU, then 32-byte fp32
+// stores and/or 16+16-byte split stores.  Must be entered with no LDS-DMA in flight.
+// Workgroup b is dispatched to XCD b % 8 (round robin).  Each XCD gets a contiguous band of tiles, so the
+// tiles that read the same activation rows (the ky halo of neighbouring M tiles, the N tiles of one M tile)
+// run on one XCD at about the same time and meet in its L2 instead of each fetching from HBM.
+__device__ __forceinline__ unsigned xcd_band_tile(unsigned b, unsigned per_xcd) {
+#ifdef DFSFM_ABL_NOXCD
+    return b;
+#else
+    return (b & 7u) * per_xcd + (b >> 3);
+#endif
+}
+
+template <int BN_>
+__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ / 64],
+                                            f32x16 (&accx)[2][BN_ / 64], int64_t m0, int n0, int tid, int wr, int wc,
+                                            int col, int kgrp) {
+    using T = V2<BN_>;
+    constexpr int NJ = BN_ / 64;
+#ifdef DFSFM_ABL_NOEPI
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(accm[i][j]), "v"(accx[i][j]));
+#endif
+    return;
+#endif
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * T::TILE_LD + wc * (BN_ / 2) + j * 32 + col] =
+                    accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
+    __syncthreads();
+    constexpr int CH = BN_ / 8;                               // 8-channel chunks per row
+    for (int e = tid; e < BM2 * CH; e += 512) {
+        const int r = e / CH, c8 = (e % CH) * 8;
+        const int64_t m = m0 + r;
+        const int n = n0 + c8;
+        if (m >= g.M || (n >= g.Cout && n >= g.Cout_s)) continue;
+        float v[8];
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8 + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = t0[q]; v[4 + q] = t1[q]; }
+        const bool full = n + 8 <= g.Cout;
+        if (full) {
+            if (g.bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += g.bias[n + q];
+            }
+            if (g.res) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+            }
+            if (g.resh) {
+                const half8 rh = *reinterpret_cast<const half8*>(g.resh + m * g.ldr + n);
+                const half8 rl = *reinterpret_cast<const half8*>(g.resl + m * g.ldr + n);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += (float)rh[q] + (float)rl[q] * (1.f / 2048.f);
+            }
+        } else {   // chunk straddles Cout (e.g. 196 = 24*8 + 4): per-channel guards
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (n + q < g.Cout) {
+                    if (g.bias) v[q] += g.bias[n + q];
+                    if (g.res) v[q] += g.res[m * g.ldr + n + q];
+                    if (g.resh) v[q] += (float)g.resh[m * g.ldr + n + q] + (float)g.resl[m * g.ldr + n + q] * (1.f / 2048.f);
+                } else {
+                    v[q] = 0.f;
+                }
+            }
+        }
+        if (g.relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+#ifdef DFSFM_ABL_NOSTORE
+        if (v[0] != 12345.678f) continue;
+#endif
+        if (g.out) {
+            if (full) {
+                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (n + q < g.Cout) g.out[m * g.ldo + n + q] = v[q];
+            }
+        }
+        if (g.outh && n < g.Cout_s) {          // Cout_s % 8 == 0: whole chunk, padded channels are zeros
+            half8 h, l;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                _Float16 a, b;
+                split1(v[q], a, b);
+                h[q] = a;
+                l[q] = b;
+            }
+            *reinterpret_cast<half8*>(g.outh + m * g.ldo_s + n) = h;
+            *reinterpret_cast<half8*>(g.outl + m * g.ldo_s + n) = l;
+        }
+    }}
+
 template <int BN_>
 __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     using T = V2<BN_>;
@@ -315,8 +426,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     // N tiles of one M tile are adjacent in dispatch order: they share the activation tile in L2 / MALL
     const int ntn = (g.Cout + BN_ - 1) / BN_;
-    const int64_t m0 = (int64_t)(blockIdx.x / ntn) * BM2;
-    const int n0 = (blockIdx.x % ntn) * BN_;
+    const unsigned tile_id = xcd_band_tile(blockIdx.x, gridDim.x >> 3);
+    if (tile_id >= g.ntiles) return;
+    const int64_t m0 = (int64_t)(tile_id / ntn) * BM2;
+    const int n0 = (tile_id % ntn) * BN_;
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
@@ -526,86 +639,304 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
 #undef DMA_A
 #undef DMA_B
 
-    // ---- epilogue through LDS: tile[row][col] fp32, then 8 channels per thread ---------------------
-    __syncthreads();
-    float* tile = reinterpret_cast<float*>(smem);
+    sf_epilogue<BN_>(g, smem, accm, accx, m0, n0, tid, wr, wc, col, kgrp);
+}
+
+// =================================================================================================
+// "same" convolutions (stride 1, pad (KW-1)/2, KW x KW taps): tap-level reuse of the activation tile.
+// The conv kernel above is bound by the global->LDS operand stream: every input pixel is
+// fetched once per tap.  With flattened pixel indices the rows an M tile needs for the KW taps of one
+// ky are ONE contiguous run of 256 + KW - 1 pixels, so the K loop is re-ordered to (ky, 32-channel
+// chunk, kx): the run is DMA'd once per (ky, chunk) into a 2-stage A ring and the kx taps read it as
+// row-shifted fragments (rows whose x + kx - pad leaves the image are zeroed in registers; rows
+// whose y + ky - pad leaves it are zero-filled by the DMA).  Weights keep a 3-stage ring, one slab
+// per tap.  A traffic drops KW-fold; everything else (3-MFMA split product, register double-buffered
+// fragments, mid-slab barrier, pinned DMA/MFMA interleave, epilogue) is as in conv_gemm_sf_kernel.
+// Weights are packed tap-padded: K = (ky, kx, ceil32(Cin)).
+// =================================================================================================
+template <int BN_, int KW>
+struct VS {
+    static constexpr int PAD = KW / 2;
+    static constexpr int AG = 17;                            // 16-row groups per A stage (256 + KW - 1 <= 272)
+    static constexpr int A_PLANE = AG * 1024;
+    static constexpr int A_STAGE = 2 * A_PLANE;             // hi, lo
+    static constexpr int B_PLANE = BN_ * 64;
+    static constexpr int B_STAGE = 2 * B_PLANE;
+    static constexpr int BN_I = (BN_ / 16) * 2 / 8;         // weight pieces per wave per slab (2 or 1)
+#ifndef DFSFM_SAME_NA
+#define DFSFM_SAME_NA 3
+#endif
+    static constexpr int NA = DFSFM_SAME_NA;                // A ring depth (super-slabs)
+    static constexpr int NB = (NA == 3 && NA * A_STAGE + 4 * B_STAGE + 1024 <= 160 * 1024) ? 4 : 3;   // B ring depth
+    static_assert(NA == 2 || NA == 3, "A ring depth");
+    static constexpr int OFF_B = NA * A_STAGE;
+    static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;  // 1 KB sink for the padding pieces
+    static constexpr int RING = OFF_DUMMY + 1024;
+    static constexpr int TILE_BYTES = BM2 * (BN_ + 4) * 4;
+    static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
+    // DMA pieces a wave issues at the mid-slab point of tap kx: A(S+NA-1) is spread over taps 0 (3) and 1 (2)
+    static constexpr int C(int kx) { return (kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
+    // pieces that may still be in flight at the mid-slab wait of tap kx: B(t+1) was issued NB-1 points ago; with a
+    // 2-deep A ring, A(S+1) (issued at taps 0/1 of this super-slab) must also have landed before tap KW-1's prefetch
+    static constexpr int NWAIT(int kx) {
+        int n = 0;
+        for (int d = 1; d <= NB - 2; ++d) n += C(((kx - d) % KW + KW) % KW);
+        if (NA == 2 && kx == KW - 1 && (KW - 2) * BN_I < n) n = (KW - 2) * BN_I;
+        return n;
+    }
+    static constexpr int NWAIT0 = 5 * (NA - 2) + (NB - 1) * BN_I;      // prologue: A(0), B(0) landed
+    // the prologue issues A(0) B(0) B(1) [A(1)] B(2).. so that slab 0's steady-state wait also covers B(1)
+    static_assert(5 * (NA - 2) + (NB - 2) * BN_I >= NWAIT(0), "prologue order does not cover slab 0's wait");
+};
+
+template <int BN_, int KW>
+__global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
+    using S_ = VS<BN_, KW>;
+    constexpr int NJ = BN_ / 64, PAD = KW / 2, BNI = S_::BN_I;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kgrp = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.Cout + BN_ - 1) / BN_;
+    const unsigned tile_id = xcd_band_tile(blockIdx.x, gridDim.x >> 3);
+    if (tile_id >= g.ntiles) return;
+    const int64_t m0 = (int64_t)(tile_id / ntn) * BM2;
+    const int n0 = (tile_id % ntn) * BN_;
+    const int Cin_p = g.Kpad / (KW * KW);                    // tap-padded channel count (multiple of 32)
+#ifdef DFSFM_ABL_NOLOOP
+    const int nchunk = Cin_p / BK, nS = 0;
+#else
+    const int nchunk = Cin_p / BK, nS = KW * nchunk;
+#endif
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.wh, 0, g.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
+
+    const int lrow = lane >> 2;
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    // A rows of this lane: groups wave, wave+8 and (waves 0/1 only: hi/lo plane of) group 16
+    int ay[3];
+    int64_t abase[3];
+    bool aok[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int grp = q < 2 ? wave + 8 * q : 16;
+#ifdef DFSFM_ABL_TILE0
+        const int64_t pix = (int64_t)(blockIdx.x & 7) * BM2 - PAD + grp * 16 + lrow;   // ablation: L2-resident A
+#else
+        const int64_t pix = m0 - PAD + grp * 16 + lrow;      // flattened pixel of LDS row grp*16 + lrow
+#endif
+        aok[q] = pix >= 0 && pix < g.M && (q < 2 || wave < 2);
+        const int64_t pp = aok[q] ? pix : 0;
+        const int ox = (int)(pp % g.W);
+        const int64_t t = pp / g.W;
+        ay[q] = (int)(t % g.H);
+        abase[q] = (t / g.H) * g.sxn + (int64_t)ay[q] * g.sxh + (int64_t)ox * g.ldx + lslot * 8;
+    }
+    const bool cok_lane = true;
+    (void)cok_lane;
+    unsigned offA[3];
+    auto addrA = [&](int Sn) __attribute__((always_inline)) {   // offsets of super-slab Sn = (ky, chunk)
+        const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
+        const bool in = Sn < nS && chunk * BK + lslot * 8 < g.Cin;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int iy = ay[q] + ky - PAD;
+            const bool ok = aok[q] & in & (iy >= 0) & (iy < g.H);
+            const int64_t off = (abase[q] + (int64_t)(ky - PAD) * g.sxh + chunk * BK) * 2;
+#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBA)
+            offA[q] = g.xbytes + (ok ? 0u : 16u);                // ablation: every piece zero-fills (no memory traffic)
+#else
+            offA[q] = ok ? (unsigned)off : g.xbytes;
+#endif
+        }
+    };
+    const unsigned bbase = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);
+    unsigned offB[2];
+    auto addrB = [&](int t) __attribute__((always_inline)) {    // offsets of slab t = (S, kx) -> (ky, chunk, kx)
+        const int Sn = t / KW, kx = t - Sn * KW;
+        const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
+        const unsigned koff = (unsigned)(((ky * KW + kx) * Cin_p + chunk * BK) * 2);
+#pragma unroll
+        for (int j = 0; j < BNI; ++j) {
+            const int grp = (wave + 8 * j) % (BN_ / 16);
+#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBB)
+            offB[j] = g.wbytes + (Sn < nS ? 0u : 16u);
+#else
+            offB[j] = Sn < nS ? bbase + koff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
+#endif
+        }
+    };
+#ifdef DFSFM_ABL_NODMA
+#define SDMA_A(p, astage) ((void)0)
+#define SDMA_B(j, bstage) ((void)0)
+#else
+    // A piece p of a super-slab: 0,1 = group wave (hi, lo); 2,3 = group wave+8 (hi, lo); 4 = group 16 (wave 0: hi,
+    // wave 1: lo, other waves: an out-of-range piece into the 1-KB sink so every wave issues the same count)
+#define SDMA_A(p, astage)                                                                                          \
+    do {                                                                                                            \
+        if ((p) < 4) {                                                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(((p) & 1) ? rxl : rxh,                                         \
+                                                     (lds_void*)(smem + (astage) * S_::A_STAGE + ((p) & 1) * S_::A_PLANE + \
+                                                                 (wave + 8 * ((p) >> 1)) * 1024),                   \
+                                                     16, offA[(p) >> 1], 0, 0, 0);                                  \
+        } else {                                                                                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 1 ? rxl : rxh,                                         \
+                                                     (lds_void*)(wave < 2 ? smem + (astage) * S_::A_STAGE + wave * S_::A_PLANE + 16 * 1024 \
+                                                                          : smem + S_::OFF_DUMMY),                  \
+                                                     16, offA[2], 0, 0, 0);                                         \
+        }                                                                                                           \
+    } while (0)
+#define SDMA_B(j, bstage)                                                                                          \
+    do {                                                                                                            \
+        const int ib_ = wave + 8 * (j);                                                                             \
+        const int plane_ = ib_ / (BN_ / 16), grp_ = ib_ % (BN_ / 16);                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(plane_ ? rwl : rwh,                                                \
+                                                 (lds_void*)(smem + S_::OFF_B + (bstage) * S_::B_STAGE +            \
+                                                             plane_ * S_::B_PLANE + grp_ * 1024),                   \
+                                                 16, offB[j], 0, 0, 0);                                             \
+    } while (0)
+#endif
+
+    f32x16 accm[2][NJ], accx[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * T::TILE_LD + wc * (BN_ / 2) + j * 32 + col] =
-                    accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
-    __syncthreads();
-    constexpr int CH = BN_ / 8;                               // 8-channel chunks per row
-    for (int e = tid; e < BM2 * CH; e += 512) {
-        const int r = e / CH, c8 = (e % CH) * 8;
-        const int64_t m = m0 + r;
-        const int n = n0 + c8;
-        if (m >= g.M || (n >= g.Cout && n >= g.Cout_s)) continue;
-        float v[8];
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8 + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = t0[q]; v[4 + q] = t1[q]; }
-        const bool full = n + 8 <= g.Cout;
-        if (full) {
-            if (g.bias) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += g.bias[n + q];
-            }
-            if (g.res) {
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n + 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
-            }
-            if (g.resh) {
-                const half8 rh = *reinterpret_cast<const half8*>(g.resh + m * g.ldr + n);
-                const half8 rl = *reinterpret_cast<const half8*>(g.resl + m * g.ldr + n);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += (float)rh[q] + (float)rl[q] * (1.f / 2048.f);
-            }
-        } else {   // chunk straddles Cout (e.g. 196 = 24*8 + 4): per-channel guards
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (n + q < g.Cout) {
-                    if (g.bias) v[q] += g.bias[n + q];
-                    if (g.res) v[q] += g.res[m * g.ldr + n + q];
-                    if (g.resh) v[q] += (float)g.resh[m * g.ldr + n + q] + (float)g.resl[m * g.ldr + n + q] * (1.f / 2048.f);
-                } else {
-                    v[q] = 0.f;
-                }
-            }
+        for (int j = 0; j < NJ; ++j) {
+            accm[i][j] = f32x16{0};
+            accx[i][j] = f32x16{0};
         }
-        if (g.relu) {
+    // x coordinate of this lane's two output rows (for the left/right border of the kx taps)
+    int oxr[2];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-        if (g.out) {
-            if (full) {
-                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
+    for (int i = 0; i < 2; ++i) oxr[i] = (int)((m0 + wr * 64 + i * 32 + col) % g.W);
+
+    half8 a0h[2], a0l[2], b0h[NJ], b0l[NJ], a1h[2], a1l[2], b1h[NJ], b1l[NJ];
+    auto read_frags = [&](int astage, int shift, int bstage, int ks, half8 (&ah)[2], half8 (&al)[2], half8 (&bh)[NJ],
+                          half8 (&bl)[NJ]) __attribute__((always_inline)) {
+#ifdef DFSFM_ABL_NOREAD
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(ah[i]), "=v"(al[i]));
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bh[j]), "=v"(bl[j]));
+#endif
+        if (ks >= 0) return;
+#endif
+#ifdef DFSFM_ABL_NOREADB
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bh[j]), "=v"(bl[j]));
+#endif
+#endif
+        const char* sa = smem + astage * S_::A_STAGE;
+        const char* sb = smem + S_::OFF_B + bstage * S_::B_STAGE;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (n + q < g.Cout) g.out[m * g.ldo + n + q] = v[q];
+        for (int i = 0; i < 2; ++i) {
+            const int off = tile_off(wr * 64 + i * 32 + col + shift, ks * 2 + kgrp);
+            half8 h = *reinterpret_cast<const half8*>(sa + off);
+            half8 l = *reinterpret_cast<const half8*>(sa + S_::A_PLANE + off);
+            if (shift != PAD) {                                  // tap leaves the image row: contributes zero
+                const bool out = (unsigned)(oxr[i] + shift - PAD) >= (unsigned)g.W;
+                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                h = out ? z : h;
+                l = out ? z : l;
             }
+            ah[i] = h;
+            al[i] = l;
         }
-        if (g.outh && n < g.Cout_s) {          // Cout_s % 8 == 0: whole chunk, padded channels are zeros
-            half8 h, l;
+#ifdef DFSFM_ABL_NOREADB
+        if (ks >= 0) return;
+#endif
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                _Float16 a, b;
-                split1(v[q], a, b);
-                h[q] = a;
-                l[q] = b;
-            }
-            *reinterpret_cast<half8*>(g.outh + m * g.ldo_s + n) = h;
-            *reinterpret_cast<half8*>(g.outl + m * g.ldo_s + n) = l;
+        for (int j = 0; j < NJ; ++j) {
+            const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
+            bh[j] = *reinterpret_cast<const half8*>(sb + off);
+            bl[j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
         }
+    };
+    auto mma3 = [&](const half8& ah, const half8& al, const half8& bh, const half8& bl, f32x16& m, f32x16& x)
+                    __attribute__((always_inline)) {
+#ifdef DFSFM_ABL_NOMMA
+        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+        return;
+#endif
+        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, m, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, x, 0, 0, 0);
+    };
+
+    // ---- schedule -------------------------------------------------------------------------------------
+    // slab t = S*KW + kx uses A stage S%NA (row shift kx) and B stage t%NB.  At the mid-slab barrier of slab t:
+    // B(t+NB) -> B stage t%NB (NB-1 slabs of lead); for kx = 0 / 1 also the first 3 / last 2 pieces of
+    // A(S+NA-1) -> the A stage A(S-1) just left (NA = 3: a whole super-slab + 1 slab of lead).
+    addrA(0);
+    SDMA_A(0, 0); SDMA_A(1, 0); SDMA_A(2, 0); SDMA_A(3, 0); SDMA_A(4, 0);
+#pragma unroll
+    for (int t = 0; t < S_::NB; ++t) {
+        if (t == 2 && S_::NA > 2) {
+            addrA(1);
+            SDMA_A(0, 1); SDMA_A(1, 1); SDMA_A(2, 1); SDMA_A(3, 1); SDMA_A(4, 1);
+        }
+        addrB(t);
+        SDMA_B(0, t);
+        if constexpr (BNI > 1) SDMA_B(1, t);
     }
+    wait_vmcnt<S_::NWAIT0>();                                         // A(0) and B(0) landed
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0, 0, a0h, a0l, b0h, b0l);
+    int bst = 0;                                                      // B stage of the current slab (t % NB)
+    int ast = 0;                                                      // A stage of the current super-slab (S % NA)
+    for (int S = 0; S < nS; ++S) {
+        const int anx = ast == S_::NA - 1 ? 0 : ast + 1;              // stage of A(S+1)
+        const int adm = ast == 0 ? S_::NA - 1 : ast - 1;              // stage A(S+NA-1) is DMA'd into (held A(S-1))
+        addrA(S + S_::NA - 1);
+        auto tap = [&](auto kxc) __attribute__((always_inline)) {
+            constexpr int kx = decltype(kxc)::value;
+            const int t = S * KW + kx;
+            read_frags(ast, kx, bst, 1, a1h, a1l, b1h, b1l);          // k-step 1 of this slab
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma3(a0h[i], a0l[i], b0h[j], b0l[j], accm[i][j], accx[i][j]);
+            addrB(t + S_::NB);
+            wait_vmcnt<S_::NWAIT(kx)>();                              // B(t+1) (and A(S+1)) have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int bnx = bst == S_::NB - 1 ? 0 : bst + 1;
+            if (kx + 1 < KW) read_frags(ast, kx + 1, bnx, 0, a0h, a0l, b0h, b0l);
+            else read_frags(anx, 0, bnx, 0, a0h, a0l, b0h, b0l);
+            // k-step 1 with this slab's DMA pieces between the MFMA groups
+            if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); }
+            if (kx == 1) { SDMA_A(3, adm); }
+            SDMA_B(0, bst);
+            mma3(a1h[0], a1l[0], b1h[0], b1l[0], accm[0][0], accx[0][0]);
+            if (kx == 0) { SDMA_A(2, adm); }
+            if (kx == 1) { SDMA_A(4, adm); }
+            if constexpr (NJ == 2) {
+                mma3(a1h[0], a1l[0], b1h[1], b1l[1], accm[0][1], accx[0][1]);
+                SDMA_B(1, bst);
+                mma3(a1h[1], a1l[1], b1h[0], b1l[0], accm[1][0], accx[1][0]);
+                mma3(a1h[1], a1l[1], b1h[1], b1l[1], accm[1][1], accx[1][1]);
+            } else {
+                mma3(a1h[1], a1l[1], b1h[0], b1l[0], accm[1][0], accx[1][0]);
+            }
+            bst = bnx;
+        };
+        tap(std::integral_constant<int, 0>{});
+        tap(std::integral_constant<int, 1>{});
+        tap(std::integral_constant<int, 2>{});
+        if constexpr (KW > 3) {
+            tap(std::integral_constant<int, 3>{});
+            tap(std::integral_constant<int, 4>{});
+        }
+        ast = anx;
+    }
+    wait_vmcnt<0>();
+#undef SDMA_A
+#undef SDMA_B
+    sf_epilogue<BN_>(g, smem, accm, accx, m0, n0, tid, wr, wc, col, kgrp);
 }
 
 // 3x3 / stride 2 / pad 1 max pooling, NHWC (nn.MaxPool2d(3, 2, 1), s2dnet.py:89-92)
@@ -689,8 +1020,25 @@ void launch_v2(const ConvArgs& g, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         attr_set = true;
     }
-    const dim3 grid((unsigned)((g.M + BM2 - 1) / BM2) * (unsigned)((g.Cout + BN_ - 1) / BN_));
-    hipLaunchKernelGGL(conv_gemm_sf_kernel<BN_>, grid, dim3(512), T::SMEM, stream, g);
+    ConvArgs a = g;
+    a.ntiles = (unsigned)((g.M + BM2 - 1) / BM2) * (unsigned)((g.Cout + BN_ - 1) / BN_);
+    const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
+    hipLaunchKernelGGL(conv_gemm_sf_kernel<BN_>, grid, dim3(512), T::SMEM, stream, a);
+}
+
+template <int BN_, int KW>
+void launch_same(const ConvArgs& g, hipStream_t stream) {
+    using S_ = VS<BN_, KW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_sf_same_kernel<BN_, KW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, S_::SMEM);
+        attr_set = true;
+    }
+    ConvArgs a = g;
+    a.ntiles = (unsigned)((g.M + BM2 - 1) / BM2) * (unsigned)((g.Cout + BN_ - 1) / BN_);
+    const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
+    hipLaunchKernelGGL((conv_gemm_sf_same_kernel<BN_, KW>), grid, dim3(512), S_::SMEM, stream, a);
 }
 
 }  // namespace
@@ -700,8 +1048,10 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
                                      const void* w_lo, int Cout, int Kpad, int kh, int kw, int stride, int pad,
                                      const float* bias, const float* residual, const void* res_hi,
                                      const void* res_lo, int64_t ldr, int relu, float* out, int64_t ldo,
-                                     void* out_hi, void* out_lo, int64_t ldo_s, int Cout_s, void* stream_) {
+                                     void* out_hi, void* out_lo, int64_t ldo_s, int Cout_s, int tap_padded,
+                                     void* stream_) {
     const bool split_in = x_hi != nullptr;
+    if (tap_padded && !split_in) return DFSFM_E_UNSUPPORTED;
     if ((!x && !split_in) || (x && split_in) || (split_in && !x_lo) || !w_hi || !w_lo) return DFSFM_E_BADARG;
     if (!out && !out_hi) return DFSFM_E_BADARG;
     if ((out_hi == nullptr) != (out_lo == nullptr) || (res_hi == nullptr) != (res_lo == nullptr)) return DFSFM_E_BADARG;
@@ -710,7 +1060,7 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
         return DFSFM_E_BADARG;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return DFSFM_E_BADARG;
-    const int K = kh * kw * Cin;
+    const int K = tap_padded ? Kpad : kh * kw * Cin;
     if (Kpad < K || Kpad % BK != 0 || ldx < Cin || (out && ldo < Cout) || ((residual || res_hi) && ldr < Cout))
         return DFSFM_E_BADARG;
     if (out_hi && (Cout_s < Cout || Cout_s % 8 != 0 || ldo_s < Cout_s || Cout_s > (Cout + 127) / 128 * 128))
@@ -744,6 +1094,14 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             return DFSFM_E_UNSUPPORTED;
         g.xbytes = (unsigned)span;
         g.wbytes = (unsigned)wspan;
+        if (tap_padded) {      // "same" conv with tap-padded weights: activation tile reused across the kx taps
+            if (kh != kw || (kw != 3 && kw != 5) || stride != 1 || pad != kw / 2 || Kpad % (kw * kw * BK) != 0 ||
+                Kpad / (kw * kw) < Cin)
+                return DFSFM_E_UNSUPPORTED;
+            if (kw == 3) { if (Cout <= 64) launch_same<64, 3>(g, stream); else launch_same<128, 3>(g, stream); }
+            else         { if (Cout <= 64) launch_same<64, 5>(g, stream); else launch_same<128, 5>(g, stream); }
+            return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(same)");
+        }
         if (Cout <= 64) launch_v2<64>(g, stream);
         else launch_v2<128>(g, stream);
         return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(v2)");

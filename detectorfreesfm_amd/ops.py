@@ -299,11 +299,17 @@ class PackedDense:
     fp16 hi / lo [ceil128(Cout), Kpad], K = kh*kw*Cin_pad in (ky,kx,ci) order, w = hi + lo/2048.
     ``cin_pad`` (>= Cin, multiple of 8) matches the channel padding of a SplitAct input."""
 
-    def __init__(self, w: torch.Tensor, bias=None, cin_pad=None):
+    def __init__(self, w: torch.Tensor, bias=None, cin_pad=None, tap_padded=False):
+        """tap_padded: every tap's channel run is padded to a multiple of 32 (K = (ky,kx,ceil32(Cin))), the
+        layout of the activation-reuse kernel for stride-1 'same' 3x3 / 5x5 convolutions on split inputs."""
         if w.dim() == 2:
             w = w[:, :, None, None]
         Cout, Cin, kh, kw = w.shape
         cp = Cin if cin_pad is None else cin_pad
+        self.Cin_act = cp                       # channels of the activation tensor this layer reads
+        self.tap_padded = bool(tap_padded)
+        if tap_padded:
+            cp = (cp + 31) // 32 * 32
         K = kh * kw * cp
         self.Cout, self.Cin, self.kh, self.kw = Cout, cp, kh, kw
         self.Kpad = (K + 31) // 32 * 32
@@ -326,8 +332,10 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
     _require_cuda(xt)
     N, H, W, Cin = xt.shape
     want = torch.float16 if split_in else torch.float32
-    if Cin != pw.Cin or xt.dtype != want or (Cin > 1 and xt.stride(3) != 1):
+    if Cin != pw.Cin_act or xt.dtype != want or (Cin > 1 and xt.stride(3) != 1):
         raise _lib.DfsfmError("conv2d_nhwc: bad input")
+    if pw.tap_padded and not (split_in and stride == 1 and pw.kh == pw.kw and pad == pw.kw // 2):
+        raise _lib.DfsfmError("conv2d_nhwc: tap-padded weights need a split-input stride-1 'same' convolution")
     if split_in and (x.lo.shape != x.hi.shape or x.lo.stride() != x.hi.stride()):
         raise _lib.DfsfmError("conv2d_nhwc: hi/lo planes differ")
     Ho = (H + 2 * pad - pw.kh) // stride + 1
@@ -364,7 +372,7 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
         None if split_in else _ptr(x), _ptr(x.hi) if split_in else None, _ptr(x.lo) if split_in else None,
         sxn, xt.stride(1), xt.stride(2), N, H, W, Cin, _ptr(pw.hi), _ptr(pw.lo), pw.Cout, pw.Kpad, pw.kh, pw.kw,
         stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 1 if relu else 0,
-        _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, _stream())
+        _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, 1 if pw.tap_padded else 0, _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
     return result
 

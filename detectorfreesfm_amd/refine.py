@@ -23,6 +23,8 @@ Output-identical work the reference wastes is skipped ("dea
 * padded view slots (image index -1) are never cropped or convolved: they are masked everywhere
   downstream, the reference feeds them a copy of the last patch (MultiviewMatcher.py:253-266).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -51,6 +53,7 @@ class HipMultiviewMatcher(ParamModule):
         if dense_backend not in ("hip", "library"):
             raise ValueError(dense_backend)
         self.dense_backend = dense_backend
+        self.same_conv = os.environ.get("DFSFM_SAME_CONV", "1") != "0"   # A/B switch for the tap-reuse conv kernel
         if not test:
             raise NotImplementedError("training path is out of scope; build with test=True")
         bb = config["backbone"]
@@ -97,12 +100,13 @@ class HipMultiviewMatcher(ParamModule):
         P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.", self.dense_backend)
                        for i in range(n_layers)]
         if self.dense_backend == "hip":
-            def pk(w, b, split_in=True):
-                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None)
-            H = {"enc": {i: pk(*P["enc"][i], split_in=(i != 0)) for i in P["enc"]}}   # conv1_1 reads fp32 patches
+            def pk(w, b, split_in=True, same=False):    # same: stride-1 'same' conv -> activation-reuse kernel
+                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
+                                       tap_padded=same and split_in and self.same_conv)
+            H = {"enc": {i: pk(*P["enc"][i], split_in=(i != 0), same=True) for i in P["enc"]}}   # conv1_1 reads fp32 patches
             for i in (0, 1):
                 a = P[f"adap{i}"]
-                H[f"adap{i}"] = (pk(a[0], a[1]), pk(a[2], a[3]))
+                H[f"adap{i}"] = (pk(a[0], a[1]), pk(a[2], a[3], same=(i == 1)))   # adap1's 5x5 is pad 2, adap0's pad 0
             P["hip"] = H
         self._packed = P
         return P

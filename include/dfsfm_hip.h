@@ -191,13 +191,17 @@ int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, const int64_t* 
  * Residual: fp32 [M, Cout] (row stride ldr) or split planes res_hi/res_lo (row stride ldr), or none.
  * Output: fp32 `out` (row stride ldo) and/or split planes out_hi/out_lo (row stride ldo_s, Cout_s >=
  *         Cout channels, Cout_s % 8 == 0; channels >= Cout are written as zeros).
+ * tap_padded != 0 (split input, kh == kw in {3,5}, stride 1, pad kw/2 only): the weights are laid out
+ *         with K = (ky, kx, ceil32(Cin)) -- Kpad = kh*kw*ceil32(Cin) -- and the kernel variant that
+ *         loads each activation row once per (ky, 32-channel chunk) and reuses it for the kw taps
+ *         is used (1/kw of the activation traffic).
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
                           int64_t ldx, int Nimg, int H, int W, int Cin, const void* w_hi, const void* w_lo,
                           int Cout, int Kpad, int kh, int kw, int stride, int pad, const float* bias,
                           const float* residual, const void* res_hi, const void* res_lo, int64_t ldr,
                           int relu, float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s,
-                          int Cout_s, void* stream);
+                          int Cout_s, int tap_padded, void* stream);
 
 /* nn.MaxPool2d(3, stride=2, padding=1) on a dense NHWC tensor, fp32 (x -> out, C % 4 == 0) or split
  * planes (x_hi/x_lo -> out_hi/out_lo, C % 8 == 0)  (S2DNet with substitute_pooling_layers,

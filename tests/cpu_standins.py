@@ -120,8 +120,9 @@ def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None, out_split
     from detectorfreesfm_amd.ops import SplitAct
     K = pw.kh * pw.kw * pw.Cin
 
-    def unpack(t):
-        return t[:pw.Cout, :K].float().reshape(pw.Cout, pw.kh, pw.kw, pw.Cin).permute(0, 3, 1, 2).contiguous()
+    def unpack(t):      # tap-padded weights carry zero channels beyond the activation's
+        w = t[:pw.Cout, :K].float().reshape(pw.Cout, pw.kh, pw.kw, pw.Cin)[..., :pw.Cin_act]
+        return w.permute(0, 3, 1, 2).contiguous()
     wh, wl = unpack(pw.hi), unpack(pw.lo)
     if isinstance(x, SplitAct):
         xh, xl = x.hi.float().permute(0, 3, 1, 2), x.lo.float().permute(0, 3, 1, 2)

@@ -34,7 +34,8 @@ layers = [  # name, N, H, W, Cin, Cout, k, stride, pad
     ("lin mlp2 76800x512->256", 1, 1, 76800, 512, 256, 1, 1, 0),
     ("lin fine mlp0 1.8Mx256->256", 1, 1, 1800000, 256, 256, 1, 1, 0),
 ]
-split = len(sys.argv) > 1 and sys.argv[1] == "split"
+split = len(sys.argv) > 1 and sys.argv[1] in ("split", "same")
+same = len(sys.argv) > 1 and sys.argv[1] == "same"     # tap-padded weights -> activation-reuse kernel
 for name, N, H, W, Cin, Cout, k, s, p in layers:
     x = torch.randn((N, H, W, Cin), device=dev)
     w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05
@@ -44,7 +45,9 @@ for name, N, H, W, Cin, Cout, k, s, p in layers:
         hi = torch.zeros((N, H, W, cp), dtype=torch.float16, device=dev); lo = torch.zeros_like(hi)
         hi[..., :Cin] = x.half(); lo[..., :Cin] = ((x - x.half().float()) * 2048).half()
         xin = ops.SplitAct(hi, lo, Cin)
-        pw = ops.PackedDense(w, torch.zeros(Cout, device=dev), cin_pad=cp)
+        tp = same and s == 1 and k > 1 and p == k // 2
+        pw = ops.PackedDense(w, torch.zeros(Cout, device=dev), cin_pad=cp, tap_padded=tp)
+        name = name + (" [same]" if tp else "")
         ms = t(lambda: ops.conv2d_nhwc(xin, pw, s, p, relu=True, out_split=True))
     else:
         pw = ops.PackedDense(w, torch.zeros(Cout, device=dev))
@@ -53,5 +56,5 @@ for name, N, H, W, Cin, Cout, k, s, p in layers:
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     byts = (x.numel() + N * Ho * Wo * Cout) * 4
-    print(f"{name:34s} {ms:8.3f} ms  {fl/ms/1e9:7.1f} TF-eff  {byts/ms/1e6:7.0f} GB/s  ({fl/1e9:.1f} GFLOP)", flush=True)
+    print(f"{name:41s} {ms:8.3f} ms  {fl/ms/1e9:7.1f} TF-eff  {byts/ms/1e6:7.0f} GB/s  ({fl/1e9:.1f} GFLOP)", flush=True)
     del x, w, pw
