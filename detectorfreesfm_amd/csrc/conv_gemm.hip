@@ -663,30 +663,28 @@ struct VS {
     static constexpr int B_PLANE = BN_ * 64;
     static constexpr int B_STAGE = 2 * B_PLANE;
     static constexpr int BN_I = (BN_ / 16) * 2 / 8;         // weight pieces per wave per slab (2 or 1)
-#ifndef DFSFM_SAME_NA
-#define DFSFM_SAME_NA 3
-#endif
-    static constexpr int NA = DFSFM_SAME_NA;                // A ring depth (super-slabs)
-    static constexpr int NB = (NA == 3 && NA * A_STAGE + 4 * B_STAGE + 1024 <= 160 * 1024) ? 4 : 3;   // B ring depth
-    static_assert(NA == 2 || NA == 3, "A ring depth");
+    static constexpr int NA = KW == 1 ? 3 : 2;              // A ring depth (super-slabs)
+    static constexpr int NB = 3;                             // B ring depth (slabs)
     static constexpr int OFF_B = NA * A_STAGE;
     static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;  // 1 KB sink for the padding pieces
     static constexpr int RING = OFF_DUMMY + 1024;
     static constexpr int TILE_BYTES = BM2 * (BN_ + 4) * 4;
     static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
-    // DMA pieces a wave issues at the mid-slab point of tap kx: A(S+NA-1) is spread over taps 0 (3) and 1 (2)
-    static constexpr int C(int kx) { return (kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
-    // pieces that may still be in flight at the mid-slab wait of tap kx: B(t+1) was issued NB-1 points ago; with a
-    // 2-deep A ring, A(S+1) (issued at taps 0/1 of this super-slab) must also have landed before tap KW-1's prefetch
+    static_assert(RING <= 160 * 1024, "LDS ring");
+    // DMA pieces a wave issues in the load segment of tap kx: B(t+NB-1), and A(S+NA-1) spread over taps 0 (3
+    // pieces) and 1 (2 pieces) -- all 5 at tap 0 for a 1x1 kernel
+    static constexpr int C(int kx) { return (KW == 1 ? 5 : kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
+    // own pieces that may still be in flight when a wave publishes slab u = (S, kx) (the barrier that opens the
+    // first load segment reading it): B(u) was the last piece of load segment u-NB+1, so everything issued in the
+    // NB-2 segments since may be outstanding; with a 2-deep A ring A(S) was issued at taps 0/1 of S-1.
     static constexpr int NWAIT(int kx) {
         int n = 0;
         for (int d = 1; d <= NB - 2; ++d) n += C(((kx - d) % KW + KW) % KW);
-        if (NA == 2 && kx == KW - 1 && (KW - 2) * BN_I < n) n = (KW - 2) * BN_I;
+        if (KW > 1 && NA == 2 && kx == 0 && (KW - 1) * BN_I < n) n = (KW - 1) * BN_I;
         return n;
     }
-    static constexpr int NWAIT0 = 5 * (NA - 2) + (NB - 1) * BN_I;      // prologue: A(0), B(0) landed
-    // the prologue issues A(0) B(0) B(1) [A(1)] B(2).. so that slab 0's steady-state wait also covers B(1)
-    static_assert(5 * (NA - 2) + (NB - 2) * BN_I >= NWAIT(0), "prologue order does not cover slab 0's wait");
+    static constexpr int NWAIT0 = 5 * (NA - 2) + (NB - 2) * BN_I;      // prologue: A(0), B(0) landed
+    static_assert(KW == 1 ? (NA == NB) : true, "1x1: A(t) and B(t) are issued in the same load segment");
 };
 
 template <int BN_, int KW>
@@ -815,124 +813,133 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) oxr[i] = (int)((m0 + wr * 64 + i * 32 + col) % g.W);
 
-    half8 a0h[2], a0l[2], b0h[NJ], b0l[NJ], a1h[2], a1l[2], b1h[NJ], b1l[NJ];
-    auto read_frags = [&](int astage, int shift, int bstage, int ks, half8 (&ah)[2], half8 (&al)[2], half8 (&bh)[NJ],
-                          half8 (&bl)[NJ]) __attribute__((always_inline)) {
-#ifdef DFSFM_ABL_NOREAD
-#if defined(__HIP_DEVICE_COMPILE__)
-        for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(ah[i]), "=v"(al[i]));
-        for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bh[j]), "=v"(bl[j]));
-#endif
-        if (ks >= 0) return;
-#endif
-#ifdef DFSFM_ABL_NOREADB
-#if defined(__HIP_DEVICE_COMPILE__)
-        for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bh[j]), "=v"(bl[j]));
-#endif
-#endif
+    // ---- ping-pong schedule ------------------------------------------------------------------------------
+    // Waves w and w+4 share a SIMD.  The two halves of the workgroup run the same slab sequence half a slab
+    // apart: while waves 0-3 are in the COMPUTE segment of slab t (24 back-to-back MFMAs on register fragments),
+    // waves 4-7 are in its LOAD segment (16 fragment reads for the whole slab, this wave's DMA pieces for slab
+    // t+NB-1, address arithmetic, border masks), and vice versa, with one s_barrier per segment.  The matrix
+    // pipe of every SIMD always has exactly one wave feeding it and never sees LDS / VMEM issue in its stream.
+    //   barrier k:        b0    b1    b2    b3    b4
+    //   waves 0-3:           L0    C0    L1    C1   ...
+    //   waves 4-7:           --    L0    C0    L1   ...
+    // Slab u is read in the two segments after barrier b(2u); every wave waits for its own pieces of slab u
+    // (counted vmcnt) just before that barrier: waves 0-3 at the end of C(u-1), waves 4-7 at the end of L(u-1).
+    const int grp = wave >> 2;
+    half8 fah[2][2], fal[2][2], fbh[2][NJ], fbl[2][NJ];             // [k-step][block] fragments of one slab
+    auto read_slab = [&](int astage, int shift, int bstage) __attribute__((always_inline)) {
         const char* sa = smem + astage * S_::A_STAGE;
         const char* sb = smem + S_::OFF_B + bstage * S_::B_STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int off = tile_off(wr * 64 + i * 32 + col + shift, ks * 2 + kgrp);
-            half8 h = *reinterpret_cast<const half8*>(sa + off);
-            half8 l = *reinterpret_cast<const half8*>(sa + S_::A_PLANE + off);
-            if (shift != PAD) {                                  // tap leaves the image row: contributes zero
-                const bool out = (unsigned)(oxr[i] + shift - PAD) >= (unsigned)g.W;
-                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                h = out ? z : h;
-                l = out ? z : l;
-            }
-            ah[i] = h;
-            al[i] = l;
-        }
-#ifdef DFSFM_ABL_NOREADB
-        if (ks >= 0) return;
-#endif
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
-            bh[j] = *reinterpret_cast<const half8*>(sb + off);
-            bl[j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
+            for (int i = 0; i < 2; ++i) {
+                const int off = tile_off(wr * 64 + i * 32 + col + shift, ks * 2 + kgrp);
+                fah[ks][i] = *reinterpret_cast<const half8*>(sa + off);
+                fal[ks][i] = *reinterpret_cast<const half8*>(sa + S_::A_PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
+                fbh[ks][j] = *reinterpret_cast<const half8*>(sb + off);
+                fbl[ks][j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
+            }
         }
     };
-    auto mma3 = [&](const half8& ah, const half8& al, const half8& bh, const half8& bl, f32x16& m, f32x16& x)
-                    __attribute__((always_inline)) {
-#ifdef DFSFM_ABL_NOMMA
-        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
-        return;
-#endif
-        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, m, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, x, 0, 0, 0);
+    auto mask_slab = [&](int shift) __attribute__((always_inline)) {   // tap leaves the image row: contributes zero
+        if (shift == PAD) return;
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool out = (unsigned)(oxr[i] + shift - PAD) >= (unsigned)g.W;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fah[ks][i] = out ? z : fah[ks][i];
+                fal[ks][i] = out ? z : fal[ks][i];
+            }
+        }
+    };
+    auto compute_slab = [&]() __attribute__((always_inline)) {
+        // 3 products per block pair; consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][i], fbh[ks][j], accm[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][i], fbl[ks][j], accx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks][i], fbh[ks][j], accx[i][j], 0, 0, 0);
+        }
     };
 
-    // ---- schedule -------------------------------------------------------------------------------------
-    // slab t = S*KW + kx uses A stage S%NA (row shift kx) and B stage t%NB.  At the mid-slab barrier of slab t:
-    // B(t+NB) -> B stage t%NB (NB-1 slabs of lead); for kx = 0 / 1 also the first 3 / last 2 pieces of
-    // A(S+NA-1) -> the A stage A(S-1) just left (NA = 3: a whole super-slab + 1 slab of lead).
-    addrA(0);
-    SDMA_A(0, 0); SDMA_A(1, 0); SDMA_A(2, 0); SDMA_A(3, 0); SDMA_A(4, 0);
+    // prologue: A(0) B(0) A(1).. B(1)..  (A(0..NA-2), B(0..NB-2))
 #pragma unroll
-    for (int t = 0; t < S_::NB; ++t) {
-        if (t == 2 && S_::NA > 2) {
-            addrA(1);
-            SDMA_A(0, 1); SDMA_A(1, 1); SDMA_A(2, 1); SDMA_A(3, 1); SDMA_A(4, 1);
+    for (int t = 0; t < (S_::NA > S_::NB ? S_::NA : S_::NB) - 1; ++t) {
+        if (t < S_::NA - 1) {
+            addrA(t);
+            SDMA_A(0, t); SDMA_A(1, t); SDMA_A(2, t); SDMA_A(3, t); SDMA_A(4, t);
         }
-        addrB(t);
-        SDMA_B(0, t);
-        if constexpr (BNI > 1) SDMA_B(1, t);
+        if (t < S_::NB - 1) {
+            addrB(t);
+            SDMA_B(0, t);
+            if constexpr (BNI > 1) SDMA_B(1, t);
+        }
     }
-    wait_vmcnt<S_::NWAIT0>();                                         // A(0) and B(0) landed
-    __builtin_amdgcn_s_barrier();
-    read_frags(0, 0, 0, 0, a0h, a0l, b0h, b0l);
+    wait_vmcnt<S_::NWAIT0>();                                         // own pieces of slab 0 have landed
+    __builtin_amdgcn_s_barrier();                                     // b0: slab 0 published
+    if (grp == 1) __builtin_amdgcn_s_barrier();                       // waves 4-7 sit out the first segment
     int bst = 0;                                                      // B stage of the current slab (t % NB)
     int ast = 0;                                                      // A stage of the current super-slab (S % NA)
     for (int S = 0; S < nS; ++S) {
         const int anx = ast == S_::NA - 1 ? 0 : ast + 1;              // stage of A(S+1)
         const int adm = ast == 0 ? S_::NA - 1 : ast - 1;              // stage A(S+NA-1) is DMA'd into (held A(S-1))
-        addrA(S + S_::NA - 1);
         auto tap = [&](auto kxc) __attribute__((always_inline)) {
             constexpr int kx = decltype(kxc)::value;
+            constexpr int kxn = (kx + 1) % KW;                        // tap of the next slab
             const int t = S * KW + kx;
-            read_frags(ast, kx, bst, 1, a1h, a1l, b1h, b1l);          // k-step 1 of this slab
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) mma3(a0h[i], a0l[i], b0h[j], b0l[j], accm[i][j], accx[i][j]);
-            addrB(t + S_::NB);
-            wait_vmcnt<S_::NWAIT(kx)>();                              // B(t+1) (and A(S+1)) have landed
+            const int bdm = bst == 0 ? S_::NB - 1 : bst - 1;          // stage of slab t+NB-1 (held slab t-1)
+            // ---- LOAD segment of slab t ----
+            read_slab(ast, kx, bst);
+            if (kx == 0) addrA(S + S_::NA - 1);
+            addrB(t + S_::NB - 1);
+            if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); SDMA_A(2, adm); }
+            if (KW == 1 || kx == 1) { SDMA_A(3, adm); SDMA_A(4, adm); }
+            SDMA_B(0, bdm);
+            if constexpr (BNI > 1) SDMA_B(1, bdm);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mask_slab(kx);
+            if (grp == 1) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 4-7 publish slab t+1 here
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            const int bnx = bst == S_::NB - 1 ? 0 : bst + 1;
-            if (kx + 1 < KW) read_frags(ast, kx + 1, bnx, 0, a0h, a0l, b0h, b0l);
-            else read_frags(anx, 0, bnx, 0, a0h, a0l, b0h, b0l);
-            // k-step 1 with this slab's DMA pieces between the MFMA groups
-            if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); }
-            if (kx == 1) { SDMA_A(3, adm); }
-            SDMA_B(0, bst);
-            mma3(a1h[0], a1l[0], b1h[0], b1l[0], accm[0][0], accx[0][0]);
-            if (kx == 0) { SDMA_A(2, adm); }
-            if (kx == 1) { SDMA_A(4, adm); }
-            if constexpr (NJ == 2) {
-                mma3(a1h[0], a1l[0], b1h[1], b1l[1], accm[0][1], accx[0][1]);
-                SDMA_B(1, bst);
-                mma3(a1h[1], a1l[1], b1h[0], b1l[0], accm[1][0], accx[1][0]);
-                mma3(a1h[1], a1l[1], b1h[1], b1l[1], accm[1][1], accx[1][1]);
-            } else {
-                mma3(a1h[1], a1l[1], b1h[0], b1l[0], accm[1][0], accx[1][0]);
-            }
-            bst = bnx;
+            // ---- COMPUTE segment of slab t ----
+            __builtin_amdgcn_s_setprio(1);
+            compute_slab();
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 0-3 publish slab t+1 here
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            bst = bst == S_::NB - 1 ? 0 : bst + 1;
         };
         tap(std::integral_constant<int, 0>{});
-        tap(std::integral_constant<int, 1>{});
-        tap(std::integral_constant<int, 2>{});
+        if constexpr (KW > 1) {
+            tap(std::integral_constant<int, 1>{});
+            tap(std::integral_constant<int, 2>{});
+        }
         if constexpr (KW > 3) {
             tap(std::integral_constant<int, 3>{});
             tap(std::integral_constant<int, 4>{});
         }
         ast = anx;
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                       // pairs with the extra barrier of waves 4-7
     wait_vmcnt<0>();
 #undef SDMA_A
 #undef SDMA_B
@@ -1101,6 +1108,10 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             if (kw == 3) { if (Cout <= 64) launch_same<64, 3>(g, stream); else launch_same<128, 3>(g, stream); }
             else         { if (Cout <= 64) launch_same<64, 5>(g, stream); else launch_same<128, 5>(g, stream); }
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(same)");
+        }
+        if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {    // 1x1 / linear: the same schedule with one tap
+            if (Cout <= 64) launch_same<64, 1>(g, stream); else launch_same<128, 1>(g, stream);
+            return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1)");
         }
         if (Cout <= 64) launch_v2<64>(g, stream);
         else launch_v2<128>(g, stream);

@@ -13,7 +13,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <int ROWS, int P, int LEAD, bool BAR, int NREAD, int NMFMA>
 __global__ __launch_bounds__(512, 1) void slab_kernel(const char* __restrict__ src, unsigned bytes, int iters,
-                                                       int row_stride, float* sink) {
+                                                       int row_stride, float* sink, int same_addr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -22,7 +22,8 @@ __global__ __launch_bounds__(512, 1) void slab_kernel(const char* __restrict__ s
     const unsigned lane_off = (unsigned)(lane / LPR) * row_stride + (lane % LPR) * 16u;
     const unsigned piece_stride = (unsigned)ROWS * row_stride;
     const unsigned npieces = bytes / piece_stride - 1;
-    unsigned pos = (unsigned)((blockIdx.x * 8 + wave) * 7919u) % npieces;
+    // same_addr: every workgroup streams the same addresses in lockstep (like the weight slabs of a GEMM)
+    unsigned pos = (unsigned)(((same_addr ? 0 : blockIdx.x) * 8 + wave) * 7919u) % npieces;
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = f32x16{0};
     half8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -60,22 +61,22 @@ __global__ __launch_bounds__(512, 1) void slab_kernel(const char* __restrict__ s
 }
 
 template <int ROWS, int P, int LEAD, bool BAR, int NREAD, int NMFMA>
-void run(const char* src, unsigned bytes, int row_stride, float* sink) {
+void run(const char* src, unsigned bytes, int row_stride, float* sink, int same_addr = 0) {
     const int iters = 2000, nwg = 256;
     auto k = slab_kernel<ROWS, P, LEAD, BAR, NREAD, NMFMA>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(512), 150 * 1024, 0, src, bytes, iters, row_stride, sink);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(512), 150 * 1024, 0, src, bytes, iters, row_stride, sink, same_addr);
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(512), 150 * 1024, 0, src, bytes, iters, row_stride, sink);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(512), 150 * 1024, 0, src, bytes, iters, row_stride, sink, same_addr);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double tot = (double)nwg * 8 * iters * P * 1024.0;
-    printf("rows %2d x %3d B  P %d lead %d bar %d reads %2d mfma %2d: %7.3f us/slab  %6.1f GB/s per CU  (mfma floor %5.3f us)\n",
-           ROWS, 1024 / ROWS, P, LEAD, (int)BAR, NREAD, NMFMA, ms * 1e3 / iters, tot / ms / 1e6 / nwg,
+    printf("%s rows %2d x %3d B  P %d lead %d bar %d reads %2d mfma %2d: %7.3f us/slab  %6.1f GB/s per CU  (mfma floor %5.3f us)\n",
+           same_addr ? "same-addr" : "own-addr ", ROWS, 1024 / ROWS, P, LEAD, (int)BAR, NREAD, NMFMA, ms * 1e3 / iters, tot / ms / 1e6 / nwg,
            NMFMA * 2 * 32 / 2.4e3);
 }
 
@@ -83,19 +84,14 @@ int main() {
     const unsigned bytes = 2u << 20;
     char* src; float* sink;
     (void)hipMalloc(&src, bytes); (void)hipMemset(src, 0, bytes); (void)hipMalloc(&sink, 64);
-    run<16, 4, 2, true, 0, 0>(src, bytes, 256, sink);
-    run<16, 0, 2, true, 16, 0>(src, bytes, 256, sink);
-    run<16, 0, 2, true, 32, 0>(src, bytes, 256, sink);
-    run<16, 4, 2, true, 16, 0>(src, bytes, 256, sink);
-    run<16, 4, 2, true, 32, 0>(src, bytes, 256, sink);
-    run<8, 4, 2, true, 16, 0>(src, bytes, 256, sink);
-    run<16, 8, 2, true, 16, 0>(src, bytes, 256, sink);
-    run<16, 0, 2, true, 16, 24>(src, bytes, 256, sink);
-    run<16, 4, 2, true, 0, 24>(src, bytes, 256, sink);
-    run<16, 4, 2, true, 16, 24>(src, bytes, 256, sink);
-    run<16, 4, 2, true, 8, 24>(src, bytes, 256, sink);
-    run<16, 2, 2, true, 16, 24>(src, bytes, 256, sink);
-    run<8, 4, 2, true, 16, 24>(src, bytes, 256, sink);
-    run<4, 4, 2, true, 16, 24>(src, bytes, 1024, sink);
+    run<16, 4, 2, true, 16, 24>(src, bytes, 256, sink, 0);
+    run<16, 4, 2, true, 16, 24>(src, bytes, 256, sink, 1);
+    run<16, 4, 2, true, 16, 24>(src, bytes, 2304, sink, 0);
+    run<16, 4, 2, true, 16, 24>(src, bytes, 2304, sink, 1);
+    run<8, 4, 2, true, 16, 24>(src, bytes, 2304, sink, 1);
+    run<16, 4, 2, true, 0, 0>(src, bytes, 2304, sink, 1);
+    run<16, 4, 2, true, 0, 0>(src, bytes, 256, sink, 1);
+    run<8, 4, 2, true, 0, 0>(src, bytes, 256, sink, 1);
+    run<16, 2, 2, true, 16, 24>(src, bytes, 2304, sink, 1);
     return 0;
 }
