@@ -342,77 +342,104 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
                 tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * T::TILE_LD + wc * (BN_ / 2) + j * 32 + col] =
                     accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
     __syncthreads();
+    // Every thread owns one 8-channel chunk (fixed: 512 % CH == 0) of IT rows.  All memory operations of the IT
+    // rows are issued before anything waits on them: tile reads, then the residual loads, then arithmetic and
+    // stores -- the epilogue is latency-bound otherwise (one dependent global load per row).
     constexpr int CH = BN_ / 8;                               // 8-channel chunks per row
-    for (int e = tid; e < BM2 * CH; e += 512) {
-        const int r = e / CH, c8 = (e % CH) * 8;
-        const int64_t m = m0 + r;
-        const int n = n0 + c8;
-        if (m >= g.M || (n >= g.Cout && n >= g.Cout_s)) continue;
-        float v[8];
+    constexpr int RPI = 512 / CH;                             // rows per pass
+    constexpr int IT = BM2 / RPI;                             // passes (8 for BN=128, 4 for BN=64)
+    const int c8 = (tid % CH) * 8, rr = tid / CH;
+    const int n = n0 + c8;
+    if (n >= g.Cout && n >= g.Cout_s) return;
+    const bool full = n + 8 <= g.Cout;
+    float bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bv[q] = (g.bias && n + q < g.Cout) ? g.bias[n + q] : 0.f;
+    float v[IT][8];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int r = it * RPI + rr;
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8 + 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = t0[q]; v[4 + q] = t1[q]; }
-        const bool full = n + 8 <= g.Cout;
+        for (int q = 0; q < 4; ++q) { v[it][q] = t0[q]; v[it][4 + q] = t1[q]; }
+    }
+    if (g.resh) {              // split residual: its channel count is padded to a multiple of 8 with zeros
+        half8 rh[IT], rl[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int64_t m = m0 + it * RPI + rr;
+            const int64_t mm = m < g.M ? m : g.M - 1;
+            rh[it] = *reinterpret_cast<const half8*>(g.resh + mm * g.ldr + n);
+            rl[it] = *reinterpret_cast<const half8*>(g.resl + mm * g.ldr + n);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[it][q] += (float)rh[it][q] + (float)rl[it][q] * (1.f / 2048.f);
+    } else if (g.res) {
         if (full) {
-            if (g.bias) {
+            f32x4 r0[IT], r1[IT];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += g.bias[n + q];
+            for (int it = 0; it < IT; ++it) {
+                const int64_t m = m0 + it * RPI + rr;
+                const int64_t mm = m < g.M ? m : g.M - 1;
+                r0[it] = *reinterpret_cast<const f32x4*>(g.res + mm * g.ldr + n);
+                r1[it] = *reinterpret_cast<const f32x4*>(g.res + mm * g.ldr + n + 4);
             }
-            if (g.res) {
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(g.res + m * g.ldr + n + 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
-            }
-            if (g.resh) {
-                const half8 rh = *reinterpret_cast<const half8*>(g.resh + m * g.ldr + n);
-                const half8 rl = *reinterpret_cast<const half8*>(g.resl + m * g.ldr + n);
+            for (int it = 0; it < IT; ++it)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += (float)rh[q] + (float)rl[q] * (1.f / 2048.f);
-            }
-        } else {   // chunk straddles Cout (e.g. 196 = 24*8 + 4): per-channel guards
+                for (int q = 0; q < 4; ++q) { v[it][q] += r0[it][q]; v[it][4 + q] += r1[it][q]; }
+        } else {               // chunk straddles Cout (e.g. 196 = 24*8 + 4): per-channel guards
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (n + q < g.Cout) {
-                    if (g.bias) v[q] += g.bias[n + q];
-                    if (g.res) v[q] += g.res[m * g.ldr + n + q];
-                    if (g.resh) v[q] += (float)g.resh[m * g.ldr + n + q] + (float)g.resl[m * g.ldr + n + q] * (1.f / 2048.f);
-                } else {
-                    v[q] = 0.f;
+            for (int it = 0; it < IT; ++it) {
+                const int64_t m = m0 + it * RPI + rr;
+                if (m < g.M) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (n + q < g.Cout) v[it][q] += g.res[m * g.ldr + n + q];
                 }
             }
         }
-        if (g.relu) {
+    }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+    for (int it = 0; it < IT; ++it) {
+        const int64_t m = m0 + it * RPI + rr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float x = v[it][q] + bv[q];
+            if (g.relu) x = fmaxf(x, 0.f);
+            v[it][q] = (full || n + q < g.Cout) ? x : 0.f;    // padded split channels are zeros
         }
 #ifdef DFSFM_ABL_NOSTORE
-        if (v[0] != 12345.678f) continue;
+        if (v[it][0] != 12345.678f) continue;
 #endif
         if (g.out) {
             if (full) {
-                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n) = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
+                *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n + 4) = f32x4{v[it][4], v[it][5], v[it][6], v[it][7]};
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (n + q < g.Cout) g.out[m * g.ldo + n + q] = v[q];
+                    if (n + q < g.Cout) g.out[m * g.ldo + n + q] = v[it][q];
             }
         }
-        if (g.outh && n < g.Cout_s) {          // Cout_s % 8 == 0: whole chunk, padded channels are zeros
+        if (g.outh && n < g.Cout_s) {          // Cout_s % 8 == 0: whole chunk
             half8 h, l;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 _Float16 a, b;
-                split1(v[q], a, b);
+                split1(v[it][q], a, b);
                 h[q] = a;
                 l[q] = b;
             }
             *reinterpret_cast<half8*>(g.outh + m * g.ldo_s + n) = h;
             *reinterpret_cast<half8*>(g.outl + m * g.ldo_s + n) = l;
         }
-    }}
+    }
+}
 
 template <int BN_>
 __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {

@@ -39,7 +39,7 @@ same = len(sys.argv) > 1 and sys.argv[1] == "same"     # tap-padded weights -> a
 for name, N, H, W, Cin, Cout, k, s, p in layers:
     x = torch.randn((N, H, W, Cin), device=dev)
     w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05
-    use_split = split and Cin % 4 == 0 and not name.startswith("lin")
+    use_split = split and Cin % 4 == 0
     if use_split:      # activations arrive / leave as split fp16 planes (v2 LDS-DMA kernel)
         cp = (Cin + 7) // 8 * 8
         hi = torch.zeros((N, H, W, cp), dtype=torch.float16, device=dev); lo = torch.zeros_like(hi)
