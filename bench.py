@@ -77,24 +77,36 @@ def kernel_rooflines(dev, batch):
     x = torch.randn((nimg, 240, 320, 128), generator=g).to(dev)
     xs = ops.SplitAct.empty(nimg, 240, 320, 128, dev)
     ops.split_rows(x, None, out_split=xs)
-    pw = ops.PackedDense(torch.randn((128, 128, 3, 3), generator=g).to(dev) * 0.03, torch.zeros(128, device=dev), cin_pad=128)
+    pw = ops.PackedDense(torch.randn((128, 128, 3, 3), generator=g).to(dev) * 0.03, torch.zeros(128, device=dev), cin_pad=128,
+                         tap_padded=True)
     ms = event_time_ms(lambda: ops.conv2d_nhwc(xs, pw, 1, 1, relu=True, out_split=True))
     flops = 2.0 * nimg * 240 * 320 * 128 * 9 * 128
-    out.append({"kernel": "conv_gemm_sf_kernel<128> (3x3, 128->128 @240x320)", "bound": "mfma",
+    out.append({"kernel": "conv_gemm_sf_same_kernel<128,3> (3x3, 128->128 @240x320)", "bound": "mfma",
                 "achieved": flops / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                 "frac": flops / ms / 1e9 / MFMA_F16_PEAK_TF, "traffic": None, "ms": ms, "units": f"{nimg} images",
                 "mfma_flops_executed_frac": 3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
-                "step_share": "75% of the coarse step, 69% of the refinement step (profiles/r01_*_step_kernel_stats.csv)"})
+                "step_share": "the conv_gemm_sf* kernels are ~70% of the coarse step and ~65% of the refinement step "
+                              "(profiles/r01_*_step_kernel_stats.csv)"})
     del x, xs, pw
     # K3+K4+K5 at batch x (4800 x 4800 x 256): algorithmic flops 2*L*S*C per pair
     L = S = 4800
     f0, f1 = synth.correlated_features(batch, L, S, 256, 7, 0.1)
     f0, f1 = f0.to(dev), f1.to(dev)
-    ms = event_time_ms(lambda: ops.coarse_match(f0, f1, (60, 80), (60, 80), 0.2, 2, 0.1))
+    s0, s1 = ops.SplitAct.empty_rows((batch, L), 256, dev), ops.SplitAct.empty_rows((batch, S), 256, dev)
+    ops.split_rows(f0, None, out_split=s0)
+    ops.split_rows(f1, None, out_split=s1)
+    ms = event_time_ms(lambda: ops.coarse_match(s0, s1, (60, 80), (60, 80), 0.2, 2, 0.1))
     flops = 2.0 * L * S * 256 * batch
-    out.append({"kernel": "coarse_match (cm_gemm x2 + select)", "bound": "mfma", "achieved": flops / ms / 1e9,
-                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TF,
-                "traffic": None, "ms": ms, "units": f"{batch} pairs"})
+    out.append({"kernel": "coarse_match_split (cm_gemm_sf x2 + select; the correlation is computed twice, 3 fp16 "
+                          "MFMA products each)", "bound": "mfma", "achieved": flops / ms / 1e9,
+                "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / MFMA_F16_PEAK_TF,
+                "traffic": None, "ms": ms, "units": f"{batch} pairs",
+                "mfma_flops_executed_frac": 6.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF})
+    ms32 = event_time_ms(lambda: ops.coarse_match(f0, f1, (60, 80), (60, 80), 0.2, 2, 0.1))
+    out.append({"kernel": "coarse_match_f32 (cm_gemm x2 + select, fp32 matrix path; generic entry point)",
+                "bound": "mfma", "achieved": flops / ms32 / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": flops / ms32 / 1e9 / MFMA_F32_PEAK_TF, "traffic": None, "ms": ms32, "units": f"{batch} pairs"})
+    del s0, s1
     # K1 at the coarse shape, N = 2*batch (both images of every pair in one call): 4*N*L*H*D*4 bytes
     N = 2 * batch
     q, k, v = (torch.randn((N, L, 8, 32), generator=g).to(dev) for _ in range(3))
@@ -220,7 +232,8 @@ def main():
             pe = matcher._pe_tokens((60, 80))
             f0, f1 = c[:args.batch], c[args.batch:]
             breakdown["transformer_ms"] = event_time_ms(lambda: matcher._transformer(f0, f1, P, pe, pe), 5, 1)
-            g0, g1 = matcher._transformer(f0, f1, P, pe, pe)
+            matcher._transformer(f0, f1, P, pe, pe)
+            g0, g1 = matcher._feat_split          # the split planes the last LayerNorm wrote
             breakdown["coarse_match_ms"] = event_time_ms(
                 lambda: ops.coarse_match(g0, g1, (60, 80), (60, 80), 0.2, 2, 0.1), 5, 1)
         del imgs, c, f0, f1, g0, g1

@@ -29,6 +29,11 @@ SIGNATURES = [
       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_size_t, c_void_p]),
+    ("dfsfm_coarse_match_split", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_size_t, c_void_p]),
     ("dfsfm_coarse_conf_matrix_f32", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("dfsfm_roi_align_f32", c_int,

@@ -298,9 +298,10 @@ class HipLoFTR(ParamModule):
             XS, XSn = new_split(2 * C), new_split(2 * C)
             ops.split_rows(f0, pe0, out=X[1], out_split=XS[1].cols(0, C))
             ops.split_rows(f1, pe1, out=X[2], out_split=XS[2].cols(0, C))
+            fin = new_split(C)      # the final features as contiguous split planes: operands of the correlation
             for li, (w, name) in enumerate(zip(P["enc"], names)):
                 last = li == len(names) - 1
-                oxs = (None, None, None) if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
+                oxs = fin if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
                 if name == "self":
                     if same:   # both images through one batched call
                         encoder_layer_split(w, X[0], XS[0], XS[0].cols(0, C), Xn[0], oxs[0], nhead, is_self=True)
@@ -308,14 +309,13 @@ class HipLoFTR(ParamModule):
                         for i in (1, 2):
                             encoder_layer_split(w, X[i], XS[i], XS[i].cols(0, C), Xn[i], oxs[i], nhead, is_self=True)
                 elif name == "cross":
-                    # feat1's cross-attention needs the UPDATED feat0 as split planes even in the last layer
-                    ox1 = oxs[1] if oxs[1] is not None else ops.SplitAct.empty_rows((N, L), C, dev)
-                    encoder_layer_split(w, X[1], XS[1], XS[2].cols(0, C), Xn[1], ox1, nhead)
-                    encoder_layer_split(w, X[2], XS[2], ox1, Xn[2], oxs[2], nhead)       # sees the updated feat0 (:96-97)
+                    encoder_layer_split(w, X[1], XS[1], XS[2].cols(0, C), Xn[1], oxs[1], nhead)
+                    encoder_layer_split(w, X[2], XS[2], oxs[1], Xn[2], oxs[2], nhead)    # sees the updated feat0 (:96-97)
                 else:
                     raise KeyError(name)
                 X, Xn = Xn, X
                 XS, XSn = XSn, XS
+            self._feat_split = (fin[1], fin[2])
             return X[1], X[2]
 
         cur = new_f32(2 * C)
@@ -386,7 +386,11 @@ class HipLoFTR(ParamModule):
         if "mask0" in data:
             raise NotImplementedError("padding masks (training-time feature) are not on the inference path")
         data.update({"bs": img0.size(0), "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
+        self._feat_split = None
         f0, f1, hw0_c, hw1_c = self.coarse_features(img0, img1)
+        if self._feat_split is not None:       # hip backend: correlate the split planes the last LayerNorm wrote
+            f0, f1 = self._feat_split
+            self._feat_split = None
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
                      "hw0_f": torch.Size((img0.shape[2] // 2, img0.shape[3] // 2)),
                      "hw1_f": torch.Size((img1.shape[2] // 2, img1.shape[3] // 2))})

@@ -25,6 +25,7 @@
 // 16-byte XOR swizzle (slot ^= (row>>1)&7) that makes every ds_read_b128 fragment read
 // conflict-free; next k-slab is prefetched into registers while the MFMAs run.
 #include "common.h"
+#include "sf_gemm.h"
 
 namespace {
 
@@ -267,6 +268,168 @@ __global__ __launch_bounds__(256, 2) void cm_gemm(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-plane variant of the correlation GEMM: features arrive as fp16 hi / lo planes (x = hi + lo/2048,
+// written by the last encoder layer's LayerNorm) and sim = f0.f1^T runs as three fp16 MFMA products per
+// k-step on the 512-thread LDS-DMA ping-pong main loop of sf_gemm.h (the 1x1 / linear schedule: f0 rows are
+// the "activations", f1 rows the "weights").  256 x 128 tiles; epilogues as in cm_gemm.  Column partials are
+// written per 128-row half tile so all 512 threads share the exp work.
+// ---------------------------------------------------------------------------------------------
+constexpr int SF_BM = 256, SF_BN = 128, SF_LD = SF_BN + 1;
+using SfRing = dfsfm_sf::VS<SF_BN, 1>;
+constexpr int SF_STATS_OFF = SfRing::RING;                            // stats live past the DMA ring
+constexpr int SF_SMEM = SF_STATS_OFF + (SF_BM + SF_BN) * (8 + 4);
+static_assert(SF_BM * SF_LD * 4 <= SF_STATS_OFF, "epilogue tile must not reach the stats");
+static_assert(SF_SMEM <= 160 * 1024, "LDS");
+
+struct GemmSfArgs {
+    const _Float16 *f0h, *f0l, *f1h, *f1l;     // [N][L][C], [N][S][C]
+    int L, S, C;
+    int ntn;                 // tiles along S
+    unsigned ntiles;         // tiles per pair (grid.x is padded to a multiple of 8)
+    float acc_mul, temperature, thr;
+    float2* row_part;        // [N][ntn][L]
+    float2* col_part;        // [N][2 * ntm][S]: one partial per 128-row half tile
+    int nhalf;               // 2 * ntm
+    const float2* row_stat;
+    const float2* col_stat;
+    unsigned long long* row_best;
+    unsigned int* col_best;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);                             // [SF_BM][SF_LD] (aliases the ring)
+    float2* s_rstat = reinterpret_cast<float2*>(smem + SF_STATS_OFF);         // [SF_BM]
+    float2* s_cstat = s_rstat + SF_BM;                                        // [SF_BN]
+    float* s_rgate = reinterpret_cast<float*>(s_cstat + SF_BN);               // [SF_BM]
+    float* s_cgate = s_rgate + SF_BM;                                         // [SF_BN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n = blockIdx.y;
+    const unsigned t_id = dfsfm_sf::xcd_band_tile(blockIdx.x, gridDim.x >> 3);
+    if (t_id >= g.ntiles) return;
+    const int tm = t_id / g.ntn, tn = t_id % g.ntn;
+    const int row0 = tm * SF_BM, col0 = tn * SF_BN;
+
+    if (MODE != MODE_STATS) {
+        if (tid < SF_BM) {
+            const int i = row0 + tid;
+            const float2 st = i < g.L ? g.row_stat[(int64_t)n * g.L + i] : make_float2(0.f, 1.f);
+            s_rstat[tid] = st;
+            s_rgate[tid] = i < g.L ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+        } else if (tid < SF_BM + SF_BN) {
+            const int j = col0 + tid - SF_BM;
+            const float2 st = j < g.S ? g.col_stat[(int64_t)n * g.S + j] : make_float2(0.f, 1.f);
+            s_cstat[tid - SF_BM] = st;
+            s_cgate[tid - SF_BM] = j < g.S ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+        }
+    }
+
+    dfsfm_sf::ConvArgs a{};
+    a.xh = g.f0h + (int64_t)n * g.L * g.C;
+    a.xl = g.f0l + (int64_t)n * g.L * g.C;
+    a.wh = g.f1h + (int64_t)n * g.S * g.C;
+    a.wl = g.f1l + (int64_t)n * g.S * g.C;
+    a.M = g.L; a.H = 1; a.W = g.L; a.Cin = g.C; a.Kpad = g.C; a.ldx = g.C;
+    a.sxh = a.sxn = (int64_t)g.L * g.C;
+    a.xbytes = (unsigned)((int64_t)g.L * g.C * 2);           // rows past L / S are zero-filled by the DMA
+    a.wbytes = (unsigned)((int64_t)g.S * g.C * 2);
+    f32x16 accm[2][2], accx[2][2];
+    dfsfm_sf::sf_same_mainloop<SF_BN, 1>(a, smem, accm, accx, row0, col0);
+    __syncthreads();                                          // ring is dead: the tile aliases it
+
+    // lane holds sim[row = wr*64 + i*32 + mfma32_row(r,half)][col = wc*64 + j*32 + (lane&31)]
+    bool any_above = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
+                const int lc = wc * 64 + j * 32 + col;
+                float s = ((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
+                if (MODE == MODE_SELECT) {
+                    if (s > s_rgate[lr] && s > s_cgate[lc]) {
+                        const float2 rs = s_rstat[lr], cs = s_cstat[lc];
+                        const float p_col = expf(s - cs.x) / cs.y;
+                        const float p_row = expf(s - rs.x) / rs.y;
+                        s = p_col * p_row;
+                        any_above |= s > g.thr;
+                    } else {
+                        s = 0.f;
+                    }
+                }
+                accm[i][j][r] = s;
+            }
+    if (MODE == MODE_SELECT) {
+        if (!__syncthreads_or(any_above)) return;             // the common tile: nothing above thr
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(wr * 64 + i * 32 + mfma32_row(r, half)) * SF_LD + wc * 64 + j * 32 + col] = accm[i][j][r];
+    __syncthreads();
+
+    const int nrow = min(SF_BM, g.L - row0), ncol = min(SF_BN, g.S - col0);
+    if (MODE == MODE_STATS) {
+        if (tid < SF_BM) {
+            if (tid < nrow) {
+                float m = -INFINITY;
+                for (int j = 0; j < ncol; ++j) m = fmaxf(m, tile[tid * SF_LD + j]);
+                float sum = 0.f;
+                for (int j = 0; j < ncol; ++j) sum += expf(tile[tid * SF_LD + j] - m);
+                g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = make_float2(m, sum);
+            }
+        } else {
+            const int c = (tid - SF_BM) & (SF_BN - 1), h = (tid - SF_BM) >> 7;   // column c, 128-row half h
+            if (c < ncol) {
+                const int i0 = h * 128, i1 = min(nrow, i0 + 128);
+                float m = -INFINITY;
+                for (int i = i0; i < i1; ++i) m = fmaxf(m, tile[i * SF_LD + c]);
+                float sum = 0.f;
+                for (int i = i0; i < i1; ++i) sum += expf(tile[i * SF_LD + c] - m);
+                // an empty half (rows past L) leaves the neutral partial (-inf, 0)
+                g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] = make_float2(m, sum);
+            }
+        }
+    } else {
+        if (tid < SF_BM) {
+            if (tid < nrow) {
+                float best = g.thr;
+                int bj = -1;
+                for (int j = 0; j < ncol; ++j) {
+                    const float v = tile[tid * SF_LD + j];
+                    if (v > best) { best = v; bj = j; }      // strict > keeps the smallest j on ties
+                }
+                if (bj >= 0) {
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(~(unsigned)(col0 + bj));
+                    atomicMax(&g.row_best[(int64_t)n * g.L + row0 + tid], key);
+                }
+            }
+        } else if (tid < SF_BM + SF_BN) {
+            const int c = tid - SF_BM;
+            if (c < ncol) {
+                float best = g.thr;
+                bool found = false;
+                for (int i = 0; i < nrow; ++i) {
+                    const float v = tile[i * SF_LD + c];
+                    if (v > best) { best = v; found = true; }
+                }
+                if (found) atomicMax(&g.col_best[(int64_t)n * g.S + col0 + c], __float_as_uint(best));
+            }
+        }
+    }
+}
+
 // Merge per-tile (max, sumexp) partials; clear row_best / col_best.
 __global__ __launch_bounds__(256) void cm_reduce_stats(const float2* __restrict__ row_part,
                                                        const float2* __restrict__ col_part,
@@ -392,7 +555,8 @@ struct Workspace {
 };
 
 Workspace carve(void* base, int N, int L, int S) {
-    const int ntm = (L + BM - 1) / BM, ntn = (S + BN - 1) / BN;
+    // col_part holds one partial per 128-row block: ceil(L/128) for cm_gemm, 2*ceil(L/256) for cm_gemm_sf
+    const int ntm = 2 * ((L + 2 * BM - 1) / (2 * BM)), ntn = (S + BN - 1) / BN;
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -469,6 +633,65 @@ extern "C" size_t dfsfm_coarse_match_workspace(int N, int L, int S) {
     return carve(nullptr, N, L, S).bytes;
 }
 
+namespace {
+
+template <int MODE>
+void launch_gemm_sf(const GemmSfArgs& g, int N, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_gemm_sf<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SF_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cm_gemm_sf<MODE>, dim3((g.ntiles + 7) / 8 * 8, N), dim3(512), SF_SMEM, stream, g);
+}
+
+// feat0/feat1 fp32, or (f0h, f0l, f1h, f1l) fp16 split planes of the same tensors.
+int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0h, const _Float16* f0l,
+                      const _Float16* f1h, const _Float16* f1l, int N, int L, int S, int C, float temperature,
+                      float thr, int border, int h0c, int w0c, int h1c, int w1c, const float* scale0,
+                      const float* scale1, float coarse_scale, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                      float* mconf, float* mkpts0, float* mkpts1, int32_t* count, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream, const char* what) {
+    if (!b_ids || !i_ids || !j_ids || !mconf || !mkpts0 || !mkpts1 || !count) return DFSFM_E_BADARG;
+    if (h0c * w0c != L || h1c * w1c != S || border < 0) return DFSFM_E_BADARG;
+    if (!(thr >= 0.f)) return DFSFM_E_UNSUPPORTED;   // best-candidate words use 0 as "none"
+    Workspace w = carve(workspace, N, L, S);
+    int nparts;
+    if (f0h) {
+        // the 1/sqrt(C) operand scaling folds into one exact multiply only for C a power of 4
+        if (!is_pow4(C) || (int64_t)L * C * 2 >= (1ll << 32) || (int64_t)S * C * 2 >= (1ll << 32))
+            return DFSFM_E_UNSUPPORTED;
+        GemmSfArgs g{};
+        g.f0h = f0h; g.f0l = f0l; g.f1h = f1h; g.f1l = f1l; g.L = L; g.S = S; g.C = C;
+        const int ntm = (L + SF_BM - 1) / SF_BM;
+        g.ntn = (S + SF_BN - 1) / SF_BN;
+        g.ntiles = (unsigned)(ntm * g.ntn);
+        g.nhalf = nparts = 2 * ntm;
+        g.acc_mul = 1.f / (float)C; g.temperature = temperature; g.thr = thr;
+        g.row_part = w.row_part; g.col_part = w.col_part; g.row_stat = w.row_stat; g.col_stat = w.col_stat;
+        g.row_best = w.row_best; g.col_best = w.col_best;
+        launch_gemm_sf<MODE_STATS>(g, N, stream);
+        hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
+                           w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, nparts, g.ntn);
+        launch_gemm_sf<MODE_SELECT>(g, N, stream);
+    } else {
+        bool prescale;
+        GemmArgs g = make_args(feat0, feat1, L, S, C, temperature, thr, w, &prescale);
+        launch_gemm<MODE_STATS>(g, N, prescale, stream);
+        hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
+                           w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, g.ntm, g.ntn);
+        launch_gemm<MODE_SELECT>(g, N, prescale, stream);
+    }
+    hipLaunchKernelGGL(cm_select, dim3(N), dim3(1024), 0, stream, w.row_best, w.col_best, w.flags, w.counts, L,
+                       S, thr, border, w0c, w1c);
+    hipLaunchKernelGGL(cm_compact, dim3(N), dim3(1024), 0, stream, w.row_best, w.flags, w.counts, N, L, w0c,
+                       w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0, mkpts1, count);
+    return check_launch(what);
+}
+
+}  // namespace
+
 extern "C" int dfsfm_coarse_match_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,
                                       float temperature, float thr, int border, int h0c, int w0c, int h1c,
                                       int w1c, const float* scale0, const float* scale1, float coarse_scale,
@@ -477,23 +700,32 @@ extern "C" int dfsfm_coarse_match_f32(const float* feat0, const float* feat1, in
                                       size_t workspace_bytes, void* stream_) {
     int rc = check_common(feat0, feat1, N, L, S, C, temperature, workspace, workspace_bytes);
     if (rc != DFSFM_OK) return rc;
-    if (!b_ids || !i_ids || !j_ids || !mconf || !mkpts0 || !mkpts1 || !count) return DFSFM_E_BADARG;
-    if (h0c * w0c != L || h1c * w1c != S || border < 0) return DFSFM_E_BADARG;
-    if (!(thr >= 0.f)) return DFSFM_E_UNSUPPORTED;   // best-candidate words use 0 as "none"
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    Workspace w = carve(workspace, N, L, S);
-    bool prescale;
-    GemmArgs g = make_args(feat0, feat1, L, S, C, temperature, thr, w, &prescale);
+    return coarse_match_impl(feat0, feat1, nullptr, nullptr, nullptr, nullptr, N, L, S, C, temperature, thr,
+                             border, h0c, w0c, h1c, w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids,
+                             mconf, mkpts0, mkpts1, count, workspace, workspace_bytes,
+                             static_cast<hipStream_t>(stream_), "dfsfm_coarse_match_f32");
+}
 
-    launch_gemm<MODE_STATS>(g, N, prescale, stream);
-    hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
-                       w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, g.ntm, g.ntn);
-    launch_gemm<MODE_SELECT>(g, N, prescale, stream);
-    hipLaunchKernelGGL(cm_select, dim3(N), dim3(1024), 0, stream, w.row_best, w.col_best, w.flags, w.counts, L,
-                       S, thr, border, w0c, w1c);
-    hipLaunchKernelGGL(cm_compact, dim3(N), dim3(1024), 0, stream, w.row_best, w.flags, w.counts, N, L, w0c,
-                       w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0, mkpts1, count);
-    return check_launch("dfsfm_coarse_match_f32");
+extern "C" int dfsfm_coarse_match_split(const void* feat0_hi, const void* feat0_lo, const void* feat1_hi,
+                                        const void* feat1_lo, int N, int L, int S, int C, float temperature,
+                                        float thr, int border, int h0c, int w0c, int h1c, int w1c,
+                                        const float* scale0, const float* scale1, float coarse_scale,
+                                        int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                                        float* mkpts0, float* mkpts1, int32_t* count, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+    if (!feat0_hi || !feat0_lo || !feat1_hi || !feat1_lo || !workspace) return DFSFM_E_BADARG;
+    if (N <= 0 || L <= 0 || S <= 0 || C <= 0 || !(temperature > 0.f)) return DFSFM_E_BADARG;
+    if (C % BK != 0 || N > 65535) return DFSFM_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(feat0_hi) | reinterpret_cast<uintptr_t>(feat0_lo) |
+         reinterpret_cast<uintptr_t>(feat1_hi) | reinterpret_cast<uintptr_t>(feat1_lo)) & 15)
+        return DFSFM_E_UNSUPPORTED;
+    if (workspace_bytes < dfsfm_coarse_match_workspace(N, L, S)) return DFSFM_E_WORKSPACE;
+    return coarse_match_impl(nullptr, nullptr, static_cast<const _Float16*>(feat0_hi),
+                             static_cast<const _Float16*>(feat0_lo), static_cast<const _Float16*>(feat1_hi),
+                             static_cast<const _Float16*>(feat1_lo), N, L, S, C, temperature, thr, border, h0c,
+                             w0c, h1c, w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0,
+                             mkpts1, count, workspace, workspace_bytes, static_cast<hipStream_t>(stream_),
+                             "dfsfm_coarse_match_split");
 }
 
 extern "C" int dfsfm_coarse_conf_matrix_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,

@@ -23,40 +23,20 @@
 // conflict-free swizzled ds_read_b128, next slab prefetched into registers and split while the
 // MFMAs run; epilogue fuses bias (folded BN), residual, ReLU.
 #include "common.h"
-#include <type_traits>
+#include "sf_gemm.h"
 
 namespace {
 
 using namespace dfsfm;
+using namespace dfsfm_sf;
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128;        // v1 tile; BK = 32 and BM2 = 256 come from sf_gemm.h
 constexpr int TILE_B = BM * BK * 2;                 // bytes of one fp16 tile (8 KB)
 constexpr int STAGE_B = 4 * TILE_B;                 // A_hi, A_lo, B_hi, B_lo
 constexpr int SMEM_BYTES = 2 * STAGE_B;             // double buffered: 64 KB
 constexpr int LUT_MAX = 256;                        // scalar-gather path: k -> (ky,kx,ci) table entries
-
-struct ConvArgs {
-    const float* x;          // fp32 NHWC input: element (n,y,x,c) at n*sxn + y*sxh + x*ldx + c
-    const _Float16* xh;      // ... or the same tensor pre-split into fp16 hi / lo planes (same strides,
-    const _Float16* xl;      //     in elements); x = xh + xl / 2048
-    const _Float16* wh;      // [Npad][Kpad]
-    const _Float16* wl;
-    const float* bias;       // [Cout] or null
-    const float* res;        // residual [M][ldr] fp32, or split planes resh/resl, or none
-    const _Float16* resh;
-    const _Float16* resl;
-    float* out;              // [M][ldo] fp32 and/or split planes outh/outl [M][ldo_s] (Cout_s channels,
-    _Float16* outh;          //     channels >= Cout written as zeros)
-    _Float16* outl;
-    int64_t ldx, sxh, sxn, ldr, ldo, ldo_s, M;
-    int H, W, Cin, Ho, Wo, Cout, Cout_s, kh, kw, stride, pad, K, Kpad, relu;
-    unsigned xbytes;         // byte size of one input plane (buffer-descriptor bound, v2 kernel)
-    unsigned wbytes;
-    unsigned ntiles;         // M tiles x N tiles (v2 kernels; the grid is padded to a multiple of 8)
-};
 
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) { split_f32(x, hi, lo); }
 
@@ -70,9 +50,6 @@ __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
     }
 }
 
-// byte offset of (row, 16-byte k-slot) inside a [128][32] fp16 tile; XOR swizzle makes the
-// ds_read_b128 fragment reads of 16 different rows conflict-free (64-byte rows, 4 rows per bank row)
-__device__ __forceinline__ int tile_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 struct RowGeom {           // one activation row handled by this thread
     int iy0, ix0;
@@ -287,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g) {
 // Out-of-image taps / rows past M use an out-of-range buffer offset, which the hardware
 // zero-fills.  The epilogue stages the tile through LDS so every store is 16-32 bytes per lane.
 // =================================================================================================
-constexpr int BM2 = 256, NST = 3;
+constexpr int NST = 3;
 
 template <int BN_>
 struct V2 {
@@ -301,23 +278,10 @@ struct V2 {
     static constexpr int SMEM = (RING > BM2 * TILE_LD * 4) ? RING : BM2 * TILE_LD * 4;
 };
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Shared epilogue of the split-input kernels: the accumulator tile goes through LDS so each thread owns 8
 // consecutive channels of one output row: bias (folded BN), fp32 / split residual, ReLU, then 32-byte fp32
 // stores and/or 16+16-byte split stores.  Must be entered with no LDS-DMA in flight.
-// Workgroup b is dispatched to XCD b % 8 (round robin).  Each XCD gets a contiguous band of tiles, so the
-// tiles that read the same activation rows (the ky halo of neighbouring M tiles, the N tiles of one M tile)
-// run on one XCD at about the same time and meet in its L2 instead of each fetching from HBM.
-__device__ __forceinline__ unsigned xcd_band_tile(unsigned b, unsigned per_xcd) {
-#ifdef DFSFM_ABL_NOXCD
-    return b;
-#else
-    return (b & 7u) * per_xcd + (b >> 3);
-#endif
-}
-
 template <int BN_>
 __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ / 64],
                                             f32x16 (&accx)[2][BN_ / 64], int64_t m0, int n0, int tid, int wr, int wc,
@@ -669,308 +633,21 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     sf_epilogue<BN_>(g, smem, accm, accx, m0, n0, tid, wr, wc, col, kgrp);
 }
 
-// =================================================================================================
-// "same" convolutions (stride 1, pad (KW-1)/2, KW x KW taps): tap-level reuse of the activation tile.
-// The conv kernel above is bound by the global->LDS operand stream: every input pixel is
-// fetched once per tap.  With flattened pixel indices the rows an M tile needs for the KW taps of one
-// ky are ONE contiguous run of 256 + KW - 1 pixels, so the K loop is re-ordered to (ky, 32-channel
-// chunk, kx): the run is DMA'd once per (ky, chunk) into a 2-stage A ring and the kx taps read it as
-// row-shifted fragments (rows whose x + kx - pad leaves the image are zeroed in registers; rows
-// whose y + ky - pad leaves it are zero-filled by the DMA).  Weights keep a 3-stage ring, one slab
-// per tap.  A traffic drops KW-fold; everything else (3-MFMA split product, register double-buffered
-// fragments, mid-slab barrier, pinned DMA/MFMA interleave, epilogue) is as in conv_gemm_sf_kernel.
-// Weights are packed tap-padded: K = (ky, kx, ceil32(Cin)).
-// =================================================================================================
-template <int BN_, int KW>
-struct VS {
-    static constexpr int PAD = KW / 2;
-    static constexpr int AG = 17;                            // 16-row groups per A stage (256 + KW - 1 <= 272)
-    static constexpr int A_PLANE = AG * 1024;
-    static constexpr int A_STAGE = 2 * A_PLANE;             // hi, lo
-    static constexpr int B_PLANE = BN_ * 64;
-    static constexpr int B_STAGE = 2 * B_PLANE;
-    static constexpr int BN_I = (BN_ / 16) * 2 / 8;         // weight pieces per wave per slab (2 or 1)
-    static constexpr int NA = KW == 1 ? 3 : 2;              // A ring depth (super-slabs)
-    static constexpr int NB = 3;                             // B ring depth (slabs)
-    static constexpr int OFF_B = NA * A_STAGE;
-    static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;  // 1 KB sink for the padding pieces
-    static constexpr int RING = OFF_DUMMY + 1024;
-    static constexpr int TILE_BYTES = BM2 * (BN_ + 4) * 4;
-    static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
-    static_assert(RING <= 160 * 1024, "LDS ring");
-    // DMA pieces a wave issues in the load segment of tap kx: B(t+NB-1), and A(S+NA-1) spread over taps 0 (3
-    // pieces) and 1 (2 pieces) -- all 5 at tap 0 for a 1x1 kernel
-    static constexpr int C(int kx) { return (KW == 1 ? 5 : kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
-    // own pieces that may still be in flight when a wave publishes slab u = (S, kx) (the barrier that opens the
-    // first load segment reading it): B(u) was the last piece of load segment u-NB+1, so everything issued in the
-    // NB-2 segments since may be outstanding; with a 2-deep A ring A(S) was issued at taps 0/1 of S-1.
-    static constexpr int NWAIT(int kx) {
-        int n = 0;
-        for (int d = 1; d <= NB - 2; ++d) n += C(((kx - d) % KW + KW) % KW);
-        if (KW > 1 && NA == 2 && kx == 0 && (KW - 1) * BN_I < n) n = (KW - 1) * BN_I;
-        return n;
-    }
-    static constexpr int NWAIT0 = 5 * (NA - 2) + (NB - 2) * BN_I;      // prologue: A(0), B(0) landed
-    static_assert(KW == 1 ? (NA == NB) : true, "1x1: A(t) and B(t) are issued in the same load segment");
-};
-
+// "same" convolution / 1x1 / linear kernel: sf_same_mainloop (sf_gemm.h) + the shared epilogue.
 template <int BN_, int KW>
 __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
-    using S_ = VS<BN_, KW>;
-    constexpr int NJ = BN_ / 64, PAD = KW / 2, BNI = S_::BN_I;
+    constexpr int NJ = BN_ / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, kgrp = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
     const int ntn = (g.Cout + BN_ - 1) / BN_;
     const unsigned tile_id = xcd_band_tile(blockIdx.x, gridDim.x >> 3);
     if (tile_id >= g.ntiles) return;
     const int64_t m0 = (int64_t)(tile_id / ntn) * BM2;
     const int n0 = (tile_id % ntn) * BN_;
-    const int Cin_p = g.Kpad / (KW * KW);                    // tap-padded channel count (multiple of 32)
-#ifdef DFSFM_ABL_NOLOOP
-    const int nchunk = Cin_p / BK, nS = 0;
-#else
-    const int nchunk = Cin_p / BK, nS = KW * nchunk;
-#endif
-
-    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.wh, 0, g.wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
-
-    const int lrow = lane >> 2;
-    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
-    // A rows of this lane: groups wave, wave+8 and (waves 0/1 only: hi/lo plane of) group 16
-    int ay[3];
-    int64_t abase[3];
-    bool aok[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int grp = q < 2 ? wave + 8 * q : 16;
-#ifdef DFSFM_ABL_TILE0
-        const int64_t pix = (int64_t)(blockIdx.x & 7) * BM2 - PAD + grp * 16 + lrow;   // ablation: L2-resident A
-#else
-        const int64_t pix = m0 - PAD + grp * 16 + lrow;      // flattened pixel of LDS row grp*16 + lrow
-#endif
-        aok[q] = pix >= 0 && pix < g.M && (q < 2 || wave < 2);
-        const int64_t pp = aok[q] ? pix : 0;
-        const int ox = (int)(pp % g.W);
-        const int64_t t = pp / g.W;
-        ay[q] = (int)(t % g.H);
-        abase[q] = (t / g.H) * g.sxn + (int64_t)ay[q] * g.sxh + (int64_t)ox * g.ldx + lslot * 8;
-    }
-    const bool cok_lane = true;
-    (void)cok_lane;
-    unsigned offA[3];
-    auto addrA = [&](int Sn) __attribute__((always_inline)) {   // offsets of super-slab Sn = (ky, chunk)
-        const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
-        const bool in = Sn < nS && chunk * BK + lslot * 8 < g.Cin;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int iy = ay[q] + ky - PAD;
-            const bool ok = aok[q] & in & (iy >= 0) & (iy < g.H);
-            const int64_t off = (abase[q] + (int64_t)(ky - PAD) * g.sxh + chunk * BK) * 2;
-#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBA)
-            offA[q] = g.xbytes + (ok ? 0u : 16u);                // ablation: every piece zero-fills (no memory traffic)
-#else
-            offA[q] = ok ? (unsigned)off : g.xbytes;
-#endif
-        }
-    };
-    const unsigned bbase = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);
-    unsigned offB[2];
-    auto addrB = [&](int t) __attribute__((always_inline)) {    // offsets of slab t = (S, kx) -> (ky, chunk, kx)
-        const int Sn = t / KW, kx = t - Sn * KW;
-        const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
-        const unsigned koff = (unsigned)(((ky * KW + kx) * Cin_p + chunk * BK) * 2);
-#pragma unroll
-        for (int j = 0; j < BNI; ++j) {
-            const int grp = (wave + 8 * j) % (BN_ / 16);
-#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBB)
-            offB[j] = g.wbytes + (Sn < nS ? 0u : 16u);
-#else
-            offB[j] = Sn < nS ? bbase + koff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
-#endif
-        }
-    };
-#ifdef DFSFM_ABL_NODMA
-#define SDMA_A(p, astage) ((void)0)
-#define SDMA_B(j, bstage) ((void)0)
-#else
-    // A piece p of a super-slab: 0,1 = group wave (hi, lo); 2,3 = group wave+8 (hi, lo); 4 = group 16 (wave 0: hi,
-    // wave 1: lo, other waves: an out-of-range piece into the 1-KB sink so every wave issues the same count)
-#define SDMA_A(p, astage)                                                                                          \
-    do {                                                                                                            \
-        if ((p) < 4) {                                                                                              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(((p) & 1) ? rxl : rxh,                                         \
-                                                     (lds_void*)(smem + (astage) * S_::A_STAGE + ((p) & 1) * S_::A_PLANE + \
-                                                                 (wave + 8 * ((p) >> 1)) * 1024),                   \
-                                                     16, offA[(p) >> 1], 0, 0, 0);                                  \
-        } else {                                                                                                    \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 1 ? rxl : rxh,                                         \
-                                                     (lds_void*)(wave < 2 ? smem + (astage) * S_::A_STAGE + wave * S_::A_PLANE + 16 * 1024 \
-                                                                          : smem + S_::OFF_DUMMY),                  \
-                                                     16, offA[2], 0, 0, 0);                                         \
-        }                                                                                                           \
-    } while (0)
-#define SDMA_B(j, bstage)                                                                                          \
-    do {                                                                                                            \
-        const int ib_ = wave + 8 * (j);                                                                             \
-        const int plane_ = ib_ / (BN_ / 16), grp_ = ib_ % (BN_ / 16);                                               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(plane_ ? rwl : rwh,                                                \
-                                                 (lds_void*)(smem + S_::OFF_B + (bstage) * S_::B_STAGE +            \
-                                                             plane_ * S_::B_PLANE + grp_ * 1024),                   \
-                                                 16, offB[j], 0, 0, 0);                                             \
-    } while (0)
-#endif
-
     f32x16 accm[2][NJ], accx[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            accm[i][j] = f32x16{0};
-            accx[i][j] = f32x16{0};
-        }
-    // x coordinate of this lane's two output rows (for the left/right border of the kx taps)
-    int oxr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) oxr[i] = (int)((m0 + wr * 64 + i * 32 + col) % g.W);
-
-    // ---- ping-pong schedule ------------------------------------------------------------------------------
-    // Waves w and w+4 share a SIMD.  The two halves of the workgroup run the same slab sequence half a slab
-    // apart: while waves 0-3 are in the COMPUTE segment of slab t (24 back-to-back MFMAs on register fragments),
-    // waves 4-7 are in its LOAD segment (16 fragment reads for the whole slab, this wave's DMA pieces for slab
-    // t+NB-1, address arithmetic, border masks), and vice versa, with one s_barrier per segment.  The matrix
-    // pipe of every SIMD always has exactly one wave feeding it and never sees LDS / VMEM issue in its stream.
-    //   barrier k:        b0    b1    b2    b3    b4
-    //   waves 0-3:           L0    C0    L1    C1   ...
-    //   waves 4-7:           --    L0    C0    L1   ...
-    // Slab u is read in the two segments after barrier b(2u); every wave waits for its own pieces of slab u
-    // (counted vmcnt) just before that barrier: waves 0-3 at the end of C(u-1), waves 4-7 at the end of L(u-1).
-    const int grp = wave >> 2;
-    half8 fah[2][2], fal[2][2], fbh[2][NJ], fbl[2][NJ];             // [k-step][block] fragments of one slab
-    auto read_slab = [&](int astage, int shift, int bstage) __attribute__((always_inline)) {
-        const char* sa = smem + astage * S_::A_STAGE;
-        const char* sb = smem + S_::OFF_B + bstage * S_::B_STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = tile_off(wr * 64 + i * 32 + col + shift, ks * 2 + kgrp);
-                fah[ks][i] = *reinterpret_cast<const half8*>(sa + off);
-                fal[ks][i] = *reinterpret_cast<const half8*>(sa + S_::A_PLANE + off);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
-                fbh[ks][j] = *reinterpret_cast<const half8*>(sb + off);
-                fbl[ks][j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
-            }
-        }
-    };
-    auto mask_slab = [&](int shift) __attribute__((always_inline)) {   // tap leaves the image row: contributes zero
-        if (shift == PAD) return;
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool out = (unsigned)(oxr[i] + shift - PAD) >= (unsigned)g.W;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                fah[ks][i] = out ? z : fah[ks][i];
-                fal[ks][i] = out ? z : fal[ks][i];
-            }
-        }
-    };
-    auto compute_slab = [&]() __attribute__((always_inline)) {
-        // 3 products per block pair; consecutive MFMAs never share an accumulator
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][i], fbh[ks][j], accm[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][i], fbl[ks][j], accx[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks][i], fbh[ks][j], accx[i][j], 0, 0, 0);
-        }
-    };
-
-    // prologue: A(0) B(0) A(1).. B(1)..  (A(0..NA-2), B(0..NB-2))
-#pragma unroll
-    for (int t = 0; t < (S_::NA > S_::NB ? S_::NA : S_::NB) - 1; ++t) {
-        if (t < S_::NA - 1) {
-            addrA(t);
-            SDMA_A(0, t); SDMA_A(1, t); SDMA_A(2, t); SDMA_A(3, t); SDMA_A(4, t);
-        }
-        if (t < S_::NB - 1) {
-            addrB(t);
-            SDMA_B(0, t);
-            if constexpr (BNI > 1) SDMA_B(1, t);
-        }
-    }
-    wait_vmcnt<S_::NWAIT0>();                                         // own pieces of slab 0 have landed
-    __builtin_amdgcn_s_barrier();                                     // b0: slab 0 published
-    if (grp == 1) __builtin_amdgcn_s_barrier();                       // waves 4-7 sit out the first segment
-    int bst = 0;                                                      // B stage of the current slab (t % NB)
-    int ast = 0;                                                      // A stage of the current super-slab (S % NA)
-    for (int S = 0; S < nS; ++S) {
-        const int anx = ast == S_::NA - 1 ? 0 : ast + 1;              // stage of A(S+1)
-        const int adm = ast == 0 ? S_::NA - 1 : ast - 1;              // stage A(S+NA-1) is DMA'd into (held A(S-1))
-        auto tap = [&](auto kxc) __attribute__((always_inline)) {
-            constexpr int kx = decltype(kxc)::value;
-            constexpr int kxn = (kx + 1) % KW;                        // tap of the next slab
-            const int t = S * KW + kx;
-            const int bdm = bst == 0 ? S_::NB - 1 : bst - 1;          // stage of slab t+NB-1 (held slab t-1)
-            // ---- LOAD segment of slab t ----
-            read_slab(ast, kx, bst);
-            if (kx == 0) addrA(S + S_::NA - 1);
-            addrB(t + S_::NB - 1);
-            if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); SDMA_A(2, adm); }
-            if (KW == 1 || kx == 1) { SDMA_A(3, adm); SDMA_A(4, adm); }
-            SDMA_B(0, bdm);
-            if constexpr (BNI > 1) SDMA_B(1, bdm);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mask_slab(kx);
-            if (grp == 1) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 4-7 publish slab t+1 here
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- COMPUTE segment of slab t ----
-            __builtin_amdgcn_s_setprio(1);
-            compute_slab();
-            __builtin_amdgcn_s_setprio(0);
-            if (grp == 0) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 0-3 publish slab t+1 here
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            bst = bst == S_::NB - 1 ? 0 : bst + 1;
-        };
-        tap(std::integral_constant<int, 0>{});
-        if constexpr (KW > 1) {
-            tap(std::integral_constant<int, 1>{});
-            tap(std::integral_constant<int, 2>{});
-        }
-        if constexpr (KW > 3) {
-            tap(std::integral_constant<int, 3>{});
-            tap(std::integral_constant<int, 4>{});
-        }
-        ast = anx;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();                       // pairs with the extra barrier of waves 4-7
-    wait_vmcnt<0>();
-#undef SDMA_A
-#undef SDMA_B
-    sf_epilogue<BN_>(g, smem, accm, accx, m0, n0, tid, wr, wc, col, kgrp);
+    sf_same_mainloop<BN_, KW>(g, smem, accm, accx, m0, n0);
+    sf_epilogue<BN_>(g, smem, accm, accx, m0, n0, tid, wave >> 1, wave & 1, lane & 31, lane >> 5);
 }
 
 // 3x3 / stride 2 / pad 1 max pooling, NHWC (nn.MaxPool2d(3, 2, 1), s2dnet.py:89-92)

@@ -81,13 +81,28 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, 
 
 def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None,
                  coarse_scale=8.0):
-    """K3+K4+K5.  feat0 [N,L,C], feat1 [N,S,C] fp32 contiguous.  Returns a dict with
+    """K3+K4+K5.  feat0 [N,L,C], feat1 [N,S,C]: fp32 contiguous tensors, or SplitAct planes (contiguous, C a
+    power of 4) -- the correlation then runs on the fp16x2-split MFMA path.  Returns a dict with
     b_ids,i_ids,j_ids (int64 [M]), mconf [M], mkpts0_c, mkpts1_c [M,2] in ascending (b,i) order."""
-    _require_cuda(feat0, feat1)
-    feat0, feat1 = feat0.contiguous(), feat1.contiguous()
-    N, L, C = feat0.shape
-    S = feat1.shape[1]
-    dev = feat0.device
+    split = isinstance(feat0, SplitAct)
+    if split != isinstance(feat1, SplitAct):
+        raise _lib.DfsfmError("coarse_match: feat0 and feat1 must both be fp32 or both be split planes")
+    if split:
+        _require_cuda(feat0.hi, feat0.lo, feat1.hi, feat1.lo)
+        for t in (feat0.hi, feat0.lo, feat1.hi, feat1.lo):
+            if not t.is_contiguous() or t.dtype != torch.float16:
+                raise _lib.DfsfmError("coarse_match: split planes must be contiguous fp16")
+        if feat0.hi.shape[-1] != feat0.C or feat1.hi.shape[-1] != feat1.C:
+            raise _lib.DfsfmError("coarse_match: split planes must not carry padded channels")
+        N, L, C = feat0.hi.shape
+        S = feat1.hi.shape[1]
+        dev = feat0.hi.device
+    else:
+        _require_cuda(feat0, feat1)
+        feat0, feat1 = feat0.contiguous(), feat1.contiguous()
+        N, L, C = feat0.shape
+        S = feat1.shape[1]
+        dev = feat0.device
     lib = _lib.lib()
     ws = _workspace(lib.dfsfm_coarse_match_workspace(N, L, S), dev)
     cap = N * L
@@ -97,11 +112,15 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=No
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
     s0 = None if scale0 is None else scale0.to(device=dev, dtype=torch.float32).contiguous()
     s1 = None if scale1 is None else scale1.to(device=dev, dtype=torch.float32).contiguous()
-    rc = lib.dfsfm_coarse_match_f32(_ptr(feat0), _ptr(feat1), N, L, S, C, float(temperature), float(thr),
-                                    int(border), hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1], _ptr(s0), _ptr(s1),
-                                    float(coarse_scale), _ptr(ids[0]), _ptr(ids[1]), _ptr(ids[2]), _ptr(mconf),
-                                    _ptr(mk[0]), _ptr(mk[1]), _ptr(count), _ptr(ws), ws.numel(), _stream())
-    _lib.check(rc, "dfsfm_coarse_match_f32")
+    tail = (N, L, S, C, float(temperature), float(thr), int(border), hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1],
+            _ptr(s0), _ptr(s1), float(coarse_scale), _ptr(ids[0]), _ptr(ids[1]), _ptr(ids[2]), _ptr(mconf),
+            _ptr(mk[0]), _ptr(mk[1]), _ptr(count), _ptr(ws), ws.numel(), _stream())
+    if split:
+        rc = lib.dfsfm_coarse_match_split(_ptr(feat0.hi), _ptr(feat0.lo), _ptr(feat1.hi), _ptr(feat1.lo), *tail)
+        _lib.check(rc, "dfsfm_coarse_match_split")
+    else:
+        rc = lib.dfsfm_coarse_match_f32(_ptr(feat0), _ptr(feat1), *tail)
+        _lib.check(rc, "dfsfm_coarse_match_f32")
     M = int(count.item())          # data-dependent size, like torch.where in the reference
     return {"b_ids": ids[0, :M], "i_ids": ids[1, :M], "j_ids": ids[2, :M], "mconf": mconf[:M],
             "mkpts0_c": mk[0, :M], "mkpts1_c": mk[1, :M]}

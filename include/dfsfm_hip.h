@@ -84,6 +84,19 @@ int dfsfm_coarse_match_f32(const float* feat0, const float* feat1, int N, int L,
                            float* mkpts0, float* mkpts1, int32_t* count,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same operation on features that arrive as fp16 split planes (feat = hi + lo/2048, the format the last
+ * encoder layer's LayerNorm writes -- see dfsfm_conv2d_nhwc_f32): the correlation runs as three fp16 MFMA
+ * products per k-step (fp32-class accuracy, ~6e-7 relative) on the LDS-DMA main loop of the linear layers
+ * instead of the fp32 matrix path.  C must be a power of 4 (the 1/sqrt(C) scaling of
+ * coarse_matching.py:103-104 then folds into one exact multiply) and a multiple of 32.
+ * Same workspace query, outputs and ordering as dfsfm_coarse_match_f32. */
+int dfsfm_coarse_match_split(const void* feat0_hi, const void* feat0_lo, const void* feat1_hi,
+                             const void* feat1_lo, int N, int L, int S, int C, float temperature, float thr,
+                             int border, int h0c, int w0c, int h1c, int w1c, const float* scale0,
+                             const float* scale1, float coarse_scale, int64_t* b_ids, int64_t* i_ids,
+                             int64_t* j_ids, float* mconf, float* mkpts0, float* mkpts1, int32_t* count,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* Dense confidence matrix conf[N,L,S] = softmax(sim,1)*softmax(sim,2) (coarse_matching.py:103-116).
  * Debug / parity aid only ("conf_matrix" is stored by the reference but no inference caller
  * reads it, src/coarse_match/coarse_match_worker.py:83-91). Same workspace as above. */

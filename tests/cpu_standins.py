@@ -32,6 +32,9 @@ def _la(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out
 
 
 def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None, coarse_scale=8.0):
+    from detectorfreesfm_amd.ops import SplitAct
+    if isinstance(feat0, SplitAct):       # split planes carry the fp32 value to 2^-22: correlate what they hold
+        feat0, feat1 = feat0.float(), feat1.float()
     hw0_i = (hw0_c[0] * coarse_scale, hw0_c[1] * coarse_scale)
     return restate.coarse_matching(feat0, feat1, hw0_c, hw1_c, hw0_i, thr, border, temperature, scale0, scale1)
 
