@@ -54,6 +54,9 @@ SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
       c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
       c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    ("dfsfm_conv2d_direct_f32", c_int,
+     [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+      c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     ("dfsfm_maxpool3x3s2_nhwc_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 ]

@@ -181,6 +181,22 @@ int dfsfm_add_scatter_tokens_f32(const float* a, const float* b, const int64_t* 
                                  int M, int C, int P, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K6/K9 first layers  Direct convolution for tiny input depth (fp32 FMA, no operand splitting)
+ * Replaces conv1 + bn1 + relu of ResNetFPN_8_2 (7x7 stride 2, 1 -> 128;
+ *   third_party/LoFTR/src/loftr/backbone/resnet_fpn.py:100-104) and conv1_1 + relu of the S2DNet VGG
+ *   encoder (3x3, 3 -> 64; src/MultiviewMatcher/backbone/S2DNet/s2dnet.py:127-175): K = kh*kw*Cin is
+ *   49 / 27, too shallow for the matrix cores.
+ * x fp32 NHWC view (strides in elements as for dfsfm_conv2d_nhwc_f32); w fp32 [kh*kw*Cin][Cout] in
+ * (ky,kx,ci) order, 256-byte aligned; bias [Cout] or NULL (folded BN); fp32 and/or split outputs
+ * (ldo_s >= Cout, Cout % 64 == 0).  Supported (Cin,kh,kw,stride,pad,Cout): (1,7,7,2,3,128) and
+ * (3,3,3,1,1,64); anything else returns DFSFM_E_UNSUPPORTED (use dfsfm_conv2d_nhwc_f32).
+ * ---------------------------------------------------------------------------------------- */
+int dfsfm_conv2d_direct_f32(const float* x, int64_t sxn, int64_t sxh, int64_t ldx, int Nimg, int H, int W,
+                            int Cin, const float* w, int Cout, int kh, int kw, int stride, int pad,
+                            const float* bias, int relu, float* out, int64_t ldo, void* out_hi, void* out_lo,
+                            int64_t ldo_s, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K2/K6/K9  Convolution / linear layer, NHWC, implicit GEMM on the fp16 matrix cores with an
  * fp16x2 operand split (fp32-class accuracy, see csrc/conv_gemm.hip), fused epilogue:
  *   out[m, co] = act( sum_{ky,kx,ci} x[n, oy*stride+ky-pad, ox*stride+kx-pad, ci] * w[co,ky,kx,ci]
