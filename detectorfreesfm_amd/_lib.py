@@ -53,7 +53,7 @@ SIGNATURES = [
     ("dfsfm_conv2d_nhwc_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
       c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
-      c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+      c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     ("dfsfm_conv2d_direct_f32", c_int,
      [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -137,11 +137,18 @@ def encoder_layer_split(w: EncoderLayerWeights, x, xs, src, out_x, out_xs, nhead
         k, v = kv[..., :C], kv[..., C:]
     msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
                                v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group, out_split=True)
-    merged = ops.linear(msg, w.pmerge)
-    ops.layernorm(merged, w.n1[0], w.n1[1], out_split=xs.cols(C, 2 * C), want_f32=False)   # norm1 -> [x | message]
+    fuse_ln = C in (64, 128)     # a row fits one N tile: LayerNorm runs in the GEMM epilogue (refinement head)
+    if fuse_ln:
+        ops.linear_ln(msg, w.pmerge, w.n1[0], w.n1[1], out_split=xs.cols(C, 2 * C))        # norm1 -> [x | message]
+    else:
+        merged = ops.linear(msg, w.pmerge)
+        ops.layernorm(merged, w.n1[0], w.n1[1], out_split=xs.cols(C, 2 * C), want_f32=False)
     h = ops.linear(xs, w.p1, relu=True, out_split=True)                                   # relu(mlp.0([x|message]))
-    o = ops.linear(h, w.p2)
-    ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=x, out=out_x, out_split=out_xs)
+    if fuse_ln:
+        ops.linear_ln(h, w.p2, w.n2[0], w.n2[1], residual=x, out=out_x, out_split=out_xs)
+    else:
+        o = ops.linear(h, w.p2)
+        ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=x, out=out_x, out_split=out_xs)
     return out_x
 
 

@@ -316,6 +316,7 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
     const int n = n0 + c8;
     if (n >= g.Cout && n >= g.Cout_s) return;
     const bool full = n + 8 <= g.Cout;
+    const bool ln = g.lng != nullptr;                         // host guarantees Cout == BN_ (one N tile, all chunks full)
     float bv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) bv[q] = (g.bias && n + q < g.Cout) ? g.bias[n + q] : 0.f;
@@ -326,7 +327,32 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8 + 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[it][q] = t0[q]; v[it][4 + q] = t1[q]; }
+        for (int q = 0; q < 4; ++q) { v[it][q] = t0[q] + bv[q]; v[it][4 + q] = t1[q] + bv[4 + q]; }
+    }
+    if (ln) {
+        // LayerNorm over the Cout channels of each row: the CH threads that own a row are consecutive lanes of one
+        // wave, so the two row reductions are CH-wide butterflies.  Same arithmetic as layernorm_kernel
+        // (epilogue.hip): mean, centred sum of squares, 1/sqrt(var + eps).
+        float gm[8], bt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { gm[q] = g.lng[n + q]; bt[q] = g.lnb[n + q]; }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[it][q];
+#pragma unroll
+            for (int off = CH / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            const float mean = s / (float)BN_;
+            float sq = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sq += (v[it][q] - mean) * (v[it][q] - mean);
+#pragma unroll
+            for (int off = CH / 2; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+            const float rstd = 1.f / sqrtf(sq / (float)BN_ + g.ln_eps);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[it][q] = (v[it][q] - mean) * rstd * gm[q] + bt[q];
+        }
     }
     if (g.resh) {              // split residual: its channel count is padded to a multiple of 8 with zeros
         half8 rh[IT], rl[IT];
@@ -373,7 +399,7 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
         if (m >= g.M) continue;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            float x = v[it][q] + bv[q];
+            float x = v[it][q];
             if (g.relu) x = fmaxf(x, 0.f);
             v[it][q] = (full || n + q < g.Cout) ? x : 0.f;    // padded split channels are zeros
         }
@@ -760,8 +786,13 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
                                      const float* bias, const float* residual, const void* res_hi,
                                      const void* res_lo, int64_t ldr, int relu, float* out, int64_t ldo,
                                      void* out_hi, void* out_lo, int64_t ldo_s, int Cout_s, int tap_padded,
-                                     void* stream_) {
+                                     const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream_) {
     const bool split_in = x_hi != nullptr;
+    if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return DFSFM_E_BADARG;
+    // fused LayerNorm: rows must sit in ONE N tile of the 1x1 schedule -> linear layers with Cout = 64 or 128
+    if (ln_gamma && !(split_in && kh == 1 && kw == 1 && stride == 1 && pad == 0 && !relu && !tap_padded &&
+                      (Cout == 64 || Cout == 128) && ln_eps > 0.f))
+        return DFSFM_E_UNSUPPORTED;
     if (tap_padded && !split_in) return DFSFM_E_UNSUPPORTED;
     if ((!x && !split_in) || (x && split_in) || (split_in && !x_lo) || !w_hi || !w_lo) return DFSFM_E_BADARG;
     if (!out && !out_hi) return DFSFM_E_BADARG;
@@ -788,6 +819,7 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
     g.M = (int64_t)Nimg * Ho * Wo; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout;
     g.Cout_s = out_hi ? Cout_s : 0;
     g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad; g.K = K; g.Kpad = Kpad; g.relu = relu;
+    g.lng = ln_gamma; g.lnb = ln_beta; g.ln_eps = ln_eps;
 
     if (split_in) {
         // v2: LDS-DMA pipeline.  Needs 8-channel granularity and < 4 GiB planes (32-bit buffer offsets).

@@ -32,6 +32,9 @@ struct ConvArgs {
     unsigned xbytes;         // byte size of one input plane (buffer-descriptor bound, v2 kernel)
     unsigned wbytes;
     unsigned ntiles;         // M tiles x N tiles (v2 kernels; the grid is padded to a multiple of 8)
+    const float* lng;        // LayerNorm fused into the epilogue (Cout == N tile): gamma, beta [Cout], eps;
+    const float* lnb;        //     out = residual + LN(acc + bias) * gamma + beta
+    float ln_eps;
 };
 
 

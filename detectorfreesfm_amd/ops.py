@@ -410,7 +410,7 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
         None if split_in else _ptr(x), _ptr(x.hi) if split_in else None, _ptr(x.lo) if split_in else None,
         sxn, xt.stride(1), xt.stride(2), N, H, W, Cin, _ptr(pw.hi), _ptr(pw.lo), pw.Cout, pw.Kpad, pw.kh, pw.kw,
         stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 1 if relu else 0,
-        _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, 1 if pw.tap_padded else 0, _stream())
+        _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, 1 if pw.tap_padded else 0, None, None, 0.0, _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
     return result
 
@@ -433,6 +433,40 @@ def linear(x, pw: PackedDense, residual=None, relu=False, out=None, out_split=Fa
     if out is None:
         out = torch.empty((rows, pw.Cout), dtype=torch.float32, device=dev)
     conv2d_nhwc(x4, pw, 1, 0, residual, relu, out)
+    return out
+
+
+def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None):
+    """residual + LayerNorm(x @ W^T + bias) * gamma + beta in one kernel (LayerNorm fused into the GEMM epilogue;
+    Cout must be 64 or 128 so a row sits in one tile).  x: SplitAct rows [rows, K]; residual: fp32 [rows, Cout]
+    row-strided view or None; results go to the fp32 view ``out`` and/or the SplitAct view ``out_split``."""
+    if not isinstance(x, SplitAct) or (out is None and out_split is None):
+        raise _lib.DfsfmError("linear_ln: needs split input rows and at least one output")
+    _require_cuda(x.hi, gamma, beta)
+    rows, ld = _rows_ld(x.hi, torch.float16)
+    K = x.hi.shape[-1]
+    if K != pw.Cin_act or x.lo.stride() != x.hi.stride():
+        raise _lib.DfsfmError("linear_ln: bad input")
+    ldo = ldo_s = ldr = 0
+    oh = ol = None
+    if out is not None:
+        rows_o, ldo = _rows_ld(out)
+        if rows_o != rows or out.shape[-1] != pw.Cout:
+            raise _lib.DfsfmError("linear_ln: out shape mismatch")
+    if out_split is not None:
+        rows_s, ldo_s = _rows_ld(out_split.hi, torch.float16)
+        if rows_s != rows or out_split.hi.shape[-1] != pw.Cout or out_split.lo.stride() != out_split.hi.stride():
+            raise _lib.DfsfmError("linear_ln: split out shape mismatch")
+        oh, ol = out_split.hi, out_split.lo
+    if residual is not None:
+        rows_r, ldr = _rows_ld(residual)
+        if rows_r != rows or residual.shape[-1] != pw.Cout:
+            raise _lib.DfsfmError("linear_ln: residual shape mismatch")
+    rc = _lib.lib().dfsfm_conv2d_nhwc_f32(
+        None, _ptr(x.hi), _ptr(x.lo), rows * ld, rows * ld, ld, 1, 1, rows, K, _ptr(pw.hi), _ptr(pw.lo), pw.Cout,
+        pw.Kpad, 1, 1, 1, 0, _ptr(pw.bias), _ptr(residual), None, None, ldr, 0, _ptr(out), ldo, _ptr(oh), _ptr(ol),
+        ldo_s, pw.Cout if oh is not None else 0, 0, _ptr(gamma), _ptr(beta), float(eps), _stream())
+    _lib.check(rc, "dfsfm_conv2d_nhwc_f32(ln)")
     return out
 
 

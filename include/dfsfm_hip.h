@@ -224,13 +224,18 @@ int dfsfm_conv2d_direct_f32(const float* x, int64_t sxn, int64_t sxh, int64_t ld
  *         with K = (ky, kx, ceil32(Cin)) -- Kpad = kh*kw*ceil32(Cin) -- and the kernel variant that
  *         loads each activation row once per (ky, 32-channel chunk) and reuses it for the kw taps
  *         is used (1/kw of the activation traffic).
+ * ln_gamma/ln_beta [Cout] (or both NULL), ln_eps: LayerNorm fused into the epilogue of a linear layer
+ *         (split input, 1x1, Cout = 64 or 128, no ReLU):  out = residual + LN(x.W^T + bias) * gamma + beta
+ *         -- the merge -> norm1 and mlp -> norm2 (+x) pairs of LoFTREncoderLayer.forward
+ *         (src/MultiviewMatcher/matcher_module/transformer.py, d_model = 128) in one pass.
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
                           int64_t ldx, int Nimg, int H, int W, int Cin, const void* w_hi, const void* w_lo,
                           int Cout, int Kpad, int kh, int kw, int stride, int pad, const float* bias,
                           const float* residual, const void* res_hi, const void* res_lo, int64_t ldr,
                           int relu, float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s,
-                          int Cout_s, int tap_padded, void* stream);
+                          int Cout_s, int tap_padded, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                          void* stream);
 
 /* nn.MaxPool2d(3, stride=2, padding=1) on a dense NHWC tensor, fp32 (x -> out, C % 4 == 0) or split
  * planes (x_hi/x_lo -> out_hi/out_lo, C % 8 == 0)  (S2DNet with substitute_pooling_layers,

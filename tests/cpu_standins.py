@@ -83,6 +83,11 @@ def _ln(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None, want_
     return out
 
 
+def _linear_ln(x, pw, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None):
+    y = _linear(x, pw)
+    return _ln(y, gamma, beta, eps, residual, out, out_split, want_f32=False)
+
+
 def _split_rows(x, add=None, out=None, out_split=None):
     y = x if add is None else (x.reshape(-1, add.shape[0], x.shape[-1]) + add).reshape(x.shape)
     if out is not None:
@@ -179,11 +184,11 @@ def cpu_ops():
     from detectorfreesfm_amd import ops
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
-                                          "maxpool3x3s2_nhwc", "split_rows")}
+                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
-    ops.split_rows = _split_rows
+    ops.split_rows, ops.linear_ln = _split_rows, _linear_ln
     try:
         yield
     finally:
