@@ -297,6 +297,11 @@ struct GemmSfArgs {
     unsigned int* col_best;
 };
 
+// exp for the softmax denominators of the split path: v_exp_f32(x * log2 e).  The argument is <= 0; the product's
+// rounding error is relative to |x|, so the terms that dominate a sum (x near 0) are accurate to ~1 ulp and the
+// terms it perturbs by up to 1e-6 relative (x ~ -20) carry weight e^-20.  Three instructions instead of ~15.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                 float m = -INFINITY;
                 for (int j = 0; j < ncol; ++j) m = fmaxf(m, tile[tid * SF_LD + j]);
                 float sum = 0.f;
-                for (int j = 0; j < ncol; ++j) sum += expf(tile[tid * SF_LD + j] - m);
+                for (int j = 0; j < ncol; ++j) sum += fast_exp(tile[tid * SF_LD + j] - m);
                 g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = make_float2(m, sum);
             }
         } else {
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                 float m = -INFINITY;
                 for (int i = i0; i < i1; ++i) m = fmaxf(m, tile[i * SF_LD + c]);
                 float sum = 0.f;
-                for (int i = i0; i < i1; ++i) sum += expf(tile[i * SF_LD + c] - m);
+                for (int i = i0; i < i1; ++i) sum += fast_exp(tile[i * SF_LD + c] - m);
                 // an empty half (rows past L) leaves the neutral partial (-inf, 0)
                 g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] = make_float2(m, sum);
             }
