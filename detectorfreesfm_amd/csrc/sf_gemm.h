@@ -79,7 +79,11 @@ struct VS {
     static constexpr int B_STAGE = 2 * B_PLANE;
     static constexpr int BN_I = (BN_ / 16) * 2 / 8;         // weight pieces per wave per slab (2 or 1)
     static constexpr int NA = KW == 1 ? 3 : 2;              // A ring depth (super-slabs)
-    static constexpr int NB = 3;                             // B ring depth (slabs)
+#ifndef DFSFM_SAME_NB4
+#define DFSFM_SAME_NB4 0
+#endif
+    // B ring depth (slabs): 4 where it fits beside a 2-deep A ring (one more slab of lead for the weight stream)
+    static constexpr int NB = (DFSFM_SAME_NB4 && KW > 1 && NA * A_STAGE + 4 * B_STAGE + 1024 <= 160 * 1024) ? 4 : 3;
     static constexpr int OFF_B = NA * A_STAGE;
     static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;  // 1 KB sink for the padding pieces
     static constexpr int RING = OFF_DUMMY + 1024;
@@ -329,9 +333,13 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- COMPUTE segment of slab t ----
+#ifndef DFSFM_ABL_NOPRIO
             __builtin_amdgcn_s_setprio(1);
+#endif
             compute_slab();
+#ifndef DFSFM_ABL_NOPRIO
             __builtin_amdgcn_s_setprio(0);
+#endif
             if (grp == 0) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 0-3 publish slab t+1 here
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
