@@ -33,7 +33,6 @@ using namespace dfsfm;
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_LD = BN + 1;                               // padded epilogue tile
-constexpr int SMEM_STAGE = 2 * (BM + BN) * BK * 4;           // 65536 B, double buffered A|B
 constexpr int SMEM_TILE = BM * TILE_LD * 4;                  // 66048 B
 constexpr int SMEM_STATS = (BM + BN) * (8 + 4);              // row/col (max,sum) + candidate gates
 constexpr int SMEM_BYTES = SMEM_TILE + SMEM_STATS;           // 68096 B -> 2 workgroups / CU
@@ -302,6 +301,33 @@ struct GemmSfArgs {
 // terms it perturbs by up to 1e-6 relative (x ~ -20) carry weight e^-20.  Three instructions instead of ~15.
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+// All-reduce over the 32 lanes of a half wave (lanes that hold the 32 columns of one accumulator row): four DPP
+// steps inside the 16-lane row (quad swaps, half mirror, mirror) + one cross-row exchange.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_max(float x) {
+    x = fmaxf(x, dpp_mov<0xB1>(x));      // quad_perm [1,0,3,2]
+    x = fmaxf(x, dpp_mov<0x4E>(x));      // quad_perm [2,3,0,1]
+    x = fmaxf(x, dpp_mov<0x141>(x));     // row_half_mirror
+    x = fmaxf(x, dpp_mov<0x140>(x));     // row_mirror
+    return fmaxf(x, __shfl_xor(x, 16));
+}
+__device__ __forceinline__ float half_wave_sum(float x) {
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    x += dpp_mov<0x141>(x);
+    x += dpp_mov<0x140>(x);
+    return x + __shfl_xor(x, 16);
+}
+// (max, sum exp) pairs of two disjoint index sets -> pair of the union
+__device__ __forceinline__ float2 merge_stat(float2 a, float2 b) {
+    const float m = fmaxf(a.x, b.x);
+    if (m == -INFINITY) return make_float2(m, 0.f);
+    return make_float2(m, a.y * fast_exp(a.x - m) + b.y * fast_exp(b.x - m));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -348,6 +374,63 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
     __syncthreads();                                          // ring is dead: the tile aliases it
 
     // lane holds sim[row = wr*64 + i*32 + mfma32_row(r,half)][col = wc*64 + j*32 + (lane&31)]
+    const int nrow = min(SF_BM, g.L - row0), ncol = min(SF_BN, g.S - col0);
+    if (MODE == MODE_STATS) {
+        // Statistics straight from the accumulator registers: a lane's 16 registers of one block are 16 rows of ONE
+        // column (column sums are lane-local), and the 32 lanes of a half wave hold the 32 columns of one row (row
+        // sums are a 32-lane butterfly).  Only the per-wave partials go through LDS.
+        float2* s_rp = reinterpret_cast<float2*>(smem);                   // [2 wc][SF_BM]
+        float2* s_cp = s_rp + 2 * SF_BM;                                  // [4 wr][SF_BN]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
+                    const int lc = wc * 64 + j * 32 + col;
+                    const float sv = ((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
+                    accm[i][j][r] = (lr < nrow && lc < ncol) ? sv : -INFINITY;     // rows past L / columns past S
+                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                     // columns: 32 lane-local rows, then the other half
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, accm[i][j][r]);
+            float e = 0.f;
+            if (m != -INFINITY) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e += fast_exp(accm[i][j][r] - m);
+            }
+            const float2 st = merge_stat(make_float2(m, e), make_float2(__shfl_xor(m, 32), __shfl_xor(e, 32)));
+            if (half == 0) s_cp[wr * SF_BN + wc * 64 + j * 32 + col] = st;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                                // rows: 2 lane-local columns, then 32 lanes
+                const float v0 = accm[i][0][r], v1 = accm[i][1][r];
+                const float m = half_wave_max(fmaxf(v0, v1));
+                float e = (m != -INFINITY) ? fast_exp(v0 - m) + fast_exp(v1 - m) : 0.f;
+                e = half_wave_sum(e);
+                if (col == 0) s_rp[wc * SF_BM + wr * 64 + i * 32 + mfma32_row(r, half)] = make_float2(m, e);
+            }
+        __syncthreads();
+        if (tid < SF_BM) {
+            if (tid < nrow)
+                g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = merge_stat(s_rp[tid], s_rp[SF_BM + tid]);
+        } else {
+            const int c = (tid - SF_BM) & (SF_BN - 1), h = (tid - SF_BM) >> 7;   // column c, 128-row half h
+            if (c < ncol)        // an empty half (rows past L) leaves the neutral partial (-inf, 0)
+                g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] =
+                    merge_stat(s_cp[(2 * h) * SF_BN + c], s_cp[(2 * h + 1) * SF_BN + c]);
+        }
+        return;
+    }
     bool any_above = false;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -358,16 +441,14 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                 const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
                 const int lc = wc * 64 + j * 32 + col;
                 float s = ((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
-                if (MODE == MODE_SELECT) {
-                    if (s > s_rgate[lr] && s > s_cgate[lc]) {
-                        const float2 rs = s_rstat[lr], cs = s_cstat[lc];
-                        const float p_col = expf(s - cs.x) / cs.y;
-                        const float p_row = expf(s - rs.x) / rs.y;
-                        s = p_col * p_row;
-                        any_above |= s > g.thr;
-                    } else {
-                        s = 0.f;
-                    }
+                if (s > s_rgate[lr] && s > s_cgate[lc]) {
+                    const float2 rs = s_rstat[lr], cs = s_cstat[lc];
+                    const float p_col = expf(s - cs.x) / cs.y;
+                    const float p_row = expf(s - rs.x) / rs.y;
+                    s = p_col * p_row;
+                    any_above |= s > g.thr;
+                } else {
+                    s = 0.f;
                 }
                 accm[i][j][r] = s;
             }
@@ -383,29 +464,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                 tile[(wr * 64 + i * 32 + mfma32_row(r, half)) * SF_LD + wc * 64 + j * 32 + col] = accm[i][j][r];
     __syncthreads();
 
-    const int nrow = min(SF_BM, g.L - row0), ncol = min(SF_BN, g.S - col0);
-    if (MODE == MODE_STATS) {
-        if (tid < SF_BM) {
-            if (tid < nrow) {
-                float m = -INFINITY;
-                for (int j = 0; j < ncol; ++j) m = fmaxf(m, tile[tid * SF_LD + j]);
-                float sum = 0.f;
-                for (int j = 0; j < ncol; ++j) sum += fast_exp(tile[tid * SF_LD + j] - m);
-                g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = make_float2(m, sum);
-            }
-        } else {
-            const int c = (tid - SF_BM) & (SF_BN - 1), h = (tid - SF_BM) >> 7;   // column c, 128-row half h
-            if (c < ncol) {
-                const int i0 = h * 128, i1 = min(nrow, i0 + 128);
-                float m = -INFINITY;
-                for (int i = i0; i < i1; ++i) m = fmaxf(m, tile[i * SF_LD + c]);
-                float sum = 0.f;
-                for (int i = i0; i < i1; ++i) sum += fast_exp(tile[i * SF_LD + c] - m);
-                // an empty half (rows past L) leaves the neutral partial (-inf, 0)
-                g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] = make_float2(m, sum);
-            }
-        }
-    } else {
+    {
         if (tid < SF_BM) {
             if (tid < nrow) {
                 float best = g.thr;
