@@ -44,8 +44,8 @@ SIGNATURES = [
       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("dfsfm_layernorm_f32", c_int,
-     [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-      c_int64, c_int64, c_int, c_void_p]),
+     [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+      c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     ("dfsfm_split_rows_f32", c_int,
      [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
       c_void_p]),

@@ -113,18 +113,18 @@ def encoder_layer(w: EncoderLayerWeights, xm, source, out, nhead, x_mask=None, s
     return out
 
 
-def encoder_layer_split(w: EncoderLayerWeights, x, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
+def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
                         q_group=1, kv_group=1, is_self=False):
-    """The same layer with every GEMM on the LDS-DMA (v2) kernel: activations that feed a GEMM are
-    kept as split fp16 planes (ops.SplitAct), produced by the epilogue of whichever kernel computes
-    them (LayerNorm, attention apply, GEMM) -- no conversion pass, no concat.
+    """The same layer with every GEMM on the split-plane LDS-DMA kernels: the token state lives ONLY as split
+    fp16 planes (ops.SplitAct, value = hi + lo/2048), written by the epilogue of whichever kernel computes it
+    (LayerNorm, attention apply, GEMM) -- no conversion pass, no concat, no fp32 copy of the residual chain.
 
-    x   fp32 [N,L,C]            residual input (row-strided view OK)
-    xs  SplitAct [N,L,2C]       first half = split(x); second half receives split(norm1(message))
-    src SplitAct [N,S,C] view   split source tokens (== xs.cols(0,C) for self-attention)
-    out_x  fp32 [N,L,C] view    receives x + norm2(mlp(...))
+    xs  SplitAct [N,L,2C]       first half = x (also the residual); second half receives norm1(message)
+    src SplitAct [N,S,C] view   source tokens (== xs.cols(0,C) for self-attention)
+    out_x  fp32 [N,L,C] view or None: receives x + norm2(mlp(...)) (the last layer's features)
     out_xs SplitAct [N,L,C] view or None: the same values as split planes for the next layer"""
-    N, L, C = x.shape
+    N, L, C2 = xs.hi.shape
+    C = C2 // 2
     D = C // nhead
     S = src.hi.shape[1]
     xs_x = xs.cols(0, C)
@@ -145,10 +145,11 @@ def encoder_layer_split(w: EncoderLayerWeights, x, xs, src, out_x, out_xs, nhead
         ops.layernorm(merged, w.n1[0], w.n1[1], out_split=xs.cols(C, 2 * C), want_f32=False)
     h = ops.linear(xs, w.p1, relu=True, out_split=True)                                   # relu(mlp.0([x|message]))
     if fuse_ln:
-        ops.linear_ln(h, w.p2, w.n2[0], w.n2[1], residual=x, out=out_x, out_split=out_xs)
+        ops.linear_ln(h, w.p2, w.n2[0], w.n2[1], residual=xs_x, out=out_x, out_split=out_xs)
     else:
         o = ops.linear(h, w.p2)
-        ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=x, out=out_x, out_split=out_xs)
+        ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=xs_x, out=out_x, out_split=out_xs,
+                      want_f32=False)
     return out_x
 
 
@@ -277,7 +278,7 @@ class HipLoFTR(ParamModule):
         """f0 [N,L,C], f1 [N,S,C] (+ optional positional-encoding tables added on the way in) -> updated
         features (contiguous fp32).  When both images have the same grid they share buffers so that
         self layers run as ONE batch of 2N sequences.
-        backend "hip": fp32 x (residual chain) + split planes [.,.,2C] = [x | norm1(message)] ping-pong
+        backend "hip": split planes [.,.,2C] = [x | norm1(message)] ping-pong, fp32 only for the result
         (encoder_layer_split); backend "library": fp32 [.,.,2C] buffers (encoder_layer)."""
         nhead = self.config["coarse"]["nhead"]
         names = self.config["coarse"]["layer_names"]
@@ -301,29 +302,30 @@ class HipLoFTR(ParamModule):
             return None, ops.SplitAct.empty_rows((N, L), width, dev), ops.SplitAct.empty_rows((N, S), width, dev)
 
         if hip:
-            X, Xn = new_f32(C), new_f32(C)
             XS, XSn = new_split(2 * C), new_split(2 * C)
-            ops.split_rows(f0, pe0, out=X[1], out_split=XS[1].cols(0, C))
-            ops.split_rows(f1, pe1, out=X[2], out_split=XS[2].cols(0, C))
+            ops.split_rows(f0, pe0, out_split=XS[1].cols(0, C))
+            ops.split_rows(f1, pe1, out_split=XS[2].cols(0, C))
             fin = new_split(C)      # the final features as contiguous split planes: operands of the correlation
+            out = (None, None, None)
             for li, (w, name) in enumerate(zip(P["enc"], names)):
                 last = li == len(names) - 1
                 oxs = fin if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
+                if last:
+                    out = new_f32(C)            # fp32 copy of the final features only
                 if name == "self":
                     if same:   # both images through one batched call
-                        encoder_layer_split(w, X[0], XS[0], XS[0].cols(0, C), Xn[0], oxs[0], nhead, is_self=True)
+                        encoder_layer_split(w, XS[0], XS[0].cols(0, C), out[0], oxs[0], nhead, is_self=True)
                     else:
                         for i in (1, 2):
-                            encoder_layer_split(w, X[i], XS[i], XS[i].cols(0, C), Xn[i], oxs[i], nhead, is_self=True)
+                            encoder_layer_split(w, XS[i], XS[i].cols(0, C), out[i], oxs[i], nhead, is_self=True)
                 elif name == "cross":
-                    encoder_layer_split(w, X[1], XS[1], XS[2].cols(0, C), Xn[1], oxs[1], nhead)
-                    encoder_layer_split(w, X[2], XS[2], oxs[1], Xn[2], oxs[2], nhead)    # sees the updated feat0 (:96-97)
+                    encoder_layer_split(w, XS[1], XS[2].cols(0, C), out[1], oxs[1], nhead)
+                    encoder_layer_split(w, XS[2], oxs[1], out[2], oxs[2], nhead)         # sees the updated feat0 (:96-97)
                 else:
                     raise KeyError(name)
-                X, Xn = Xn, X
                 XS, XSn = XSn, XS
             self._feat_split = (fin[1], fin[2])
-            return X[1], X[2]
+            return out[1], out[2]
 
         cur = new_f32(2 * C)
         nxt = new_f32(2 * C)

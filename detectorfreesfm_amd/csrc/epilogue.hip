@@ -18,7 +18,9 @@ template <int VEC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        const float* __restrict__ residual, int64_t ldr,
+                                                        const float* __restrict__ residual,
+                                                        const _Float16* __restrict__ resh,
+                                                        const _Float16* __restrict__ resl, int64_t ldr,
                                                         float* __restrict__ out, int64_t ldo, int64_t rows,
                                                         _Float16* __restrict__ outh, _Float16* __restrict__ outl,
                                                         int64_t ldos) {
@@ -56,6 +58,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const float* rr = residual + row * ldr + lane * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = rr[e] + o[e];
+    } else if (resh) {   // residual kept as split planes (hi + lo/2048): no fp32 copy of the token state exists
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            o[e] = ((float)resh[row * ldr + lane * VEC + e] + (float)resl[row * ldr + lane * VEC + e] * (1.f / 2048.f)) + o[e];
     }
     if (out) {
         float* orow = out + row * ldo + lane * VEC;
@@ -132,12 +138,16 @@ __global__ __launch_bounds__(256) void add_scatter_tokens_kernel(const float* __
 }  // namespace
 
 extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                                   const float* residual, int64_t ldr, float* out, int64_t ldo, void* out_hi,
-                                   void* out_lo, int64_t ldo_s, int64_t rows, int C, void* stream_) {
+                                   const float* residual, const void* res_hi, const void* res_lo, int64_t ldr,
+                                   float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s,
+                                   int64_t rows, int C, void* stream_) {
     if (rows == 0) return DFSFM_OK;
+    if ((res_hi == nullptr) != (res_lo == nullptr) || (residual && res_hi)) return DFSFM_E_BADARG;
+    const _Float16* rh = static_cast<const _Float16*>(res_hi);
+    const _Float16* rl = static_cast<const _Float16*>(res_lo);
     if (!x || !gamma || !beta || (!out && !out_hi) || rows < 0 || C <= 0) return DFSFM_E_BADARG;
     if ((out_hi == nullptr) != (out_lo == nullptr)) return DFSFM_E_BADARG;
-    if (ldx < C || (out && ldo < C) || (out_hi && ldo_s < C) || (residual && ldr < C)) return DFSFM_E_BADARG;
+    if (ldx < C || (out && ldo < C) || (out_hi && ldo_s < C) || ((residual || res_hi) && ldr < C)) return DFSFM_E_BADARG;
     _Float16* oh = static_cast<_Float16*>(out_hi);
     _Float16* ol = static_cast<_Float16*>(out_lo);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -146,11 +156,11 @@ extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gam
         if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
             (out && ((ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))))
             return DFSFM_E_UNSUPPORTED;
-        hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows, oh, ol, ldo_s);
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 128) {
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows, oh, ol, ldo_s);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 64) {
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, ldr, out, ldo, rows, oh, ol, ldo_s);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else {
         return DFSFM_E_UNSUPPORTED;
     }

@@ -230,12 +230,19 @@ def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None,
             raise _lib.DfsfmError("layernorm: split out shape mismatch")
         oh, ol = out_split.hi, out_split.lo
     ldr = 0
-    if residual is not None:
+    r32 = rh = rl = None
+    if isinstance(residual, SplitAct):
+        rows_r, ldr = _rows_ld(residual.hi, torch.float16)
+        if rows_r != rows or residual.hi.shape[-1] != C or residual.lo.stride() != residual.hi.stride():
+            raise _lib.DfsfmError("layernorm: split residual shape mismatch")
+        rh, rl = residual.hi, residual.lo
+    elif residual is not None:
         rows_r, ldr = _rows_ld(residual)
         if rows_r != rows:
             raise _lib.DfsfmError("layernorm: residual shape mismatch")
-    rc = _lib.lib().dfsfm_layernorm_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), ldr,
-                                        _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
+        r32 = residual
+    rc = _lib.lib().dfsfm_layernorm_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(r32), _ptr(rh),
+                                        _ptr(rl), ldr, _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
     _lib.check(rc, "dfsfm_layernorm_f32")
     return out
 
@@ -439,7 +446,7 @@ def linear(x, pw: PackedDense, residual=None, relu=False, out=None, out_split=Fa
 def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None):
     """residual + LayerNorm(x @ W^T + bias) * gamma + beta in one kernel (LayerNorm fused into the GEMM epilogue;
     Cout must be 64 or 128 so a row sits in one tile).  x: SplitAct rows [rows, K]; residual: fp32 [rows, Cout]
-    row-strided view or None; results go to the fp32 view ``out`` and/or the SplitAct view ``out_split``."""
+    row-strided view, a SplitAct view, or None; results go to the fp32 view ``out`` and/or the SplitAct view ``out_split``."""
     if not isinstance(x, SplitAct) or (out is None and out_split is None):
         raise _lib.DfsfmError("linear_ln: needs split input rows and at least one output")
     _require_cuda(x.hi, gamma, beta)
@@ -458,13 +465,20 @@ def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=No
         if rows_s != rows or out_split.hi.shape[-1] != pw.Cout or out_split.lo.stride() != out_split.hi.stride():
             raise _lib.DfsfmError("linear_ln: split out shape mismatch")
         oh, ol = out_split.hi, out_split.lo
-    if residual is not None:
+    r32 = rh = rl = None
+    if isinstance(residual, SplitAct):
+        rows_r, ldr = _rows_ld(residual.hi, torch.float16)
+        if rows_r != rows or residual.hi.shape[-1] != pw.Cout or residual.lo.stride() != residual.hi.stride():
+            raise _lib.DfsfmError("linear_ln: split residual shape mismatch")
+        rh, rl = residual.hi, residual.lo
+    elif residual is not None:
         rows_r, ldr = _rows_ld(residual)
         if rows_r != rows or residual.shape[-1] != pw.Cout:
             raise _lib.DfsfmError("linear_ln: residual shape mismatch")
+        r32 = residual
     rc = _lib.lib().dfsfm_conv2d_nhwc_f32(
         None, _ptr(x.hi), _ptr(x.lo), rows * ld, rows * ld, ld, 1, 1, rows, K, _ptr(pw.hi), _ptr(pw.lo), pw.Cout,
-        pw.Kpad, 1, 1, 1, 0, _ptr(pw.bias), _ptr(residual), None, None, ldr, 0, _ptr(out), ldo, _ptr(oh), _ptr(ol),
+        pw.Kpad, 1, 1, 1, 0, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 0, _ptr(out), ldo, _ptr(oh), _ptr(ol),
         ldo_s, pw.Cout if oh is not None else 0, 0, _ptr(gamma), _ptr(beta), float(eps), _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32(ln)")
     return out

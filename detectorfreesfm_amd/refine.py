@@ -285,28 +285,28 @@ class HipMultiviewMatcher(ParamModule):
                 continue
             qm = tmask[sl, :Vq].contiguous()
             if mt["enable"] and hip:
-                # fp32 x (residual chain) + split planes [., ., 2C] = [x | norm1(message)], ping-pong
-                rx = [torch.empty((nt, WW, C), dtype=torch.float32, device=dev) for _ in range(2)]
-                qx = [torch.empty((nt, Vq * WW, C), dtype=torch.float32, device=dev) for _ in range(2)]
+                # split planes [., ., 2C] = [x | norm1(message)], ping-pong; fp32 only for the last layer's output
                 rs = [ops.SplitAct.empty_rows((nt, WW), 2 * C, dev) for _ in range(2)]
                 qs = [ops.SplitAct.empty_rows((nt, Vq * WW), 2 * C, dev) for _ in range(2)]
-                ops.split_rows(feats[sl, 0].contiguous(), None, out=rx[0], out_split=rs[0].cols(0, C))
-                ops.split_rows(feats[sl, 1:cv].contiguous().view(nt, Vq * WW, C), None, out=qx[0], out_split=qs[0].cols(0, C))
+                ops.split_rows(feats[sl, 0].contiguous(), None, out_split=rs[0].cols(0, C))
+                ops.split_rows(feats[sl, 1:cv].contiguous().view(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
+                ref = qry = None
                 for li, (w, name) in enumerate(zip(P["layers"], names)):   # matcher_module/transformer.py:158-172
                     last = li == len(names) - 1
                     ors = None if last else rs[1].cols(0, C)
                     oqs = None if last else qs[1].cols(0, C)
+                    if last:
+                        ref = torch.empty((nt, WW, C), dtype=torch.float32, device=dev)
+                        qry = torch.empty((nt, Vq * WW, C), dtype=torch.float32, device=dev)
                     if name == "self":
-                        encoder_layer_split(w, rx[0], rs[0], rs[0].cols(0, C), rx[1], ors, nhead, is_self=True)
-                        encoder_layer_split(w, qx[0], qs[0], qs[0].cols(0, C), qx[1], oqs, nhead, qm, qm, WW, WW,
-                                            is_self=True)
+                        encoder_layer_split(w, rs[0], rs[0].cols(0, C), ref, ors, nhead, is_self=True)
+                        encoder_layer_split(w, qs[0], qs[0].cols(0, C), qry, oqs, nhead, qm, qm, WW, WW, is_self=True)
                     elif name == "cross":                 # both sides from the PRE-update tensors (:163)
-                        encoder_layer_split(w, qx[0], qs[0], rs[0].cols(0, C), qx[1], oqs, nhead, qm, None, WW, 1)
-                        encoder_layer_split(w, rx[0], rs[0], qs[0].cols(0, C), rx[1], ors, nhead, None, qm, 1, WW)
+                        encoder_layer_split(w, qs[0], rs[0].cols(0, C), qry, oqs, nhead, qm, None, WW, 1)
+                        encoder_layer_split(w, rs[0], qs[0].cols(0, C), ref, ors, nhead, None, qm, 1, WW)
                     else:
                         raise NotImplementedError(name)
-                    rx.reverse(); qx.reverse(); rs.reverse(); qs.reverse()
-                ref, qry = rx[0], qx[0]
+                    rs.reverse(); qs.reverse()
             elif mt["enable"]:
                 # library control: fp32 [., ., 2C] buffers (x | norm1(message)), see encoder_layer
                 rb = [torch.empty((nt, WW, 2 * C), dtype=torch.float32, device=dev) for _ in range(2)]

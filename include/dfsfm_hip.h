@@ -157,12 +157,15 @@ int dfsfm_fine_match_f32(const float* ref, const float* qry, const uint8_t* trac
  *   src/MultiviewMatcher/matcher_module/transformer.py:82,88-95
  * and, through `ldo`, the torch.cat([x, message]) of :55 / :87: norm1 writes straight into the
  * second half of a [rows, 2C] buffer whose first half holds x.  ldx/ldr/ldo are row strides in
- * floats.  C must be 64, 128 or 256.  The result is written as fp32 (`out`, may be NULL) and/or
- * as split fp16 planes out_hi/out_lo (row stride ldo_s) for the GEMMs that consume it.
+ * floats.  C must be 64, 128 or 256.  The residual is fp32 (`residual`) or split fp16 planes
+ * (res_hi/res_lo, row stride ldr in halves) -- between encoder layers the token state only exists as
+ * split planes.  The result is written as fp32 (`out`, may be NULL) and/or as split fp16 planes
+ * out_hi/out_lo (row stride ldo_s) for the GEMMs that consume it.
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                        const float* residual, int64_t ldr, float* out, int64_t ldo, void* out_hi,
-                        void* out_lo, int64_t ldo_s, int64_t rows, int C, void* stream);
+                        const float* residual, const void* res_hi, const void* res_lo, int64_t ldr,
+                        float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, int64_t rows,
+                        int C, void* stream);
 
 /* out[r, :] = x[r, :] (+ add[r % add_rows, :]) as fp32 (`out`, may be NULL) and/or split planes.
  * Used once per forward to add the positional encoding (LoFTR loftr.py:58-59: the [h*w, C] table

@@ -72,8 +72,11 @@ def _fm(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, re
 
 
 def _ln(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None, want_f32=True):
+    from detectorfreesfm_amd.ops import SplitAct
     y = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
     if residual is not None:
+        if isinstance(residual, SplitAct):
+            residual = residual.float()
         y = residual.reshape(y.shape) + y
     if out_split is not None:
         _put_split(out_split, y)
