@@ -64,6 +64,37 @@ def test_loftr_features_vs_oracle_640x480(built_lib):
         assert err < 1e-4, err
 
 
+def test_loftr_832_config5_batch_invariance(built_lib):
+    """BASELINE config 5 frame size (832x832 -> 104x104 grid, L = S = 10816): a batch of 2 pairs gives the same
+    features (to summation-order noise) and the same matches as the two pairs run alone."""
+    cfg = loftr_coarse_only_config(1e-3)
+    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    m = HipLoFTR(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    data = synth.coarse_pair_batch(2, 832, 832, seed=5)
+    with torch.no_grad():
+        f0, f1, hw0, hw1 = m.coarse_features(data["image0"].to(DEV), data["image1"].to(DEV))
+        assert hw0 == (104, 104) and f0.shape == (2, 10816, 256)
+        assert torch.isfinite(f0).all() and torch.isfinite(f1).all()
+        for p in range(2):
+            g0, g1, _, _ = m.coarse_features(data["image0"][p:p + 1].to(DEV), data["image1"][p:p + 1].to(DEV))
+            for a, b in ((f0[p], g0[0]), (f1[p], g1[0])):
+                assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5
+    d = synth.to_device(data, DEV)
+    m(d)
+    assert d["i_ids"].numel() > 0 and int(d["j_ids"].max()) < 10816
+    key = d["b_ids"] * 10816 + d["i_ids"]
+    assert (key[1:] > key[:-1]).all()                      # ascending (b, i) like torch.where
+    for p in range(2):
+        s = synth.to_device({k: v[p:p + 1] for k, v in data.items()}, DEV)
+        m(s)
+        sel = d["b_ids"] == p
+        a = set(zip(d["i_ids"][sel].tolist(), d["j_ids"][sel].tolist()))
+        b = set(zip(s["i_ids"].tolist(), s["j_ids"].tolist()))
+        assert len(a & b) >= 0.99 * max(len(a), len(b), 1)
+
+
 def test_loftr_batch8_equals_singles(built_lib):
     """Batch of 8 pairs == 8 single-pair calls (pairs are independent units of work)."""
     cfg = loftr_coarse_only_config(1e-3)
