@@ -159,3 +159,35 @@ def test_multiview_vs_oracle_config3_shape(built_lib):
     assert same.float().mean() >= 0.9
     dr = (d["reference_points_refined"][-1].cpu() - o["reference_points_refined"]).abs().max(-1)[0][0]   # [V-1,T]
     assert dr[:, same][mask[0][:, same]].max() < 2e-3
+
+
+def test_multiview_chunk16000_equals_two_chunks(built_lib):
+    """BASELINE config 5 refinement chunk (chunk_size = 16000 tracks, 5 views): tracks are independent units, so
+    one 16000-track bag must reproduce the results of its two 8000-track halves."""
+    cfg = multiview_refinement_config()
+    sd = random_state_dict(multiview_param_spec(cfg), 1)
+    m = HipMultiviewMatcher(cfg, test=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    T = 16000
+    data = synth.refine_bag(T, 5, 480, 640, seed=31)
+    d = synth.to_device(data, DEV)
+    m(d)
+    q, r = d["query_points_refined"], d["reference_points_refined"][-1]
+    assert q.shape == (1, T, 2) and r.shape == (1, 4, T, 2)
+    assert torch.isfinite(q).all() and torch.isfinite(r).all()
+    # refined points stay inside the search window around the coarse points (W = 15 -> +-7 px)
+    assert (r.cpu() - data["reference_points_coarse"]).abs().max().item() <= 7.5
+    per_track = ("query_points", "reference_points_coarse", "query_img_idxs", "reference_img_idxs",
+                 "track_valid_mask", "scales_relative", "view_point_vector", "query_movable_mask")
+    for lo, hi in ((0, 8000), (8000, T)):
+        part = dict(data)
+        for k in per_track:
+            t = data[k]
+            part[k] = t[..., lo:hi, :] if k in ("query_points", "reference_points_coarse", "view_point_vector") else t[..., lo:hi]
+        h = synth.to_device(part, DEV)
+        m(h)
+        same = (h["query_points_refined"] - q[:, lo:hi]).abs().max(-1)[0][0] < 1e-4       # argmin flips between near-ties
+        assert same.float().mean().item() >= 0.99
+        dr = (h["reference_points_refined"][-1] - r[:, :, lo:hi]).abs().max(-1)[0][0]       # [4, n]
+        assert dr[:, same].max().item() < 1e-3
