@@ -57,6 +57,10 @@ SIGNATURES = [
     ("dfsfm_conv2d_direct_f32", c_int,
      [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("dfsfm_merge_keypoints_workspace", c_size_t, [c_int64]),
+    ("dfsfm_merge_keypoints", c_int,
+     [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_size_t, c_void_p]),
     ("dfsfm_maxpool3x3s2_nhwc_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 ]

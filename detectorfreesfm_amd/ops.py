@@ -484,6 +484,36 @@ def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=No
     return out
 
 
+def merge_keypoints(rows, img0, img1, n_images):
+    """Scene-wide keypoint merge + match re-indexing (coarse_match.py:203-237 on the device).
+    rows [M,5] fp32 (x0,y0,x1,y1,conf), img0/img1 [M] image index of each side (device tensors).
+    Returns (kpts [K,2] fp32, scores [K] fp32, offsets [n_images+1] int64, match_ids [M,2] int64): image i owns
+    keypoints offsets[i]:offsets[i+1] in id order."""
+    _require_cuda(rows, img0, img1)
+    rows = rows.to(torch.float32).contiguous().view(-1, 5)
+    img0 = img0.to(torch.int32).contiguous()
+    img1 = img1.to(torch.int32).contiguous()
+    M = rows.shape[0]
+    if img0.numel() != M or img1.numel() != M:
+        raise _lib.DfsfmError("merge_keypoints: img0/img1 must have one entry per match row")
+    dev = rows.device
+    lib = _lib.lib()
+    ws = _workspace(lib.dfsfm_merge_keypoints_workspace(M), dev)
+    kpts = torch.empty((2 * M, 2), dtype=torch.float32, device=dev)
+    scores = torch.empty((2 * M,), dtype=torch.float32, device=dev)
+    offsets = torch.empty((n_images + 1,), dtype=torch.int64, device=dev)
+    ids = torch.empty((M, 2), dtype=torch.int64, device=dev)
+    nk = torch.zeros((1,), dtype=torch.int64, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rc = lib.dfsfm_merge_keypoints(_ptr(rows), _ptr(img0), _ptr(img1), M, int(n_images), _ptr(kpts), _ptr(scores),
+                                   _ptr(offsets), _ptr(ids), _ptr(nk), _ptr(status), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "dfsfm_merge_keypoints")
+    K, st = int(nk.item()), int(status.item())
+    if st != 0:
+        raise _lib.DfsfmError("merge_keypoints: image index or keypoint coordinate out of range")
+    return kpts[:K], scores[:K], offsets, ids
+
+
 def maxpool3x3s2_nhwc(x):
     """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor (fp32) or SplitAct."""
     if isinstance(x, SplitAct):

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from .coarse import HipLoFTR
 from .config import loftr_coarse_only_config, multiview_refinement_config
 from .refine import HipMultiviewMatcher
@@ -127,3 +128,35 @@ def extract_results(data, matcher=None):
     return ([query_points_refined[mask], query_img_ids[mask], query_pt2D_idxs[mask]],
             [reference_points_refined[ref_movable_mask], reference_img_ids[ref_movable_mask],
              reference_pt2D_idxs[ref_movable_mask]], data.get("time"))
+
+
+def merge_match_tables(matches: dict, names: list, pair_name_split: str, device="cuda"):
+    """Drop-in for the "Combine keypoints / Update matches / Post-processing keypoints" block of
+    detector_free_coarse_matching (src/coarse_match/coarse_match.py:203-237: Match2Kpts + keypoint_worker +
+    update_matches(merge=False) + transform_keypoints) on the device, one call for the whole scene.
+
+    matches: {f"{name0}{split}{name1}": ndarray [N,5] (mkpts0, mkpts1, mconf)} as produced by match_worker;
+    names: image list.  Returns (final_keypoints {name: [K,2] float32}, final_scores {name: [K] float32},
+    updated_matches {pair: [N,2] int}) exactly like the reference's three dictionaries."""
+    index = {n: i for i, n in enumerate(names)}
+    keys = list(matches.keys())
+    tabs = [np.asarray(matches[k], dtype=np.float32).reshape(-1, 5) for k in keys]
+    lens = [t.shape[0] for t in tabs]
+    if sum(lens) == 0:
+        return ({n: np.empty((0, 2)) for n in names}, {n: np.empty((0,), np.float32) for n in names},
+                {k: np.empty((0, 2)).astype(int) for k in keys})
+    rows = torch.from_numpy(np.concatenate(tabs, 0)).to(device)
+    pair_imgs = np.array([[index[a], index[b]] for a, b in (k.split(pair_name_split) for k in keys)], dtype=np.int32)
+    rep = torch.repeat_interleave(torch.from_numpy(pair_imgs), torch.tensor(lens), dim=0).to(device)
+    kpts, scores, offsets, ids = ops.merge_keypoints(rows, rep[:, 0], rep[:, 1], len(names))
+    kpts, scores, offsets, ids = kpts.cpu().numpy(), scores.cpu().numpy(), offsets.cpu().numpy(), ids.cpu().numpy()
+    final_keypoints, final_scores = {}, {}
+    for i, n in enumerate(names):
+        k = kpts[offsets[i]:offsets[i + 1]]
+        final_keypoints[n] = k if len(k) else np.empty((0, 2))        # transform_keypoints' corner case (:264-266)
+        final_scores[n] = scores[offsets[i]:offsets[i + 1]]
+    updated, pos = {}, 0
+    for k, n in zip(keys, lens):
+        updated[k] = ids[pos:pos + n].astype(int)
+        pos += n
+    return final_keypoints, final_scores, updated

@@ -246,6 +246,28 @@ int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, in
 int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int Nimg, int H, int W,
                                 int C, float* out, void* out_hi, void* out_lo, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Match-table consumers: scene-wide keypoint merge and match re-indexing
+ * Replaces the per-image / per-pair Python loops of coarse_match.py:203-237:
+ *   Match2Kpts.__getitem__ (src/coarse_match/utils/merge_kpts.py:36-61), agg_groupby_2d (:4-17),
+ *   keypoint_worker / update_matches(merge=False) / transform_keypoints
+ *   (src/coarse_match/coarse_match_worker.py:151-175, 182-243, 250-270).
+ * rows [M,5] = (x0, y0, x1, y1, conf) of every match of the scene, pairs concatenated in table order;
+ * img0/img1 [M] = image index of each side (an image never meets itself in a pair).
+ * Every endpoint becomes the integer keypoint (int)x, (int)y of its image (0 <= x, y < 2^20); equal
+ * keypoints of an image merge, their confidences summed in float64 in table order; an image's
+ * keypoints are numbered by descending summed score, ties in (x, y) lexicographic order.
+ *   kpts [2M,2] fp32, scores [2M] fp32: keypoints of image i at offsets[i] .. offsets[i+1], in id order
+ *   offsets [n_images+1] int64;  match_ids [M,2] int64 = (id of side 0 in img0, id of side 1 in img1)
+ *   *n_kpts (device int64) = total number of keypoints;  *status (device int32) != 0 if an image
+ *   index or coordinate was out of range (outputs are then unspecified).
+ * No host synchronisation.  Workspace: dfsfm_merge_keypoints_workspace(M) bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t dfsfm_merge_keypoints_workspace(int64_t M);
+int dfsfm_merge_keypoints(const float* rows, const int32_t* img0, const int32_t* img1, int64_t M, int n_images,
+                          float* kpts, float* scores, int64_t* offsets, int64_t* match_ids, int64_t* n_kpts,
+                          int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

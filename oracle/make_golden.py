@@ -146,5 +146,37 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def merge_golden():
+    """Match-table consumer stage: the reference's own Match2Kpts / keypoint_worker /
+    update_matches / transform_keypoints on seeded match tables -> tests/golden/merge_keypoints.npz."""
+    from oracle import restate_merge as rm
+    Match2Kpts, keypoint_worker, update_matches, transform_keypoints = ref_import.import_match_table_consumers()
+    out = {}
+    for tag, (ni, npairs, seed) in {"a": (6, 9, 0), "b": (12, 40, 2), "c": (3, 3, 5)}.items():
+        matches, names, split = rm.synthetic_scene(ni, npairs, seed)
+        if tag == "c":                       # an image without any match and an empty pair table
+            names = names + ["scene/unmatched.jpg"]
+            matches[f"{names[0]}{split}{names[2]}"] = np.zeros((0, 5), np.float32)
+        all_kpts = Match2Kpts(matches, names, name_split=split)
+        keypoints = keypoint_worker(all_kpts[0:len(names)], verbose=False)
+        upd = update_matches(matches, keypoints, merge=False, verbose=False, pair_name_split=split)
+        fk, fs = transform_keypoints(keypoints, verbose=False)
+        rows, i0, i1, sl = rm.tables_to_flat(matches, names, split)
+        offs = np.cumsum([0] + [len(fs[n]) for n in names]).astype(np.int64)
+        kp = np.concatenate([np.asarray(fk[n], np.float32).reshape(-1, 2) for n in names], 0)
+        sc = np.concatenate([np.asarray(fs[n], np.float32) for n in names], 0)
+        ids = np.zeros((rows.shape[0], 2), np.int64)
+        for k, (lo, hi) in sl.items():
+            ids[lo:hi] = upd[k].reshape(-1, 2)
+        out.update({f"{tag}_rows": rows, f"{tag}_img0": i0, f"{tag}_img1": i1, f"{tag}_n_images": np.int64(len(names)),
+                    f"{tag}_kpts": kp, f"{tag}_scores": sc, f"{tag}_offsets": offs, f"{tag}_ids": ids})
+    np.savez_compressed(os.path.join(OUT, "merge_keypoints.npz"), **out)
+    print("merge_keypoints.npz", {k: v.shape for k, v in out.items() if k.endswith("rows")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "merge":
+        merge_golden()
+    else:
+        main()
+        merge_golden()

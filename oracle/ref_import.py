@@ -251,3 +251,29 @@ def import_multiview_matcher():
     install_stubs()
     from src.MultiviewMatcher.MultiviewMatcher import MultiviewMatcher
     return MultiviewMatcher
+
+
+def import_match_table_consumers():
+    """Return the reference's own ``Match2Kpts``, ``keypoint_worker``, ``update_matches`` and
+    ``transform_keypoints`` (src/coarse_match/utils/merge_kpts.py:19-61, coarse_match_worker.py:151-270).
+
+    ``coarse_match_worker`` imports ray / pytorch_lightning / the dataset stack at module level, none of which
+    the three functions use.  Their *unchanged source text* is compiled from the reference file (ast, no
+    edits) into a namespace that provides what they reference: numpy, the real ``agg_groupby_2d`` and
+    identity stand-ins for ``tqdm`` / ``logger``."""
+    import ast
+    import numpy as np
+    _ensure_path()
+    install_stubs()
+    mk = importlib.import_module("src.coarse_match.utils.merge_kpts")
+    path = os.path.join(REFERENCE_ROOT, "src", "coarse_match", "coarse_match_worker.py")
+    with open(path) as fh:
+        tree = ast.parse(fh.read())
+    wanted = ("keypoint_worker", "update_matches", "transform_keypoints")
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
+    for n in body:
+        n.decorator_list = []
+    ns = {"np": np, "agg_groupby_2d": mk.agg_groupby_2d, "tqdm": (lambda it, *a, **k: it),
+          "logger": sys.modules["loguru"].logger}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return mk.Match2Kpts, ns["keypoint_worker"], ns["update_matches"], ns["transform_keypoints"]

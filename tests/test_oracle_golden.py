@@ -125,3 +125,35 @@ def test_oracle_vs_live_reference_and_key_layout():
         o = restate.loftr_coarse_forward(sd, cfg, data)
     for k in ("i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
         assert torch.equal(d[k], o[k]), k
+
+
+# ---------------------------------------------------------------- match-table consumers
+def test_merge_oracle_vs_golden(golden):
+    """oracle/restate_merge.py against fixtures written by the reference's own Match2Kpts / keypoint_worker /
+    update_matches / transform_keypoints (oracle/make_golden.py merge): bit-for-bit."""
+    from oracle import restate_merge as rm
+    gz = golden("merge_keypoints")
+    for tag in ("a", "b", "c"):
+        kp, sc, off, ids = rm.merge_keypoints(gz[f"{tag}_rows"], gz[f"{tag}_img0"], gz[f"{tag}_img1"],
+                                              int(gz[f"{tag}_n_images"]))
+        assert np.array_equal(off, gz[f"{tag}_offsets"])
+        assert np.array_equal(kp, gz[f"{tag}_kpts"]) and np.array_equal(sc, gz[f"{tag}_scores"])
+        assert np.array_equal(ids, gz[f"{tag}_ids"])
+
+
+def test_merge_oracle_vs_live_reference():
+    from oracle import ref_import, restate_merge as rm
+    if not ref_import.reference_available():
+        pytest.skip("reference tree not present")
+    Match2Kpts, keypoint_worker, update_matches, transform_keypoints = ref_import.import_match_table_consumers()
+    matches, names, split = rm.synthetic_scene(7, 15, seed=11)
+    keypoints = keypoint_worker(Match2Kpts(matches, names, name_split=split)[0:len(names)], verbose=False)
+    upd = update_matches(matches, keypoints, merge=False, verbose=False, pair_name_split=split)
+    fk, fs = transform_keypoints(keypoints, verbose=False)
+    rows, i0, i1, sl = rm.tables_to_flat(matches, names, split)
+    kp, sc, off, ids = rm.merge_keypoints(rows, i0, i1, len(names))
+    for i, n in enumerate(names):
+        assert np.array_equal(kp[off[i]:off[i + 1]], np.asarray(fk[n], np.float32).reshape(-1, 2))
+        assert np.array_equal(sc[off[i]:off[i + 1]], fs[n])
+    for k, (lo, hi) in sl.items():
+        assert np.array_equal(ids[lo:hi], upd[k].reshape(-1, 2))
