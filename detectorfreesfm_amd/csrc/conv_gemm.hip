@@ -16,12 +16,15 @@
 // error vs fp64 is 5.9e-7 for both this scheme and fp32 (K=1152), and the end-to-end outputs of
 // both plugins are unchanged.  Operand range: |x| < 65504.
 //
-// One kernel family: out[m, co] = sum_{ky,kx,ci} in[pix(m,ky,kx), ci] * w[co, ky, kx, ci], NHWC,
-// M = Nimg*Ho*Wo output pixels, K = kh*kw*Cin flattened (slabs may straddle taps, 4-channel
-// granularity), weights pre-split to fp16 [Npad][Kpad] hi / lo.  A linear layer is the 1x1 case
-// with a row stride.  128x128 tile, BK=32, 4 waves x (2x2 MFMA 32x32x16 tiles), fragments read with
-// conflict-free swizzled ds_read_b128, next slab prefetched into registers and split while the
-// MFMAs run; epilogue fuses bias (folded BN), residual, ReLU.
+// One family: out[m, co] = sum_{ky,kx,ci} in[pix(m,ky,kx), ci] * w[co, ky, kx, ci], NHWC, M = Nimg*Ho*Wo output
+// pixels, weights pre-split to fp16 [Npad][Kpad] hi / lo; a linear layer is the 1x1 case with a row stride.
+//   conv_gemm_sf_same_kernel<BN,KW>  split-plane inputs, stride-1 "same" 3x3 / 5x5 convs and every 1x1 / linear:
+//                                    the activation-reuse, ping-pong LDS-DMA main loop of sf_gemm.h
+//   conv_gemm_sf_kernel<BN>          split-plane inputs, any geometry (stride-2 convs, pad-0 5x5): K flattened over
+//                                    (ky,kx,ci), 3-stage LDS-DMA ring of whole slabs, lock-step waves
+//   conv_gemm_kernel<VEC_A>          fp32 inputs (image stem): splits in registers while staging, 128x128 tile
+// All share sf_epilogue-style fusion of bias (folded BN), residual, ReLU, optional LayerNorm, fp32 / split stores.
+// Ablation builds (-DDFSFM_ABL_*, tools/abl_conv.sh) switch single resources off for measurements.
 #include "common.h"
 #include "sf_gemm.h"
 
