@@ -137,7 +137,7 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
         k, v = kv[..., :C], kv[..., C:]
     msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
                                v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group, out_split=True)
-    fuse_ln = C in (64, 128)     # a row fits one N tile: LayerNorm runs in the GEMM epilogue (refinement head)
+    fuse_ln = C in (64, 128, 256)    # a row fits one workgroup tile: LayerNorm runs in the GEMM epilogue
     if fuse_ln:
         ops.linear_ln(msg, w.pmerge, w.n1[0], w.n1[1], out_split=xs.cols(C, 2 * C))        # norm1 -> [x | message]
     else:

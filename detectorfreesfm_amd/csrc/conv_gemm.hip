@@ -285,12 +285,13 @@ struct V2 {
 // Shared epilogue of the split-input kernels: the accumulator tile goes through LDS so each thread owns 8
 // consecutive channels of one output row: bias (folded BN), fp32 / split residual, ReLU, then 32-byte fp32
 // stores and/or 16+16-byte split stores.  Must be entered with no LDS-DMA in flight.
-template <int BN_>
-__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ / 64],
-                                            f32x16 (&accx)[2][BN_ / 64], int64_t m0, int n0, int tid, int wr, int wc,
-                                            int col, int kgrp) {
-    using T = V2<BN_>;
-    constexpr int NJ = BN_ / 64;
+template <int BN_, int BM_ = BM2>
+__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * BM_ / (64 * BM2)],
+                                            f32x16 (&accx)[2][BN_ * BM_ / (64 * BM2)], int64_t m0, int n0, int tid,
+                                            int wr, int wc, int col, int kgrp) {
+    constexpr int TILE_LD_ = BN_ + 4;                        // fp32 staging-tile row (floats)
+    constexpr int NJ = BN_ * BM_ / (64 * BM2);               // 32-wide column blocks per wave (waves: BM_/64 x 512/BM_)
+    constexpr int WCOLS = NJ * 32;                            // columns per wave
 #ifdef DFSFM_ABL_NOEPI
 #if defined(__HIP_DEVICE_COMPILE__)
     for (int i = 0; i < 2; ++i)
@@ -306,7 +307,7 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * T::TILE_LD + wc * (BN_ / 2) + j * 32 + col] =
+                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * TILE_LD_ + wc * WCOLS + j * 32 + col] =
                     accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
     __syncthreads();
     // Every thread owns one 8-channel chunk (fixed: 512 % CH == 0) of IT rows.  All memory operations of the IT
@@ -314,7 +315,7 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
     // stores -- the epilogue is latency-bound otherwise (one dependent global load per row).
     constexpr int CH = BN_ / 8;                               // 8-channel chunks per row
     constexpr int RPI = 512 / CH;                             // rows per pass
-    constexpr int IT = BM2 / RPI;                             // passes (8 for BN=128, 4 for BN=64)
+    constexpr int IT = BM_ / RPI;                             // passes (8 for BN=128, 4 for BN=64; 8 for 128 x 256)
     const int c8 = (tid % CH) * 8, rr = tid / CH;
     const int n = n0 + c8;
     if (n >= g.Cout && n >= g.Cout_s) return;
@@ -327,8 +328,8 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int r = it * RPI + rr;
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * T::TILE_LD + c8 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + r * TILE_LD_ + c8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + r * TILE_LD_ + c8 + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { v[it][q] = t0[q] + bv[q]; v[it][4 + q] = t1[q] + bv[4 + q]; }
     }
@@ -663,20 +664,21 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
 }
 
 // "same" convolution / 1x1 / linear kernel: sf_same_mainloop (sf_gemm.h) + the shared epilogue.
-template <int BN_, int KW>
+template <int BN_, int KW, int WM = 4>
 __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
-    constexpr int NJ = BN_ / 64;
+    using S_ = VS<BN_, KW, WM>;
+    constexpr int NJ = BN_ / (32 * S_::WN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntn = (g.Cout + BN_ - 1) / BN_;
     const unsigned tile_id = xcd_band_tile(blockIdx.x, gridDim.x >> 3);
     if (tile_id >= g.ntiles) return;
-    const int64_t m0 = (int64_t)(tile_id / ntn) * BM2;
+    const int64_t m0 = (int64_t)(tile_id / ntn) * S_::BM;
     const int n0 = (tile_id % ntn) * BN_;
     f32x16 accm[2][NJ], accx[2][NJ];
-    sf_same_mainloop<BN_, KW>(g, smem, accm, accx, m0, n0);
-    sf_epilogue<BN_>(g, smem, accm, accx, m0, n0, tid, wave >> 1, wave & 1, lane & 31, lane >> 5);
+    sf_same_mainloop<BN_, KW, WM>(g, smem, accm, accx, m0, n0);
+    sf_epilogue<BN_, S_::BM>(g, smem, accm, accx, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane & 31, lane >> 5);
 }
 
 // 3x3 / stride 2 / pad 1 max pooling, NHWC (nn.MaxPool2d(3, 2, 1), s2dnet.py:89-92)
@@ -766,19 +768,19 @@ void launch_v2(const ConvArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(conv_gemm_sf_kernel<BN_>, grid, dim3(512), T::SMEM, stream, a);
 }
 
-template <int BN_, int KW>
+template <int BN_, int KW, int WM = 4>
 void launch_same(const ConvArgs& g, hipStream_t stream) {
-    using S_ = VS<BN_, KW>;
+    using S_ = VS<BN_, KW, WM>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_sf_same_kernel<BN_, KW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_sf_same_kernel<BN_, KW, WM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, S_::SMEM);
         attr_set = true;
     }
     ConvArgs a = g;
-    a.ntiles = (unsigned)((g.M + BM2 - 1) / BM2) * (unsigned)((g.Cout + BN_ - 1) / BN_);
+    a.ntiles = (unsigned)((g.M + S_::BM - 1) / S_::BM) * (unsigned)((g.Cout + BN_ - 1) / BN_);
     const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
-    hipLaunchKernelGGL((conv_gemm_sf_same_kernel<BN_, KW>), grid, dim3(512), S_::SMEM, stream, a);
+    hipLaunchKernelGGL((conv_gemm_sf_same_kernel<BN_, KW, WM>), grid, dim3(512), S_::SMEM, stream, a);
 }
 
 }  // namespace
@@ -792,9 +794,9 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
                                      const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream_) {
     const bool split_in = x_hi != nullptr;
     if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return DFSFM_E_BADARG;
-    // fused LayerNorm: rows must sit in ONE N tile of the 1x1 schedule -> linear layers with Cout = 64 or 128
+    // fused LayerNorm: rows must sit in ONE N tile of the 1x1 schedule -> linear layers with Cout = 64, 128 or 256
     if (ln_gamma && !(split_in && kh == 1 && kw == 1 && stride == 1 && pad == 0 && !relu && !tap_padded &&
-                      (Cout == 64 || Cout == 128) && ln_eps > 0.f))
+                      (Cout == 64 || Cout == 128 || Cout == 256) && ln_eps > 0.f))
         return DFSFM_E_UNSUPPORTED;
     if (tap_padded && !split_in) return DFSFM_E_UNSUPPORTED;
     if ((!x && !split_in) || (x && split_in) || (split_in && !x_lo) || !w_hi || !w_lo) return DFSFM_E_BADARG;
@@ -847,6 +849,10 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             if (kw == 3) { if (Cout <= 64) launch_same<64, 3>(g, stream); else launch_same<128, 3>(g, stream); }
             else         { if (Cout <= 64) launch_same<64, 5>(g, stream); else launch_same<128, 5>(g, stream); }
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(same)");
+        }
+        if (ln_gamma && Cout == 256) {     // a 256-channel row in ONE workgroup: the 128 x 256 tile (waves 2 x 4)
+            launch_same<256, 1, 2>(g, stream);
+            return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1, 128x256 tile)");
         }
         if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {    // 1x1 / linear: the same schedule with one tap
             if (Cout <= 64) launch_same<64, 1>(g, stream); else launch_same<128, 1>(g, stream);

@@ -69,10 +69,15 @@ __device__ __forceinline__ unsigned xcd_band_tile(unsigned b, unsigned per_xcd) 
 // fragments, mid-slab barrier, pinned DMA/MFMA interleave, epilogue) is as in conv_gemm_sf_kernel.
 // Weights are packed tap-padded: K = (ky, kx, ceil32(Cin)).
 // =================================================================================================
-template <int BN_, int KW>
+// WM = waves along M: 4 -> 256 x BN tile (BN 64 / 128, waves 4 x 2); 2 -> 128 x 256 tile (waves 2 x 4, 1x1 only):
+// a whole 256-channel row in one workgroup, for the LayerNorm-fused linear layers of the coarse transformer.
+template <int BN_, int KW, int WM = 4>
 struct VS {
+    static_assert(WM == 4 || (WM == 2 && KW == 1), "the 128-row tile is for 1x1 / linear layers");
     static constexpr int PAD = KW / 2;
-    static constexpr int AG = 17;                            // 16-row groups per A stage (256 + KW - 1 <= 272)
+    static constexpr int BM = WM * 64, WN = 8 / WM;
+    static constexpr int AG = WM == 4 ? 17 : 8;              // 16-row groups per A stage (256 + KW - 1 <= 272)
+    static constexpr int APW = WM == 4 ? 5 : 2;              // A pieces per wave and super-slab
     static constexpr int A_PLANE = AG * 1024;
     static constexpr int A_STAGE = 2 * A_PLANE;             // hi, lo
     static constexpr int B_PLANE = BN_ * 64;
@@ -87,12 +92,12 @@ struct VS {
     static constexpr int OFF_B = NA * A_STAGE;
     static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;  // 1 KB sink for the padding pieces
     static constexpr int RING = OFF_DUMMY + 1024;
-    static constexpr int TILE_BYTES = BM2 * (BN_ + 4) * 4;
+    static constexpr int TILE_BYTES = BM * (BN_ + 4) * 4;
     static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
     static_assert(RING <= 160 * 1024, "LDS ring");
     // DMA pieces a wave issues in the load segment of tap kx: B(t+NB-1), and A(S+NA-1) spread over taps 0 (3
     // pieces) and 1 (2 pieces) -- all 5 at tap 0 for a 1x1 kernel
-    static constexpr int C(int kx) { return (KW == 1 ? 5 : kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
+    static constexpr int C(int kx) { return (KW == 1 ? APW : kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
     // own pieces that may still be in flight when a wave publishes slab u = (S, kx) (the barrier that opens the
     // first load segment reading it): B(u) was the last piece of load segment u-NB+1, so everything issued in the
     // NB-2 segments since may be outstanding; with a 2-deep A ring A(S) was issued at taps 0/1 of S-1.
@@ -102,20 +107,20 @@ struct VS {
         if (KW > 1 && NA == 2 && kx == 0 && (KW - 1) * BN_I < n) n = (KW - 1) * BN_I;
         return n;
     }
-    static constexpr int NWAIT0 = 5 * (NA - 2) + (NB - 2) * BN_I;      // prologue: A(0), B(0) landed
+    static constexpr int NWAIT0 = APW * (NA - 2) + (NB - 2) * BN_I;    // prologue: A(0), B(0) landed
     static_assert(KW == 1 ? (NA == NB) : true, "1x1: A(t) and B(t) are issued in the same load segment");
 };
 
-template <int BN_, int KW>
-__device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ / 64],
-                                                 f32x16 (&accx)[2][BN_ / 64], int64_t m0, int n0) {
-    using S_ = VS<BN_, KW>;
-    constexpr int NJ = BN_ / 64, PAD = KW / 2, BNI = S_::BN_I;
+template <int BN_, int KW, int WM = 4>
+__device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * WM / 256],
+                                                 f32x16 (&accx)[2][BN_ * WM / 256], int64_t m0, int n0) {
+    using S_ = VS<BN_, KW, WM>;
+    constexpr int WN = 8 / WM, NJ = BN_ / (32 * WN), PAD = KW / 2, BNI = S_::BN_I, NQ = WM == 4 ? 3 : 1;
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kgrp = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     const int Cin_p = g.Kpad / (KW * KW);                    // tap-padded channel count (multiple of 32)
 #ifdef DFSFM_ABL_NOLOOP
     const int nchunk = Cin_p / BK, nS = 0;
@@ -131,11 +136,11 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     const int lrow = lane >> 2;
     const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
     // A rows of this lane: groups wave, wave+8 and (waves 0/1 only: hi/lo plane of) group 16
-    int ay[3];
+    int ay[3];                                                   // NQ used
     int64_t abase[3];
     bool aok[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int grp = q < 2 ? wave + 8 * q : 16;
 #ifdef DFSFM_ABL_TILE0
         const int64_t pix = (int64_t)(blockIdx.x & 7) * BM2 - PAD + grp * 16 + lrow;   // ablation: L2-resident A
@@ -151,12 +156,12 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     }
     const bool cok_lane = true;
     (void)cok_lane;
-    unsigned offA[3];
+    unsigned offA[3];                                            // NQ used
     auto addrA = [&](int Sn) __attribute__((always_inline)) {   // offsets of super-slab Sn = (ky, chunk)
         const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
         const bool in = Sn < nS && chunk * BK + lslot * 8 < g.Cin;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int iy = ay[q] + ky - PAD;
             const bool ok = aok[q] & in & (iy >= 0) & (iy < g.H);
             const int64_t off = (abase[q] + (int64_t)(ky - PAD) * g.sxh + chunk * BK) * 2;
@@ -168,7 +173,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
         }
     };
     const unsigned bbase = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);
-    unsigned offB[2];
+    unsigned offB[4];                                            // BNI used (a dependent bound here drops the host stub)
     auto addrB = [&](int t) __attribute__((always_inline)) {    // offsets of slab t = (S, kx) -> (ky, chunk, kx)
         const int Sn = t / KW, kx = t - Sn * KW;
         const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
@@ -252,7 +257,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int off = tile_off(wc * (BN_ / 2) + j * 32 + col, ks * 2 + kgrp);
+                const int off = tile_off(wc * (BN_ / WN) + j * 32 + col, ks * 2 + kgrp);
                 fbh[ks][j] = *reinterpret_cast<const half8*>(sb + off);
                 fbl[ks][j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
             }
@@ -298,12 +303,13 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     for (int t = 0; t < (S_::NA > S_::NB ? S_::NA : S_::NB) - 1; ++t) {
         if (t < S_::NA - 1) {
             addrA(t);
-            SDMA_A(0, t); SDMA_A(1, t); SDMA_A(2, t); SDMA_A(3, t); SDMA_A(4, t);
+            SDMA_A(0, t); SDMA_A(1, t);
+            if constexpr (S_::APW == 5) { SDMA_A(2, t); SDMA_A(3, t); SDMA_A(4, t); }
         }
         if (t < S_::NB - 1) {
             addrB(t);
-            SDMA_B(0, t);
-            if constexpr (BNI > 1) SDMA_B(1, t);
+#pragma unroll
+            for (int j = 0; j < BNI; ++j) SDMA_B(j, t);
         }
     }
     wait_vmcnt<S_::NWAIT0>();                                         // own pieces of slab 0 have landed
@@ -323,10 +329,13 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             read_slab(ast, kx, bst);
             if (kx == 0) addrA(S + S_::NA - 1);
             addrB(t + S_::NB - 1);
-            if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); SDMA_A(2, adm); }
-            if (KW == 1 || kx == 1) { SDMA_A(3, adm); SDMA_A(4, adm); }
-            SDMA_B(0, bdm);
-            if constexpr (BNI > 1) SDMA_B(1, bdm);
+            if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); }
+            if constexpr (S_::APW == 5) {
+                if (kx == 0) { SDMA_A(2, adm); }
+                if (KW == 1 || kx == 1) { SDMA_A(3, adm); SDMA_A(4, adm); }
+            }
+#pragma unroll
+            for (int j = 0; j < BNI; ++j) SDMA_B(j, bdm);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             mask_slab(kx);
             if (grp == 1) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 4-7 publish slab t+1 here

@@ -445,7 +445,7 @@ def linear(x, pw: PackedDense, residual=None, relu=False, out=None, out_split=Fa
 
 def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None):
     """residual + LayerNorm(x @ W^T + bias) * gamma + beta in one kernel (LayerNorm fused into the GEMM epilogue;
-    Cout must be 64 or 128 so a row sits in one tile).  x: SplitAct rows [rows, K]; residual: fp32 [rows, Cout]
+    Cout must be 64, 128 or 256 so a row sits in one workgroup tile).  x: SplitAct rows [rows, K]; residual: fp32 [rows, Cout]
     row-strided view, a SplitAct view, or None; results go to the fp32 view ``out`` and/or the SplitAct view ``out_split``."""
     if not isinstance(x, SplitAct) or (out is None and out_split is None):
         raise _lib.DfsfmError("linear_ln: needs split input rows and at least one output")

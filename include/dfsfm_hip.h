@@ -228,9 +228,10 @@ int dfsfm_conv2d_direct_f32(const float* x, int64_t sxn, int64_t sxh, int64_t ld
  *         loads each activation row once per (ky, 32-channel chunk) and reuses it for the kw taps
  *         is used (1/kw of the activation traffic).
  * ln_gamma/ln_beta [Cout] (or both NULL), ln_eps: LayerNorm fused into the epilogue of a linear layer
- *         (split input, 1x1, Cout = 64 or 128, no ReLU):  out = residual + LN(x.W^T + bias) * gamma + beta
+ *         (split input, 1x1, Cout = 64, 128 or 256, no ReLU):  out = residual + LN(x.W^T + bias) * gamma + beta
  *         -- the merge -> norm1 and mlp -> norm2 (+x) pairs of LoFTREncoderLayer.forward
- *         (src/MultiviewMatcher/matcher_module/transformer.py, d_model = 128) in one pass.
+ *         (third_party/LoFTR/src/loftr/loftr_module/transformer.py:50-58, d_model 256;
+ *         src/MultiviewMatcher/matcher_module/transformer.py:82-95, d_model 128) in one pass.
  * ---------------------------------------------------------------------------------------- */
 int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
                           int64_t ldx, int Nimg, int H, int W, int Cin, const void* w_hi, const void* w_lo,
