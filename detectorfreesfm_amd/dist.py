@@ -4,8 +4,8 @@ collective of the path: an all-gather of variable-length match tables (SURVEY.md
 The reference fans pairs / tracks out over Ray tasks and merges pickled numpy results through the
 object store (src/coarse_match/coarse_match.py:127-140, src/post_optimization/matcher_model/
 multiview_match.py:39-62).  Here every rank takes a static contiguous shard (no data-path
-collective), and the tables are collected with two ``torch.distributed`` all-gathers (sizes, then
-a padded payload) -- RCCL over xGMI with backend "nccl" on MI355X, gloo on CPU for the tests.
+collective), and the tables are collected with ``torch.distributed`` all-gathers (table count, row
+counts, then one padded payload) -- RCCL over xGMI with backend "nccl" on MI355X, gloo on CPU for the tests.
 """
 from typing import List, Sequence, Tuple
 
@@ -32,8 +32,8 @@ def exhaustive_pairs(n_images: int) -> List[Tuple[int, int]]:
 
 def all_gather_tables(tables: List[torch.Tensor], group=None) -> List[torch.Tensor]:
     """Gather every rank's list of [M_k, W] float32 tables; returns the concatenated list in rank
-    order on every rank.  Two collectives regardless of the number of tables:
-    (1) all-gather of the per-rank table count + row counts (padded to the max table count),
+    order on every rank.  Three small-to-one-large collectives regardless of the number of tables:
+    (0) all-gather of (table count, width), (1) all-gather of the row counts (padded to the max table count),
     (2) all-gather of one flat payload per rank padded to the largest payload."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return list(tables)
