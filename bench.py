@@ -170,7 +170,22 @@ def cpu_baseline(seconds_budget=25.0):
                           "sample": "1 bag of 64 tracks x 5 views through oracle.restate.multiview_matcher_forward"}}
 
 
+def _claim_stdout():
+    """Route everything that any library writes to file descriptor 1 (RCCL prints a banner there when a process
+    group is created, flushed at exit) to stderr and return a private handle on the real stdout, so that the ONE
+    JSON line is the only -- and therefore the last -- thing on it."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
+def _emit(real_stdout_fd, obj):
+    os.write(real_stdout_fd, (json.dumps(obj) + "\n").encode())
+
+
 def main():
+    out_fd = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -186,7 +201,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # DFSFM_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barriers, max-reduce, table all-gather) with a
+    # single rank; the driver's multi-GPU runs set WORLD_SIZE > 1
+    distributed = world > 1 or os.environ.get("DFSFM_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -197,7 +214,7 @@ def main():
 
     if args.kernels_only:
         rl = kernel_rooflines(dev, args.batch)
-        print(json.dumps({"rooflines": rl}))
+        _emit(out_fd, {"rooflines": rl})
         return
 
     # ---- coarse matcher: configs[1] ---------------------------------------------------------------
@@ -291,7 +308,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(result))
+        _emit(out_fd, result)
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
