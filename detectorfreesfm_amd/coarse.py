@@ -380,6 +380,31 @@ class HipLoFTR(ParamModule):
         f0, f1 = self._transformer(f0, f1, P)
         return f0, f1, hw0_c, hw1_c
 
+    # -- "backbone once per image" (SURVEY 8(f) rank 1: the reference re-runs the CNN for every pair an image is in)
+    @torch.no_grad()
+    def image_tokens(self, images):
+        """[B,1,H,W] -> (coarse backbone tokens [B, h*w, C] fp32, (h, w)).  Per-image results do not depend on what
+        else is in the batch, so they can be cached and paired freely (``match_tokens``)."""
+        if self.dense_backend != "hip":
+            raise NotImplementedError("token caching is implemented for dense_backend='hip'")
+        P = self._packed or self._pack()
+        c = self._backbone_hip(images, P)
+        return c.flatten(1, 2), tuple(c.shape[1:3])
+
+    @torch.no_grad()
+    def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None):
+        """Positional encoding + transformer + coarse matching on cached backbone tokens of N pairs
+        (tok0 [N,L,C], tok1 [N,S,C]); the same dict of matches ``forward`` leaves in ``data``."""
+        P = self._packed or self._pack()
+        self._feat_split = None
+        f0, f1 = self._transformer(tok0, tok1, P, self._pe_tokens(tuple(hw0_c)), self._pe_tokens(tuple(hw1_c)))
+        if self._feat_split is not None:
+            f0, f1 = self._feat_split
+            self._feat_split = None
+        mc = self.config["match_coarse"]
+        return ops.coarse_match(f0, f1, tuple(hw0_c), tuple(hw1_c), mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
+                                scale0, scale1, hw0_i[0] / hw0_c[0])
+
     def _pe_tokens(self, hw):
         """Positional encoding in token-major layout [h*w, C] (cached per grid size)."""
         cache = self.__dict__.setdefault("_pe_cache", {})

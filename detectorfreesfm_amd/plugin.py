@@ -160,3 +160,37 @@ def merge_match_tables(matches: dict, names: list, pair_name_split: str, device=
         updated[k] = ids[pos:pos + n].astype(int)
         pos += n
     return final_keypoints, final_scores, updated
+
+
+@torch.no_grad()
+def match_scene_cached(matcher: HipLoFTR, images, pairs, batch=8, scales=None):
+    """Exhaustive / covisible pair matching of one scene with the backbone evaluated ONCE per image.
+
+    The reference's match_worker (src/coarse_match/coarse_match_worker.py:102-145) feeds every pair through
+    detector+matcher, so an image that appears in k pairs pays for k backbone passes -- 55 % of the coarse step
+    here.  Backbone tokens are a per-image quantity: they are computed once, kept on the device, and paired by
+    index; positional encoding, transformer and matching run per pair exactly as in ``HipLoFTR.forward``.
+
+    images: tensor [n_images,1,H,W] (same size); pairs: list of (i, j); scales: optional [n_images,2] (h, w scale).
+    Returns {(i, j): ndarray [M,5]} rows (x0, y0, x1, y1, conf), the per-pair tables match_worker stores."""
+    dev = next(matcher.buffers()).device if any(True for _ in matcher.buffers()) else images.device
+    n = images.shape[0]
+    toks, hw_c = [], None
+    for lo in range(0, n, 2 * batch):
+        t, hw_c = matcher.image_tokens(images[lo:lo + 2 * batch].to(dev))
+        toks.append(t)
+    toks = torch.cat(toks, 0)
+    hw_i = tuple(images.shape[2:])
+    out = {}
+    for lo in range(0, len(pairs), batch):
+        chunk = pairs[lo:lo + batch]
+        i0 = torch.tensor([p[0] for p in chunk], device=dev)
+        i1 = torch.tensor([p[1] for p in chunk], device=dev)
+        s0 = None if scales is None else scales[i0.cpu()]
+        s1 = None if scales is None else scales[i1.cpu()]
+        m = matcher.match_tokens(toks[i0], toks[i1], hw_c, hw_c, hw_i, s0, s1)
+        b = m["b_ids"].cpu().numpy()
+        rows = torch.cat([m["mkpts0_c"], m["mkpts1_c"], m["mconf"][:, None]], -1).cpu().numpy()
+        for k, pr in enumerate(chunk):
+            out[tuple(pr)] = rows[b == k]
+    return out

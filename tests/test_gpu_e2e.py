@@ -191,3 +191,29 @@ def test_multiview_chunk16000_equals_two_chunks(built_lib):
         assert same.float().mean().item() >= 0.99
         dr = (h["reference_points_refined"][-1] - r[:, :, lo:hi]).abs().max(-1)[0][0]       # [4, n]
         assert dr[:, same].max().item() < 1e-3
+
+
+def test_scene_matching_cached_tokens_equals_pairwise(built_lib):
+    """plugin.match_scene_cached: backbone once per image, every pair matched from the cached tokens -- the same
+    tables as feeding each pair through HipLoFTR.forward."""
+    from detectorfreesfm_amd import plugin
+    cfg = loftr_coarse_only_config(1e-3)
+    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    m = HipLoFTR(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    base = synth.coarse_pair_batch(3, 96, 128, seed=1000)
+    images = torch.cat([base["image0"], base["image1"]], 0)                         # 6 images
+    pairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    tables = plugin.match_scene_cached(m, images, pairs, batch=4)
+    total = 0
+    for (i, j) in pairs:
+        d = synth.to_device({"image0": images[i:i + 1], "image1": images[j:j + 1]}, DEV)
+        m(d)
+        ref = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).cpu().numpy()
+        got = tables[(i, j)]
+        a = {tuple(r[:4]) for r in got}
+        b = {tuple(r[:4]) for r in ref}
+        assert len(a & b) >= 0.98 * max(len(a), len(b), 1)          # batch size changes K1's partial-sum split
+        total += len(b)
+    assert total > 50

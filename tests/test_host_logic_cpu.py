@@ -108,3 +108,29 @@ def test_refine_padded_tensor_images_and_plugin_builders(tmp_path):
     assert table.ndim == 2 and table.shape[1] == 5 and table.shape[0] > 0
     with pytest.raises(NotImplementedError):
         plugin.build_model({"matcher": "loftr_official", "match_thr": 0.2})
+
+
+def test_scene_matching_with_cached_backbone_tokens():
+    """plugin.match_scene_cached (backbone once per image) == the pairwise forward of every pair,
+    including per-image scales; host logic on the CPU stand-ins."""
+    cfg = loftr_coarse_only_config(1e-3)
+    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    m = HipLoFTR(cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(4)
+    base = synth.coarse_pair_batch(2, 96, 128, seed=1000)
+    images = torch.cat([base["image0"], base["image1"], torch.rand((1, 1, 96, 128), generator=g)], 0)   # 5 images
+    scales = torch.tensor([[1.0, 1.0], [1.5, 2.0], [1.0, 1.25], [2.0, 1.0], [1.0, 1.0]])
+    pairs = [(0, 2), (1, 3), (0, 1), (2, 0), (3, 4)]
+    with cpu_ops():
+        tables = plugin.match_scene_cached(m, images, pairs, batch=2, scales=scales)
+        n_total = 0
+        for (i, j) in pairs:
+            d = {"image0": images[i:i + 1], "image1": images[j:j + 1], "scale0": scales[i:i + 1], "scale1": scales[j:j + 1]}
+            m(d)
+            ref = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).numpy()
+            got = tables[(i, j)]
+            assert got.shape == ref.shape and np.array_equal(got[:, :4], ref[:, :4])
+            assert np.allclose(got[:, 4], ref[:, 4], atol=1e-4)      # CPU stand-in convs depend on the batch blocking
+            n_total += len(ref)
+    assert n_total > 20
