@@ -134,3 +134,49 @@ def test_scene_matching_with_cached_backbone_tokens():
             assert np.allclose(got[:, 4], ref[:, 4], atol=1e-4)      # CPU stand-in convs depend on the batch blocking
             n_total += len(ref)
     assert n_total > 20
+
+
+def test_config0_example_scene_plumbing(tmp_path):
+    """BASELINE configs[0]: two of the reference's example JPEGs through the CPU-only path (plumbing, no GPU).
+    cv2 / h5py are not installed here: PIL (grayscale decode + the reference's own pil_LANCZOS resize,
+    src/dataset/utils.py:124-177) and .npz stand in for them.  Checks the plugin's dict contract, the (M,5) table of
+    match_worker (coarse_match_worker.py:83-91,139-141), and the keypoints / matches layout of coarse_match.py:239-254."""
+    import os
+    from PIL import Image
+    from oracle import restate_merge as rm
+    root = "/root/reference/SfM_dataset/example_dataset/example_scene/images"
+    if not os.path.isdir(root):
+        pytest.skip("reference example scene not present")
+    names = sorted(os.listdir(root))[:2]
+
+    def read_gray(name, wh=(320, 240)):              # df=8-compatible size, small enough for the CPU stand-ins
+        im = Image.open(os.path.join(root, name)).convert("L")
+        w, h = im.size
+        arr = np.asarray(im.resize(wh, resample=Image.LANCZOS), dtype=np.float32)
+        return torch.from_numpy(arr)[None, None] / 255.0, torch.tensor([[h / wh[1], w / wh[0]]], dtype=torch.float32)
+
+    (i0, s0), (i1, s1) = read_gray(names[0]), read_gray(names[1])
+    data = {"image0": i0, "image1": i1, "scale0": s0, "scale1": s1}
+    cfg = loftr_coarse_only_config(1e-3)
+    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    detector, matcher = plugin.build_model({"matcher": "loftr_hip", "type": "coarse_only", "match_thr": 1e-3, "seed": 0,
+                                            "loftr_hip": {"weight_path": None}})
+    matcher.load_state_dict(sd, strict=True)
+    with cpu_ops():
+        d = dict(data)
+        mk0, mk1, mc = plugin.extract_matches(d, detector=detector, matcher=matcher)
+        table = plugin.match_table(d)
+    o = restate.loftr_coarse_forward(sd, cfg, data)
+    assert table.shape == (o["i_ids"].numel(), 5) and table.shape[0] > 0
+    assert np.array_equal(table[:, :2], o["mkpts0_f"].numpy()) and np.array_equal(table[:, 2:4], o["mkpts1_f"].numpy())
+    assert np.allclose(table[:, 4], o["mconf"].numpy(), atol=1e-4)
+    assert (table[:, 0] <= Image.open(os.path.join(root, names[0])).size[0]).all()       # original-image pixels
+    # scene-level merge (numpy restatement of coarse_match.py:203-237) and the two on-disk tables as .npz
+    matches = {f"{names[0]} {names[1]}": table}
+    rows, a, b, sl = rm.tables_to_flat(matches, names, " ")
+    kp, sc, off, ids = rm.merge_keypoints(rows, a, b, 2)
+    np.savez(tmp_path / "keypoints.npz", **{n: kp[off[i]:off[i + 1]] for i, n in enumerate(names)})
+    np.savez(tmp_path / "matches.npz", **{"-".join(names): ids.T})                         # value.T like :249-252
+    kz, mz = np.load(tmp_path / "keypoints.npz"), np.load(tmp_path / "matches.npz")
+    assert kz[names[0]].shape[1] == 2 and mz["-".join(names)].shape == (2, table.shape[0])
+    assert (mz["-".join(names)][0] < len(kz[names[0]])).all() and (mz["-".join(names)][1] < len(kz[names[1]])).all()
