@@ -305,6 +305,22 @@ def main():
             result["roofline"]["traffic_unit"] = "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)"
             result["roofline"]["algorithmic_bytes"] = pj["algorithmic_bytes_per_launch"]
             result["roofline"]["traffic_source"] = "profiles/r01_pmc_conv_gemm_sf_same.json"
+    if rank == 0 and not args.no_rooflines:
+        # per-kernel HBM traffic of the other hand-written kernels, from the committed PMC passes of
+        # `bench.py --kernels-only` (2*FETCH_SIZE + WRITE_SIZE per launch, summed over the kernels of an entry point)
+        pmc_all = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_kernels_only_traffic.json")
+        if os.path.exists(pmc_all):
+            with open(pmc_all) as fh:
+                rows = json.load(fh)["kernels"]
+            groups = {"linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_kernel",),
+                      "fine_match": ("fine_match_kernel",), "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact"),
+                      "coarse_match_f32": ("cm_gemm<",)}
+            for r in result["rooflines"]:
+                for key, subs in groups.items():
+                    if r["kernel"].startswith(key):
+                        mb = sum(k["fetch_MB_x2"] + k["write_MB"] for k in rows if any(s_ in k["kernel"] for s_ in subs))
+                        r["traffic"] = mb * 1024 * 1024
+                        r["traffic_unit"] = "bytes per call (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_kernels_only_traffic.json)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
