@@ -305,6 +305,7 @@ def main():
             result["roofline"]["traffic_unit"] = "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)"
             result["roofline"]["algorithmic_bytes"] = pj["algorithmic_bytes_per_launch"]
             result["roofline"]["traffic_source"] = "profiles/r01_pmc_conv_gemm_sf_same.json"
+            dom["traffic"] = pj["hbm_bytes_per_launch"]
     if rank == 0 and not args.no_rooflines:
         # per-kernel HBM traffic of the other hand-written kernels, from the committed PMC passes of
         # `bench.py --kernels-only` (2*FETCH_SIZE + WRITE_SIZE per launch, summed over the kernels of an entry point)
