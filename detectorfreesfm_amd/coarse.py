@@ -6,10 +6,11 @@ dict), same ``state_dict`` layout (``load_state_dict(strict=True)`` of the offic
 ``matcher.`` prefix stripped), same in-place ``forward(data)`` contract
 (src/coarse_match/coarse_match_worker.py:83-99 reads ``m_bids, mkpts0_f, mkpts1_f, mconf``).
 
-Hot kernels are hand-written HIP (``libdfsfm_hip.so``): linear attention (K1) inside every
-encoder layer and the fused correlation / dual-softmax / mutual-NN / keypoint stage (K3-K5).
-The dense convolutions and ``nn.Linear`` GEMMs go to MIOpen / hipBLASLt through PyTorch-ROCm in
-fp32.  Output-identical work the reference wastes is skipped:
+Every kernel of the path is hand-written HIP (``libdfsfm_hip.so``): the ResNet convolutions and all ``nn.Linear``
+GEMMs on the fp16x2-split MFMA implicit-GEMM kernels (folded BN, ReLU, residual, LayerNorm in the epilogue), linear
+attention (K1) inside every encoder layer, and the fused correlation / dual-softmax / mutual-NN / keypoint stage
+(K3-K5).  ``dense_backend="library"`` (MIOpen / hipBLASLt fp32 through PyTorch) exists only as an explicit
+measurement control.  Output-identical work the reference wastes is skipped:
 the FPN top-down branch (dead when fine.enable=False, resnet_fpn.py:110-116) and the dense
 ``conf_matrix`` (never read by an inference caller).
 """

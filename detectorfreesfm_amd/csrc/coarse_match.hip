@@ -646,20 +646,12 @@ template <int MODE>
 void launch_gemm(const GemmArgs& g, int N, bool prescale, hipStream_t stream) {
     dim3 grid(g.ntm * g.ntn, N), blk(256);
     // > 64 KiB of dynamic LDS needs the opt-in attribute (set once per kernel instance).
-    static bool attr_set[2] = {false, false};
+    static dfsfm::SmemAttr smem_attr[2];
     if (prescale) {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_gemm<MODE, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-            attr_set[1] = true;
-        }
+        smem_attr[1].ensure(reinterpret_cast<const void*>(&cm_gemm<MODE, true>), SMEM_BYTES);
         hipLaunchKernelGGL((cm_gemm<MODE, true>), grid, blk, SMEM_BYTES, stream, g);
     } else {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_gemm<MODE, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-            attr_set[0] = true;
-        }
+        smem_attr[0].ensure(reinterpret_cast<const void*>(&cm_gemm<MODE, false>), SMEM_BYTES);
         hipLaunchKernelGGL((cm_gemm<MODE, false>), grid, blk, SMEM_BYTES, stream, g);
     }
 }
@@ -701,12 +693,8 @@ namespace {
 
 template <int MODE>
 void launch_gemm_sf(const GemmSfArgs& g, int N, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_gemm_sf<MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SF_SMEM);
-        attr_set = true;
-    }
+    static dfsfm::SmemAttr smem_attr;
+    smem_attr.ensure(reinterpret_cast<const void*>(&cm_gemm_sf<MODE>), SF_SMEM);
     hipLaunchKernelGGL(cm_gemm_sf<MODE>, dim3((g.ntiles + 7) / 8 * 8, N), dim3(512), SF_SMEM, stream, g);
 }
 

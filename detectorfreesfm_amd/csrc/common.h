@@ -24,6 +24,21 @@ inline int check_launch(const char* what) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// > 64 KiB of dynamic LDS needs the opt-in attribute, per kernel instance AND per device: one static instance of
+// this per launch site remembers the devices it has been set on (a process may drive several GPUs).
+struct SmemAttr {
+    unsigned long long done = 0;
+    void ensure(const void* fn, int bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done & bit)) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            done |= bit;
+        }
+    }
+};
+
 // C/D fragment row of a 32x32 MFMA accumulator register (MI355X guide, section 3):
 // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ int mfma32_row(int reg, int half) {
@@ -38,10 +53,14 @@ __device__ __forceinline__ float elu_plus_one(float x) {
 
 // fp16x2 split of an fp32 value: v = hi + lo/2048 (22 significant bits); values below the fp16 normal
 // range go entirely to lo so the matrix cores never see an fp16 subnormal (csrc/conv_gemm.hip).
+// Both planes saturate at the largest finite fp16 (65504) instead of overflowing to inf: an out-of-range
+// activation (|v| > 65536) yields a finite, wrong value that `hi == +-65504` flags (ops.check_split_range),
+// never an inf - inf = NaN that would spread through the matches.
 __device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
-    const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)x : (_Float16)0.f;
+    const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)xc : (_Float16)0.f;
     hi = h;
-    lo = (_Float16)((x - (float)h) * 2048.f);
+    lo = (_Float16)__builtin_amdgcn_fmed3f((x - (float)h) * 2048.f, -65504.f, 65504.f);
 }
 
 typedef _Float16 dfsfm_half4 __attribute__((ext_vector_type(4)));

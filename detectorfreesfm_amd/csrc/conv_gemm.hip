@@ -46,10 +46,10 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) { sp
 __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float x = v[e];
-        const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)x : (_Float16)0.f;
+        _Float16 h, l;
+        split_f32(v[e], h, l);
         hi[e] = h;
-        lo[e] = (_Float16)((x - (float)h) * 2048.f);
+        lo[e] = l;
     }
 }
 
@@ -756,12 +756,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_sf_kernel(const _Float1
 template <int BN_>
 void launch_v2(const ConvArgs& g, hipStream_t stream) {
     using T = V2<BN_>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_sf_kernel<BN_>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
-        attr_set = true;
-    }
+    static dfsfm::SmemAttr smem_attr;
+    smem_attr.ensure(reinterpret_cast<const void*>(&conv_gemm_sf_kernel<BN_>), T::SMEM);
     ConvArgs a = g;
     a.ntiles = (unsigned)((g.M + BM2 - 1) / BM2) * (unsigned)((g.Cout + BN_ - 1) / BN_);
     const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
@@ -771,12 +767,8 @@ void launch_v2(const ConvArgs& g, hipStream_t stream) {
 template <int BN_, int KW, int WM = 4>
 void launch_same(const ConvArgs& g, hipStream_t stream) {
     using S_ = VS<BN_, KW, WM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_sf_same_kernel<BN_, KW, WM>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, S_::SMEM);
-        attr_set = true;
-    }
+    static dfsfm::SmemAttr smem_attr;
+    smem_attr.ensure(reinterpret_cast<const void*>(&conv_gemm_sf_same_kernel<BN_, KW, WM>), S_::SMEM);
     ConvArgs a = g;
     a.ntiles = (unsigned)((g.M + S_::BM - 1) / S_::BM) * (unsigned)((g.Cout + BN_ - 1) / BN_);
     const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
@@ -866,20 +858,12 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
     const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && (sxh % 4 == 0) && (sxn % 4 == 0) &&
                      !(reinterpret_cast<uintptr_t>(x) & 15);
     const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((Cout + BN - 1) / BN)), blk(256);
-    static bool attr_set[2] = {false, false};
+    static dfsfm::SmemAttr smem_attr[2];
     if (vec) {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-            attr_set[0] = true;
-        }
+        smem_attr[0].ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<true>), SMEM_BYTES);
         hipLaunchKernelGGL(conv_gemm_kernel<true>, grid, blk, SMEM_BYTES, stream, g);
     } else {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES + LUT_MAX * 4);
-            attr_set[1] = true;
-        }
+        smem_attr[1].ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<false>), SMEM_BYTES + LUT_MAX * 4);
         hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, blk, SMEM_BYTES + LUT_MAX * 4, stream, g);
     }
     return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32");

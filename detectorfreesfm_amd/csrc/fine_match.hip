@@ -233,12 +233,8 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
 template <int C>
 void launch(const FineArgs& g, hipStream_t stream) {
     const size_t smem = (size_t)MAXL * (C + 4) * 4 + MAXWW * 8 + (size_t)g.Vq * MAXL * 3 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<C>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    static dfsfm::SmemAttr smem_attr;
+    smem_attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C>), 96 * 1024);
     hipLaunchKernelGGL((fine_match_kernel<C>), dim3(g.T), dim3(256), smem, stream, g);
 }
 

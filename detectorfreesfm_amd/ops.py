@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns the device memory and the stream.  Every funct
 hand-written gfx950 kernels from ``libdfsfm_hip.so``; none has a PyTorch/CPU fallback.
 """
 import ctypes
+import functools
+import os
 from typing import Optional
 
 import torch
@@ -11,6 +13,47 @@ import torch
 from . import _lib
 
 _workspaces = {}
+FP16_MAX = 65504.0
+# opt-in range guard of the split-plane representation (|v| < 65504): every producer of split
+# planes checks its output for saturation (one abs-max reduction + host sync per launch: a debugging aid, off by default)
+_debug_range = os.environ.get("DFSFM_DEBUG_RANGE", "0") == "1"
+
+
+def set_debug_range(on: bool):
+    global _debug_range
+    _debug_range = bool(on)
+
+
+def check_split_range(sa, what: str):
+    """Raises if a split-plane tensor holds a saturated element: split_f32 clamps hi to +-65504, the largest finite
+    fp16, so |hi| == 65504 means the fp32 value was out of the representable range (or exactly on its edge)."""
+    if sa.hi.numel() and float(sa.hi.abs().max()) >= FP16_MAX:
+        raise _lib.DfsfmError(f"{what}: activation outside the split-plane range |v| < {FP16_MAX:.0f} "
+                              "(the fp16x2 representation would saturate; rescale the layer)")
+
+
+def _device_of(a):
+    if isinstance(a, torch.Tensor):
+        return a.device if a.is_cuda else None
+    if isinstance(a, (SplitAct, PackedDense)):
+        return a.hi.device if a.hi.is_cuda else None
+    return None
+
+
+def _on_device(fn):
+    """Runs an op with its operands' device current, so that the launch stream (``_stream``), the workspace and the
+    kernels all belong to that device even when the caller never called torch.cuda.set_device (a process may drive
+    several GPUs); operands spread over different devices are refused."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        devs = {d for d in map(_device_of, list(args) + list(kw.values())) if d is not None}
+        if len(devs) > 1:
+            raise _lib.DfsfmError(f"{fn.__name__}: operands live on different devices {sorted(map(str, devs))}")
+        if not devs:
+            return fn(*args, **kw)
+        with torch.cuda.device(next(iter(devs))):
+            return fn(*args, **kw)
+    return wrapper
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -45,6 +88,7 @@ def _as_u8(m: Optional[torch.Tensor]):
     return (m != 0).contiguous().view(torch.uint8)
 
 
+@_on_device
 def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out=None,
                      out_split=False):
     """K1.  q [N,L,H,D]; k,v [N,S,H,D] fp32 (row-strided views allowed: stride(-1)=1,
@@ -76,9 +120,12 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, 
                                         _ptr(out), N, L, S, H, D, q.stride(1), k.stride(1), v.stride(1),
                                         ldo, eps, _ptr(oh), _ptr(ol), ldos, _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "dfsfm_linear_attention_f32")
+    if _debug_range and out_split:
+        check_split_range(res, "linear_attention")
     return res
 
 
+@_on_device
 def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None,
                  coarse_scale=8.0):
     """K3+K4+K5.  feat0 [N,L,C], feat1 [N,S,C]: fp32 contiguous tensors, or SplitAct planes (contiguous, C a
@@ -126,6 +173,7 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=No
             "mkpts0_c": mk[0, :M], "mkpts1_c": mk[1, :M]}
 
 
+@_on_device
 def coarse_conf_matrix(feat0, feat1, temperature):
     """Dense dual-softmax confidence matrix [N,L,S] (parity/debug aid)."""
     _require_cuda(feat0, feat1)
@@ -141,6 +189,7 @@ def coarse_conf_matrix(feat0, feat1, temperature):
     return conf
 
 
+@_on_device
 def roi_align(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapolation_value=0.0,
               mean=None, std=None, out=None, channels_last=False):
     """K8.  feat [Nimg,C,H,W]; boxes [M,4] (x1,y1,x2,y2); returns / fills out [*,C,crop_h,crop_w]
@@ -164,16 +213,51 @@ def roi_align(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapol
     return out
 
 
+@_on_device
 def fine_match(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, ref_pts=None,
-               scale_r=None, rs_t=0, rs_n=0):
-    """K11+K12.  ref [T,WW,C], qry [T,Vq,WW,C]; track_mask [T,Vq]; movable [T] or None.
+               scale_r=None):
+    """K11+K12.  ref [T,WW,C], qry [T,Vq,WW,C] fp32; track_mask [T,Vq]; movable [T] or None.
+    query_pts / scale_q [T,2]; ref_pts / scale_r view-major [>=Vq, T, 2] (the reference's [V-1,T,2] layout; strided
+    views such as ``x[0, :, i:]`` are taken as they are).  Any float dtype / device placement of the four point
+    tensors is accepted like in the reference and converted to device fp32 here.
     Returns dict(best_index, left_norm, coords, std[, query_refined, ref_refined])."""
     _require_cuda(ref, qry)
+    if ref.dtype != torch.float32 or qry.dtype != torch.float32 or ref.device != qry.device:
+        raise _lib.DfsfmError("fine_match: ref / qry must be fp32 tensors on one device")
     ref, qry = ref.contiguous(), qry.contiguous()
     T, Vq, WW, C = qry.shape
+    if ref.shape != (T, WW, C):
+        raise _lib.DfsfmError("fine_match: ref must be [T, W*W, C] matching qry [T, Vq, W*W, C]")
     dev = ref.device
-    tm = _as_u8(track_mask)
-    mv = _as_u8(movable)
+    tm = _as_u8(track_mask.to(dev))
+    mv = None if movable is None else _as_u8(movable.to(dev))
+    if tm.shape != (T, Vq) or (mv is not None and mv.shape != (T,)):
+        raise _lib.DfsfmError("fine_match: mask shapes")
+
+    def f32(t, shape):
+        if t is None:
+            return None
+        t = t.to(device=dev, dtype=torch.float32)
+        if t.shape != shape:
+            raise _lib.DfsfmError(f"fine_match: expected a tensor of shape {shape}, got {tuple(t.shape)}")
+        return t
+
+    query_pts, scale_q = f32(query_pts, (T, 2)), f32(scale_q, (T, 2))
+    if (query_pts is None) != (scale_q is None) or (ref_pts is None) != (scale_r is None):
+        raise _lib.DfsfmError("fine_match: points and their scales come in pairs")
+    if query_pts is not None:
+        query_pts, scale_q = query_pts.contiguous(), scale_q.contiguous()
+    rs_t = rs_n = 0
+    if ref_pts is not None:
+        if ref_pts.dim() != 3 or ref_pts.shape[0] < Vq or ref_pts.shape[1:] != (T, 2) or scale_r.shape != ref_pts.shape:
+            raise _lib.DfsfmError("fine_match: ref_pts / scale_r must be view-major [>=Vq, T, 2]")
+        ref_pts, scale_r = f32(ref_pts, ref_pts.shape), f32(scale_r, scale_r.shape)
+
+        def pair_layout(t):
+            return t.stride(2) == 1 and t.stride(1) % 2 == 0 and t.stride(0) % 2 == 0
+        if not (pair_layout(ref_pts) and pair_layout(scale_r) and ref_pts.stride() == scale_r.stride()):
+            ref_pts, scale_r = ref_pts.contiguous(), scale_r.contiguous()
+        rs_n, rs_t = ref_pts.stride(0) // 2, ref_pts.stride(1) // 2
     best = torch.empty((T,), dtype=torch.int32, device=dev)
     left_norm = torch.empty((T, 2), dtype=torch.float32, device=dev)
     coords = torch.empty((T, Vq, 2), dtype=torch.float32, device=dev)
@@ -208,6 +292,7 @@ def _rows_ld(t: torch.Tensor, dtype=torch.float32):
     return rows, ld
 
 
+@_on_device
 def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None, want_f32=True):
     """(residual or 0) + LayerNorm(x)*gamma + beta over the last dim (row-strided views OK).
     Written as fp32 into ``out`` (allocated if None and want_f32) and/or as split planes into the
@@ -244,9 +329,12 @@ def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None,
     rc = _lib.lib().dfsfm_layernorm_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(r32), _ptr(rh),
                                         _ptr(rl), ldr, _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
     _lib.check(rc, "dfsfm_layernorm_f32")
+    if _debug_range and out_split is not None:
+        check_split_range(out_split, "layernorm")
     return out
 
 
+@_on_device
 def split_rows(x, add=None, out=None, out_split=None):
     """out / out_split = x (+ add broadcast over row blocks); x [..., C] fp32 rows, add [R, C] contiguous."""
     _require_cuda(x)
@@ -266,8 +354,11 @@ def split_rows(x, add=None, out=None, out_split=None):
     rc = _lib.lib().dfsfm_split_rows_f32(_ptr(x), ldx, _ptr(add), add_rows, _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos,
                                          rows, C, _stream())
     _lib.check(rc, "dfsfm_split_rows_f32")
+    if _debug_range and out_split is not None:
+        check_split_range(out_split, "split_rows")
 
 
+@_on_device
 def add_scatter_tokens(a, b, slot, dst):
     """dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p]);  a,b [M,C,P] contiguous, dst [*,P,C] contiguous."""
     _require_cuda(a, dst)
@@ -350,6 +441,8 @@ class PackedDense:
         wk[..., :Cin] = w.detach().float().permute(0, 2, 3, 1)
         full = torch.zeros((npad, self.Kpad), dtype=torch.float32, device=w.device)
         full[:Cout, :K] = wk.reshape(Cout, K)
+        if not bool(torch.isfinite(full).all()) or float(full.abs().max()) >= FP16_MAX:
+            raise _lib.DfsfmError(f"PackedDense: weights must be finite with |w| < {FP16_MAX:.0f} (split-plane range)")
         hi = torch.where(full.abs() >= 2.0 ** -14, full, torch.zeros_like(full)).half()
         self.hi = hi.contiguous()
         self.lo = ((full - hi.float()) * 2048.0).half().contiguous()
@@ -362,6 +455,7 @@ class PackedDense:
             self.use_direct = (Cin, kh, kw, Cout) in _DIRECT_DEFAULT
 
 
+@_on_device
 def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, out=None, out_split=False):
     """K6/K9.  x: fp32 [N,H,W,Cin] NHWC view, or a SplitAct.  residual: fp32 [.., Cout] view or SplitAct.
     Returns fp32 [N,Ho,Wo,Cout] (or fills ``out``), or a SplitAct when ``out_split``."""
@@ -412,6 +506,8 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
             _ptr(x), sxn, xt.stride(1), xt.stride(2), N, H, W, Cin, _ptr(pw.w32), pw.Cout, pw.kh, pw.kw, stride, pad,
             _ptr(pw.bias), 1 if relu else 0, _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, _stream())
         _lib.check(rc, "dfsfm_conv2d_direct_f32")
+        if _debug_range and out_split:
+            check_split_range(result, "conv2d_nhwc(direct)")
         return result
     rc = _lib.lib().dfsfm_conv2d_nhwc_f32(
         None if split_in else _ptr(x), _ptr(x.hi) if split_in else None, _ptr(x.lo) if split_in else None,
@@ -419,6 +515,8 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
         stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 1 if relu else 0,
         _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, 1 if pw.tap_padded else 0, None, None, 0.0, _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
+    if _debug_range and out_split:
+        check_split_range(result, "conv2d_nhwc")
     return result
 
 
@@ -443,6 +541,7 @@ def linear(x, pw: PackedDense, residual=None, relu=False, out=None, out_split=Fa
     return out
 
 
+@_on_device
 def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None):
     """residual + LayerNorm(x @ W^T + bias) * gamma + beta in one kernel (LayerNorm fused into the GEMM epilogue;
     Cout must be 64, 128 or 256 so a row sits in one workgroup tile).  x: SplitAct rows [rows, K]; residual: fp32 [rows, Cout]
@@ -481,9 +580,12 @@ def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=No
         pw.Kpad, 1, 1, 1, 0, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 0, _ptr(out), ldo, _ptr(oh), _ptr(ol),
         ldo_s, pw.Cout if oh is not None else 0, 0, _ptr(gamma), _ptr(beta), float(eps), _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32(ln)")
+    if _debug_range and out_split is not None:
+        check_split_range(out_split, "linear_ln")
     return out
 
 
+@_on_device
 def merge_keypoints(rows, img0, img1, n_images):
     """Scene-wide keypoint merge + match re-indexing (coarse_match.py:203-237 on the device).
     rows [M,5] fp32 (x0,y0,x1,y1,conf), img0/img1 [M] image index of each side (device tensors).
@@ -514,6 +616,7 @@ def merge_keypoints(rows, img0, img1, n_images):
     return kpts[:K], scores[:K], offsets, ids
 
 
+@_on_device
 def maxpool3x3s2_nhwc(x):
     """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor (fp32) or SplitAct."""
     if isinstance(x, SplitAct):

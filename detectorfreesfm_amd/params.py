@@ -137,6 +137,30 @@ def random_state_dict(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def planted_loftr_state_dict(spec: Spec, seed: int = 0, alpha: float = 3.0) -> Dict[str, torch.Tensor]:
+    """``random_state_dict`` with ONE tensor re-scaled so that synthetic frames produce real matches.
+
+    Seeded random weights make the coarse features a large position-independent vector plus a small content
+    term, so the dual-softmax is flat (0 matches at thr 0.2).  Here ``backbone.layer3_outconv``
+    becomes ``alpha * W (I - mu mu^T / |mu|^2)``: mu is the position mean of that layer's input for the seeded
+    weights (a committed 256-vector, data/planted_mu_seed<seed>.npy, measured once by oracle/make_planted.py),
+    so the common vector is projected out and the content term amplified.  On ``synth.coarse_pair_batch``
+    frames (image1 = image0 rolled by a whole number of coarse cells) ~3600 of 4800 cells then match at
+    thr 0.2 with confidences spread over (0.2, 1] -- the tables the benchmarks and end-to-end parity tests use.
+    Everything else (BN statistics, the transformer) stays the seeded random tensor."""
+    import os
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"planted_mu_seed{seed}.npy")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: run `python -m oracle.make_planted` for this seed")
+    sd = random_state_dict(spec, seed)
+    mu = torch.from_numpy(np.load(path)).double()
+    W = sd["backbone.layer3_outconv.weight"][:, :, 0, 0].double()
+    Wn = alpha * (W - torch.outer(W @ mu, mu) / (mu @ mu))
+    sd["backbone.layer3_outconv.weight"] = Wn.float()[:, :, None, None].contiguous()
+    return sd
+
+
 class ParamModule(nn.Module):
     """nn.Module whose parameters/buffers carry the reference's dotted names.
 

@@ -59,15 +59,24 @@ class HipMultiviewMatcher(ParamModule):
         bb = config["backbone"]
         s2d = bb["s2dnet"]
         mt = config["multiview_transform"]
+        mtest = config["multiview_matching_test"]
         ok = (bb["type"] == "S2DNet" and s2d["num_layers"] == 2 and s2d["combine"] and
               s2d["substitute_pooling_layers"] and s2d["zoomin_strategy"] == "post" and
               config["n_matching_steps"] == 1 and not config["enable_multiview_scale_align"] and
               mt["sparse"] and not mt["enable_rescaled_crop"] and mt["attention"] == "linear" and
               mt["attention_type"] == "multiview" and mt["norm_method"] == "layernorm" and
-              mt["rezero"] is None and not mt["final_proj"] and mt["type"] == "LoFTR")
+              mt["rezero"] is None and not mt["final_proj"] and mt["type"] == "LoFTR" and
+              # what the fused K11/K12 kernel hard-codes (fine_matching.py:36-98,129-179,258-285)
+              mtest["type"] == "s2d" and mtest["best_left_strategy"] == "smallest_mean_std" and
+              mtest["s2d"]["type"] == "heatmap" and mtest["s2d"]["obtain_offset_method"] == "argsoftmax")
         if not ok:
             raise NotImplementedError("HipMultiviewMatcher implements the shipped refinement configuration "
                                       "(hydra_training_configs/experiment/multiview_refinement_matching.yaml)")
+        W, crop = mt["window_size"], mt["crop_size"]
+        if not (crop // 2 - W // 2 - 2 >= 0 and crop // 2 + W // 2 + 3 <= crop):
+            # the dead-work shortcut evaluates adaptation layer 0 on the centre (W+4)^2 crop with a pad-0 5x5; it
+            # equals the reference's pad-2 convolution of the full map only while that halo stays inside the patch
+            raise NotImplementedError(f"window_size {W} too close to crop_size {crop}: need crop >= window + 6")
         self.config = config
         self.max_backbone_patches = max_backbone_patches
         self.register_spec(multiview_param_spec(config))
@@ -175,6 +184,9 @@ class HipMultiviewMatcher(ParamModule):
         left = cfg["multiview_matching_test"]["left_point_movement_window_size"]
         if left is None:
             raise NotImplementedError("left_point_movement_window_size=None (training config)")
+        if "keypoint_relocalized_offset" in data:
+            # the reference overrides best_index with it (fine_matching.py:150-158); silently ignoring it would diverge
+            raise NotImplementedError("data['keypoint_relocalized_offset'] (keypoint relocalisation) is not supported")
         WW = W * W
         C = mt["d_model"]
         images = data["images"]
@@ -336,8 +348,8 @@ class HipMultiviewMatcher(ParamModule):
                 ref = feats[sl, 0].contiguous()
                 qry = feats[sl, 1:cv].reshape(nt, Vq * WW, C)
             m = ops.fine_match(ref, qry.view(nt, Vq, WW, C), qm, None if movable is None else movable[sl],
-                               W, left, qpts[sl], pt_scales[0, 0, sl], ref_coarse[0, :, i:],
-                               pt_scales[0, 1:, i:], 1, T)
+                               W, left, qpts[sl], pt_scales[0, 0, sl], ref_coarse[0, :, sl],
+                               pt_scales[0, 1:, sl])
             q_out[sl] = m["query_refined"]
             r_out[0, :Vq, sl] = m["ref_refined"].transpose(0, 1)
             s_out[0, :Vq, sl] = m["std"].transpose(0, 1)

@@ -21,6 +21,16 @@ def coarse_pair_batch(n_pairs: int, H: int = 480, W: int = 640, seed: int = 1000
             "scale0": torch.ones(n_pairs, 2), "scale1": torch.ones(n_pairs, 2)}
 
 
+def coarse_pair_two_sizes(H0: int = 96, W0: int = 128, H1: int = 80, W1: int = 112, seed: int = 1000, shift=(1, 2)):
+    """A pair whose two frames differ in size (LoFTR.forward's two-backbone-call branch, loftr.py:45-49):
+    image1 = the (H1, W1) window of image0 that starts ``shift`` coarse cells in, + 0.02 N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand((1, 1, H0, W0), generator=g)
+    y0, x0 = 8 * shift[0], 8 * shift[1]
+    b = a[:, :, y0:y0 + H1, x0:x0 + W1] + 0.02 * torch.randn((1, 1, H1, W1), generator=g)
+    return {"image0": a, "image1": b.contiguous(), "scale0": torch.ones(1, 2), "scale1": torch.ones(1, 2)}
+
+
 def correlated_features(N: int, L: int, S: int, C: int = 256, seed: int = 7, noise: float = 0.1):
     """Kernel-level K3/K4 input: f0 ~ N(0,1), f1 = f0[perm] + noise*N(0,1) (random weights give
     ~0 matches at thr 0.2, so matching tests feed correlated features directly)."""

@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 from oracle import ref_import  # noqa: E402
 from detectorfreesfm_amd import synth  # noqa: E402
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config  # noqa: E402
-from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict  # noqa: E402
+from detectorfreesfm_amd.params import (loftr_param_spec, multiview_param_spec, planted_loftr_state_dict,  # noqa: E402
+                                        random_state_dict)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -33,6 +34,10 @@ CASES = {
     "fine_matching": dict(seed=21, T=6, Vq=3, W=15, left=7, C=128),
     "loftr_e2e": dict(weight_seed=0, data_seed=1000, n_pairs=1, H=96, W=128, thr=1e-3),
     "multiview_e2e": dict(weight_seed=1, data_seed=2000, T=40, V=4, H=120, W=160),
+    # "planted" weights (params.planted_loftr_state_dict): confident matches at the production threshold
+    "loftr_e2e_planted": dict(weight_seed=0, alpha=3.0, data_seed=1000, n_pairs=2, H=96, W=128, thr=0.2),
+    # two frames of different size: LoFTR.forward's two-backbone-call branch (loftr.py:45-49), L != S
+    "loftr_e2e_two_sizes": dict(weight_seed=0, alpha=3.0, data_seed=1000, H0=96, W0=128, H1=80, W1=112, thr=0.2),
 }
 
 
@@ -129,6 +134,35 @@ def main():
                  j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_f=data["mkpts0_f"].numpy(),
                  mkpts1_f=data["mkpts1_f"].numpy(), conf_rowmax=data["conf_matrix"].max(2)[0].numpy(),
                  scale0=data["scale0"].numpy(), scale1=data["scale1"].numpy(), **c)
+
+        # coarse end-to-end with planted weights, production threshold, per-pair scales
+        c = CASES["loftr_e2e_planted"]
+        cfg = loftr_coarse_only_config(c["thr"])
+        sd = planted_loftr_state_dict(loftr_param_spec(cfg), c["weight_seed"], c["alpha"])
+        m = LoFTR(cfg).eval()
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+        data["scale0"] = torch.tensor([[1.5, 2.0], [1.0, 1.0]])
+        data["scale1"] = torch.tensor([[1.0, 1.25], [0.5, 2.0]])
+        m(data)
+        assert data["i_ids"].numel() > 100
+        np.savez(os.path.join(OUT, "loftr_e2e_planted.npz"), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(),
+                 j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_f=data["mkpts0_f"].numpy(),
+                 mkpts1_f=data["mkpts1_f"].numpy(), scale0=data["scale0"].numpy(), scale1=data["scale1"].numpy(), **c)
+
+        c = CASES["loftr_e2e_two_sizes"]
+        cfg = loftr_coarse_only_config(c["thr"])
+        sd = planted_loftr_state_dict(loftr_param_spec(cfg), c["weight_seed"], c["alpha"])
+        m = LoFTR(cfg).eval()
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        data = synth.coarse_pair_two_sizes(c["H0"], c["W0"], c["H1"], c["W1"], c["data_seed"])
+        data["scale0"] = torch.tensor([[1.5, 2.0]])
+        data["scale1"] = torch.tensor([[1.0, 1.25]])
+        m(data)
+        assert data["i_ids"].numel() > 30
+        np.savez(os.path.join(OUT, "loftr_e2e_two_sizes.npz"), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(),
+                 j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_f=data["mkpts0_f"].numpy(),
+                 mkpts1_f=data["mkpts1_f"].numpy(), scale0=data["scale0"].numpy(), scale1=data["scale1"].numpy(), **c)
 
         # refinement end-to-end: the real MultiviewMatcher with seeded weights (RoIAlign = stand-in)
         c = CASES["multiview_e2e"]

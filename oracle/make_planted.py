@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE ONLY -- calibration constant of the "planted" synthetic LoFTR weights.
+
+``python -m oracle.make_planted`` -> detectorfreesfm_amd/data/planted_mu_seed0.npy
+
+Seeded random LoFTR weights give a flat confidence matrix (0 matches at thr 0.2, SURVEY.md 8c "test-input
+caveat"): the coarse features are a large position-independent vector plus a small content term.
+``params.planted_loftr_state_dict`` removes that common vector analytically from the ONE layer that has no
+successor bias -- ``backbone.layer3_outconv.weight`` W -> alpha * W (I - mu mu^T / |mu|^2) -- where mu is the
+mean of the layer's input over positions.  mu depends only on the seed-0 weights; it is measured once here,
+through the oracle's backbone (restate.resnet_fpn_8_2, i.e. the reference's ResNetFPN_8_2 arithmetic) on the
+first config-2 frame, and committed (256 doubles), so the weights are bit-identical on every machine."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import restate  # noqa: E402
+from detectorfreesfm_amd import synth  # noqa: E402
+from detectorfreesfm_amd.config import loftr_coarse_only_config  # noqa: E402
+from detectorfreesfm_amd.params import loftr_param_spec, random_state_dict  # noqa: E402
+
+
+def main(seed=0):
+    cfg = loftr_coarse_only_config(0.2)
+    sd = random_state_dict(loftr_param_spec(cfg), seed)
+    img = synth.coarse_pair_batch(1, 480, 640, seed=1000)["image0"]
+    with torch.no_grad():
+        c, _ = restate.resnet_fpn_8_2(sd, "backbone.", img, False)
+    W = sd["backbone.layer3_outconv.weight"][:, :, 0, 0].double()
+    mu = torch.linalg.solve(W, c.double().mean((0, 2, 3)))
+    out = os.path.join(ROOT, "detectorfreesfm_amd", "data", f"planted_mu_seed{seed}.npy")
+    np.save(out, mu.numpy())
+    print(out, mu.shape, float(mu.mean()))
+
+
+if __name__ == "__main__":
+    main()

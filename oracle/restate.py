@@ -16,7 +16,7 @@ Every function cites the reference file:line it follows (paths relative to /root
 How it is pinned: the reference ships NO golden vectors / known-answer tests for this path
 (SURVEY.md section 4).  The oracle is therefore pinned against outputs of the reference's own
 Python modules executed in the build container (``oracle/ref_import.py`` +
-``oracle/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_vs_reference.py`` also
+``oracle/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` also
 re-checks it live whenever /root/reference is present).
 
 PARITY UNPINNED for one stage: ``roi_align_crop`` restates longcw/RoIAlign.pytorch
@@ -419,6 +419,7 @@ def fine_matching(ref, qry, W, left_win, track_mask, movable_mask):
     off = torch.stack([best % left_win, best // left_win], -1)
     left_norm = (off / (left_win - 1)) * 2 - 1
     ids = torch.arange(T)
+    fine_matching.last_score = score          # [T,L] candidate scores, kept for the parity tests' tie analysis
     return left_norm, coords[ids, best], std[ids, best], best
 
 
@@ -480,7 +481,7 @@ def multiview_matcher_forward(sd, cfg, data, chunk_track=1000):
 
     tvm = data["track_valid_mask"].transpose(1, 2)[0]                                           # [T,V-1]
     movable = data["query_movable_mask"][0] if "query_movable_mask" in data else torch.ones(T, dtype=torch.bool)
-    q_ref_out, r_ref_out, std_out = [], [], []
+    q_ref_out, r_ref_out, std_out, score_out, best_out = [], [], [], [], []
     i = 0
     layer_names = list(mt["layer_names"]) * mt["layer_iter_n"]
     for cv, nt in zip(chunk_views, num_tracks):
@@ -489,7 +490,9 @@ def multiview_matcher_forward(sd, cfg, data, chunk_track=1000):
         tm = tvm[sl, :cv - 1]
         if mt["enable"]:
             fr, fq = multiview_transformer(sd, "fine_transformer.", fr, fq, layer_names, mt["nhead"], tm)
-        left_norm, coords, std, _ = fine_matching(fr, fq, W, left, tm, movable[sl])
+        left_norm, coords, std, best = fine_matching(fr, fq, W, left, tm, movable[sl])
+        score_out.append(fine_matching.last_score)
+        best_out.append(best)
         s_q = pt_scales[0, 0, sl]                                                               # [nt,2]
         s_r = pt_scales[0, 1:cv, sl].transpose(0, 1)                                            # [nt,cv-1,2]
         q_ref = data["query_points"][0, sl] + left_norm * (left // 2) * s_q                     # fine_matching.py:221-232
@@ -501,4 +504,5 @@ def multiview_matcher_forward(sd, cfg, data, chunk_track=1000):
     return {"query_points_refined": torch.cat(q_ref_out, 0)[None],
             "reference_points_refined": torch.cat(r_ref_out, 1)[None],
             "std": torch.cat(std_out, 1)[None],
+            "cand_score": torch.cat(score_out, 0), "best_index": torch.cat(best_out, 0),
             "features_ref": f_ref, "features_qry": f_qry}

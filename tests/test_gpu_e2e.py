@@ -1,77 +1,149 @@
-"""End-to-end parity of the two plugins on a real MI355X: against fixtures produced by the real
-reference, and against the oracle on fresh seeded inputs."""
+"""End-to-end parity of the two plugins on a real MI355X: against fixtures produced by the real reference, and
+against the oracle on fresh seeded inputs.
+
+Assertions are the north_star's: match indices identical, confidences / refined coordinates within 1e-4.  The only
+exemptions are per entry and analysed against the oracle's own dense confidence matrix / candidate scores
+(tests/parity.py): a confidence within 1e-5 of the threshold, a mutual-max tie within 1e-6, an argmin between
+candidate scores closer than 1e-5.  Every exempted entry is listed; none is waved through as a percentage."""
 import numpy as np
 import pytest
 import torch
 
-from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, synth
+import parity
+from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, plugin, synth
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config
-from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict
+from detectorfreesfm_amd.params import (loftr_param_spec, multiview_param_spec, planted_loftr_state_dict,
+                                        random_state_dict)
 from oracle import restate
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+MATCH_KEYS = ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f")
 
 
 def _case(npz):
     return {k: npz[k].item() for k in npz.files if npz[k].ndim == 0}
 
 
-def _match_sets(d, ids=("i_ids", "j_ids")):
-    return set(zip(*(np.asarray(d[k].cpu() if hasattr(d[k], "cpu") else d[k]).tolist() for k in ids)))
-
-
-def test_loftr_e2e_golden(built_lib, golden):
-    gz = golden("loftr_e2e")
-    c = _case(gz)
-    cfg = loftr_coarse_only_config(c["thr"])
-    sd = random_state_dict(loftr_param_spec(cfg), c["weight_seed"])
+def _loftr(thr, planted=True, seed=0):
+    cfg = loftr_coarse_only_config(thr)
+    spec = loftr_param_spec(cfg)
+    sd = planted_loftr_state_dict(spec, seed) if planted else random_state_dict(spec, seed)
     m = HipLoFTR(cfg)
     m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+    return cfg, sd, m.eval().to(DEV)
+
+
+def _refiner(seed=1):
+    cfg = multiview_refinement_config()
+    sd = random_state_dict(multiview_param_spec(cfg), seed)
+    m = HipMultiviewMatcher(cfg, test=True)
+    m.load_state_dict(sd, strict=True)
+    return cfg, sd, m.eval().to(DEV)
+
+
+def _oracle_coarse(sd, cfg, data):
+    """Oracle tables + its dense confidence matrix (for the per-entry exemption analysis)."""
+    with torch.no_grad():
+        o = restate.loftr_coarse_forward(sd, cfg, data, with_fine_backbone=False)
+        conf = restate.dual_softmax_conf(o["feat_c0"], o["feat_c1"], cfg["match_coarse"]["dsmax_temperature"])
+    return o, conf
+
+
+def _strict_coarse(d, ref, conf, thr, label):
+    ex = parity.check_coarse(d, ref, conf, thr)
+    parity.check_coarse_rows(d, ref, ex)
+    print(f"[{label}] {len(ref['i_ids'])} reference matches, {len(d['i_ids'])} on the GPU, exempted entries: {ex}")
+    return ex
+
+
+def _same_tables(a, b, thr):
+    """HIP vs HIP (different batch composition): same rows; a row may be absent from one side only if its
+    confidence is within parity.TOL_THR of thr."""
+    A = {(int(x), int(y)): (int(j), float(c)) for x, y, j, c in zip(a["b_ids"], a["i_ids"], a["j_ids"], a["mconf"])}
+    B = {(int(x), int(y)): (int(j), float(c)) for x, y, j, c in zip(b["b_ids"], b["i_ids"], b["j_ids"], b["mconf"])}
+    bad = [(k, A.get(k), B.get(k)) for k in set(A) ^ set(B) if abs((A.get(k) or B.get(k))[1] - thr) > parity.TOL_THR]
+    bad += [(k, A[k], B[k]) for k in set(A) & set(B) if A[k][0] != B[k][0] or abs(A[k][1] - B[k][1]) > parity.TOL_CONF]
+    assert not bad, bad[:5]
+    return len(set(A) & set(B))
+
+
+# ---------------------------------------------------------------- coarse matcher
+def test_loftr_e2e_golden(built_lib, golden):
+    """Seeded random weights, thr 1e-3 (flat confidences: the hardest case for index parity)."""
+    gz = golden("loftr_e2e")
+    c = _case(gz)
+    cfg, sd, m = _loftr(c["thr"], planted=False, seed=c["weight_seed"])
     data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
     data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
     d = synth.to_device(data, DEV)
     m(d)
-    ref = {k: gz[k] for k in ("i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f")}
-    hip, gold = _match_sets(d), _match_sets(ref)
-    # thr=1e-3 with random weights: conf values sit near thr, so a few entries may flip on float
-    # noise of the MIOpen/hipBLASLt summation order; everything else must be the same matches.
-    assert len(hip & gold) >= 0.9 * len(gold)
-    lut = {(int(i), int(j)): n for n, (i, j) in enumerate(zip(gz["i_ids"], gz["j_ids"]))}
-    sel = [(n, lut[(int(i), int(j))]) for n, (i, j) in enumerate(zip(d["i_ids"].cpu(), d["j_ids"].cpu())) if (int(i), int(j)) in lut]
-    a, b = zip(*sel)
-    assert np.abs(d["mconf"].cpu().numpy()[list(a)] - gz["mconf"][list(b)]).max() < 1e-4
-    assert np.array_equal(d["mkpts0_f"].cpu().numpy()[list(a)], gz["mkpts0_f"][list(b)])
-    assert np.array_equal(d["mkpts1_f"].cpu().numpy()[list(a)], gz["mkpts1_f"][list(b)])
-    assert (d["m_bids"] == 0).all()
+    _, conf = _oracle_coarse(sd, cfg, data)
+    ex = _strict_coarse(d, {k: gz[k] for k in MATCH_KEYS}, conf, c["thr"], "loftr_e2e")
+    assert len(ex) <= 2 and (d["m_bids"] == 0).all()
+
+
+def test_loftr_e2e_planted_golden(built_lib, golden):
+    """Planted weights, production threshold 0.2, 2 pairs with different scales: fixture from the real reference."""
+    gz = golden("loftr_e2e_planted")
+    c = _case(gz)
+    cfg, sd, m = _loftr(c["thr"], seed=c["weight_seed"])
+    data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    d = synth.to_device(data, DEV)
+    m(d)
+    _, conf = _oracle_coarse(sd, cfg, data)
+    ex = _strict_coarse(d, {k: gz[k] for k in MATCH_KEYS}, conf, c["thr"], "loftr_e2e_planted")
+    assert len(ex) == 0 and len(d["i_ids"]) == len(gz["i_ids"]) > 100
+    assert np.array_equal(d["i_ids"].cpu().numpy(), gz["i_ids"]) and np.array_equal(d["j_ids"].cpu().numpy(), gz["j_ids"])
+
+
+def test_loftr_e2e_two_sizes_golden(built_lib, golden):
+    """Frames of different size: two backbone calls, L != S (loftr.py:45-49)."""
+    gz = golden("loftr_e2e_two_sizes")
+    c = _case(gz)
+    cfg, sd, m = _loftr(c["thr"], seed=c["weight_seed"])
+    data = synth.coarse_pair_two_sizes(c["H0"], c["W0"], c["H1"], c["W1"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    d = synth.to_device(data, DEV)
+    m(d)
+    assert tuple(d["hw0_c"]) == (12, 16) and tuple(d["hw1_c"]) == (10, 14)
+    _, conf = _oracle_coarse(sd, cfg, data)
+    ex = _strict_coarse(d, {k: gz[k] for k in MATCH_KEYS}, conf, c["thr"], "loftr_e2e_two_sizes")
+    assert len(ex) == 0 and len(gz["i_ids"]) > 30
+
+
+def test_loftr_640x480_planted_vs_oracle(built_lib):
+    """BASELINE configs[1] frame size, production threshold, ~3600 matches per pair: every row identical to the
+    oracle's (indices, pixel coordinates), confidences within 1e-4."""
+    cfg, sd, m = _loftr(0.2)
+    data = synth.coarse_pair_batch(1, 480, 640, seed=1100)
+    d = synth.to_device(data, DEV)
+    m(d)
+    o, conf = _oracle_coarse(sd, cfg, data)
+    assert o["i_ids"].numel() > 3000
+    ex = _strict_coarse(d, o, conf, 0.2, "640x480 planted")
+    assert len(ex) <= 3
 
 
 def test_loftr_features_vs_oracle_640x480(built_lib):
     """BASELINE config 2 frame size: transformer output features vs the oracle (1e-4 relative)."""
-    cfg = loftr_coarse_only_config(0.2)
-    sd = random_state_dict(loftr_param_spec(cfg), 0)
-    m = HipLoFTR(cfg)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
-    data = synth.coarse_pair_batch(1, 480, 640, seed=1000)
-    with torch.no_grad():
-        f0, f1, hw0, hw1 = m.coarse_features(data["image0"].to(DEV), data["image1"].to(DEV))
-        o = restate.loftr_coarse_forward(sd, cfg, data, with_fine_backbone=False)
-    assert hw0 == (60, 80)
-    for a, b in ((f0, o["feat_c0"]), (f1, o["feat_c1"])):
-        err = (a.cpu() - b).abs().max() / b.abs().max()
-        assert err < 1e-4, err
+    for planted in (False, True):
+        cfg, sd, m = _loftr(0.2, planted=planted)
+        data = synth.coarse_pair_batch(1, 480, 640, seed=1000)
+        with torch.no_grad():
+            f0, f1, hw0, hw1 = m.coarse_features(data["image0"].to(DEV), data["image1"].to(DEV))
+            o = restate.loftr_coarse_forward(sd, cfg, data, with_fine_backbone=False)
+        assert hw0 == (60, 80)
+        for a, b in ((f0, o["feat_c0"]), (f1, o["feat_c1"])):
+            err = (a.cpu() - b).abs().max() / b.abs().max()
+            assert err < 1e-4, err
 
 
 def test_loftr_832_config5_batch_invariance(built_lib):
     """BASELINE config 5 frame size (832x832 -> 104x104 grid, L = S = 10816): a batch of 2 pairs gives the same
-    features (to summation-order noise) and the same matches as the two pairs run alone."""
-    cfg = loftr_coarse_only_config(1e-3)
-    sd = random_state_dict(loftr_param_spec(cfg), 0)
-    m = HipLoFTR(cfg)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+    features (to summation-order noise) and the same match rows as the two pairs run alone."""
+    cfg, sd, m = _loftr(0.2)
     data = synth.coarse_pair_batch(2, 832, 832, seed=5)
     with torch.no_grad():
         f0, f1, hw0, hw1 = m.coarse_features(data["image0"].to(DEV), data["image1"].to(DEV))
@@ -83,25 +155,22 @@ def test_loftr_832_config5_batch_invariance(built_lib):
                 assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5
     d = synth.to_device(data, DEV)
     m(d)
-    assert d["i_ids"].numel() > 0 and int(d["j_ids"].max()) < 10816
+    assert d["i_ids"].numel() > 10000 and int(d["j_ids"].max()) < 10816
     key = d["b_ids"] * 10816 + d["i_ids"]
     assert (key[1:] > key[:-1]).all()                      # ascending (b, i) like torch.where
     for p in range(2):
         s = synth.to_device({k: v[p:p + 1] for k, v in data.items()}, DEV)
         m(s)
-        sel = d["b_ids"] == p
-        a = set(zip(d["i_ids"][sel].tolist(), d["j_ids"][sel].tolist()))
-        b = set(zip(s["i_ids"].tolist(), s["j_ids"].tolist()))
-        assert len(a & b) >= 0.99 * max(len(a), len(b), 1)
+        sel = (d["b_ids"] == p).cpu()
+        a = {k: d[k].cpu()[sel] for k in ("i_ids", "j_ids", "mconf")}
+        a["b_ids"] = torch.zeros_like(a["i_ids"])
+        n = _same_tables(a, {k: s[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf")}, 0.2)
+        assert n > 5000
 
 
-def test_loftr_batch8_equals_singles(built_lib):
-    """Batch of 8 pairs == 8 single-pair calls (pairs are independent units of work)."""
-    cfg = loftr_coarse_only_config(1e-3)
-    sd = random_state_dict(loftr_param_spec(cfg), 0)
-    m = HipLoFTR(cfg)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+def test_loftr_batch_equals_singles(built_lib):
+    """Batch of 4 pairs == 4 single-pair calls (pairs are independent units of work)."""
+    cfg, sd, m = _loftr(0.2)
     data = synth.coarse_pair_batch(4, 96, 128, seed=77)
     d = synth.to_device(data, DEV)
     m(d)
@@ -109,99 +178,183 @@ def test_loftr_batch8_equals_singles(built_lib):
     for p in range(4):
         s = synth.to_device({k: v[p:p + 1] for k, v in data.items()}, DEV)
         m(s)
-        sel = d["b_ids"] == p
-        a = set(zip(d["i_ids"][sel].tolist(), d["j_ids"][sel].tolist()))
-        b = set(zip(s["i_ids"].tolist(), s["j_ids"].tolist()))
-        assert len(a & b) >= 0.9 * max(len(a), len(b), 1)
-        tot += len(b)
-    assert tot > 20
+        sel = (d["b_ids"] == p).cpu()
+        a = {k: d[k].cpu()[sel] for k in ("i_ids", "j_ids", "mconf")}
+        a["b_ids"] = torch.zeros_like(a["i_ids"])
+        tot += _same_tables(a, {k: s[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf")}, 0.2)
+    assert tot > 200
 
 
-@pytest.mark.parametrize("name", ["multiview_e2e"])
-def test_multiview_e2e_golden(built_lib, golden, name):
-    gz = golden(name)
+def test_coarse_plugin_surface(built_lib, tmp_path):
+    """The reference's own call sequence (coarse_match_worker.py:21-99,139-141) on the HIP plugin: build_model
+    from a checkpoint file with ``matcher.``-prefixed keys -> .cuda() -> extract_matches -> (M,5) table."""
+    cfg = loftr_coarse_only_config(0.2)
+    sd = planted_loftr_state_dict(loftr_param_spec(cfg), 0)
+    ckpt = tmp_path / "loftr.ckpt"
+    torch.save({"state_dict": {"matcher." + k: v for k, v in sd.items()}}, ckpt)
+    detector, matcher = plugin.build_model({"matcher": "loftr_hip", "type": "coarse_only", "match_thr": 0.2, "seed": 666,
+                                            "loftr_hip": {"weight_path": str(ckpt)}})
+    detector.cuda()
+    matcher.cuda()
+    data = synth.coarse_pair_batch(1, 96, 128, seed=1003)
+    data["scale0"], data["scale1"] = torch.tensor([[1.5, 2.0]]), torch.tensor([[0.75, 1.25]])
+    d = {k: v.cuda() for k, v in data.items()}
+    d.update(pair_key="a b", f_name0="a", f_name1="b")
+    mk0, mk1, mc = plugin.extract_matches(d, detector=detector, matcher=matcher)
+    table = plugin.match_table(d)
+    assert table.shape == (len(mc), 5) and table.dtype == np.float32 and len(mc) > 50
+    assert np.array_equal(table[:, :2], mk0) and np.array_equal(table[:, 2:4], mk1) and np.array_equal(table[:, 4], mc)
+    o, conf = _oracle_coarse(sd, cfg, data)
+    ex = _strict_coarse(d, o, conf, 0.2, "coarse plugin")
+    assert len(ex) == 0
+    assert np.array_equal(mk0, o["mkpts0_f"].numpy()) and np.array_equal(mk1, o["mkpts1_f"].numpy())
+    assert np.abs(mc - o["mconf"].numpy()).max() <= parity.TOL_CONF
+    with pytest.raises(NotImplementedError):
+        plugin.build_model({"matcher": "loftr_official", "match_thr": 0.2})
+
+
+# ---------------------------------------------------------------- refinement head
+def _strict_refine(d, o, data, left, label, tol_px=parity.TOL_PX):
+    """d: HIP data dict after forward; o: oracle outputs (or a fixture dict with the same keys + cand_score)."""
+    valid = data["track_valid_mask"][0]
+    qs = data["scales"][0, data["query_img_idxs"][0]][:, [1, 0]] if "scales" in data else torch.ones_like(data["query_points"][0])
+    flips = parity.check_refine(d["query_points_refined"][0], d["reference_points_refined"][-1][0], d["std"][-1][0],
+                                o["query_points_refined"][0], o["reference_points_refined"][0], o["std"][0], valid,
+                                data["query_points"][0], qs, o["cand_score"], left, tol_px)
+    print(f"[{label}] {valid.shape[1]} tracks, argmin flips between near-tied candidates (track, hip, ref, gap): {flips}")
+    return flips
+
+
+def test_multiview_e2e_golden(built_lib, golden):
+    gz = golden("multiview_e2e")
     c = _case(gz)
-    cfg = multiview_refinement_config()
-    sd = random_state_dict(multiview_param_spec(cfg), c["weight_seed"])
-    m = HipMultiviewMatcher(cfg, test=True)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+    cfg, sd, m = _refiner(c["weight_seed"])
     data = synth.refine_bag(c["T"], c["V"], c["H"], c["W"], c["data_seed"], variable_lengths=True)
     data["scales"] = torch.from_numpy(gz["scales"])
     d = synth.to_device(data, DEV)
     m(d)
-    mask = data["track_valid_mask"].numpy()
-    q = d["query_points_refined"].cpu().numpy()
-    r = d["reference_points_refined"][-1].cpu().numpy()
-    s = d["std"][-1].cpu().numpy()
-    # candidate argmin may legitimately flip between near-tied scores; offsets must agree to 1e-4 px*scale
-    same = np.abs(q - gz["query_points_refined"]).max(-1)[0] < 1e-4
-    assert same.mean() >= 0.9, same.mean()
-    assert np.abs(r - gz["reference_points_refined"])[0][:, same][mask[0][:, same]].max() < 2e-3
-    assert np.abs(s - gz["std"])[0][:, same][mask[0][:, same]].max() < 1e-3
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data)      # candidate scores (bit-pinned to the fixture on CPU)
+    ref = {"query_points_refined": gz["query_points_refined"], "reference_points_refined": gz["reference_points_refined"],
+           "std": gz["std"], "cand_score": o["cand_score"]}
+    flips = _strict_refine(d, ref, data, 7, "multiview_e2e")
+    assert len(flips) <= 1
 
 
 def test_multiview_vs_oracle_config3_shape(built_lib):
-    """BASELINE config 3 shapes at a size the oracle finishes in seconds: 5 views, 480x640 frames."""
-    cfg = multiview_refinement_config()
-    sd = random_state_dict(multiview_param_spec(cfg), 1)
-    m = HipMultiviewMatcher(cfg, test=True)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+    """BASELINE config 3 shapes at a size the oracle finishes in seconds: 5 views, 480x640 frames, ragged lengths."""
+    cfg, sd, m = _refiner(1)
     data = synth.refine_bag(T=60, V=5, H=480, W=640, seed=2000, variable_lengths=True)
     d = synth.to_device(data, DEV)
     m(d)
     with torch.no_grad():
         o = restate.multiview_matcher_forward(sd, cfg, data)
-    mask = data["track_valid_mask"]
-    dq = (d["query_points_refined"].cpu() - o["query_points_refined"]).abs().max(-1)[0][0]
-    same = dq < 1e-4
-    assert same.float().mean() >= 0.9
-    dr = (d["reference_points_refined"][-1].cpu() - o["reference_points_refined"]).abs().max(-1)[0][0]   # [V-1,T]
-    assert dr[:, same][mask[0][:, same]].max() < 2e-3
+    flips = _strict_refine(d, o, data, 7, "config3 shape")
+    assert len(flips) <= 1
+
+
+def _subset_bag(data, idx):
+    """The tracks ``idx`` (ascending -> still sorted by descending length) of a bag, as a bag of their own."""
+    part = dict(data)
+    for k in ("query_points", "reference_points_coarse", "view_point_vector"):
+        part[k] = data[k][..., idx, :]
+    for k in ("query_img_idxs", "reference_img_idxs", "track_valid_mask", "scales_relative", "query_movable_mask"):
+        part[k] = data[k][..., idx]
+    return part
+
+
+def test_multiview_config3_T2000_ragged(built_lib):
+    """BASELINE configs[2] at full size (2000 tracks x 5 views, ragged lengths 2..5, some immovable): tracks are
+    independent units, so a seeded sample of 96 tracks is checked against the oracle run on those tracks alone."""
+    cfg, sd, m = _refiner(1)
+    data = synth.refine_bag(T=2000, V=5, H=480, W=640, seed=2001, variable_lengths=True)
+    g = torch.Generator().manual_seed(3)
+    data["query_movable_mask"] = (torch.rand((1, 2000), generator=g) > 0.1)
+    d = synth.to_device(data, DEV)
+    m(d)
+    assert torch.isfinite(d["query_points_refined"]).all()
+    idx = torch.sort(torch.randperm(2000, generator=g)[:96])[0]
+    sub = _subset_bag(data, idx)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, sub)
+    dsub = {"query_points_refined": d["query_points_refined"][:, idx.to(DEV)],
+            "reference_points_refined": [d["reference_points_refined"][-1][:, :, idx.to(DEV)]],
+            "std": [d["std"][-1][:, :, idx.to(DEV)]]}
+    flips = _strict_refine(dsub, o, sub, 7, "config3 T=2000 ragged (96-track sample)")
+    assert len(flips) <= 2
+    imm = ~data["query_movable_mask"][0]
+    assert torch.equal(d["query_points_refined"][0].cpu()[imm], data["query_points"][0][imm])     # unmovable => centre
 
 
 def test_multiview_chunk16000_equals_two_chunks(built_lib):
-    """BASELINE config 5 refinement chunk (chunk_size = 16000 tracks, 5 views): tracks are independent units, so
-    one 16000-track bag must reproduce the results of its two 8000-track halves."""
-    cfg = multiview_refinement_config()
-    sd = random_state_dict(multiview_param_spec(cfg), 1)
-    m = HipMultiviewMatcher(cfg, test=True)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+    """BASELINE config 5 refinement chunk (chunk_size = 16000 tracks, 5 views): tracks are independent units and no
+    kernel's summation order depends on how many tracks share a launch, so one 16000-track bag must reproduce its
+    two 8000-track halves exactly."""
+    cfg, sd, m = _refiner(1)
     T = 16000
     data = synth.refine_bag(T, 5, 480, 640, seed=31)
     d = synth.to_device(data, DEV)
     m(d)
-    q, r = d["query_points_refined"], d["reference_points_refined"][-1]
+    q, r, s = d["query_points_refined"], d["reference_points_refined"][-1], d["std"][-1]
     assert q.shape == (1, T, 2) and r.shape == (1, 4, T, 2)
     assert torch.isfinite(q).all() and torch.isfinite(r).all()
     # refined points stay inside the search window around the coarse points (W = 15 -> +-7 px)
     assert (r.cpu() - data["reference_points_coarse"]).abs().max().item() <= 7.5
-    per_track = ("query_points", "reference_points_coarse", "query_img_idxs", "reference_img_idxs",
-                 "track_valid_mask", "scales_relative", "view_point_vector", "query_movable_mask")
     for lo, hi in ((0, 8000), (8000, T)):
-        part = dict(data)
-        for k in per_track:
-            t = data[k]
-            part[k] = t[..., lo:hi, :] if k in ("query_points", "reference_points_coarse", "view_point_vector") else t[..., lo:hi]
-        h = synth.to_device(part, DEV)
+        h = synth.to_device(_subset_bag(data, torch.arange(lo, hi)), DEV)
         m(h)
-        same = (h["query_points_refined"] - q[:, lo:hi]).abs().max(-1)[0][0] < 1e-4       # argmin flips between near-ties
-        assert same.float().mean().item() >= 0.99
-        dr = (h["reference_points_refined"][-1] - r[:, :, lo:hi]).abs().max(-1)[0][0]       # [4, n]
-        assert dr[:, same].max().item() < 1e-3
+        assert torch.equal(h["query_points_refined"], q[:, lo:hi])
+        assert (h["reference_points_refined"][-1] - r[:, :, lo:hi]).abs().max().item() <= 1e-6
+        assert (h["std"][-1] - s[:, :, lo:hi]).abs().max().item() <= 1e-6
+
+
+def test_refine_plugin_surface(built_lib, tmp_path):
+    """The reference's call sequence (multiview_match_worker.py:16-82) on the HIP plugin: build_model from a Lightning
+    checkpoint (``matcher.`` prefix, ``loftr_fine`` -> ``fine_transformer``, foreign keys dropped) -> .cuda() ->
+    extract_results -> the two [points, img_ids, pt2d_idxs] lists."""
+    cfg = multiview_refinement_config()
+    sd = random_state_dict(multiview_param_spec(cfg), 1)
+    ck = {("matcher." + k.replace("fine_transformer", "loftr_fine")): v for k, v in sd.items()}
+    ck["matcher.loftr_coarse.layers.0.q_proj.weight"] = torch.zeros(4, 4)
+    ck["loss.some_buffer"] = torch.zeros(3)
+    path = tmp_path / "mv.ckpt"
+    torch.save({"state_dict": ck}, path)
+    matcher = plugin.build_refine_model({"weight_path": [str(path)], "seed": 666}, None, 0)
+    matcher.cuda()
+    T, V = 48, 4
+    data = synth.refine_bag(T, V, 120, 160, seed=2100, variable_lengths=True)
+    g = torch.Generator().manual_seed(8)
+    data["query_movable_mask"] = torch.rand((1, T), generator=g) > 0.2
+    data["query_img_ids"] = torch.randint(1, 50, (1, T), generator=g)
+    data["query_pt2d_idxs"] = torch.randint(0, 5000, (1, T), generator=g)
+    data["reference_img_ids"] = torch.randint(1, 50, (1, V - 1, T), generator=g)
+    data["reference_pt2d_idxs"] = torch.randint(0, 5000, (1, V - 1, T), generator=g)
+    d = synth.to_device(data, DEV)
+    (q_pts, q_ids, q_idx), (r_pts, r_ids, r_idx), _ = plugin.extract_results(d, matcher=matcher)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data)
+    flips = _strict_refine(d, o, data, 7, "refine plugin")
+    ok = np.ones(T, bool)
+    ok[[f[0] for f in flips]] = False
+    mask = data["track_valid_mask"].numpy()
+    mov = data["query_movable_mask"].numpy()
+    assert q_pts.shape == (mask.sum(), 2) and r_pts.shape == (mov.sum(), 2)
+    assert np.array_equal(q_ids, data["reference_img_ids"].numpy()[mask]) and np.array_equal(q_idx, data["reference_pt2d_idxs"].numpy()[mask])
+    assert np.array_equal(r_ids, data["query_img_ids"].numpy()[mov]) and np.array_equal(r_idx, data["query_pt2d_idxs"].numpy()[mov])
+    keep = np.broadcast_to(ok[None, None], mask.shape)[mask]
+    assert np.abs(q_pts - o["reference_points_refined"].numpy()[mask])[keep].max() <= parity.TOL_PX
+    keep = ok[None][mov]
+    assert np.abs(r_pts - o["query_points_refined"].numpy()[mov])[keep].max() <= parity.TOL_PX
+    # window shrink of later refinement iterations (multiview_match_worker.py:20-34)
+    m2 = plugin.build_refine_model({"weight_path": [None]}, rewindow_size_factor=2)
+    assert m2.config["multiview_transform"]["window_size"] == 11
+    assert m2.config["multiview_matching_test"]["left_point_movement_window_size"] == 3
 
 
 def test_scene_matching_cached_tokens_equals_pairwise(built_lib):
     """plugin.match_scene_cached: backbone once per image, every pair matched from the cached tokens -- the same
     tables as feeding each pair through HipLoFTR.forward."""
-    from detectorfreesfm_amd import plugin
-    cfg = loftr_coarse_only_config(1e-3)
-    sd = random_state_dict(loftr_param_spec(cfg), 0)
-    m = HipLoFTR(cfg)
-    m.load_state_dict(sd, strict=True)
-    m = m.eval().to(DEV)
+    cfg, sd, m = _loftr(0.2)
     base = synth.coarse_pair_batch(3, 96, 128, seed=1000)
     images = torch.cat([base["image0"], base["image1"]], 0)                         # 6 images
     pairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
@@ -212,8 +365,10 @@ def test_scene_matching_cached_tokens_equals_pairwise(built_lib):
         m(d)
         ref = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).cpu().numpy()
         got = tables[(i, j)]
-        a = {tuple(r[:4]) for r in got}
-        b = {tuple(r[:4]) for r in ref}
-        assert len(a & b) >= 0.98 * max(len(a), len(b), 1)          # batch size changes K1's partial-sum split
-        total += len(b)
-    assert total > 50
+        A = {tuple(r[:4]): r[4] for r in got}
+        B = {tuple(r[:4]): r[4] for r in ref}
+        bad = [k for k in set(A) ^ set(B) if abs((A.get(k) if k in A else B.get(k)) - 0.2) > parity.TOL_THR]
+        bad += [k for k in set(A) & set(B) if abs(A[k] - B[k]) > parity.TOL_CONF]
+        assert not bad, bad[:5]
+        total += len(B)
+    assert total > 100

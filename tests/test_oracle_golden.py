@@ -6,7 +6,8 @@ import torch
 
 from detectorfreesfm_amd import synth
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config
-from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict
+from detectorfreesfm_amd.params import (loftr_param_spec, multiview_param_spec, planted_loftr_state_dict,
+                                        random_state_dict)
 from oracle import ref_import, restate
 from oracle.make_golden import fine_inputs, la_inputs
 
@@ -64,6 +65,36 @@ def test_loftr_e2e(golden):
     with torch.no_grad():
         o = restate.loftr_coarse_forward(sd, cfg, data)
     assert len(gz["i_ids"]) > 10
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+        assert np.array_equal(o[k].numpy(), gz[k]), k
+
+
+def test_loftr_e2e_planted(golden):
+    """Planted weights (confident matches at thr 0.2), 2 pairs, per-pair scales: oracle == real reference."""
+    gz = golden("loftr_e2e_planted")
+    c = _case(gz)
+    cfg = loftr_coarse_only_config(c["thr"])
+    sd = planted_loftr_state_dict(loftr_param_spec(cfg), c["weight_seed"], c["alpha"])
+    data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    with torch.no_grad():
+        o = restate.loftr_coarse_forward(sd, cfg, data)
+    assert len(gz["i_ids"]) > 100 and gz["mconf"].max() > 0.9
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+        assert np.array_equal(o[k].numpy(), gz[k]), k
+
+
+def test_loftr_e2e_two_sizes(golden):
+    """Frames of different size (two backbone calls, L != S; loftr.py:45-49): oracle == real reference."""
+    gz = golden("loftr_e2e_two_sizes")
+    c = _case(gz)
+    cfg = loftr_coarse_only_config(c["thr"])
+    sd = planted_loftr_state_dict(loftr_param_spec(cfg), c["weight_seed"], c["alpha"])
+    data = synth.coarse_pair_two_sizes(c["H0"], c["W0"], c["H1"], c["W1"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    with torch.no_grad():
+        o = restate.loftr_coarse_forward(sd, cfg, data)
+    assert len(gz["i_ids"]) > 30
     for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
         assert np.array_equal(o[k].numpy(), gz[k]), k
 
