@@ -1,20 +1,30 @@
 #!/usr/bin/env python
 """Hot-path benchmark (driver contract: prints ONE JSON line on rank 0).
 
-A *step* = one pass of the coarse matcher over one batch of 8 synthetic 640x480 pairs that are
-already resident in HBM (BASELINE.json configs[1]); ``value`` = image pairs per second over all
-ranks.  The same run also times the refinement head (configs[2]: 2000 tracks x 5 views) and
-reports it under ``secondary``.  Pairs / track bags shard across ranks with no data-path
-collective (weak scaling: every rank runs its own batch); with N>1 every step ends with the
-path's one real exchange, the all-gather of the match tables (RCCL over xGMI).
+Default workload (``--workload pairs``): a *step* = one pass of the coarse matcher over one batch of 8 synthetic
+640x480 pairs that are already resident in HBM (BASELINE.json configs[1]); ``value`` = image pairs per second over
+all ranks.  The same run also times the refinement head (configs[2]: 2000 tracks x 5 views) and reports it under
+``secondary``.  Four distinct resident batches rotate through the steps; the weights are the seeded "planted" set
+(params.planted_loftr_state_dict), so every step ends with a real match table (~3600 rows per pair at thr 0.2).
+Pairs / track bags shard across ranks with no data-path collective (weak scaling: every rank runs its own batch);
+with N>1 every step ends with the path's one real exchange, the all-gather of the match tables (RCCL over xGMI).
 
-Extra objects: ``roofline`` (dominant hand-written kernel, measured live with events on the
-launch stream), ``rooflines`` (all hand-written kernels), ``breakdown`` (stage times), and on
-rank 0 at N=1 ``cpu_baseline`` (the oracle = CPU port of the reference path, host cores).
+``--gpus N`` without a launcher (WORLD_SIZE unset) re-executes itself under ``torch.distributed.run`` with N ranks
+on 127.0.0.1; under the driver's own torchrun it just reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+Other workloads (explicit, not the headline): ``--workload scene300`` = configs[3] (300 images, 44 850 exhaustive
+pairs sharded over the ranks, backbone once per image, all-gather of the tables, keypoint merge on rank 0);
+``--workload hires832`` = configs[4] (832x832 pairs + one 16 000-track refinement chunk).
+
+Extra objects: ``roofline`` (dominant hand-written kernel, measured live with events on the launch stream),
+``rooflines`` (all hand-written kernels), ``step_roofline`` (whole-step algorithmic flops), ``breakdown`` (stage
+times), and on rank 0 at N=1 ``cpu_baseline`` (the oracle = CPU port of the reference path, host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,14 +33,22 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, ops, synth  # noqa: E402
+from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, ops, plugin, synth  # noqa: E402
 from detectorfreesfm_amd import dist as ddist  # noqa: E402
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config  # noqa: E402
-from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict  # noqa: E402
+from detectorfreesfm_amd.params import (loftr_param_spec, multiview_param_spec, planted_loftr_state_dict,  # noqa: E402
+                                        random_state_dict)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
 MFMA_F16_PEAK_TF = 2500.0    # fp16/bf16 dense MFMA peak (spec; 2178-2382 TF measured micro-benchmarks)
+N_RESIDENT = 4               # distinct resident input batches rotated through the steps
+
+# algorithmic flops (hook-counted on the reference): per 640x480 image / pair / 5-view track
+BACKBONE_FLOP_PER_IMAGE = 163.4e9      # ResNetFPN_8_2 without the dead FPN top-down branch (327 G per pair)
+TRANSFORMER_FLOP_PER_PAIR = 103.0e9    # 16 encoder-layer applications x 6.45 G
+MATCH_FLOP_PER_PAIR = 11.8e9           # 2*L*S*C, counted once
+REFINE_FLOP_PER_TRACK = 6.6e9          # S2DNet 5.1 G + transformer 1.47 G + fine correlation 0.011 G
 
 
 def event_time_ms(fn, iters=10, warmup=2):
@@ -47,14 +65,14 @@ def event_time_ms(fn, iters=10, warmup=2):
 
 
 def timed_steps(step, steps, warmup, distributed):
-    for _ in range(warmup):
-        step()
+    for i in range(warmup):
+        step(i)
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(warmup + i)
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -64,6 +82,18 @@ def timed_steps(step, steps, warmup, distributed):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def _rl(kernel, bound, work, ms, units, **extra):
+    """One roofline entry: ``work`` = algorithmic flops (mfma) or bytes (hbm) of the timed call."""
+    if bound == "mfma":
+        ach, peak, unit = work / ms / 1e9, extra.pop("peak", MFMA_F16_PEAK_TF), "TFLOP/s"
+    else:
+        ach, peak, unit = work / ms / 1e6, HBM_PEAK_GBS, "GB/s"
+    d = {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+         "traffic": None, "ms": ms, "units": units}
+    d.update(extra)
+    return d
 
 
 def kernel_rooflines(dev, batch):
@@ -81,13 +111,22 @@ def kernel_rooflines(dev, batch):
                          tap_padded=True)
     ms = event_time_ms(lambda: ops.conv2d_nhwc(xs, pw, 1, 1, relu=True, out_split=True))
     flops = 2.0 * nimg * 240 * 320 * 128 * 9 * 128
-    out.append({"kernel": "conv_gemm_sf_same_kernel<128,3> (3x3, 128->128 @240x320)", "bound": "mfma",
-                "achieved": flops / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / ms / 1e9 / MFMA_F16_PEAK_TF, "traffic": None, "ms": ms, "units": f"{nimg} images",
-                "mfma_flops_executed_frac": 3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
-                "step_share": "the conv_gemm_sf* kernels are ~70% of the coarse step and ~65% of the refinement step "
-                              "(profiles/r01_*_step_kernel_stats.csv)"})
+    out.append(_rl("conv_gemm_sf_same_kernel<128,3> (3x3, 128->128 @240x320)", "mfma", flops, ms, f"{nimg} images",
+                   mfma_flops_executed_frac=3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
+                   step_share="the conv_gemm_sf* kernels are ~70% of the coarse step and ~65% of the refinement step "
+                              "(profiles/*_step_kernel_stats.csv)"))
     del x, xs, pw
+    # K10 linears of the refinement head (the <128,1,4> instance that dominates the refinement step): mlp.0 of one
+    # encoder layer on the query tokens of a 2000-track x 4-view bag, [rows,256] -> relu -> [rows,256] split planes.
+    # HBM-bound: algorithmic bytes = rows * (K + Cout) * 4 (operands and result are fp32-class, 4 B per element).
+    rows = 2000 * 4 * 225
+    xs = ops.SplitAct.empty_rows((rows,), 256, dev)
+    ops.split_rows(torch.randn((rows, 256), generator=g).to(dev), None, out_split=xs)
+    pw = ops.PackedDense(torch.randn((256, 256), generator=g).to(dev) * 0.06)
+    ms = event_time_ms(lambda: ops.linear(xs, pw, relu=True, out_split=True))
+    out.append(_rl("conv_gemm_sf_same_kernel<128,1> (refinement mlp.0: 256->256 on 1.8 M rows)", "hbm",
+                   rows * 512.0 * 4, ms, f"{rows} rows", tflops_algorithmic=2.0 * rows * 256 * 256 / ms / 1e9))
+    del xs, pw
     # K3+K4+K5 at batch x (4800 x 4800 x 256): algorithmic flops 2*L*S*C per pair
     L = S = 4800
     f0, f1 = synth.correlated_features(batch, L, S, 256, 7, 0.1)
@@ -97,24 +136,17 @@ def kernel_rooflines(dev, batch):
     ops.split_rows(f1, None, out_split=s1)
     ms = event_time_ms(lambda: ops.coarse_match(s0, s1, (60, 80), (60, 80), 0.2, 2, 0.1))
     flops = 2.0 * L * S * 256 * batch
-    out.append({"kernel": "coarse_match_split (cm_gemm_sf x2 + select; the correlation is computed twice, 3 fp16 "
-                          "MFMA products each)", "bound": "mfma", "achieved": flops / ms / 1e9,
-                "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / MFMA_F16_PEAK_TF,
-                "traffic": None, "ms": ms, "units": f"{batch} pairs",
-                "mfma_flops_executed_frac": 6.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF})
+    out.append(_rl("coarse_match_split (split-plane correlation + dual-softmax + mutual-NN + compaction)", "mfma", flops, ms,
+                   f"{batch} pairs"))
     ms32 = event_time_ms(lambda: ops.coarse_match(f0, f1, (60, 80), (60, 80), 0.2, 2, 0.1))
-    out.append({"kernel": "coarse_match_f32 (cm_gemm x2 + select, fp32 matrix path; generic entry point)",
-                "bound": "mfma", "achieved": flops / ms32 / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / ms32 / 1e9 / MFMA_F32_PEAK_TF, "traffic": None, "ms": ms32, "units": f"{batch} pairs"})
+    out.append(_rl("coarse_match_f32 (cm_gemm x2 + select, fp32 matrix path; generic entry point)", "mfma", flops, ms32,
+                   f"{batch} pairs", peak=MFMA_F32_PEAK_TF))
     del s0, s1
     # K1 at the coarse shape, N = 2*batch (both images of every pair in one call): 4*N*L*H*D*4 bytes
     N = 2 * batch
     q, k, v = (torch.randn((N, L, 8, 32), generator=g).to(dev) for _ in range(3))
     ms = event_time_ms(lambda: ops.linear_attention(q, k, v))
-    byts = 4.0 * N * L * 256 * 4
-    out.append({"kernel": "linear_attention D=32", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "ms": ms,
-                "units": f"{N} x 4800 tokens"})
+    out.append(_rl("linear_attention D=32", "hbm", 4.0 * N * L * 256 * 4, ms, f"{N} x 4800 tokens"))
     del q, k, v, f0, f1
     # K8: 2000 tracks x 5 views of 3x35x35 patches; algorithmic bytes = written + read per patch
     M = 10000
@@ -124,20 +156,16 @@ def kernel_rooflines(dev, batch):
     buf = torch.empty((M, 3, 35, 35), device=dev)
     ms = event_time_ms(lambda: ops.roi_align(img, boxes, 35, 35, out=buf))
     del buf
-    byts = M * (3 * 35 * 35 * 4 + 3 * 36 * 36 * 4)
-    out.append({"kernel": "roi_align 3x35x35", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "ms": ms,
-                "units": f"{M} patches"})
-    # K11+K12: 2000 tracks, 4 query views, W=15, C=128: ((V-1)*WW + WW)*C*4 bytes per track
+    out.append(_rl("roi_align 3x35x35", "hbm", M * (3 * 35 * 35 * 4 + 3 * 36 * 36 * 4.0), ms, f"{M} patches"))
+    # K11+K12: 2000 tracks, 4 query views, W=15, C=128.  Bytes the algorithm needs per track: the (V-1) query windows
+    # + the 49 candidate rows of the reference window (left=7) = (4*225 + 49)*128*4 = 486 KB  (SURVEY 8d quotes the
+    # full reference window, 576 KB; the other 176 rows are never part of the result)
     T, Vq, WW, C = 2000, 4, 225, 128
     ref = torch.randn((T, WW, C), generator=g).to(dev)
     qry = torch.randn((T, Vq, WW, C), generator=g).to(dev)
     mask = torch.ones((T, Vq), dtype=torch.bool, device=dev)
     ms = event_time_ms(lambda: ops.fine_match(ref, qry, mask, None, 15, 7))
-    byts = T * (Vq + 1) * WW * C * 4.0
-    out.append({"kernel": "fine_match W=15", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "ms": ms,
-                "units": f"{T} tracks"})
+    out.append(_rl("fine_match W=15", "hbm", T * (Vq * WW + 49) * C * 4.0, ms, f"{T} tracks"))
     return out
 
 
@@ -148,7 +176,7 @@ def cpu_baseline(seconds_budget=25.0):
     from oracle import restate
     cores = torch.get_num_threads()
     cfg = loftr_coarse_only_config(0.2)
-    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    sd = planted_loftr_state_dict(loftr_param_spec(cfg), 0)
     data = synth.coarse_pair_batch(1, 480, 640, seed=1000)
     with torch.no_grad():
         restate.loftr_coarse_forward(sd, cfg, data)      # warm-up
@@ -184,49 +212,68 @@ def _emit(real_stdout_fd, obj):
     os.write(real_stdout_fd, (json.dumps(obj) + "\n").encode())
 
 
-def main():
-    out_fd = _claim_stdout()
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU (BASELINE configs[1]: 8)")
-    ap.add_argument("--tracks", type=int, default=2000, help="tracks per refinement bag (configs[2]: 2000)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rooflines", action="store_true")
-    ap.add_argument("--kernels-only", action="store_true",
-                    help="only time the hand-written kernels at the bench shapes (compact rocprofv3 target)")
-    args = ap.parse_args()
+def _self_spawn(n_gpus: int) -> int:
+    """``bench.py --gpus N`` started without a launcher: run the same command line as N ranks of one node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # DFSFM_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barriers, max-reduce, table all-gather) with a
-    # single rank; the driver's multi-GPU runs set WORLD_SIZE > 1
-    distributed = world > 1 or os.environ.get("DFSFM_BENCH_FORCE_DIST") == "1"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if args.kernels_only:
-        rl = kernel_rooflines(dev, args.batch)
-        _emit(out_fd, {"rooflines": rl})
-        return
-
-    # ---- coarse matcher: configs[1] ---------------------------------------------------------------
-    cfg = loftr_coarse_only_config(0.2)
+def build_coarse(dev, thr=0.2):
+    cfg = loftr_coarse_only_config(thr)
     matcher = HipLoFTR(cfg)
-    matcher.load_state_dict(random_state_dict(loftr_param_spec(cfg), 0), strict=True)
-    matcher = matcher.eval().to(dev)
-    data = synth.to_device(synth.coarse_pair_batch(args.batch, 480, 640, seed=1000 + 100 * rank), dev)
+    matcher.load_state_dict(planted_loftr_state_dict(loftr_param_spec(cfg), 0), strict=True)
+    return matcher.eval().to(dev)
+
+
+def build_refiner(dev):
+    rcfg = multiview_refinement_config()
+    refiner = HipMultiviewMatcher(rcfg, test=True)
+    refiner.load_state_dict(random_state_dict(multiview_param_spec(rcfg), 1), strict=True)
+    return refiner.eval().to(dev)
+
+
+def load_pmc(result):
+    """Attach the HBM traffic measured by the committed rocprofv3 --pmc passes (tools/pmc_collect.py writes
+    profiles/r02_pmc_traffic.json; traffic cannot be counted from inside this process).  Corrected as the MI355X
+    guide prescribes: 2*FETCH_SIZE (16-byte/lane streaming reads) + WRITE_SIZE, per launch."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_kernels_only_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
+        return
+    with open(path) as fh:
+        rows = json.load(fh)["kernels"]
+    groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
+              "conv_gemm_sf_same_kernel<128,1>": ("conv_gemm_sf_same_kernel<128, 1", "conv_gemm_sf_same_kernel<128,1"),
+              "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_kernel",),
+              "fine_match": ("fine_match_kernel",),
+              "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact", "cm_top", "cm_eval"),
+              "coarse_match_f32": ("cm_gemm<",)}
+    for r in result["rooflines"]:
+        for key, subs in groups.items():
+            if r["kernel"].startswith(key):
+                sel = [k for k in rows if any(s_ in k["kernel"] for s_ in subs)]
+                if sel:
+                    r["traffic"] = sum(k["fetch_MB_x2"] + k["write_MB"] for k in sel) * 1024 * 1024
+                    r["traffic_unit"] = f"bytes per call (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/{name})"
+
+
+def run_pairs(args, dev, rank, world, distributed, out_fd):
+    """configs[1] (+ configs[2] as ``secondary``)."""
+    matcher = build_coarse(dev)
+    batches = [synth.to_device(synth.coarse_pair_batch(args.batch, 480, 640, seed=1000 + 1000 * rank + 10 * k), dev)
+               for k in range(N_RESIDENT)]
     n_matches = [0]
 
-    def coarse_step():
-        d = dict(data)
+    def coarse_step(i):
+        d = dict(batches[i % N_RESIDENT])
         matcher(d)
         table = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1)
         if distributed:
@@ -241,6 +288,7 @@ def main():
     # stage breakdown of one coarse step (events, rank 0 only, outside the timed region)
     breakdown = {}
     if rank == 0:
+        data = batches[0]
         P = matcher._packed or matcher._pack()
         imgs = torch.cat([data["image0"], data["image1"]], 0)
         with torch.no_grad():
@@ -256,14 +304,12 @@ def main():
         del imgs, c, f0, f1, g0, g1
 
     # ---- refinement head: configs[2] --------------------------------------------------------------
-    rcfg = multiview_refinement_config()
-    refiner = HipMultiviewMatcher(rcfg, test=True)
-    refiner.load_state_dict(random_state_dict(multiview_param_spec(rcfg), 1), strict=True)
-    refiner = refiner.eval().to(dev)
-    rdata = synth.to_device(synth.refine_bag(args.tracks, 5, 480, 640, seed=2000 + 100 * rank), dev)
+    refiner = build_refiner(dev)
+    bags = [synth.to_device(synth.refine_bag(args.tracks, 5, 480, 640, seed=2000 + 1000 * rank + 10 * k), dev)
+            for k in range(N_RESIDENT)]
 
-    def refine_step():
-        d = dict(rdata)
+    def refine_step(i):
+        d = dict(bags[i % N_RESIDENT])
         refiner(d)
         if distributed:
             rows = torch.cat([d["query_points_refined"][0], d["reference_points_refined"][-1][0].reshape(-1, 2)], 0)
@@ -273,59 +319,185 @@ def main():
     rdt = timed_steps(refine_step, r_steps, min(args.warmup, 2), distributed)
     tracks_per_s = args.tracks * world * r_steps / rdt
 
+    step_flops = args.batch * (2 * BACKBONE_FLOP_PER_IMAGE + TRANSFORMER_FLOP_PER_PAIR + MATCH_FLOP_PER_PAIR)
     result = {
         "metric": "coarse_image_pairs_per_sec", "value": pairs_per_s, "unit": "image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"configs[1]: LoFTR coarse_only, 640x480, batch {args.batch} pairs per GPU per step, "
-                               "seeded random weights, inputs resident in HBM; match-table all-gather per step when N>1",
+                               f"{N_RESIDENT} distinct resident batches rotating, seeded planted weights (real match tables "
+                               "at thr 0.2), inputs resident in HBM; match-table all-gather per step when N>1",
                    "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
         "secondary": {"metric": "refinement_tracks_per_sec", "value": tracks_per_s, "unit": "tracks/s",
                       "steps": r_steps, "ms_per_step": 1000.0 * rdt / r_steps,
-                      "workload": f"configs[2]: MultiviewMatcher, {args.tracks} tracks x 5 views, 640x480 RGB, W=15, crop 35"},
+                      "workload": f"configs[2]: MultiviewMatcher, {args.tracks} tracks x 5 views, 640x480 RGB, W=15, crop 35, "
+                                  f"{N_RESIDENT} distinct resident bags rotating",
+                      "step_roofline": {"algorithmic_flops_per_step": args.tracks * REFINE_FLOP_PER_TRACK,
+                                        "achieved_tflops": args.tracks * REFINE_FLOP_PER_TRACK * world * r_steps / rdt / 1e12,
+                                        "frac_of_fp16_mfma_peak": args.tracks * REFINE_FLOP_PER_TRACK * r_steps / rdt / 1e12 / MFMA_F16_PEAK_TF}},
         "matches_last_step": n_matches[0],
+        "step_roofline": {"algorithmic_flops_per_step": step_flops,
+                          "achieved_tflops_per_gpu": step_flops * args.steps / dt / 1e12,
+                          "frac_of_fp16_mfma_peak": step_flops * args.steps / dt / 1e12 / MFMA_F16_PEAK_TF,
+                          "frac_of_fp32_mfma_peak": step_flops * args.steps / dt / 1e12 / MFMA_F32_PEAK_TF,
+                          "note": "algorithmic flops counted once (SURVEY 8a/8d); the split scheme executes 3 fp16 MFMA "
+                                  "products per algorithmic product"},
         "breakdown": breakdown,
     }
     if rank == 0 and not args.no_rooflines:
         rl = kernel_rooflines(dev, args.batch)
         result["rooflines"] = rl
-        dom = rl[0]     # conv_gemm_sf: by far the largest share of both steps (profiles/r01_*_step_kernel_stats.csv)
-        result["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-        result["roofline"]["kernel"] = dom["kernel"]
+        load_pmc(result)
+        dom = rl[0]     # conv_gemm_sf: by far the largest share of both steps (profiles/*_step_kernel_stats.csv)
+        result["roofline"] = {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}
         result["roofline"]["mfma_flops_executed_frac"] = dom["mfma_flops_executed_frac"]
-        # HBM traffic of that launch cannot be counted from inside this process: it comes from the separate
-        # rocprofv3 --pmc passes committed under profiles/ (same kernel, same shape), corrected as the MI355X
-        # guide prescribes (FETCH_SIZE x2 for 16-byte/lane streaming reads on gfx950).
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_conv_gemm_sf_same.json")
-        if os.path.exists(pmc):
-            with open(pmc) as fh:
-                pj = json.load(fh)
-            result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_unit"] = "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)"
-            result["roofline"]["algorithmic_bytes"] = pj["algorithmic_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = "profiles/r01_pmc_conv_gemm_sf_same.json"
-            dom["traffic"] = pj["hbm_bytes_per_launch"]
-    if rank == 0 and not args.no_rooflines:
-        # per-kernel HBM traffic of the other hand-written kernels, from the committed PMC passes of
-        # `bench.py --kernels-only` (2*FETCH_SIZE + WRITE_SIZE per launch, summed over the kernels of an entry point)
-        pmc_all = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_kernels_only_traffic.json")
-        if os.path.exists(pmc_all):
-            with open(pmc_all) as fh:
-                rows = json.load(fh)["kernels"]
-            groups = {"linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_kernel",),
-                      "fine_match": ("fine_match_kernel",), "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact"),
-                      "coarse_match_f32": ("cm_gemm<",)}
-            for r in result["rooflines"]:
-                for key, subs in groups.items():
-                    if r["kernel"].startswith(key):
-                        mb = sum(k["fetch_MB_x2"] + k["write_MB"] for k in rows if any(s_ in k["kernel"] for s_ in subs))
-                        r["traffic"] = mb * 1024 * 1024
-                        r["traffic_unit"] = "bytes per call (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_kernels_only_traffic.json)"
+        result["roofline"]["algorithmic_bytes"] = 2 * args.batch * 240 * 320 * 128 * 4 * 2 + 9 * 128 * 128 * 4
+        if "traffic_unit" in dom:
+            result["roofline"]["traffic_unit"] = dom["traffic_unit"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         _emit(out_fd, result)
+
+
+def run_scene(args, dev, rank, world, distributed, out_fd):
+    """configs[3]: ETH3D-shaped scene, exhaustive pairs sharded over the ranks (the analogue of
+    src/coarse_match/coarse_match.py:127-140): backbone once per image on every rank, the rank's contiguous shard of
+    the pair list matched from the cached tokens, ONE all-gather of the tables, keypoint merge on rank 0."""
+    n_img = args.scene_images
+    matcher = build_coarse(dev)
+    g = torch.Generator().manual_seed(4242)
+    base = torch.rand((1, 1, 480, 640), generator=g)
+    # a camera sweep: image k = the base texture rolled by k coarse cells (+ noise) -> every pair has a planted flow
+    images = torch.cat([torch.roll(base, shifts=(8 * (k % 7), 8 * k), dims=(2, 3)) + 0.02 * torch.randn((1, 1, 480, 640), generator=g)
+                        for k in range(n_img)], 0).to(dev)
+    pairs = ddist.exhaustive_pairs(n_img)
+    if args.scene_pairs:
+        pairs = pairs[:args.scene_pairs]
+    lo, hi = ddist.shard_range(len(pairs), rank, world)
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    tables = plugin.match_scene_cached(matcher, images, pairs[lo:hi], batch=args.batch, to_host=False)
+    torch.cuda.synchronize()
+    t_match = time.perf_counter() - t0
+    flat = [tables[p] for p in pairs[lo:hi]]
+    gathered = ddist.all_gather_tables(flat) if distributed else flat
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0 - t_match
+    n_rows, n_kpts = sum(int(t.shape[0]) for t in gathered), 0
+    if rank == 0:
+        rows = torch.cat(gathered, 0)
+        lens = torch.tensor([t.shape[0] for t in gathered])
+        pid = torch.tensor(pairs, dtype=torch.int32)
+        rep = torch.repeat_interleave(pid, lens, dim=0).to(dev)
+        kpts, scores, offsets, ids = ops.merge_keypoints(rows, rep[:, 0].contiguous(), rep[:, 1].contiguous(), n_img)
+        n_kpts = int(kpts.shape[0])
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        _emit(out_fd, {
+            "metric": "coarse_image_pairs_per_sec", "value": len(pairs) / dt, "unit": "image-pairs/s", "n_gpus": world,
+            "steps": 1, "warmup": 0, "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"configs[3]: {n_img} images 640x480, {len(pairs)} exhaustive pairs, backbone once per image, "
+                                   "tables all-gathered once, keypoint merge on rank 0",
+                       "parallelism": f"contiguous pair shards over {world} rank(s); one all-gather of match tables"},
+            "phases_s": {"match_rank0": t_match, "all_gather_rank0": t_gather, "total_max_over_ranks": dt},
+            "match_rows": n_rows, "keypoints": n_kpts})
+
+
+def run_hires(args, dev, rank, world, distributed, out_fd):
+    """configs[4]: 832x832 frames through the LoFTR coarse matcher + one 16 000-track refinement chunk."""
+    matcher = build_coarse(dev)
+    nb = max(1, args.batch // 2)
+    batches = [synth.to_device(synth.coarse_pair_batch(nb, 832, 832, seed=500 + 1000 * rank + 10 * k), dev) for k in range(2)]
+    n_matches = [0]
+
+    def coarse_step(i):
+        d = dict(batches[i % 2])
+        matcher(d)
+        n_matches[0] = int(d["mconf"].shape[0])
+    dt = timed_steps(coarse_step, args.steps, args.warmup, distributed)
+    refiner = build_refiner(dev)
+    T = 16000
+    bag = synth.to_device(synth.refine_bag(T, 5, 832, 832, seed=2500 + rank), dev)
+
+    def refine_step(i):
+        refiner(dict(bag))
+    r_steps = max(2, args.steps // 4)
+    rdt = timed_steps(refine_step, r_steps, 1, distributed)
+    if rank == 0:
+        flops = nb * (2 * BACKBONE_FLOP_PER_IMAGE * (832 * 832) / (640 * 480) + 16 * 6.45e9 * 10816 / 4800 + 2.0 * 10816 * 10816 * 256)
+        _emit(out_fd, {
+            "metric": "coarse_image_pairs_per_sec", "value": nb * world * args.steps / dt, "unit": "image-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"configs[4]: LoFTR coarse_only at 832x832 (L = S = 10816), batch {nb} pairs per GPU per step; "
+                                   "refinement chunk_size 16000 x 5 views", "parallelism": f"{world} rank(s), weak"},
+            "matches_last_step": n_matches[0],
+            "step_roofline": {"algorithmic_flops_per_step": flops, "achieved_tflops_per_gpu": flops * args.steps / dt / 1e12,
+                              "frac_of_fp16_mfma_peak": flops * args.steps / dt / 1e12 / MFMA_F16_PEAK_TF},
+            "secondary": {"metric": "refinement_tracks_per_sec", "value": T * world * r_steps / rdt, "unit": "tracks/s",
+                          "steps": r_steps, "ms_per_step": 1000.0 * rdt / r_steps,
+                          "workload": "configs[4]: one 16 000-track x 5-view chunk, 832x832 RGB frames"}})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--tracks", type=int, default=2000, help="tracks per refinement bag (configs[2]: 2000)")
+    ap.add_argument("--workload", choices=("pairs", "scene300", "hires832"), default="pairs")
+    ap.add_argument("--scene-images", type=int, default=300)
+    ap.add_argument("--scene-pairs", type=int, default=0, help="truncate the exhaustive pair list (0 = all)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rooflines", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="only time the hand-written kernels at the bench shapes (compact rocprofv3 target)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_spawn(args.gpus))
+
+    out_fd = _claim_stdout()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DFSFM_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barriers, max-reduce, table all-gather) with a
+    # single rank; multi-GPU runs have WORLD_SIZE > 1
+    distributed = world > 1 or os.environ.get("DFSFM_BENCH_FORCE_DIST") == "1"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        probe = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(probe)                 # RCCL really is up: the sum must equal the world size
+        assert int(probe.item()) == world, (int(probe.item()), world)
+
+    if args.kernels_only:
+        _emit(out_fd, {"rooflines": kernel_rooflines(dev, args.batch)})
+    elif args.workload == "pairs":
+        run_pairs(args, dev, rank, world, distributed, out_fd)
+    elif args.workload == "scene300":
+        run_scene(args, dev, rank, world, distributed, out_fd)
+    else:
+        run_hires(args, dev, rank, world, distributed, out_fd)
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -163,7 +163,7 @@ def merge_match_tables(matches: dict, names: list, pair_name_split: str, device=
 
 
 @torch.no_grad()
-def match_scene_cached(matcher: HipLoFTR, images, pairs, batch=8, scales=None):
+def match_scene_cached(matcher: HipLoFTR, images, pairs, batch=8, scales=None, to_host=True):
     """Exhaustive / covisible pair matching of one scene with the backbone evaluated ONCE per image.
 
     The reference's match_worker (src/coarse_match/coarse_match_worker.py:102-145) feeds every pair through
@@ -172,25 +172,56 @@ def match_scene_cached(matcher: HipLoFTR, images, pairs, batch=8, scales=None):
     index; positional encoding, transformer and matching run per pair exactly as in ``HipLoFTR.forward``.
 
     images: tensor [n_images,1,H,W] (same size); pairs: list of (i, j); scales: optional [n_images,2] (h, w scale).
-    Returns {(i, j): ndarray [M,5]} rows (x0, y0, x1, y1, conf), the per-pair tables match_worker stores."""
-    dev = next(matcher.buffers()).device if any(True for _ in matcher.buffers()) else images.device
-    n = images.shape[0]
+    Only the images that occur in ``pairs`` are run through the backbone (a rank's shard of a scene).
+    Returns {(i, j): [M,5]} rows (x0, y0, x1, y1, conf), the per-pair tables match_worker stores: numpy arrays, or
+    device tensors with ``to_host=False`` (for the all-gather / device-side keypoint merge)."""
+    dev = next(matcher.parameters()).device
+    used = sorted({int(i) for p in pairs for i in p})
+    slot = {img: k for k, img in enumerate(used)}
     toks, hw_c = [], None
-    for lo in range(0, n, 2 * batch):
-        t, hw_c = matcher.image_tokens(images[lo:lo + 2 * batch].to(dev))
+    for lo in range(0, len(used), 2 * batch):
+        idx = torch.tensor(used[lo:lo + 2 * batch])
+        t, hw_c = matcher.image_tokens(images[idx].to(dev))
         toks.append(t)
-    toks = torch.cat(toks, 0)
+    toks = torch.cat(toks, 0) if toks else None
     hw_i = tuple(images.shape[2:])
     out = {}
     for lo in range(0, len(pairs), batch):
         chunk = pairs[lo:lo + batch]
-        i0 = torch.tensor([p[0] for p in chunk], device=dev)
-        i1 = torch.tensor([p[1] for p in chunk], device=dev)
-        s0 = None if scales is None else scales[i0.cpu()]
-        s1 = None if scales is None else scales[i1.cpu()]
+        i0 = torch.tensor([slot[int(p[0])] for p in chunk], device=dev)
+        i1 = torch.tensor([slot[int(p[1])] for p in chunk], device=dev)
+        s0 = None if scales is None else scales[[int(p[0]) for p in chunk]]
+        s1 = None if scales is None else scales[[int(p[1]) for p in chunk]]
         m = matcher.match_tokens(toks[i0], toks[i1], hw_c, hw_c, hw_i, s0, s1)
-        b = m["b_ids"].cpu().numpy()
-        rows = torch.cat([m["mkpts0_c"], m["mkpts1_c"], m["mconf"][:, None]], -1).cpu().numpy()
-        for k, pr in enumerate(chunk):
-            out[tuple(pr)] = rows[b == k]
+        rows = torch.cat([m["mkpts0_c"], m["mkpts1_c"], m["mconf"][:, None]], -1)
+        counts = torch.bincount(m["b_ids"], minlength=len(chunk)).tolist()       # rows come in ascending b order
+        parts = rows.split(counts)
+        if to_host:
+            parts = [p.cpu().numpy() for p in parts]
+        for pr, tab in zip(chunk, parts):
+            out[tuple(pr)] = tab
     return out
+
+
+@torch.no_grad()
+def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", batch=8, scales=None, pairs=None, group=None):
+    """One scene on all ranks of the process group -- the analogue of the reference's Ray fan-out + merge
+    (src/coarse_match/coarse_match.py:127-140, 203-237): every rank matches a contiguous shard of the pair list
+    (``match_scene_cached``: backbone once per image), the match tables are collected with ONE all-gather
+    (``dist.all_gather_tables``: RCCL over xGMI, gloo in the CPU tests), and the keypoint merge runs on the device.
+
+    images [n_images,1,H,W]; names: image names in the same order; pairs: list of (i, j) (default: exhaustive, in the
+    order of src/construct_pairs/pairs_exhaustive.py).  Returns on EVERY rank the reference's dictionaries
+    (matches {"name0<split>name1": [M,5]}, final_keypoints, final_scores, updated_matches)."""
+    from . import dist as ddist
+    import torch.distributed as tdist
+    pairs = ddist.exhaustive_pairs(len(names)) if pairs is None else [tuple(p) for p in pairs]
+    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
+    rank = tdist.get_rank(group) if world > 1 else 0
+    lo, hi = ddist.shard_range(len(pairs), rank, world)
+    mine = match_scene_cached(matcher, images, pairs[lo:hi], batch=batch, scales=scales, to_host=False)
+    tables = ddist.all_gather_tables([mine[p] for p in pairs[lo:hi]], group=group)      # rank order == pair order
+    assert len(tables) == len(pairs)
+    matches = {f"{names[i]}{pair_name_split}{names[j]}": t.cpu().numpy() for (i, j), t in zip(pairs, tables)}
+    kp, sc, upd = merge_match_tables(matches, names, pair_name_split, device=next(matcher.parameters()).device)
+    return matches, kp, sc, upd

@@ -182,16 +182,24 @@ def _maxpool(x):
     return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
 
 
+def _merge(rows, img0, img1, n_images):
+    """ops.merge_keypoints on the numpy restatement of the reference's consumer stage (oracle/restate_merge.py)."""
+    from oracle import restate_merge as rm
+    kp, sc, off, ids = rm.merge_keypoints(rows.numpy().astype("float32").reshape(-1, 5), img0.numpy().astype("int32"),
+                                          img1.numpy().astype("int32"), int(n_images))
+    return torch.from_numpy(kp), torch.from_numpy(sc), torch.from_numpy(off), torch.from_numpy(ids)
+
+
 @contextlib.contextmanager
 def cpu_ops():
     from detectorfreesfm_amd import ops
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
-                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln")}
+                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
-    ops.split_rows, ops.linear_ln = _split_rows, _linear_ln
+    ops.split_rows, ops.linear_ln, ops.merge_keypoints = _split_rows, _linear_ln, _merge
     try:
         yield
     finally:

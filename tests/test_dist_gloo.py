@@ -50,6 +50,52 @@ def test_all_gather_tables_world2():
     assert sum(n for _, _, n in res) == 10
 
 
+def _scene_worker(rank, world, port, q):
+    """plugin.match_scene_sharded on 2 gloo ranks (CPU stand-ins behind ``ops``) == the single-process scene."""
+    import numpy as np
+    from cpu_standins import cpu_ops
+    from detectorfreesfm_amd import HipLoFTR, plugin, synth
+    from detectorfreesfm_amd.config import loftr_coarse_only_config
+    from detectorfreesfm_amd.params import loftr_param_spec, planted_loftr_state_dict
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = loftr_coarse_only_config(0.2)
+    m = HipLoFTR(cfg).eval()
+    m.load_state_dict(planted_loftr_state_dict(loftr_param_spec(cfg), 0), strict=True)
+    base = synth.coarse_pair_batch(2, 64, 96, seed=1000)
+    images = torch.cat([base["image0"], base["image1"]], 0)            # 4 images -> 6 exhaustive pairs, 3 per rank
+    names = [f"scene/img{k}.jpg" for k in range(4)]
+    with cpu_ops(), torch.no_grad():
+        matches, kp, sc, upd = plugin.match_scene_sharded(m, images, names, " ", batch=2)
+        ok = len(matches) == 6 and list(matches) == [f"{names[i]} {names[j]}" for i, j in ddist.exhaustive_pairs(4)]
+        if rank == 0:          # the same scene in one process
+            full = plugin.match_scene_cached(m, images, ddist.exhaustive_pairs(4), batch=2)
+            ref = {f"{names[i]} {names[j]}": t for (i, j), t in full.items()}
+            kp1, sc1, upd1 = plugin.merge_match_tables(ref, names, " ", device="cpu")
+            ok = ok and all(np.array_equal(matches[k][:, :4], ref[k][:, :4]) and
+                            np.allclose(matches[k][:, 4], ref[k][:, 4], atol=1e-5) for k in ref)
+            ok = ok and all(np.array_equal(kp[n], kp1[n]) for n in names) and all(np.array_equal(upd[k], upd1[k]) for k in ref)
+            ok = ok and sum(len(t) for t in ref.values()) > 20
+    q.put((rank, bool(ok), sum(len(t) for t in matches.values())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_sharded_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2] > 20          # every rank holds the full set of tables
+
+
 def test_single_process_passthrough():
     t = [torch.ones(3, 5), torch.zeros(0, 5)]
     assert ddist.all_gather_tables(t)[0] is t[0]

@@ -3,13 +3,13 @@ import sys, torch
 sys.path.insert(0, '.')
 from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, synth
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config
-from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, random_state_dict
+from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, planted_loftr_state_dict, random_state_dict
 which = sys.argv[1] if len(sys.argv) > 1 else 'coarse'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = 'cuda:0'
 if which == 'coarse':
     cfg = loftr_coarse_only_config(0.2)
-    m = HipLoFTR(cfg); m.load_state_dict(random_state_dict(loftr_param_spec(cfg), 0)); m = m.eval().to(dev)
+    m = HipLoFTR(cfg); m.load_state_dict(planted_loftr_state_dict(loftr_param_spec(cfg), 0)); m = m.eval().to(dev)
     data = synth.to_device(synth.coarse_pair_batch(8, 480, 640, seed=1000), dev)
 else:
     cfg = multiview_refinement_config()
