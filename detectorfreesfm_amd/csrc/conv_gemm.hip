@@ -27,6 +27,7 @@
 // Ablation builds (-DDFSFM_ABL_*, tools/abl_conv.sh) switch single resources off for measurements.
 #include "common.h"
 #include "sf_gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -285,12 +286,13 @@ struct V2 {
 // Shared epilogue of the split-input kernels: the accumulator tile goes through LDS so each thread owns 8
 // consecutive channels of one output row: bias (folded BN), fp32 / split residual, ReLU, then 32-byte fp32
 // stores and/or 16+16-byte split stores.  Must be entered with no LDS-DMA in flight.
-template <int BN_, int BM_ = BM2>
-__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * BM_ / (64 * BM2)],
-                                            f32x16 (&accx)[2][BN_ * BM_ / (64 * BM2)], int64_t m0, int n0, int tid,
+// NT = threads of the workgroup (512: 8 waves; 256: the 4-wave linear kernel); every wave owns 64 rows.
+template <int BN_, int BM_ = BM2, int NT = 512>
+__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * BM_ / (32 * NT)],
+                                            f32x16 (&accx)[2][BN_ * BM_ / (32 * NT)], int64_t m0, int n0, int tid,
                                             int wr, int wc, int col, int kgrp) {
     constexpr int TILE_LD_ = BN_ + 4;                        // fp32 staging-tile row (floats)
-    constexpr int NJ = BN_ * BM_ / (64 * BM2);               // 32-wide column blocks per wave (waves: BM_/64 x 512/BM_)
+    constexpr int NJ = BN_ * BM_ / (32 * NT);                // 32-wide column blocks per wave (waves: BM_/64 x NT/BM_)
     constexpr int WCOLS = NJ * 32;                            // columns per wave
 #ifdef DFSFM_ABL_NOEPI
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -310,11 +312,11 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
                 tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * TILE_LD_ + wc * WCOLS + j * 32 + col] =
                     accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
     __syncthreads();
-    // Every thread owns one 8-channel chunk (fixed: 512 % CH == 0) of IT rows.  All memory operations of the IT
+    // Every thread owns one 8-channel chunk (fixed: NT % CH == 0) of IT rows.  All memory operations of the IT
     // rows are issued before anything waits on them: tile reads, then the residual loads, then arithmetic and
     // stores -- the epilogue is latency-bound otherwise (one dependent global load per row).
     constexpr int CH = BN_ / 8;                               // 8-channel chunks per row
-    constexpr int RPI = 512 / CH;                             // rows per pass
+    constexpr int RPI = NT / CH;                              // rows per pass
     constexpr int IT = BM_ / RPI;                             // passes (8 for BN=128, 4 for BN=64; 8 for 128 x 256)
     const int c8 = (tid % CH) * 8, rr = tid / CH;
     const int n = n0 + c8;
@@ -681,6 +683,183 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
     sf_epilogue<BN_, S_::BM>(g, smem, accm, accx, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane & 31, lane >> 5);
 }
 
+// =================================================================================================
+// Linear layers / 1x1 convolutions, second schedule: 128 x 128 tile, 256 threads (4 waves as 2 x 2, 64 x 64 each),
+// TWO workgroups per CU.  The 512-thread kernel above owns a whole CU, so while it runs its epilogue (LDS staging,
+// LayerNorm / split arithmetic, the output burst) nothing feeds the matrix pipe or the load path, and with K = 128..512
+// the epilogue is 30-40 % of a tile; the K <= 256 linears of the refinement head are HBM-bound and reach only a third of
+// the HBM rate because loads (main loop) and stores (epilogue) never overlap inside a CU.  Here the co-resident
+// workgroup's main loop runs under this one's epilogue, tiles are 2-4x finer (less quantisation loss on 256 CUs), and
+// the HBM stream of one workgroup overlaps the MFMA phase of the other.
+// Ring: A NA_ deep (3: two slabs of the HBM-resident operand in flight), B (weights, L2-resident) 2 deep; per iteration
+// ONE barrier: [wait own pieces of slab t] [barrier] [DMA B(t+1), A(t+NA_-1)] [16 fragment reads] [24 MFMAs].
+// B is issued before A, so the newest (NA_-2)*4 pieces in the queue are exactly the A slabs that may stay in flight.
+// =================================================================================================
+template <int NA_>
+struct LIN {
+    static constexpr int BM = 128, BN = 128, NT = 256;
+    static constexpr int PLANE = 128 * 64;                   // [128 rows][32 halves]
+    static constexpr int STAGE = 2 * PLANE;                  // hi, lo
+    static constexpr int NA = NA_, NB = 2;
+    static constexpr int OFF_B = NA * STAGE;
+    static constexpr int RING = OFF_B + NB * STAGE;          // 80 KB (NA 3) / 64 KB (NA 2)
+    static constexpr int TILE_BYTES = BM * (BN + 4) * 4;
+    static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
+    static constexpr int NWAIT = (NA - 2) * 4;               // own pieces allowed in flight when slab t is published
+    static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int NA_>
+__global__ __launch_bounds__(256, 2) void linear_gemm_sf_kernel(ConvArgs g) {
+    using T = LIN<NA_>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kgrp = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.Cout + T::BN - 1) / T::BN;
+    const unsigned tile_id = xcd_band_tile(blockIdx.x, gridDim.x >> 3);
+    if (tile_id >= g.ntiles) return;
+    const int64_t m0 = (int64_t)(tile_id / ntn) * T::BM;
+    const int n0 = (tile_id % ntn) * T::BN;
+    const int nk = g.Kpad / BK;
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.wh, 0, g.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
+
+    // lane -> (row within a 16-row group, 16-byte k-slot); the XOR swizzle sits on the SOURCE address
+    const int lrow = lane >> 2;
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    // this wave stages 16-row groups `wave` and `wave + 4` of both operands (hi and lo plane each: 4 + 4 pieces)
+    int64_t abase[2];
+    bool aok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t pix = m0 + (wave + 4 * q) * 16 + lrow;
+        aok[q] = pix < g.M;
+        const int64_t pp = aok[q] ? pix : 0;
+        const int ox = (int)(pp % g.W);
+        const int64_t t = pp / g.W;
+        const int oy = (int)(t % g.H);
+        abase[q] = (t / g.H) * g.sxn + (int64_t)oy * g.sxh + (int64_t)ox * g.ldx + lslot * 8;
+    }
+    const unsigned bbase = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);
+    unsigned offA[2], offB[2];
+    auto addrA = [&](int t) __attribute__((always_inline)) {
+        const bool in = t < nk && t * BK + lslot * 8 < g.Cin;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) offA[q] = (aok[q] && in) ? (unsigned)((abase[q] + t * BK) * 2) : g.xbytes;
+    };
+    auto addrB = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            offB[q] = t < nk ? bbase + (unsigned)(wave + 4 * q) * 16u * (unsigned)g.Kpad * 2u + (unsigned)(t * BK * 2) : g.wbytes;
+    };
+#define LDMA_A(stage)                                                                                                  \
+    do {                                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                              \
+            char* d_ = smem + (stage) * T::STAGE + (wave + 4 * q_) * 1024;                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)d_, 16, offA[q_], 0, 0, 0);                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(d_ + T::PLANE), 16, offA[q_], 0, 0, 0);           \
+        }                                                                                                               \
+    } while (0)
+#define LDMA_B(stage)                                                                                                  \
+    do {                                                                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                              \
+            char* d_ = smem + T::OFF_B + (stage) * T::STAGE + (wave + 4 * q_) * 1024;                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_void*)d_, 16, offB[q_], 0, 0, 0);                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d_ + T::PLANE), 16, offB[q_], 0, 0, 0);           \
+        }                                                                                                               \
+    } while (0)
+
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            accm[i][j] = f32x16{0};
+            accx[i][j] = f32x16{0};
+        }
+
+    // prologue: B(0), A(0) .. A(NA-2)
+    addrB(0);
+    LDMA_B(0);
+#pragma unroll
+    for (int t = 0; t < T::NA - 1; ++t) {
+        addrA(t);
+        LDMA_A(t);
+    }
+    int ast = 0, bst = 0;                                    // stages of A(t), B(t)
+    for (int t = 0; t < nk; ++t) {
+        wait_vmcnt<T::NWAIT>();                              // own pieces of B(t), A(t) have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                        // slab t published; every wave is done with slab t-1
+        __builtin_amdgcn_sched_barrier(0);
+        const int adm = ast == 0 ? T::NA - 1 : ast - 1;      // stage of A(t-1) = where A(t+NA-1) goes
+        addrB(t + 1);
+        LDMA_B(bst ^ 1);
+        addrA(t + T::NA - 1);
+        LDMA_A(adm);
+        const char* sa = smem + ast * T::STAGE;
+        const char* sb = smem + T::OFF_B + bst * T::STAGE;
+        // fragments of both k-steps live in registers (64 VGPRs): k-step 1 is read under k-step 0's MFMAs; the other
+        // workgroup's wave on this SIMD covers the head of the segment
+        half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        auto read_ks = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = tile_off(wr * 64 + i * 32 + col, ks * 2 + kgrp);
+                ah[ks][i] = *reinterpret_cast<const half8*>(sa + off);
+                al[ks][i] = *reinterpret_cast<const half8*>(sa + T::PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = tile_off(wc * 64 + j * 32 + col, ks * 2 + kgrp);
+                bh[ks][j] = *reinterpret_cast<const half8*>(sb + off);
+                bl[ks][j] = *reinterpret_cast<const half8*>(sb + T::PLANE + off);
+            }
+        };
+        auto mma_ks = [&](int ks) __attribute__((always_inline)) {      // consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], accm[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], accx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], accx[i][j], 0, 0, 0);
+        };
+        read_ks(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        read_ks(1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_ks(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k-step 1 fragments; also: this wave's reads of slab t are complete (WAR for t+1's DMA)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_ks(1);
+        __builtin_amdgcn_s_setprio(0);
+        ast = ast == T::NA - 1 ? 0 : ast + 1;
+        bst ^= 1;
+    }
+    wait_vmcnt<0>();                                         // the zero-fill tail pieces, before LDS is reused
+#undef LDMA_A
+#undef LDMA_B
+    sf_epilogue<T::BN, T::BM, T::NT>(g, smem, accm, accx, m0, n0, tid, wr, wc, col, kgrp);
+}
+
 // 3x3 / stride 2 / pad 1 max pooling, NHWC (nn.MaxPool2d(3, 2, 1), s2dnet.py:89-92)
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 int H, int W, int C, int Ho, int Wo, int64_t total4) {
@@ -775,6 +954,27 @@ void launch_same(const ConvArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL((conv_gemm_sf_same_kernel<BN_, KW, WM>), grid, dim3(512), S_::SMEM, stream, a);
 }
 
+template <int NA_>
+void launch_lin(const ConvArgs& g, hipStream_t stream) {
+    using T = LIN<NA_>;
+    static dfsfm::SmemAttr smem_attr;
+    smem_attr.ensure(reinterpret_cast<const void*>(&linear_gemm_sf_kernel<NA_>), T::SMEM);
+    ConvArgs a = g;
+    a.ntiles = (unsigned)((g.M + T::BM - 1) / T::BM) * (unsigned)((g.Cout + T::BN - 1) / T::BN);
+    const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
+    hipLaunchKernelGGL(linear_gemm_sf_kernel<NA_>, grid, dim3(T::NT), T::SMEM, stream, a);
+}
+
+// DFSFM_LIN2: 1 (default) = 128 x 128 / two-workgroups-per-CU schedule for linear layers with Cout > 64, A ring 3 deep;
+// 2 = the same with a 2-deep A ring; 0 = the 512-thread schedule everywhere (A/B control).
+int lin2_mode() {
+    static const int mode = [] {
+        const char* e = getenv("DFSFM_LIN2");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 }  // namespace
 
 extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
@@ -847,6 +1047,10 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1, 128x256 tile)");
         }
         if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {    // 1x1 / linear: the same schedule with one tap
+            if (Cout > 64 && (!ln_gamma || Cout == 128) && lin2_mode() != 0) {
+                if (lin2_mode() == 2) launch_lin<2>(g, stream); else launch_lin<3>(g, stream);
+                return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(linear, 128x128 tile)");
+            }
             if (Cout <= 64) launch_same<64, 1>(g, stream); else launch_same<128, 1>(g, stream);
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1)");
         }
