@@ -26,6 +26,7 @@
 // conflict-free; next k-slab is prefetched into registers while the MFMAs run.
 #include "common.h"
 #include "sf_gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,7 +38,8 @@ constexpr int SMEM_TILE = BM * TILE_LD * 4;                  // 66048 B
 constexpr int SMEM_STATS = (BM + BN) * (8 + 4);              // row/col (max,sum) + candidate gates
 constexpr int SMEM_BYTES = SMEM_TILE + SMEM_STATS;           // 68096 B -> 2 workgroups / CU
 
-enum { MODE_STATS = 0, MODE_SELECT = 1, MODE_CONF = 2 };
+enum { MODE_STATS = 0, MODE_SELECT = 1, MODE_CONF = 2, MODE_CAND = 3 };
+constexpr int CAND_SLOTS_MAX = 8;                             // candidate slots per (row, column tile) the workspace is sized for
 
 struct GemmArgs {
     const float* f0;
@@ -294,6 +296,9 @@ struct GemmSfArgs {
     const float2* col_stat;
     unsigned long long* row_best;
     unsigned int* col_best;
+    float2* cand;            // MODE_CAND: [N][ntn][L][slots] (sim, column index bits) of entries that pass the tile-local gates
+    uint8_t* cand_cnt;       //            [N][ntn][L] number of valid slots
+    int slots;
 };
 
 // exp for the softmax denominators of the split path: v_exp_f32(x * log2 e).  The argument is <= 0; the product's
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
     const int tm = t_id / g.ntn, tn = t_id % g.ntn;
     const int row0 = tm * SF_BM, col0 = tn * SF_BN;
 
-    if (MODE != MODE_STATS) {
+    if (MODE == MODE_SELECT) {
         if (tid < SF_BM) {
             const int i = row0 + tid;
             const float2 st = i < g.L ? g.row_stat[(int64_t)n * g.L + i] : make_float2(0.f, 1.f);
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
 
     // lane holds sim[row = wr*64 + i*32 + mfma32_row(r,half)][col = wc*64 + j*32 + (lane&31)]
     const int nrow = min(SF_BM, g.L - row0), ncol = min(SF_BN, g.S - col0);
-    if (MODE == MODE_STATS) {
+    if (MODE == MODE_STATS || MODE == MODE_CAND) {
         // Statistics straight from the accumulator registers: a lane's 16 registers of one block are 16 rows of ONE
         // column (column sums are lane-local), and the 32 lanes of a half wave hold the 32 columns of one row (row
         // sums are a 32-lane butterfly).  Only the per-wave partials go through LDS.
@@ -419,15 +424,58 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                 e = half_wave_sum(e);
                 if (col == 0) s_rp[wc * SF_BM + wr * 64 + i * 32 + mfma32_row(r, half)] = make_float2(m, e);
             }
+        // MODE_CAND (single-GEMM path, thr >= 1/8): besides the partial statistics, remember every entry that could still
+        // reach conf > thr.  conf = p_row * p_col > thr needs p_row > thr and p_col > thr; the log-sum-exp of a whole
+        // row / column is >= that of its part inside this tile, so an entry that fails the gate built from the TILE's
+        // statistics (s > max + log(thr * sum) - 1e-3, the gate cm_gemm_sf<SELECT> applies with the global statistics)
+        // fails the global one too: the survivors are a superset of the true candidates, at most floor(1 / (thr e^-1e-3))
+        // per row and tile, and the exact decision is taken later from their stored fp32 similarities (cm_eval).
+        float* s_rg = reinterpret_cast<float*>(smem + 8192);              // [SF_BM] tile-local row gate
+        float* s_cg = s_rg + SF_BM;                                       // [SF_BN] tile-local column gate
+        int* s_cnt = reinterpret_cast<int*>(s_cg + SF_BN);                // [SF_BM] slots taken per row
         __syncthreads();
         if (tid < SF_BM) {
-            if (tid < nrow)
-                g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = merge_stat(s_rp[tid], s_rp[SF_BM + tid]);
+            const float2 st = merge_stat(s_rp[tid], s_rp[SF_BM + tid]);
+            if (tid < nrow) g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = st;
+            if (MODE == MODE_CAND) {
+                s_rg[tid] = (tid < nrow && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+                s_cnt[tid] = 0;
+            }
         } else {
             const int c = (tid - SF_BM) & (SF_BN - 1), h = (tid - SF_BM) >> 7;   // column c, 128-row half h
+            const float2 st = merge_stat(s_cp[(2 * h) * SF_BN + c], s_cp[(2 * h + 1) * SF_BN + c]);
             if (c < ncol)        // an empty half (rows past L) leaves the neutral partial (-inf, 0)
-                g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] =
-                    merge_stat(s_cp[(2 * h) * SF_BN + c], s_cp[(2 * h + 1) * SF_BN + c]);
+                g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] = st;
+            if (MODE == MODE_CAND && h == 0) {
+                const float2 all = merge_stat(st, merge_stat(s_cp[2 * SF_BN + c], s_cp[3 * SF_BN + c]));
+                s_cg[c] = (c < ncol && all.x != -INFINITY) ? all.x + logf(g.thr * all.y) - 1e-3f : INFINITY;
+            }
+        }
+        if (MODE == MODE_CAND) {
+            __syncthreads();
+            float cg[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cg[j] = s_cg[wc * 64 + j * 32 + col];
+            const int64_t slot0 = ((int64_t)n * g.ntn + tn) * g.L + row0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
+                    const float rg = s_rg[lr];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float sv = accm[i][j][r];                       // -inf outside the matrix
+                        if (sv > rg && sv > cg[j]) {
+                            const int slot = atomicAdd(&s_cnt[lr], 1);
+                            if (slot < g.slots)
+                                g.cand[(slot0 + lr) * g.slots + slot] =
+                                    make_float2(sv, __int_as_float(col0 + wc * 64 + j * 32 + col));
+                        }
+                    }
+                }
+            __syncthreads();
+            if (tid < nrow) g.cand_cnt[slot0 + tid] = (uint8_t)min(s_cnt[tid], g.slots);
         }
         return;
     }
@@ -528,6 +576,40 @@ __global__ __launch_bounds__(256) void cm_reduce_stats(const float2* __restrict_
     }
 }
 
+// Single-GEMM path: exact confidences of the stored candidates (reference operation order: exp(s - max) / sum per
+// axis, then the product -- coarse_matching.py:106-116) with the GLOBAL statistics; row-best (conf, smallest j) needs no
+// atomics (one thread sees every candidate of its row), column-best via the same order-independent atomicMax as the
+// two-pass path.  Decisions and values are identical to cm_gemm_sf<SELECT>: same fp32 similarity, same arithmetic.
+__global__ __launch_bounds__(256) void cm_eval(const float2* __restrict__ cand, const uint8_t* __restrict__ cand_cnt,
+                                               const float2* __restrict__ row_stat, const float2* __restrict__ col_stat,
+                                               unsigned long long* __restrict__ row_best, unsigned int* __restrict__ col_best,
+                                               int L, int S, int ntn, int slots, float thr) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const float2 rs = row_stat[(int64_t)n * L + i];
+    unsigned long long key = 0ull;
+    for (int t = 0; t < ntn; ++t) {
+        const int64_t e = ((int64_t)n * ntn + t) * L + i;
+        const int c = cand_cnt[e];
+        for (int q = 0; q < c; ++q) {
+            const float2 cd = cand[e * slots + q];
+            const float s = cd.x;
+            const int j = __float_as_int(cd.y);
+            const float2 cs = col_stat[(int64_t)n * S + j];
+            const float p_col = expf(s - cs.x) / cs.y;
+            const float p_row = expf(s - rs.x) / rs.y;
+            const float conf = p_col * p_row;
+            if (conf > thr) {
+                atomicMax(&col_best[(int64_t)n * S + j], __float_as_uint(conf));
+                const unsigned long long k = ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned)(~(unsigned)j);
+                key = k > key ? k : key;
+            }
+        }
+    }
+    if (key != 0ull) row_best[(int64_t)n * L + i] = key;
+}
+
 // Per-row decision; one workgroup per pair.  flags[n][i] = 1 iff row i yields a match.
 __global__ __launch_bounds__(1024) void cm_select(const unsigned long long* __restrict__ row_best,
                                                   const unsigned int* __restrict__ col_best,
@@ -615,6 +697,8 @@ struct Workspace {
     unsigned int* col_best;
     uint8_t* flags;
     int32_t* counts;
+    float2* cand;            // [N][ntn][L][CAND_SLOTS_MAX]
+    uint8_t* cand_cnt;       // [N][ntn][L]
     size_t bytes;
 };
 
@@ -636,6 +720,8 @@ Workspace carve(void* base, int N, int L, int S) {
     w.col_best = reinterpret_cast<unsigned int*>(take((size_t)N * S * 4));
     w.flags = reinterpret_cast<uint8_t*>(take((size_t)N * L));
     w.counts = reinterpret_cast<int32_t*>(take((size_t)N * 4));
+    w.cand_cnt = reinterpret_cast<uint8_t*>(take((size_t)N * ntn * L));
+    w.cand = reinterpret_cast<float2*>(take((size_t)N * ntn * L * CAND_SLOTS_MAX * sizeof(float2)));
     w.bytes = off;
     return w;
 }
@@ -723,10 +809,24 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
         g.acc_mul = 1.f / (float)C; g.temperature = temperature; g.thr = thr;
         g.row_part = w.row_part; g.col_part = w.col_part; g.row_stat = w.row_stat; g.col_stat = w.col_stat;
         g.row_best = w.row_best; g.col_best = w.col_best;
-        launch_gemm_sf<MODE_STATS>(g, N, stream);
-        hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
-                           w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, nparts, g.ntn);
-        launch_gemm_sf<MODE_SELECT>(g, N, stream);
+        // Single-GEMM path: at most floor(1 / (thr e^-1e-3)) entries of a row (or column) can pass the row gate, so for
+        // thr >= 1/8 a fixed number of candidate slots per (row, column tile) holds every possible match and the second
+        // correlation pass is replaced by an O(candidates) evaluation.  DFSFM_CM_TWOPASS=1 forces the two-pass path (A/B).
+        static const bool force_two_pass = [] { const char* e = getenv("DFSFM_CM_TWOPASS"); return e && atoi(e) != 0; }();
+        const int slots = thr > 0.f ? (int)floorf(1.f / (thr * 0.998f)) : CAND_SLOTS_MAX + 1;
+        if (slots <= CAND_SLOTS_MAX && !force_two_pass) {
+            g.cand = w.cand; g.cand_cnt = w.cand_cnt; g.slots = slots;
+            launch_gemm_sf<MODE_CAND>(g, N, stream);
+            hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
+                               w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, nparts, g.ntn);
+            hipLaunchKernelGGL(cm_eval, dim3((L + 255) / 256, N), dim3(256), 0, stream, w.cand, w.cand_cnt, w.row_stat,
+                               w.col_stat, w.row_best, w.col_best, L, S, g.ntn, slots, thr);
+        } else {
+            launch_gemm_sf<MODE_STATS>(g, N, stream);
+            hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
+                               w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, nparts, g.ntn);
+            launch_gemm_sf<MODE_SELECT>(g, N, stream);
+        }
     } else {
         bool prescale;
         GemmArgs g = make_args(feat0, feat1, L, S, C, temperature, thr, w, &prescale);

@@ -751,12 +751,20 @@ __global__ __launch_bounds__(256, 2) void linear_gemm_sf_kernel(ConvArgs g) {
     auto addrA = [&](int t) __attribute__((always_inline)) {
         const bool in = t < nk && t * BK + lslot * 8 < g.Cin;
 #pragma unroll
+#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBA)
+        for (int q = 0; q < 2; ++q) offA[q] = g.xbytes + (in ? 0u : 16u);      // ablation: A pieces zero-fill (no traffic)
+#else
         for (int q = 0; q < 2; ++q) offA[q] = (aok[q] && in) ? (unsigned)((abase[q] + t * BK) * 2) : g.xbytes;
+#endif
     };
     auto addrB = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
+#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBB)
+            offB[q] = g.wbytes + (t < nk ? 0u : 16u);
+#else
             offB[q] = t < nk ? bbase + (unsigned)(wave + 4 * q) * 16u * (unsigned)g.Kpad * 2u + (unsigned)(t * BK * 2) : g.wbytes;
+#endif
     };
 #define LDMA_A(stage)                                                                                                  \
     do {                                                                                                                \
