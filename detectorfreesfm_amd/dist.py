@@ -25,6 +25,21 @@ def shard_list(items: Sequence, rank: int, world_size: int):
     return items[lo:hi]
 
 
+def shard_tracks(n_tracks: int, rank: int, world_size: int, seed=None) -> List[int]:
+    """Indices (into ``point_cloud_assigned_imgID_kptID``) of the feature tracks one rank refines -- the analogue of
+    ``chunk_index_balance(len(...), n_workers, shuffle=True)`` (src/utils/ray_utils.py:122-131, called at
+    src/post_optimization/matcher_model/multiview_match.py:39-43): an (optionally seeded-shuffled) index array dealt
+    round-robin.  The unit is the TRACK: each rank builds its bags from its own subset (``BagPlanner(...,
+    worker_split_idxs=...)``), so the bags a long track is split into -- which depend on one another through
+    ``UpdatedQueryPts`` -- always run on one rank, in order.  No data-path collective; results are collected with
+    ``all_gather_tables`` ((M,4) rows [x, y, image id, keypoint index])."""
+    idx = list(range(n_tracks))
+    if seed is not None:
+        import random
+        random.Random(seed).shuffle(idx)
+    return idx[rank::world_size]
+
+
 def exhaustive_pairs(n_images: int) -> List[Tuple[int, int]]:
     """All i<j pairs in the order of src/construct_pairs/pairs_exhaustive.py:5-11."""
     return [(i, j) for i in range(n_images) for j in range(i + 1, n_images)]

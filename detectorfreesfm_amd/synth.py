@@ -73,6 +73,80 @@ def refine_bag(T: int = 2000, V: int = 5, H: int = 480, W: int = 640, seed: int 
     return data
 
 
+class _Obj:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class SyntheticSfMScene:
+    """A COLMAP-shaped scene with the attributes ``MatchingMultiviewData`` reads from ``colmap_image_dataset``
+    (src/dataset/coarse_sfm_refinement_dataset.py:76-115, 361-390): cameras on a ring around a point cloud, every 3D
+    point observed by 2..max_views images (a few of them twice in one image, as COLMAP tracks can be), keypoints =
+    noisy projections, the reference node of a track chosen by the 'middle' point-scale rule (:236-297)."""
+
+    def __init__(self, n_images=10, n_points=200, seed=0, hw=(96, 128), max_views=12, with_scale=True):
+        import numpy as np
+        rng = np.random.default_rng(seed)
+        H, W = hw
+        f = 0.9 * W
+        self.colmap_images, self.colmap_3ds, self.image_intrin_extrins = {}, {}, {}
+        ids = list(range(1, n_images + 1))
+        for i in ids:
+            ang = 2 * np.pi * (i - 1) / n_images + 0.1 * rng.standard_normal()
+            c = np.array([3.0 * np.cos(ang), 0.3 * rng.standard_normal(), 3.0 * np.sin(ang)])
+            z = -c / np.linalg.norm(c)
+            x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+            x /= np.linalg.norm(x)
+            R = np.stack([x, np.cross(z, x), z])
+            self.image_intrin_extrins[i] = {"intrin": np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]]),
+                                            "extrin": [R, -R @ c]}
+        kpts = {i: [] for i in ids}
+        obs_p3d = {i: [] for i in ids}
+        self.point_cloud_assigned_imgID_kptID = {}
+        for pid in range(1, n_points + 1):
+            xyz = 0.6 * rng.standard_normal(3)
+            nv = int(rng.integers(2, min(max_views, n_images) + 1))
+            seen = [int(v) for v in rng.choice(ids, size=nv, replace=False)]
+            if rng.random() < 0.1:
+                seen.append(seen[int(rng.integers(0, len(seen)))])      # the same image twice in one track
+            image_ids, p2d, scales = [], [], []
+            for i in seen:
+                K, (R, t) = self.image_intrin_extrins[i]["intrin"], self.image_intrin_extrins[i]["extrin"]
+                cam = R @ xyz + t
+                uv = (K @ cam)[:2] / (cam[2] + 1e-4) + rng.standard_normal(2)
+                image_ids.append(i)
+                p2d.append(len(kpts[i]))
+                kpts[i].append(uv)
+                obs_p3d[i].append(pid)
+                scales.append(K[0, 0] / (cam[2] + 1e-4))
+            self.colmap_3ds[pid] = _Obj(xyz=xyz, image_ids=np.array(image_ids, dtype=np.int32),
+                                        point2D_idxs=np.array(p2d, dtype=np.int32))
+            order = np.argsort(np.array(scales))
+            a = int(order[len(order) // 2])
+            self.point_cloud_assigned_imgID_kptID[pid] = (image_ids[a], p2d[a])
+        self.keyframe_dict = {}
+        for i in ids:
+            self.colmap_images[i] = _Obj(xys=np.array(kpts[i], dtype=np.float64).reshape(-1, 2),
+                                         point3D_ids=np.array(obs_p3d[i], dtype=np.int64))
+            state = np.full(len(kpts[i]), -3, dtype=np.int64)
+            for pid, (img, k) in self.point_cloud_assigned_imgID_kptID.items():
+                if img == i:
+                    state[k] = pid
+            self.keyframe_dict[i] = state[state >= 0].astype(np.int32)
+        self.colmapID2frameID_dict = {i: i - 1 for i in ids}
+        self.colmap_cameras = {}                                   # read by the reference's constructor, unused
+        g = torch.Generator().manual_seed(seed)
+        self._items = [{"image": torch.rand((3, H, W), generator=g),
+                        **({"scale": torch.tensor([1.0 + 0.25 * (k % 3), 1.0 + 0.5 * (k % 2)])} if with_scale else {})}
+                       for k in range(n_images)]
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, frame_id):
+        return self._items[frame_id]
+
+
 def to_device(data: dict, device):
     out = {}
     for k, v in data.items():

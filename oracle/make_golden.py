@@ -208,9 +208,31 @@ def merge_golden():
     print("merge_keypoints.npz", {k: v.shape for k, v in out.items() if k.endswith("rows")})
 
 
+def bags_golden():
+    """Host-side feeding: the reference's own MatchingMultiviewData on a seeded synthetic scene
+    -> tests/golden/bags.npz (bag lists as JSON + the tensors of every bag, concatenated)."""
+    import json
+    from detectorfreesfm_amd.synth import SyntheticSfMScene
+    RefData, _ = ref_import.import_matching_data()
+    kw, cfg = dict(n_images=24, n_points=400, seed=1, max_views=24), {"max_track_length": 9, "chunk": 50}
+    ref = RefData(SyntheticSfMScene(**kw), cfg)
+    bags = [{"bag_image_ids": [int(i) for i in b["bag_image_ids"]], "track_ids": [int(t) for t in b["track_ids"]],
+             "track_corresponding_imgs": [[int(c[0]), [int(x) for x in c[1]]] for c in b["track_corresponding_imgs"]]}
+            for b in ref.image_bags]
+    keys = ("query_points", "reference_points_coarse", "track_valid_mask", "query_img_idxs", "reference_img_idxs",
+            "scales_relative", "view_point_vector", "query_img_ids", "query_pt2d_idxs", "reference_img_ids",
+            "reference_pt2d_idxs")
+    cat = {k: np.concatenate([ref[i][k].numpy().reshape(-1) for i in range(len(ref))]) for k in keys}
+    np.savez_compressed(os.path.join(OUT, "bags.npz"), bags=json.dumps(bags), scene=json.dumps(kw), cfg=json.dumps(cfg), **cat)
+    print("bags.npz", len(bags), "bags")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "merge":
         merge_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "bags":
+        bags_golden()
     else:
         main()
         merge_golden()
+        bags_golden()

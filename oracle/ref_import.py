@@ -277,3 +277,44 @@ def import_match_table_consumers():
           "logger": sys.modules["loguru"].logger}
     exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
     return mk.Match2Kpts, ns["keypoint_worker"], ns["update_matches"], ns["transform_keypoints"]
+
+
+def _compile_defs(rel_path, names, ns):
+    """Compile the UNCHANGED source of the named top-level functions / classes of a reference file into ``ns``."""
+    import ast
+    path = os.path.join(REFERENCE_ROOT, rel_path)
+    with open(path) as fh:
+        tree = ast.parse(fh.read())
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert len(body) == len(names), (rel_path, names, [n.name for n in body])
+    for n in body:
+        n.decorator_list = []
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def import_matching_data():
+    """Return the reference's own ``MatchingMultiviewData`` (with ``FeatureTrackStatus``) and ``UpdatedQueryPts``
+    (src/post_optimization/data_construct/construct_matching_data.py:10-476,
+    src/post_optimization/matcher_model/multiview_match_worker.py:85-108).
+
+    Their modules import cv2 / ray / pytorch_lightning at module level, none of which these classes use: the classes'
+    unchanged source text is compiled (ast, no edits) into a namespace that holds what they reference -- numpy, torch,
+    ``Dataset``, ``time``, a no-op ``logger`` and the reference's own ``chunks_balance`` / geometry helpers, compiled
+    the same way from src/utils/ray_utils.py and src/post_optimization/utils/geometry_utils.py."""
+    import time
+    import numpy as np
+    import torch
+    from torch.utils.data.dataset import Dataset
+    _ensure_path()
+    install_stubs()
+    ns = {"np": np, "torch": torch, "Dataset": Dataset, "time": time.time, "logger": sys.modules["loguru"].logger}
+    _compile_defs(os.path.join("src", "utils", "ray_utils.py"), ("chunks_balance",), ns)
+    _compile_defs(os.path.join("src", "post_optimization", "utils", "geometry_utils.py"),
+                  ("convert_pose2T", "convert_T2pose", "project_point_cloud_to_image", "transform_point_cloud_to_camera"), ns)
+    _compile_defs(os.path.join("src", "post_optimization", "data_construct", "construct_matching_data.py"),
+                  ("FeatureTrackStatus", "MatchingMultiviewData"), ns)
+    ns2 = {"np": np, "torch": torch}
+    _compile_defs(os.path.join("src", "post_optimization", "matcher_model", "multiview_match_worker.py"),
+                  ("UpdatedQueryPts",), ns2)
+    return ns["MatchingMultiviewData"], ns2["UpdatedQueryPts"]
