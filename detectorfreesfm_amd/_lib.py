@@ -49,6 +49,8 @@ SIGNATURES = [
     ("dfsfm_split_rows_f32", c_int,
      [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
       c_void_p]),
+    ("dfsfm_resample_separable_f32", c_int,
+     [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("dfsfm_add_scatter_tokens_f32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("dfsfm_conv2d_nhwc_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -137,6 +137,73 @@ __global__ __launch_bounds__(256) void add_scatter_tokens_kernel(const float* __
 
 }  // namespace
 
+namespace {
+
+// Separable resampling of NHWC patch maps: out[m, oy, ox, c] = sum_qy sum_qx By[oy, qy] * Bx[ox, qx] * y[m, qy, qx, c].
+// Replaces nn.Upsample(mode='bicubic', align_corners=True) + centre crop of S2DNet's second adaptation map
+// (backbone/S2DNet/s2dnet.py:164-193): By / Bx are the rows of PyTorch's own interpolation matrix that fall inside
+// the window, so the coefficients are torch's.  One workgroup per (patch, 64-channel slice): the slice of y and the
+// row-resampled intermediate live in LDS (21 + 35 KB for 9x9 -> 15x15: two workgroups per CU); HBM-bound
+// (41 KB read, 115 KB written per 128-channel patch).
+constexpr int RS_CH = 64;
+
+__global__ __launch_bounds__(256) void resample_sep_kernel(const float* __restrict__ y, const float* __restrict__ By,
+                                                           const float* __restrict__ Bx, float* __restrict__ out, int hin,
+                                                           int win, int hout, int wout, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem_rs[];
+    float* s_by = reinterpret_cast<float*>(smem_rs);                  // [hout][hin]
+    float* s_bx = s_by + ((hout * hin + 3) & ~3);                     // [wout][win]   (16-byte aligned sections)
+    f32x4* s_y = reinterpret_cast<f32x4*>(s_bx + ((wout * win + 3) & ~3));   // [hin*win][16]
+    f32x4* s_t = s_y + hin * win * (RS_CH / 4);                       // [hout][win][16]
+    const int m = blockIdx.x, c0 = blockIdx.y * RS_CH, tid = threadIdx.x;
+    for (int e = tid; e < hout * hin; e += 256) s_by[e] = By[e];
+    for (int e = tid; e < wout * win; e += 256) s_bx[e] = Bx[e];
+    const float* ym = y + (int64_t)m * hin * win * C + c0;
+    for (int e = tid; e < hin * win * (RS_CH / 4); e += 256) {
+        const int q = e / (RS_CH / 4), c4 = e % (RS_CH / 4);
+        s_y[e] = *reinterpret_cast<const f32x4*>(ym + (int64_t)q * C + c4 * 4);
+    }
+    __syncthreads();
+    for (int e = tid; e < hout * win * (RS_CH / 4); e += 256) {       // rows first: t[oy][qx] = sum_qy By[oy][qy] y[qy][qx]
+        const int c4 = e % (RS_CH / 4), r = e / (RS_CH / 4), qx = r % win, oy = r / win;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int qy = 0; qy < hin; ++qy) {
+            const float w = s_by[oy * hin + qy];
+            const f32x4 v = s_y[(qy * win + qx) * (RS_CH / 4) + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = fmaf(w, v[k], a[k]);
+        }
+        s_t[e] = a;
+    }
+    __syncthreads();
+    float* om = out + (int64_t)m * hout * wout * C + c0;
+    for (int e = tid; e < hout * wout * (RS_CH / 4); e += 256) {      // then columns
+        const int c4 = e % (RS_CH / 4), p = e / (RS_CH / 4), ox = p % wout, oy = p / wout;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int qx = 0; qx < win; ++qx) {
+            const float w = s_bx[ox * win + qx];
+            const f32x4 v = s_t[(oy * win + qx) * (RS_CH / 4) + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = fmaf(w, v[k], a[k]);
+        }
+        *reinterpret_cast<f32x4*>(om + (int64_t)p * C + c4 * 4) = a;
+    }
+}
+
+}  // namespace
+
+extern "C" int dfsfm_resample_separable_f32(const float* y, int M, int hin, int win, int C, const float* By, const float* Bx,
+                                            int hout, int wout, float* out, void* stream_) {
+    if (M == 0) return DFSFM_OK;
+    if (!y || !By || !Bx || !out || M < 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || C <= 0) return DFSFM_E_BADARG;
+    if (C % RS_CH != 0 || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return DFSFM_E_UNSUPPORTED;
+    const size_t smem = (size_t)(((hout * hin + 3) & ~3) + ((wout * win + 3) & ~3)) * 4 + (size_t)(hin * win + hout * win) * RS_CH * 4;
+    if (smem > 64 * 1024) return DFSFM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(resample_sep_kernel, dim3((unsigned)M, (unsigned)(C / RS_CH)), dim3(256), smem, static_cast<hipStream_t>(stream_),
+                       y, By, Bx, out, hin, win, hout, wout, C);
+    return dfsfm::check_launch("dfsfm_resample_separable_f32");
+}
+
 extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                    const float* residual, const void* res_hi, const void* res_lo, int64_t ldr,
                                    float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s,

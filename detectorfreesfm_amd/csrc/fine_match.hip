@@ -6,15 +6,16 @@
 //   :195-219 (_s2d_heatmap), :258-285 (argsoftmax), :129-179 (_obtain_left_normalized_offset),
 //   :221-252 (build_moved_query / build_mkpts)
 //
-// One workgroup per feature track; 576 KB of features in, < 100 B out -> HBM-bound at the fp32
-// ridge (AI ~ 20 flop/B).  Wave w owns query views w, w+4, ...: it streams the view's W*W x C
-// window from HBM straight into MFMA A-fragments (each lane reads 256 contiguous bytes of one
-// row per 32-row tile), multiplies against the <= 64 candidate rows of the reference window held
-// in LDS (v_mfma_f32_32x32x2_f32; sim^T[r][l], so the softmax axis r is lane-local), and folds
-// every 32-row tile into an online softmax carrying the five moments (sum e, e*gx, e*gy, e*gx^2,
-// e*gy^2).  The heat-map is never materialised.  Lane halves are merged with one shuffle; the
-// masked mean over views and the first-minimum argmin over candidates run in wave 0.
+// One workgroup per feature track; 486 KB of features in (the query windows + the 49 candidate rows),
+// < 100 B out -> HBM-bound.  Wave w owns query views w, w+4, ...: it DMAs the view's W*W x C window
+// through a private two-stage LDS ring (whole 256-byte row segments), multiplies 32-row tiles against
+// the <= 64 candidate rows of the reference window (fp16x2-split planes in LDS; three
+// v_mfma_f32_32x32x16_f16 per product; sim^T[r][l], so the softmax axis r is lane-local), and folds
+// every tile into an online softmax carrying the five moments (sum e, e*gx, e*gy, e*gx^2, e*gy^2).
+// The heat-map is never materialised.  Lane halves are merged with one shuffle; the masked mean over
+// views and the first-minimum argmin over candidates run in wave 0.
 #include "common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -48,34 +49,58 @@ struct Moments {
     float m, s0, sx, sy, sxx, syy;
 };
 
-template <int C>
+// v2 schedule.  The first version streamed the query windows straight into fp32-MFMA fragments: 16-byte pieces of 64
+// different rows per load instruction (a quarter of the L1 / TA rate), 128 fragment registers that pinned it to one
+// wave per SIMD, and 64-cycle fp32 MFMAs -- 1.6 TB/s.  Now every wave DMAs its view's window into a private LDS ring
+// in whole 256-byte row segments (buffer_load ... lds, swizzle on the source address, zero fill past the window),
+// reads the fragments back conflict-free, splits them into fp16 hi / lo planes in registers (v = hi + lo/2048, the
+// representation of every other GEMM of the path) and runs three fp16 MFMAs per product: fp32-class similarities at
+// 3/16 of the fp32-MFMA cost.  No workgroup barrier in the stream: ring, DMA queue and vmcnt are per wave.
+template <int C, bool FAST>
 __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
-    constexpr int KH = C / 2;            // k values owned by one lane half
-    constexpr int NQ = KH / 4;           // float4 per lane per row
-    constexpr int REF_LD = C + 4;        // pad: conflict-free ds_read_b128 across rows
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int NKH = C / 64;              // 64-channel (256-byte) segments of a row = DMA stages per 32-row tile
+    constexpr int SLOTS = C / 8;             // 16-byte slots of one fp16 reference row
+    constexpr int STAGE = 32 * 256;          // one A stage: 32 rows x 64 fp32
+    constexpr int NSTG = 3;                  // ring depth per wave: two stages (16 KB) in flight while one is multiplied
+    // slot swizzle of a reference row: 16 slots (C = 128, 256-byte rows) -> row & 15; 8 slots (C = 64) -> (row >> 1) & 7
+    auto rswz = [](int l) __attribute__((always_inline)) { return C == 128 ? (l & 15) : ((l >> 1) & 7); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_ref = reinterpret_cast<float*>(smem);                    // [MAXL][REF_LD]
-    float2* s_grid = reinterpret_cast<float2*>(s_ref + MAXL * REF_LD);  // [MAXWW]
-    float* s_res = reinterpret_cast<float*>(s_grid + MAXWW);          // [Vq][MAXL][3]
+    _Float16* s_rh = reinterpret_cast<_Float16*>(smem);                       // [MAXL][C] hi plane, slot-swizzled
+    _Float16* s_rl = s_rh + MAXL * C;                                         // lo plane
+    float2* s_grid = reinterpret_cast<float2*>(s_rl + MAXL * C);              // [MAXWW]
+    float* s_res = reinterpret_cast<float*>(s_grid + MAXWW);                  // [Vq][MAXL][3]
+    char* s_ring = reinterpret_cast<char*>(s_res) + ((g.Vq * MAXL * 3 * 4 + 15) & ~15);   // [4 waves][NSTG stages][STAGE]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
     const int t = blockIdx.x;
     const int W = g.W, WW = W * W, left = g.left, L = left * left, Vq = g.Vq;
-    const int NT = (WW + 31) / 32;       // 32-row tiles of the window
+    const int NT = (WW + 31) / 32;           // 32-row tiles of the window
 
-    // candidate rows: centre left x left window of the reference patch (select_left_point)
+    // candidate rows: centre left x left window of the reference patch (select_left_point), split once
     {
         const int c0 = W / 2 - left / 2;
         const float* rbase = g.ref + (int64_t)t * WW * C;
-        for (int e = tid; e < MAXL * (C / 4); e += 256) {
-            const int l = e / (C / 4), c4 = e % (C / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int e = tid; e < MAXL * SLOTS; e += 256) {
+            const int l = e / SLOTS, q = e % SLOTS;
+            half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = h;
             if (l < L) {
                 const int r = (c0 + l / left) * W + c0 + l % left;
-                v = *reinterpret_cast<const f32x4*>(rbase + (int64_t)r * C + c4 * 4);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rbase + (int64_t)r * C + q * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(rbase + (int64_t)r * C + q * 8 + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    _Float16 a, b;
+                    split_f32(v0[k], a, b); h[k] = a; lo[k] = b;
+                    split_f32(v1[k], a, b); h[4 + k] = a; lo[4 + k] = b;
+                }
             }
-            *reinterpret_cast<f32x4*>(s_ref + l * REF_LD + c4 * 4) = v;
+            const int o = l * C + ((q ^ rswz(l)) * 8);       // XOR swizzle: fragment reads of 16 rows hit 16 bank groups
+            *reinterpret_cast<half8*>(s_rh + o) = h;
+            *reinterpret_cast<half8*>(s_rl + o) = lo;
         }
         // kornia create_meshgrid(W, W, normalized): (x / (W-1) - 0.5) * 2
         for (int r = tid; r < MAXWW; r += 256) {
@@ -87,35 +112,68 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     __syncthreads();
 
     const float temp = (float)(1.0 / sqrt((double)C));   // softmax_temp = 1 / C**.5 (python double -> f32)
+    char* ring = s_ring + wave * NSTG * STAGE;
+    // DMA lane geometry: one instruction = 4 rows x 256 B; lane -> (row in piece, physical slot); logical slot on the source
+    const int drow = lane >> 4, dps = lane & 15;
     for (int n = wave; n < Vq; n += 4) {
         const float* qbase = g.qry + ((int64_t)t * Vq + n) * WW * C;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, WW * C * 4, 0x00020000);
         Moments st[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) st[b] = Moments{-INFINITY, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-        f32x4 a_cur[NQ], a_nxt[NQ];
-        auto load_tile = [&](f32x4* dst, int rt) {
-            const int r = rt * 32 + col;
+        const int nstage = NT * NKH;
+        auto issue = [&](int s) __attribute__((always_inline)) {      // stage s = (tile s / NKH, segment s % NKH); 8 pieces
+            const int rt = s / NKH, kh = s - rt * NKH;
+            char* dst = ring + (s % NSTG) * STAGE;
 #pragma unroll
-            for (int qd = 0; qd < NQ; ++qd) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dst[qd] = r < WW ? *reinterpret_cast<const f32x4*>(qbase + (int64_t)r * C + half * KH + qd * 4) : z;
+            for (int p = 0; p < 8; ++p) {
+                const int row = p * 4 + drow;
+                // rows past the window (and stages past the end) fall outside the descriptor: zero fill, no traffic
+                const unsigned off = s < nstage ? (unsigned)(((rt * 32 + row) * C + kh * 64 + ((dps ^ (row & 15)) * 4)) * 4)
+                                                : 0xFFFFFF00u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(dst + p * 1024), 16, off, 0, 0, 0);
             }
         };
-        load_tile(a_cur, 0);
-        for (int rt = 0; rt < NT; ++rt) {
-            if (rt + 1 < NT) load_tile(a_nxt, rt + 1);
-            f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // previous view's fragment reads are done
+        issue(0);
+        issue(1);
+        f32x16 accm[2], accx[2];
+        for (int s = 0; s < nstage; ++s) {
+            const int rt = s / NKH, kh = s - rt * NKH;
+            issue(s + 2);                                             // into the stage consumed in the previous iteration
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // stage s has landed (s+1, s+2 may still fly)
+            if (kh == 0) {
 #pragma unroll
-            for (int qd = 0; qd < NQ; ++qd) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_ref + col * REF_LD + half * KH + qd * 4);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(s_ref + (32 + col) * REF_LD + half * KH + qd * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {   // A[i=r][k=c] = qry[r][c], B[k=c][j=l] = ref[l][c]
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[qd][e], b0[e], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[qd][e], b1[e], acc[1], 0, 0, 0);
-                }
+                for (int b = 0; b < 2; ++b) { accm[b] = f32x16{0}; accx[b] = f32x16{0}; }
             }
+            const char* sa = ring + (s % NSTG) * STAGE + col * 256;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {                          // 16 channels per MFMA k-step, 8 per lane half
+                const int sl = (ks * 2 + half) * 2;                   // first of the two fp32 slots
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + ((sl ^ (col & 15)) * 16));
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + (((sl + 1) ^ (col & 15)) * 16));
+                const int q = (kh * 64 + ks * 16 + half * 8) / 8;     // fp16 slot of the reference rows
+                const half8 bh0 = *reinterpret_cast<const half8*>(s_rh + col * C + ((q ^ rswz(col)) * 8));
+                const half8 bl0 = *reinterpret_cast<const half8*>(s_rl + col * C + ((q ^ rswz(col)) * 8));
+                const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
+                const half8 bl1 = *reinterpret_cast<const half8*>(s_rl + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
+                half8 ah, al;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    _Float16 x, y;
+                    split_f32(a0[k], x, y); ah[k] = x; al[k] = y;
+                    split_f32(a1[k], x, y); ah[4 + k] = x; al[4 + k] = y;
+                }
+                // A[i = window row][k], B[k][j = candidate]: sim^T keeps the softmax axis (rows) lane-local
+                accm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, accm[0], 0, 0, 0);
+                accm[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, accm[1], 0, 0, 0);
+                accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, accx[0], 0, 0, 0);
+                accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, accx[1], 0, 0, 0);
+                accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, accx[0], 0, 0, 0);
+                accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, accx[1], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // reads of this stage retired before it is refilled
+            if (kh != NKH - 1) continue;
             // online softmax over this tile's rows r = rt*32 + mfma32_row(reg, half)
             const int rbase_t = rt * 32 + 4 * half;
             if (rbase_t < WW) {   // at least one valid row in this lane half
@@ -126,34 +184,29 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rr = rt * 32 + mfma32_row(r, half);
-                        x[r] = rr < WW ? temp * acc[b][r] : -INFINITY;
+                        x[r] = rr < WW ? temp * (accm[b][r] + accx[b][r] * (1.f / 2048.f)) : -INFINITY;
                         tmax = fmaxf(tmax, x[r]);
                     }
                     const float m_new = fmaxf(st[b].m, tmax);
-                    const float sc = expf(st[b].m - m_new);     // exp(-inf) = 0 on the first tile
+                    const float sc = FAST ? __expf(st[b].m - m_new) : expf(st[b].m - m_new);     // exp(-inf) = 0 on the first tile
                     float s0 = st[b].s0 * sc, sx = st[b].sx * sc, sy = st[b].sy * sc;
                     float sxx = st[b].sxx * sc, syy = st[b].syy * sc;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; ++r) {          // rows past the window carry x = -inf -> e = 0: no branch
                         const int rr = rt * 32 + mfma32_row(r, half);
-                        if (rr < WW) {
-                            const float e = expf(x[r] - m_new);
-                            const float2 gxy = s_grid[rr];
-                            s0 += e;
-                            sx += e * gxy.x;
-                            sy += e * gxy.y;
-                            sxx += e * (gxy.x * gxy.x);
-                            syy += e * (gxy.y * gxy.y);
-                        }
+                        const float e = FAST ? __expf(x[r] - m_new) : expf(x[r] - m_new);
+                        const float2 gxy = s_grid[rr];       // rr < MAXWW always
+                        s0 += e;
+                        sx += e * gxy.x;
+                        sy += e * gxy.y;
+                        sxx += e * (gxy.x * gxy.x);
+                        syy += e * (gxy.y * gxy.y);
                     }
                     st[b] = Moments{m_new, s0, sx, sy, sxx, syy};
                 }
             }
-            if (rt + 1 < NT) {
-#pragma unroll
-                for (int qd = 0; qd < NQ; ++qd) a_cur[qd] = a_nxt[qd];
-            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the zero-fill tail stage
         // merge the two lane halves (rows 4*half + ...) and finish: expectation and std
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -230,12 +283,13 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     }
 }
 
-template <int C>
+template <int C, bool FAST>
 void launch(const FineArgs& g, hipStream_t stream) {
-    const size_t smem = (size_t)MAXL * (C + 4) * 4 + MAXWW * 8 + (size_t)g.Vq * MAXL * 3 * 4;
+    // reference planes (hi, lo) + grid + per-view results + 4 waves x 3 stages x 8 KB of DMA ring
+    const size_t smem = (size_t)MAXL * C * 4 + MAXWW * 8 + (((size_t)g.Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + 4 * 3 * 32 * 256;
     static dfsfm::SmemAttr smem_attr;
-    smem_attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C>), 96 * 1024);
-    hipLaunchKernelGGL((fine_match_kernel<C>), dim3(g.T), dim3(256), smem, stream, g);
+    smem_attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C, FAST>), 160 * 1024);
+    hipLaunchKernelGGL((fine_match_kernel<C, FAST>), dim3(g.T), dim3(256), smem, stream, g);
 }
 
 }  // namespace
@@ -257,8 +311,9 @@ extern "C" int dfsfm_fine_match_f32(const float* ref, const float* qry, const ui
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     FineArgs g{ref, qry, track_mask, movable, T, Vq, W, left, query_pts, scale_q, ref_pts, scale_r,
                rs_t, rs_n, best_index, left_norm, coords, std, query_refined, ref_refined};
-    if (C == 128) launch<128>(g, stream);
-    else if (C == 64) launch<64>(g, stream);
+    static const bool fast = [] { const char* e = getenv("DFSFM_FINE_FASTEXP"); return e && atoi(e) != 0; }();   // A/B switch
+    if (C == 128) { if (fast) launch<128, true>(g, stream); else launch<128, false>(g, stream); }
+    else if (C == 64) { if (fast) launch<64, true>(g, stream); else launch<64, false>(g, stream); }
     else return DFSFM_E_UNSUPPORTED;
     return dfsfm::check_launch("dfsfm_fine_match_f32");
 }

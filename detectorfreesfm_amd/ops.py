@@ -359,6 +359,23 @@ def split_rows(x, add=None, out=None, out_split=None):
 
 
 @_on_device
+def resample_separable(y, By, Bx, out=None):
+    """out[m, oy*wout+ox, c] = sum By[oy,qy] Bx[ox,qx] y[m,qy,qx,c];  y [M,hin,win,C] fp32 contiguous (NHWC patches),
+    By [hout,hin], Bx [wout,win] fp32 -> [M, hout*wout, C]."""
+    _require_cuda(y, By, Bx)
+    M, hin, win, C = y.shape
+    hout, wout = By.shape[0], Bx.shape[0]
+    if y.dtype != torch.float32 or not y.is_contiguous() or By.shape[1] != hin or Bx.shape[1] != win:
+        raise _lib.DfsfmError("resample_separable: need contiguous fp32 y [M,hin,win,C] and By [hout,hin], Bx [wout,win]")
+    By, Bx = By.to(torch.float32).contiguous(), Bx.to(torch.float32).contiguous()
+    if out is None:
+        out = torch.empty((M, hout * wout, C), dtype=torch.float32, device=y.device)
+    rc = _lib.lib().dfsfm_resample_separable_f32(_ptr(y), M, hin, win, C, _ptr(By), _ptr(Bx), hout, wout, _ptr(out), _stream())
+    _lib.check(rc, "dfsfm_resample_separable_f32")
+    return out
+
+
+@_on_device
 def add_scatter_tokens(a, b, slot, dst):
     """dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p]);  a,b [M,C,P] contiguous, dst [*,P,C] contiguous."""
     _require_cuda(a, dst)

@@ -225,3 +225,66 @@ def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", b
     matches = {f"{names[i]}{pair_name_split}{names[j]}": t.cpu().numpy() for (i, j), t in zip(pairs, tables)}
     kp, sc, upd = merge_match_tables(matches, names, pair_name_split, device=next(matcher.parameters()).device)
     return matches, kp, sc, upd
+
+
+def _batched(bag: dict, device):
+    """What the reference's DataLoader(batch_size=1) + dict_to_cuda hand to the matcher: a leading batch dimension on
+    every tensor (multiview_match_worker.py:115,126)."""
+    out = {}
+    for k, v in bag.items():
+        if isinstance(v, list):
+            out[k] = [t[None].to(device) for t in v]
+        elif isinstance(v, torch.Tensor):
+            out[k] = v[None].to(device)
+        else:
+            out[k] = v
+    return out
+
+
+@torch.no_grad()
+def match_tracks_worker(colmap_dataset, matcher, subset_track_idxs=None, dataset_cfgs=None, device="cuda",
+                        reference_lookup=True):
+    """``matchWorker`` (src/post_optimization/matcher_model/multiview_match_worker.py:111-141) on the device: bags from
+    ``BagPlanner`` (this rank's track subset), already-refined query points in ``DeviceUpdatedQueryPts`` (no per-track
+    Python loop between forward passes), one ``extract_results`` per bag.  Returns the reference's ``results_list``:
+    one float64 ndarray [M,4] per bag, rows [x, y, image id, keypoint index] (queries of the valid slots first, then the
+    movable reference nodes)."""
+    from .bags import BagPlanner, DeviceUpdatedQueryPts
+    planner = BagPlanner(colmap_dataset, dataset_cfgs, worker_split_idxs=subset_track_idxs)
+    matcher.to(device)
+    buf = DeviceUpdatedQueryPts(planner.colmap_images, device=device, reference_lookup=reference_lookup)
+    results = []
+    for k in range(len(planner)):
+        data = _batched(planner.bag_tensors(k), device)
+        buf.find_movable_and_update(data)
+        (q_pts, q_ids, q_idx), (r_pts, r_ids, r_idx), _ = extract_results(data, matcher=matcher)
+        mov = data["query_movable_mask"]
+        buf.update_query_pts(data["query_points_refined"][mov], data["query_img_ids"][mov], data["query_pt2d_idxs"][mov])
+        pts = np.concatenate([q_pts, r_pts], axis=0)
+        ids = np.concatenate([q_ids, r_ids], axis=0)
+        idx = np.concatenate([q_idx, r_idx], axis=0)
+        results.append(np.concatenate([pts, ids[:, None], idx[:, None]], axis=1))
+    return results
+
+
+@torch.no_grad()
+def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, device="cuda", group=None):
+    """One scene's feature tracks on all ranks of the process group -- the analogue of ``multiview_matcher`` with Ray
+    (src/post_optimization/matcher_model/multiview_match.py:39-62): tracks are dealt to the ranks by index
+    (``dist.shard_tracks``: all bags of one track on one rank), every rank runs ``match_tracks_worker`` on its subset,
+    and the [M,4] result rows are collected with ONE all-gather of variable-length tables (RCCL over xGMI / gloo).
+    Returns the concatenated list of per-bag arrays, identical on every rank (rank order, then bag order)."""
+    from . import dist as ddist
+    import torch.distributed as tdist
+    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
+    rank = tdist.get_rank(group) if world > 1 else 0
+    n = len(colmap_dataset.point_cloud_assigned_imgID_kptID)
+    mine = match_tracks_worker(colmap_dataset, matcher, ddist.shard_tracks(n, rank, world, seed), dataset_cfgs, device)
+    if world == 1:
+        return mine
+    dev = torch.device(device)
+    # ids fit float64 exactly; the reference's own rows are float64 for the same reason (np.concatenate with int columns)
+    hi = [torch.from_numpy(a.astype(np.float32)).to(dev) for a in mine]
+    lo = [torch.from_numpy((a - a.astype(np.float32).astype(np.float64)).astype(np.float32)).to(dev) for a in mine]
+    tabs = ddist.all_gather_tables([torch.cat([h, l], 1) for h, l in zip(hi, lo)], group=group)
+    return [(t[:, :4].double() + t[:, 4:].double()).cpu().numpy() for t in tabs]

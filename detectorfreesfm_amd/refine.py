@@ -18,8 +18,8 @@ MIOpen / hipBLASLt fp32 control path for measurement.
 Output-identical work the reference wastes is skipped ("dead work"):
 * only the centre (W+4)^2 of relu1_2 feeds adaptation layer 0 (the reference convolves the full
   35x35 map and crops to WxW afterwards, s2dnet.py:164-193);
-* the bicubic align_corners upsample of adaptation layer 1 is evaluated only at the WxW centre,
-  as one GEMM with PyTorch's own interpolation coefficients;
+* the bicubic align_corners upsample of adaptation layer 1 is evaluated only at the WxW centre, by a separable
+  resampling kernel fed with PyTorch's own interpolation coefficients;
 * padded view slots (image index -1) are never cropped or convolved: they are masked everywhere
   downstream, the reference feeds them a copy of the last patch (MultiviewMatcher.py:253-266).
 """
@@ -138,11 +138,10 @@ class HipMultiviewMatcher(ParamModule):
         y1 = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["adap1"][0], 1, 0, **S), H["adap1"][1], 1, 2)
         h4 = y1.shape[1]
         key = (h4, crop, W)
-        if P.get("bicubic_key") != key:
-            B = _bicubic_rows(h4, crop, c - r, c + r + 1)
-            P["bicubic"] = torch.kron(B, B).contiguous().to(y1.device)           # [W*W, h4*h4]
-            P["bicubic_key"] = key
-        up = torch.bmm(P["bicubic"].expand(m, -1, -1), y1.view(m, h4 * h4, -1))   # [m, W*W, od]
+        if P.get("bicubic_rows_key") != key:
+            P["bicubic_rows"] = _bicubic_rows(h4, crop, c - r, c + r + 1).to(y1.device)   # [W, h4]: torch's own coefficients
+            P["bicubic_rows_key"] = key
+        up = ops.resample_separable(y1, P["bicubic_rows"], P["bicubic_rows"])     # [m, W*W, od]
         a0 = ops.conv2d_nhwc(f0, H["adap0"][0], 1, 0, **S)                        # [m,W+4,W+4,64]
         ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out=dst)           # + hypercolumn sum, fused
         return dst

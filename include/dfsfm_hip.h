@@ -174,6 +174,15 @@ int dfsfm_split_rows_f32(const float* x, int64_t ldx, const float* add, int64_t 
                          int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, int64_t rows, int C,
                          void* stream);
 
+/* Separable resampling of NHWC patch feature maps:
+ *   out[m, oy, ox, c] = sum_{qy,qx} By[oy, qy] * Bx[ox, qx] * y[m, qy, qx, c]
+ * Replaces nn.Upsample(mode='bicubic', align_corners=True) followed by the centre-window crop of S2DNet's coarse
+ * adaptation map (src/MultiviewMatcher/backbone/S2DNet/s2dnet.py:164-193): By [hout,hin] / Bx [wout,win] are the rows
+ * of the interpolation matrix that fall inside the window (the caller obtains them from the framework's own bicubic
+ * kernel, so the coefficients are the reference's).  y [M,hin,win,C], out [M,hout*wout,C] fp32, C % 64 == 0. */
+int dfsfm_resample_separable_f32(const float* y, int M, int hin, int win, int C, const float* By, const float* Bx,
+                                 int hout, int wout, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K9 -> K10 hand-off  dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p])
  * a, b [M, C, P] (NCHW patch features, P = W*W), slot [M] int64 or NULL (identity), dst [*, P, C].

@@ -182,6 +182,14 @@ def _maxpool(x):
     return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
 
 
+def _resample(y, By, Bx, out=None):
+    r = torch.einsum("ab,cd,mbdk->mack", By, Bx, y).reshape(y.shape[0], By.shape[0] * Bx.shape[0], y.shape[-1])
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
 def _merge(rows, img0, img1, n_images):
     """ops.merge_keypoints on the numpy restatement of the reference's consumer stage (oracle/restate_merge.py)."""
     from oracle import restate_merge as rm
@@ -195,11 +203,12 @@ def cpu_ops():
     from detectorfreesfm_amd import ops
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
-                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints")}
+                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
     ops.split_rows, ops.linear_ln, ops.merge_keypoints = _split_rows, _linear_ln, _merge
+    ops.resample_separable = _resample
     try:
         yield
     finally:

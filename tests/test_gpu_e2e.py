@@ -372,3 +372,42 @@ def test_scene_matching_cached_tokens_equals_pairwise(built_lib):
         assert not bad, bad[:5]
         total += len(B)
     assert total > 100
+
+
+def test_refine_scene_worker_vs_oracle(built_lib):
+    """The reference's worker loop (multiview_match_worker.py:111-141) on a synthetic COLMAP-shaped scene: BagPlanner
+    bags -> DeviceUpdatedQueryPts -> HipMultiviewMatcher -> [M,4] rows, against the oracle fed with the same bags."""
+    from detectorfreesfm_amd.bags import BagPlanner
+    from detectorfreesfm_amd.synth import SyntheticSfMScene
+    cfg, sd, m = _refiner(1)
+    scene = SyntheticSfMScene(n_images=20, n_points=150, seed=5, hw=(120, 160), max_views=7)
+    dcfg = {"max_track_length": 6, "chunk": 60}
+    results = plugin.match_tracks_worker(scene, m, None, dcfg, device=DEV)
+    planner = BagPlanner(scene, dcfg)
+    assert len(results) == len(planner) > 2
+    n_rows = 0
+    for k in range(len(planner)):
+        bag = {key: (v if isinstance(v, list) else v[None]) for key, v in planner.bag_tensors(k).items()}
+        bag["images"] = [im[None] for im in bag["images"]]
+        bag["query_movable_mask"] = torch.ones_like(bag["query_img_idxs"], dtype=torch.bool)   # the reference's lookup never hits
+        with torch.no_grad():
+            o = restate.multiview_matcher_forward(sd, cfg, bag)
+        mask = bag["track_valid_mask"].numpy()
+        T = mask.shape[-1]
+        rows = results[k]
+        assert rows.shape == (mask.sum() + T, 4) and rows.dtype == np.float64
+        assert np.array_equal(rows[:mask.sum(), 2], bag["reference_img_ids"].numpy()[mask])
+        assert np.array_equal(rows[:mask.sum(), 3], bag["reference_pt2d_idxs"].numpy()[mask])
+        assert np.array_equal(rows[mask.sum():, 2], bag["query_img_ids"].numpy()[0])
+        # per-track comparison with the argmin-tie rule of tests/parity.py
+        hip = {"query_points_refined": torch.from_numpy(rows[mask.sum():, :2])[None], "std": [o["std"]]}
+        r = np.zeros(mask.shape + (2,))
+        r[mask] = rows[:mask.sum(), :2]
+        hip["reference_points_refined"] = [torch.from_numpy(r)]
+        flips = parity.check_refine(hip["query_points_refined"][0], hip["reference_points_refined"][-1][0], o["std"][0],
+                                    o["query_points_refined"][0], o["reference_points_refined"][0], o["std"][0],
+                                    bag["track_valid_mask"][0], bag["query_points"][0],
+                                    bag["scales"][0][bag["query_img_idxs"][0]][:, [1, 0]], o["cand_score"], 7)
+        assert len(flips) <= 3, flips           # each one already verified as a < 1e-5 score tie by check_refine
+        n_rows += rows.shape[0]
+    assert n_rows > 400
