@@ -113,10 +113,10 @@ def kernel_rooflines(dev, batch):
     flops = 2.0 * nimg * 240 * 320 * 128 * 9 * 128
     out.append(_rl("conv_gemm_sf_same_kernel<128,3> (3x3, 128->128 @240x320)", "mfma", flops, ms, f"{nimg} images",
                    mfma_flops_executed_frac=3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
-                   step_share="the conv_gemm_sf* kernels are ~70% of the coarse step and ~65% of the refinement step "
-                              "(profiles/*_step_kernel_stats.csv)"))
+                   step_share="45% of the coarse step and 22% of the refinement step; all conv / linear GEMM kernels together "
+                              "77% / 81% (profiles/r02_*_step_kernel_stats.csv)"))
     del x, xs, pw
-    # K10 linears of the refinement head (the <128,1,4> instance that dominates the refinement step): mlp.0 of one
+    # K10 linears of the refinement head (linear_gemm_sf_kernel, the largest share of the refinement step): mlp.0 of one
     # encoder layer on the query tokens of a 2000-track x 4-view bag, [rows,256] -> relu -> [rows,256] split planes.
     # HBM-bound: algorithmic bytes = rows * (K + Cout) * 4 (operands and result are fp32-class, 4 B per element).
     rows = 2000 * 4 * 225
@@ -124,7 +124,7 @@ def kernel_rooflines(dev, batch):
     ops.split_rows(torch.randn((rows, 256), generator=g).to(dev), None, out_split=xs)
     pw = ops.PackedDense(torch.randn((256, 256), generator=g).to(dev) * 0.06)
     ms = event_time_ms(lambda: ops.linear(xs, pw, relu=True, out_split=True))
-    out.append(_rl("conv_gemm_sf_same_kernel<128,1> (refinement mlp.0: 256->256 on 1.8 M rows)", "hbm",
+    out.append(_rl("linear_gemm_sf_kernel (refinement mlp.0: 256->256 on 1.8 M rows)", "hbm",
                    rows * 512.0 * 4, ms, f"{rows} rows", tflops_algorithmic=2.0 * rows * 256 * 256 / ms / 1e9))
     del xs, pw
     # K3+K4+K5 at batch x (4800 x 4800 x 256): algorithmic flops 2*L*S*C per pair
@@ -251,7 +251,7 @@ def load_pmc(result):
     with open(path) as fh:
         rows = json.load(fh)["kernels"]
     groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
-              "conv_gemm_sf_same_kernel<128,1>": ("conv_gemm_sf_same_kernel<128, 1", "conv_gemm_sf_same_kernel<128,1"),
+              "linear_gemm_sf_kernel": ("linear_gemm_sf_kernel",),
               "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_kernel",),
               "fine_match": ("fine_match_kernel",),
               "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact", "cm_top", "cm_eval"),
