@@ -753,6 +753,12 @@ __global__ __launch_bounds__(256, 2) void linear_gemm_sf_kernel(ConvArgs g) {
 #pragma unroll
 #if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBA)
         for (int q = 0; q < 2; ++q) offA[q] = g.xbytes + (in ? 0u : 16u);      // ablation: A pieces zero-fill (no traffic)
+#elif defined(DFSFM_ABL_ROW128)
+        // timing-only ablation (results are wrong): a piece reads 8 rows x 128 contiguous bytes instead of 16 rows x 64
+        for (int q = 0; q < 2; ++q) {
+            const int64_t row = m0 + (wave + 4 * q) * 8 + (lane >> 3);
+            offA[q] = (row < g.M && in) ? (unsigned)((row * g.ldx + (t >> 1) * 64 + (lane & 7) * 8) * 2) : g.xbytes;
+        }
 #else
         for (int q = 0; q < 2; ++q) offA[q] = (aok[q] && in) ? (unsigned)((abase[q] + t * BK) * 2) : g.xbytes;
 #endif
@@ -762,6 +768,8 @@ __global__ __launch_bounds__(256, 2) void linear_gemm_sf_kernel(ConvArgs g) {
         for (int q = 0; q < 2; ++q)
 #if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBB)
             offB[q] = g.wbytes + (t < nk ? 0u : 16u);
+#elif defined(DFSFM_ABL_ROW128)
+            offB[q] = t < nk ? (unsigned)((((int64_t)(n0 + (wave + 4 * q) * 8 + (lane >> 3)) * g.Kpad) + (t >> 1) * 64 + (lane & 7) * 8) * 2) : g.wbytes;
 #else
             offB[q] = t < nk ? bbase + (unsigned)(wave + 4 * q) * 16u * (unsigned)g.Kpad * 2u + (unsigned)(t * BK * 2) : g.wbytes;
 #endif
