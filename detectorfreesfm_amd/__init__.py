@@ -4,10 +4,12 @@ Two drop-in plugins behind the reference's own Python surfaces, with the hot ker
 hand-written HIP (``csrc/`` -> ``libdfsfm_hip.so``, C ABI in ``include/dfsfm_hip.h``):
 
 * ``HipLoFTR``             coarse matcher (LoFTR coarse_only)
+* ``HipMatchformer``       coarse matcher (MatchFormer-LA large, coarse_only)
 * ``HipMultiviewMatcher``  multiview refinement head
 """
 from .coarse import HipLoFTR
+from .matchformer import HipMatchformer, matchformer_coarse_only_config
 from .refine import HipMultiviewMatcher
 from .config import loftr_coarse_only_config, multiview_refinement_config
 
-__all__ = ["HipLoFTR", "HipMultiviewMatcher", "loftr_coarse_only_config", "multiview_refinement_config"]
+__all__ = ["HipLoFTR", "HipMatchformer", "HipMultiviewMatcher", "matchformer_coarse_only_config", "loftr_coarse_only_config", "multiview_refinement_config"]

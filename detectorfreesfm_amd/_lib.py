@@ -34,6 +34,11 @@ SIGNATURES = [
       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_size_t, c_void_p]),
+    ("dfsfm_coarse_match_split_masked", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_size_t, c_void_p]),
     ("dfsfm_coarse_conf_matrix_f32", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("dfsfm_roi_align_f32", c_int,
@@ -49,6 +54,9 @@ SIGNATURES = [
     ("dfsfm_split_rows_f32", c_int,
      [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
       c_void_p]),
+    ("dfsfm_dwconv3x3_nhwc_f32", c_int,
+     [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("dfsfm_bilinear_up_nhwc_f32", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("dfsfm_resample_separable_f32", c_int,
      [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("dfsfm_add_scatter_tokens_f32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

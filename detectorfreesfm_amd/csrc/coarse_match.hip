@@ -296,6 +296,8 @@ struct GemmSfArgs {
     const float2* col_stat;
     unsigned long long* row_best;
     unsigned int* col_best;
+    const uint8_t* mask0;    // optional padding masks [N][L], [N][S] (1 = valid): masked rows / columns take no part
+    const uint8_t* mask1;    //     (the reference fills their similarities with -1e9, coarse_matching.py:110-113)
     float2* cand;            // MODE_CAND: [N][ntn][L][slots] (sim, column index bits) of entries that pass the tile-local gates
     uint8_t* cand_cnt;       //            [N][ntn][L] number of valid slots
     int slots;
@@ -356,12 +358,12 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
             const int i = row0 + tid;
             const float2 st = i < g.L ? g.row_stat[(int64_t)n * g.L + i] : make_float2(0.f, 1.f);
             s_rstat[tid] = st;
-            s_rgate[tid] = i < g.L ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+            s_rgate[tid] = (i < g.L && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
         } else if (tid < SF_BM + SF_BN) {
             const int j = col0 + tid - SF_BM;
             const float2 st = j < g.S ? g.col_stat[(int64_t)n * g.S + j] : make_float2(0.f, 1.f);
             s_cstat[tid - SF_BM] = st;
-            s_cgate[tid - SF_BM] = j < g.S ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+            s_cgate[tid - SF_BM] = (j < g.S && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
         }
     }
 
@@ -395,7 +397,9 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                     const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
                     const int lc = wc * 64 + j * 32 + col;
                     const float sv = ((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
-                    accm[i][j][r] = (lr < nrow && lc < ncol) ? sv : -INFINITY;     // rows past L / columns past S
+                    bool ok = lr < nrow && lc < ncol;                              // rows past L / columns past S
+                    if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)] && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
+                    accm[i][j][r] = ok ? sv : -INFINITY;
                 }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                                     // columns: 32 lane-local rows, then the other half
@@ -790,10 +794,12 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
                       float thr, int border, int h0c, int w0c, int h1c, int w1c, const float* scale0,
                       const float* scale1, float coarse_scale, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
                       float* mconf, float* mkpts0, float* mkpts1, int32_t* count, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream, const char* what) {
+                      size_t workspace_bytes, hipStream_t stream, const char* what, const uint8_t* mask0 = nullptr,
+                      const uint8_t* mask1 = nullptr) {
     if (!b_ids || !i_ids || !j_ids || !mconf || !mkpts0 || !mkpts1 || !count) return DFSFM_E_BADARG;
     if (h0c * w0c != L || h1c * w1c != S || border < 0) return DFSFM_E_BADARG;
     if (!(thr >= 0.f)) return DFSFM_E_UNSUPPORTED;   // best-candidate words use 0 as "none"
+    if ((mask0 == nullptr) != (mask1 == nullptr) || (mask0 && !f0h)) return DFSFM_E_UNSUPPORTED;   // masks: split entry point only
     Workspace w = carve(workspace, N, L, S);
     int nparts;
     if (f0h) {
@@ -809,6 +815,7 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
         g.acc_mul = 1.f / (float)C; g.temperature = temperature; g.thr = thr;
         g.row_part = w.row_part; g.col_part = w.col_part; g.row_stat = w.row_stat; g.col_stat = w.col_stat;
         g.row_best = w.row_best; g.col_best = w.col_best;
+        g.mask0 = mask0; g.mask1 = mask1;
         // Single-GEMM path: at most floor(1 / (thr e^-1e-3)) entries of a row (or column) can pass the row gate, so for
         // thr >= 1/8 a fixed number of candidate slots per (row, column tile) holds every possible match and the second
         // correlation pass is replaced by an O(candidates) evaluation.  DFSFM_CM_TWOPASS=1 forces the two-pass path (A/B).
@@ -878,6 +885,28 @@ extern "C" int dfsfm_coarse_match_split(const void* feat0_hi, const void* feat0_
                              w0c, h1c, w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0,
                              mkpts1, count, workspace, workspace_bytes, static_cast<hipStream_t>(stream_),
                              "dfsfm_coarse_match_split");
+}
+
+extern "C" int dfsfm_coarse_match_split_masked(const void* feat0_hi, const void* feat0_lo, const void* feat1_hi,
+                                               const void* feat1_lo, const uint8_t* mask0, const uint8_t* mask1, int N,
+                                               int L, int S, int C, float temperature, float thr, int border, int h0c,
+                                               int w0c, int h1c, int w1c, const float* scale0, const float* scale1,
+                                               float coarse_scale, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                                               float* mconf, float* mkpts0, float* mkpts1, int32_t* count, void* workspace,
+                                               size_t workspace_bytes, void* stream_) {
+    if (!feat0_hi || !feat0_lo || !feat1_hi || !feat1_lo || !workspace || !mask0 || !mask1) return DFSFM_E_BADARG;
+    if (N <= 0 || L <= 0 || S <= 0 || C <= 0 || !(temperature > 0.f)) return DFSFM_E_BADARG;
+    if (C % BK != 0 || N > 65535) return DFSFM_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(feat0_hi) | reinterpret_cast<uintptr_t>(feat0_lo) |
+         reinterpret_cast<uintptr_t>(feat1_hi) | reinterpret_cast<uintptr_t>(feat1_lo)) & 15)
+        return DFSFM_E_UNSUPPORTED;
+    if (workspace_bytes < dfsfm_coarse_match_workspace(N, L, S)) return DFSFM_E_WORKSPACE;
+    return coarse_match_impl(nullptr, nullptr, static_cast<const _Float16*>(feat0_hi),
+                             static_cast<const _Float16*>(feat0_lo), static_cast<const _Float16*>(feat1_hi),
+                             static_cast<const _Float16*>(feat1_lo), N, L, S, C, temperature, thr, border, h0c,
+                             w0c, h1c, w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0,
+                             mkpts1, count, workspace, workspace_bytes, static_cast<hipStream_t>(stream_),
+                             "dfsfm_coarse_match_split_masked", mask0, mask1);
 }
 
 extern "C" int dfsfm_coarse_conf_matrix_f32(const float* feat0, const float* feat1, int N, int L, int S, int C,

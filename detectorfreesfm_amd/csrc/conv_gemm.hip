@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g) {
                     v = accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f) + b;
                     if (g.res) v += g.res[m * g.ldr + n];
                     if (g.resh) v += (float)g.resh[m * g.ldr + n] + (float)g.resl[m * g.ldr + n] * (1.f / 2048.f);
-                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (g.relu == 1) v = fmaxf(v, 0.f);
+                    else if (g.relu == 2) v = v > 0.f ? v : 0.01f * v;
                     if (g.out) g.out[m * g.ldo + n] = v;
                 }
                 if (g.outh && n < g.Cout_s) {
@@ -406,7 +407,8 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float x = v[it][q];
-            if (g.relu) x = fmaxf(x, 0.f);
+            if (g.relu == 1) x = fmaxf(x, 0.f);
+            else if (g.relu == 2) x = x > 0.f ? x : 0.01f * x;      // nn.LeakyReLU() (MatchFormer FPN)
             v[it][q] = (full || n + q < g.Cout) ? x : 0.f;    // padded split channels are zeros
         }
 #ifdef DFSFM_ABL_NOSTORE
@@ -1003,6 +1005,7 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
     const bool split_in = x_hi != nullptr;
     if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return DFSFM_E_BADARG;
     // fused LayerNorm: rows must sit in ONE N tile of the 1x1 schedule -> linear layers with Cout = 64, 128 or 256
+    if (relu < 0 || relu > 2) return DFSFM_E_BADARG;
     if (ln_gamma && !(split_in && kh == 1 && kw == 1 && stride == 1 && pad == 0 && !relu && !tap_padded &&
                       (Cout == 64 || Cout == 128 || Cout == 256) && ln_eps > 0.f))
         return DFSFM_E_UNSUPPORTED;

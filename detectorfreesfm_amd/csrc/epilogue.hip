@@ -228,6 +228,10 @@ extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gam
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 64) {
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
+    } else if (C == 192) {    // MatchFormer stage 2
+        hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
+    } else if (C == 512) {    // MatchFormer stage 4
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else {
         return DFSFM_E_UNSUPPORTED;
     }

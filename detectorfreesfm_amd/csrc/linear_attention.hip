@@ -456,6 +456,112 @@ __global__ __launch_bounds__(256, 2) void la_apply_staged_d32(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic head dimension (D % 4 == 0, D <= 64; no masks): plain fp32 FMA kernels for the head sizes the MFMA kernels
+// do not cover -- MatchFormer-LA uses D = 24 (dim 192) and D = 64 (dim 512) beside 16 and 32
+// (third_party/MatchFormer/model/backbone/match_LA_large.py:64-89).  Same partial layout (KV[d][v] then Ksum[d]) and
+// the same arithmetic as the reference: v / S inside the KV sum, (phi(Q) KV) Z S on the way out.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void la_kv_partial_generic(const float* __restrict__ k, const float* __restrict__ v,
+                                                             float* __restrict__ part, int S, int H, int ldk, int ldv,
+                                                             int rows_per_chunk, int nchunks) {
+    constexpr int EPT = (D * D + 255) / 256;                 // KV elements per thread (consecutive v of one d)
+    static_assert(D % EPT == 0 && D % 4 == 0, "thread tiling of the D x D block");
+    __shared__ float s_k[32][D], s_v[32][D];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, n = blockIdx.y, h = blockIdx.z;
+    const int s_begin = chunk * rows_per_chunk, s_end = min(S, s_begin + rows_per_chunk);
+    const float Sf = (float)S;
+    const float* kn = k + (int64_t)n * S * ldk + h * D;
+    const float* vn = v + (int64_t)n * S * ldv + h * D;
+    const int e0 = tid * EPT, d = e0 / D, v0 = e0 % D;
+    const bool own = e0 < D * D;
+    float acc[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) acc[i] = 0.f;
+    float ksum = 0.f;
+    for (int s0 = s_begin; s0 < s_end; s0 += 32) {
+        for (int e = tid; e < 32 * D; e += 256) {
+            const int r = e / D, c = e % D, srow = s0 + r;
+            float kx = 0.f, vx = 0.f;
+            if (srow < s_end) {
+                kx = elu_plus_one(kn[(int64_t)srow * ldk + c]);
+                vx = vn[(int64_t)srow * ldv + c] / Sf;
+            }
+            s_k[r][c] = kx;
+            s_v[r][c] = vx;
+        }
+        __syncthreads();
+        if (own) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const float a = s_k[r][d];
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) acc[i] = fmaf(a, s_v[r][v0 + i], acc[i]);
+                if (v0 == 0) ksum += a;
+            }
+        }
+        __syncthreads();
+    }
+    if (own) {
+        float* p = part + (((int64_t)n * nchunks + chunk) * H + h) * (D * D + D);
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) p[e0 + i] = acc[i];
+        if (v0 == 0) p[D * D + d] = ksum;
+    }
+}
+
+// 64 query rows x one head per workgroup; thread = (row, quarter of the D outputs)
+template <int D>
+__global__ __launch_bounds__(256) void la_apply_generic(const float* __restrict__ q, const float* __restrict__ kvf,
+                                                        float* __restrict__ out, int L, int S, int H, int ldq, int ldo,
+                                                        float eps, _Float16* __restrict__ outh, _Float16* __restrict__ outl,
+                                                        int ldos) {
+    constexpr int VQ = D / 4;                                // outputs per thread
+    static_assert(VQ % 2 == 0, "4-float stores");
+    __shared__ float s_kv[D * D + D];
+    __shared__ float s_q[64][D + 1];
+    const int tid = threadIdx.x, n = blockIdx.y, h = blockIdx.z;
+    const int l0 = blockIdx.x * 64;
+    const float* kv = kvf + ((int64_t)n * H + h) * (D * D + D);
+    for (int e = tid; e < D * D + D; e += 256) s_kv[e] = kv[e];
+    for (int e = tid; e < 64 * D; e += 256) {
+        const int r = e / D, c = e % D, l = l0 + r;
+        s_q[r][c] = l < L ? elu_plus_one(q[((int64_t)n * L + l) * ldq + h * D + c]) : 0.f;
+    }
+    __syncthreads();
+    const int r = tid >> 2, part = tid & 3, l = l0 + r;
+    if (l >= L) return;
+    float z = 0.f;
+#pragma unroll 8
+    for (int dd = 0; dd < D; ++dd) z = fmaf(s_q[r][dd], s_kv[D * D + dd], z);
+    const float Z = 1.f / (z + eps), Sf = (float)S;
+    float acc[VQ];
+#pragma unroll
+    for (int i = 0; i < VQ; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int dd = 0; dd < D; ++dd) {
+        const float a = s_q[r][dd];
+#pragma unroll
+        for (int i = 0; i < VQ; ++i) acc[i] = fmaf(a, s_kv[dd * D + part * VQ + i], acc[i]);
+    }
+    const int64_t o32 = ((int64_t)n * L + l) * ldo + h * D + part * VQ;
+    const int64_t o16 = ((int64_t)n * L + l) * ldos + h * D + part * VQ;
+#pragma unroll
+    for (int i = 0; i < VQ; i += 2) {                         // VQ = 6 (D = 24) is not a multiple of 4: 2-float pieces
+        const float a = (acc[i] * Z) * Sf, b = (acc[i + 1] * Z) * Sf;
+        if (out) { out[o32 + i] = a; out[o32 + i + 1] = b; }
+        if (outh) {
+            _Float16 ha, la_, hb, lb;
+            split_f32(a, ha, la_);
+            split_f32(b, hb, lb);
+            outh[o16 + i] = ha; outl[o16 + i] = la_;
+            outh[o16 + i + 1] = hb; outl[o16 + i + 1] = lb;
+        }
+    }
+}
+
 // Sum the chunk partials: one thread per element, four interleaved partial sums (fixed order ->
 // deterministic) so that the chunk loads are independent instead of one serial latency chain.
 __global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ part,
@@ -493,7 +599,7 @@ int chunk_rows(int N, int S) {
 }  // namespace
 
 extern "C" size_t dfsfm_linear_attention_workspace(int N, int S, int H, int D) {
-    if (N <= 0 || S <= 0 || H <= 0 || (D != 16 && D != 32)) return 0;
+    if (N <= 0 || S <= 0 || H <= 0 || (D != 16 && D != 32 && D != 24 && D != 64)) return 0;
     const int rows = chunk_rows(N, S);
     const int nchunks = (S + rows - 1) / rows;
     const size_t kvsz = (size_t)D * D + D;
@@ -516,7 +622,8 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
     _Float16* oh = static_cast<_Float16*>(out_hi);
     _Float16* ol = static_cast<_Float16*>(out_lo);
     if (N <= 0 || L <= 0 || S <= 0 || H <= 0) return DFSFM_E_BADARG;
-    if (D != 16 && D != 32) return DFSFM_E_UNSUPPORTED;
+    if (D != 16 && D != 32 && D != 24 && D != 64) return DFSFM_E_UNSUPPORTED;
+    if ((D == 24 || D == 64) && (q_mask || kv_mask)) return DFSFM_E_UNSUPPORTED;   // the generic kernels take no masks
     if (ldq < H * D || ldk < H * D || ldv < H * D || (out && ldo < H * D)) return DFSFM_E_BADARG;
     if ((ldq & 3) || (out && (ldo & 3))) return DFSFM_E_UNSUPPORTED;   // float4 row access
     if ((reinterpret_cast<uintptr_t>(q) & 15) || (out && (reinterpret_cast<uintptr_t>(out) & 15)))
@@ -536,6 +643,16 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
                                                  dfsfm::align_up((size_t)N * H * kvsz * sizeof(float), 256))
                       : kvf;
     dim3 gA(nchunks, N), blk(256);
+    if (D == 24 || D == 64) {
+        const dim3 gG(nchunks, N, H), gP((L + 63) / 64, N, H);
+        if (D == 24) hipLaunchKernelGGL(la_kv_partial_generic<24>, gG, blk, 0, stream, k, v, part, S, H, ldk, ldv, rows, nchunks);
+        else hipLaunchKernelGGL(la_kv_partial_generic<64>, gG, blk, 0, stream, k, v, part, S, H, ldk, ldv, rows, nchunks);
+        if (nchunks > 1)
+            hipLaunchKernelGGL(la_kv_finalize, dim3(N * H, (kvsz + 255) / 256), blk, 0, stream, part, kvf, H, nchunks, kvsz);
+        if (D == 24) hipLaunchKernelGGL(la_apply_generic<24>, gP, blk, 0, stream, q, kvf, out, L, S, H, ldq, ldo, eps, oh, ol, ldo_s);
+        else hipLaunchKernelGGL(la_apply_generic<64>, gP, blk, 0, stream, q, kvf, out, L, S, H, ldq, ldo, eps, oh, ol, ldo_s);
+        return dfsfm::check_launch("dfsfm_linear_attention_f32(generic D)");
+    }
     const bool k_aligned = !(ldk & 3) && !(ldv & 3) && !(reinterpret_cast<uintptr_t>(k) & 15) &&
                            !(reinterpret_cast<uintptr_t>(v) & 15);
     const bool staged = (H == 8) && k_aligned;          // whole-row LDS staging (coalesced 16-B loads)

@@ -127,7 +127,7 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, 
 
 @_on_device
 def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None,
-                 coarse_scale=8.0):
+                 coarse_scale=8.0, mask0=None, mask1=None):
     """K3+K4+K5.  feat0 [N,L,C], feat1 [N,S,C]: fp32 contiguous tensors, or SplitAct planes (contiguous, C a
     power of 4) -- the correlation then runs on the fp16x2-split MFMA path.  Returns a dict with
     b_ids,i_ids,j_ids (int64 [M]), mconf [M], mkpts0_c, mkpts1_c [M,2] in ascending (b,i) order."""
@@ -159,10 +159,23 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=No
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
     s0 = None if scale0 is None else scale0.to(device=dev, dtype=torch.float32).contiguous()
     s1 = None if scale1 is None else scale1.to(device=dev, dtype=torch.float32).contiguous()
+    if (mask0 is None) != (mask1 is None):
+        raise _lib.DfsfmError("coarse_match: mask0 and mask1 come together")
+    if mask0 is not None:
+        if not split or int(border) != 0:
+            raise _lib.DfsfmError("coarse_match: padding masks need the split-plane entry point and border 0")
+        mk0 = _as_u8(mask0.to(dev).reshape(N, -1))
+        mk1 = _as_u8(mask1.to(dev).reshape(N, -1))
+        if mk0.shape != (N, L) or mk1.shape != (N, S):
+            raise _lib.DfsfmError("coarse_match: masks must be [N, h0c, w0c] / [N, h1c, w1c]")
     tail = (N, L, S, C, float(temperature), float(thr), int(border), hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1],
             _ptr(s0), _ptr(s1), float(coarse_scale), _ptr(ids[0]), _ptr(ids[1]), _ptr(ids[2]), _ptr(mconf),
             _ptr(mk[0]), _ptr(mk[1]), _ptr(count), _ptr(ws), ws.numel(), _stream())
-    if split:
+    if split and mask0 is not None:
+        rc = lib.dfsfm_coarse_match_split_masked(_ptr(feat0.hi), _ptr(feat0.lo), _ptr(feat1.hi), _ptr(feat1.lo),
+                                                 _ptr(mk0), _ptr(mk1), *tail)
+        _lib.check(rc, "dfsfm_coarse_match_split_masked")
+    elif split:
         rc = lib.dfsfm_coarse_match_split(_ptr(feat0.hi), _ptr(feat0.lo), _ptr(feat1.hi), _ptr(feat1.lo), *tail)
         _lib.check(rc, "dfsfm_coarse_match_split")
     else:
@@ -359,6 +372,46 @@ def split_rows(x, add=None, out=None, out_split=None):
 
 
 @_on_device
+def dwconv3x3(x, w, bias, mode=0, out_split=False):
+    """Depth-wise 3x3 conv (groups = C, pad 1) + bias on x [N,H,W,C] fp32 NHWC (contiguous) with the consumer fused:
+    mode 0 plain, 1 ``x * sigmoid(.)`` (MatchFormer Positional), 2 erf-GELU (MatchFormer Mlp).  w [C,1,3,3] or the packed
+    [9,C] form; returns fp32 [N,H,W,C] or a SplitAct."""
+    _require_cuda(x, w, bias)
+    N, H, W, C = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise _lib.DfsfmError("dwconv3x3: need a contiguous fp32 NHWC tensor")
+    w9c = w if w.dim() == 2 else w.reshape(C, 9).t().contiguous()
+    if w9c.shape != (9, C):
+        raise _lib.DfsfmError("dwconv3x3: weight must be [C,1,3,3] or [9,C]")
+    w9c, bias = w9c.to(torch.float32).contiguous(), bias.to(torch.float32).contiguous()
+    out = oh = ol = res = None
+    if out_split:
+        res = SplitAct.empty(N, H, W, C, x.device)
+        oh, ol = res.hi, res.lo
+    else:
+        res = out = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dfsfm_dwconv3x3_nhwc_f32(_ptr(x), N, H, W, C, _ptr(w9c), _ptr(bias), int(mode), _ptr(out), _ptr(oh),
+                                             _ptr(ol), _stream())
+    _lib.check(rc, "dfsfm_dwconv3x3_nhwc_f32")
+    if _debug_range and out_split:
+        check_split_range(res, "dwconv3x3")
+    return res
+
+
+@_on_device
+def bilinear_up(x, hout, wout):
+    """F.interpolate(mode='bilinear', align_corners=True) of x [N,hin,win,C] fp32 NHWC -> [N,hout,wout,C]."""
+    _require_cuda(x)
+    N, hin, win, C = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise _lib.DfsfmError("bilinear_up: need a contiguous fp32 NHWC tensor")
+    out = torch.empty((N, hout, wout, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dfsfm_bilinear_up_nhwc_f32(_ptr(x), N, hin, win, C, int(hout), int(wout), _ptr(out), _stream())
+    _lib.check(rc, "dfsfm_bilinear_up_nhwc_f32")
+    return out
+
+
+@_on_device
 def resample_separable(y, By, Bx, out=None):
     """out[m, oy*wout+ox, c] = sum By[oy,qy] Bx[ox,qx] y[m,qy,qx,c];  y [M,hin,win,C] fp32 contiguous (NHWC patches),
     By [hout,hin], Bx [wout,win] fp32 -> [M, hout*wout, C]."""
@@ -529,7 +582,7 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
     rc = _lib.lib().dfsfm_conv2d_nhwc_f32(
         None if split_in else _ptr(x), _ptr(x.hi) if split_in else None, _ptr(x.lo) if split_in else None,
         sxn, xt.stride(1), xt.stride(2), N, H, W, Cin, _ptr(pw.hi), _ptr(pw.lo), pw.Cout, pw.Kpad, pw.kh, pw.kw,
-        stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 1 if relu else 0,
+        stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, int(relu),
         _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, 1 if pw.tap_padded else 0, None, None, 0.0, _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
     if _debug_range and out_split:

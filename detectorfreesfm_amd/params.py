@@ -101,6 +101,53 @@ def multiview_param_spec(cfg: dict) -> Spec:
     return s
 
 
+MF_EMBED = (128, 192, 256, 512)        # Matchformer_LA_large: embed_dims, 3 blocks per stage, mlp_ratio 4, 8 heads
+MF_PATCH = (7, 3, 3, 3)
+
+
+def matchformer_param_spec() -> Spec:
+    """Matchformer (backbone 'largela') -- third_party/MatchFormer/model/matchformer.py:10-19 and
+    model/backbone/match_LA_large.py:118-218: 229 tensors, in the reference's ``state_dict`` order."""
+    s: Spec = []
+    cin = 1
+    for st, C in enumerate(MF_EMBED):
+        p = f"backbone.AttentionBlock{st + 1}."
+        k = MF_PATCH[st]
+        s += [(p + "patch_embed.proj.weight", (C, cin, k, k), "conv_fan_out:1"), (p + "patch_embed.proj.bias", (C,), "bn_b"),
+              (p + "patch_embed.pos.pa_conv.weight", (C, 1, 3, 3), f"conv_fan_out:{C}"),
+              (p + "patch_embed.pos.pa_conv.bias", (C,), "bn_b"),
+              (p + "patch_embed.norm.weight", (C,), "bn_w"), (p + "patch_embed.norm.bias", (C,), "bn_b")]
+        for i in range(3):
+            q = f"{p}block.{i}."
+            s += [(q + "norm1.weight", (C,), "bn_w"), (q + "norm1.bias", (C,), "bn_b"),
+                  (q + "attn.q.weight", (C, C), "tn02"), (q + "attn.q.bias", (C,), "bn_b"),
+                  (q + "attn.kv.weight", (2 * C, C), "tn02"), (q + "attn.kv.bias", (2 * C,), "bn_b"),
+                  (q + "norm.weight", (C,), "bn_w"), (q + "norm.bias", (C,), "bn_b"),
+                  (q + "mlp.fc1.weight", (4 * C, C), "tn02"), (q + "mlp.fc1.bias", (4 * C,), "bn_b"),
+                  (q + "mlp.dwconv.dwconv.weight", (4 * C, 1, 3, 3), f"conv_fan_out:{4 * C}"),
+                  (q + "mlp.dwconv.dwconv.bias", (4 * C,), "bn_b"),
+                  (q + "mlp.fc2.weight", (C, 4 * C), "tn02"), (q + "mlp.fc2.bias", (C,), "bn_b")]
+        s += [(p + "norm.weight", (C,), "bn_w"), (p + "norm.bias", (C,), "bn_b")]
+        cin = C
+    e = MF_EMBED
+    p = "backbone."
+    s.append((p + "layer4_outconv.weight", (e[3], e[3], 1, 1), "conv_fan_out:1"))
+    s.append((p + "layer3_outconv.weight", (e[3], e[2], 1, 1), "conv_fan_out:1"))
+    def outconv2(nm, a, b):
+        s.append((f"{p}{nm}.0.weight", (a, a, 3, 3), "conv_fan_out:1"))
+        _bn(s, f"{p}{nm}.1.", a)
+        s.append((f"{p}{nm}.3.weight", (b, a, 3, 3), "conv_fan_out:1"))
+    outconv2("layer3_outconv2", e[3], e[2])
+    s.append((p + "layer2_outconv.weight", (e[2], e[1], 1, 1), "conv_fan_out:1"))
+    outconv2("layer2_outconv2", e[2], e[1])
+    s.append((p + "layer1_outconv.weight", (e[1], e[0], 1, 1), "conv_fan_out:1"))
+    outconv2("layer1_outconv2", e[1], e[0])
+    # fine-level modules: present in every checkpoint, unused when fine.enable=False (matchformer.py:17-18)
+    s += [("fine_preprocess.down_proj.weight", (128, 256), "kaiming_out"), ("fine_preprocess.down_proj.bias", (128,), "zeros"),
+          ("fine_preprocess.merge_feat.weight", (128, 256), "kaiming_out"), ("fine_preprocess.merge_feat.bias", (128,), "zeros")]
+    return s
+
+
 def random_state_dict(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     sd = {}
@@ -111,6 +158,11 @@ def random_state_dict(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
         elif kind == "xavier":             # nn.init.xavier_uniform_
             bound = math.sqrt(6.0 / (shape[0] + shape[1]))
             t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind == "tn02":               # timm trunc_normal_(std=.02) (match_LA_large.py:208-211)
+            t = (torch.randn(shape, generator=g) * 0.02).clamp(-2.0, 2.0)
+        elif kind.startswith("conv_fan_out"):   # normal_(0, sqrt(2 / (kh*kw*out / groups))) (:215-218)
+            groups = int(kind.split(":")[1])
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[0] * shape[2] * shape[3] / groups))
         elif kind == "torch_conv_w":       # kaiming_uniform_(a=sqrt(5)) -> U(-1/sqrt(fan_in), ..)
             bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
             t = (torch.rand(shape, generator=g) * 2 - 1) * bound
@@ -158,6 +210,25 @@ def planted_loftr_state_dict(spec: Spec, seed: int = 0, alpha: float = 3.0) -> D
     W = sd["backbone.layer3_outconv.weight"][:, :, 0, 0].double()
     Wn = alpha * (W - torch.outer(W @ mu, mu) / (mu @ mu))
     sd["backbone.layer3_outconv.weight"] = Wn.float()[:, :, None, None].contiguous()
+    return sd
+
+
+def planted_matchformer_state_dict(spec: Spec, seed: int = 0, alpha: float = 3.0) -> Dict[str, torch.Tensor]:
+    """The MatchFormer counterpart of ``planted_loftr_state_dict``: the last FPN convolution that produces the coarse
+    features (``backbone.layer3_outconv2.3``, 3x3, no bias) gets every tap projected off the position mean mu of its
+    input, ``alpha * W_t (I - mu mu^T / |mu|^2)`` (mu: 512 committed doubles, oracle/make_planted.py), so that synthetic
+    frames give real matches at thr 0.2."""
+    import os
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"planted_mu_matchformer_seed{seed}.npy")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: run `python -m oracle.make_planted matchformer` for this seed")
+    sd = random_state_dict(spec, seed)
+    mu = torch.from_numpy(np.load(path)).double()
+    W = sd["backbone.layer3_outconv2.3.weight"].double()
+    proj = torch.einsum("oikl,i->okl", W, mu)
+    Wn = alpha * (W - proj[:, None] * mu[None, :, None, None] / (mu @ mu))
+    sd["backbone.layer3_outconv2.3.weight"] = Wn.float().contiguous()
     return sd
 
 

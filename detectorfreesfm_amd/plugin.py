@@ -1,8 +1,8 @@
 """Reference-shaped plugin builders (same names, argument meaning and error behaviour).
 
 coarse   ``build_model(args) -> (detector, matcher)``, ``extract_preds``, ``extract_matches``
-         mirror src/coarse_match/coarse_match_worker.py:21-99; selected with the NEW matcher name
-         ``args['matcher'] == 'loftr_hip'`` (``neuralsfm.NEUSFM_coarse_matcher``), so the
+         mirror src/coarse_match/coarse_match_worker.py:21-99; selected with the NEW matcher names
+         ``args['matcher'] == 'loftr_hip'`` / ``'matchformer_hip'`` (``neuralsfm.NEUSFM_coarse_matcher``), so the
          reference's own 'loftr_official' / 'aspanformer' / 'matchformer' branches stay intact.
 refine   ``build_refine_model(args, rewindow_size_factor, model_idx) -> matcher`` and
          ``extract_results`` mirror src/post_optimization/matcher_model/multiview_match_worker.py:16-82.
@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import ops
 from .coarse import HipLoFTR
 from .config import loftr_coarse_only_config, multiview_refinement_config
+from .matchformer import HipMatchformer, matchformer_coarse_only_config
 from .refine import HipMultiviewMatcher
 
 
@@ -40,6 +41,19 @@ def build_model(args: dict):
     'loftr_hip': {'weight_path': path-or-None, 'cfg': optional lower-cased LoFTR config}}."""
     if "seed" in args:
         torch.manual_seed(args["seed"])
+    if args["matcher"] == "matchformer_hip":            # the 'matchformer' branch of the reference (:59-74)
+        if args.get("type", "coarse_only") != "coarse_only":
+            raise NotImplementedError("matchformer_hip provides the coarse_only matcher")
+        margs = args.get("matchformer_hip", {})
+        cfg = margs.get("cfg") or matchformer_coarse_only_config(args["match_thr"])
+        cfg["match_coarse"]["thr"] = args["match_thr"]
+        matcher = HipMatchformer(config=cfg)
+        if margs.get("weight_path") is not None:            # the MatchFormer checkpoints are bare state dicts (:70)
+            matcher.load_state_dict(torch.load(margs["weight_path"], map_location="cpu"), strict=True)
+        detector = DetectorWrapper()
+        detector.eval()
+        matcher.eval()
+        return detector, matcher
     if args["matcher"] != "loftr_hip":
         raise NotImplementedError(args["matcher"])
     if args.get("type", "coarse_only") != "coarse_only":

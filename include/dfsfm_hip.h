@@ -97,6 +97,18 @@ int dfsfm_coarse_match_split(const void* feat0_hi, const void* feat0_lo, const v
                              int64_t* j_ids, float* mconf, float* mkpts0, float* mkpts1, int32_t* count,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with padding masks (mask0 [N,L], mask1 [N,S] uint8, 1 = valid): rows / columns of padded coarse cells take
+ * no part in the softmaxes and produce no match, as `sim_matrix.masked_fill_(~(mask_c0[..., None] * mask_c1[:, None]), -INF)`
+ * does in the reference (third_party/LoFTR/src/loftr/utils/coarse_matching.py:110-113; the MatchFormer copy
+ * third_party/MatchFormer/model/backbone/coarse_matching.py:104-107).  `border` must be 0 with masks
+ * (mask_border_with_padding is not implemented; MatchFormer's config has BORDER_RM = 0). */
+int dfsfm_coarse_match_split_masked(const void* feat0_hi, const void* feat0_lo, const void* feat1_hi,
+                                    const void* feat1_lo, const uint8_t* mask0, const uint8_t* mask1, int N, int L, int S,
+                                    int C, float temperature, float thr, int border, int h0c, int w0c, int h1c, int w1c,
+                                    const float* scale0, const float* scale1, float coarse_scale, int64_t* b_ids,
+                                    int64_t* i_ids, int64_t* j_ids, float* mconf, float* mkpts0, float* mkpts1,
+                                    int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Dense confidence matrix conf[N,L,S] = softmax(sim,1)*softmax(sim,2) (coarse_matching.py:103-116).
  * Debug / parity aid only ("conf_matrix" is stored by the reference but no inference caller
  * reads it, src/coarse_match/coarse_match_worker.py:83-91). Same workspace as above. */
@@ -173,6 +185,19 @@ int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const f
 int dfsfm_split_rows_f32(const float* x, int64_t ldx, const float* add, int64_t add_rows, float* out,
                          int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, int64_t rows, int C,
                          void* stream);
+
+/* Depth-wise 3x3 convolution (groups = C, stride 1, pad 1, bias) on an NHWC fp32 map with its consumer fused:
+ *   mode 0: dw(x) + b      mode 1: x * sigmoid(dw(x) + b)      mode 2: GELU(dw(x) + b)   (erf form)
+ * Replaces Positional (pa_conv + sigmoid gate) and the DWConv + GELU of Mlp of MatchFormer-LA
+ *   third_party/MatchFormer/model/backbone/match_LA_large.py:15-27, 39-41, 108-116
+ * x [N,H,W,C] fp32; w9c [9][C] fp32 = weight[c,0,ky,kx] at [(ky*3+kx)][c]; bias [C]; C % 8 == 0.
+ * out [N,H,W,C] fp32 and / or out_hi / out_lo [N,H,W,C] fp16 split planes (either may be NULL). */
+int dfsfm_dwconv3x3_nhwc_f32(const float* x, int N, int H, int W, int C, const float* w9c, const float* bias, int mode,
+                             float* out, void* out_hi, void* out_lo, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=True) of NHWC fp32 maps (FPN top-down path, match_LA_large.py:232-236).
+ * x [N,hin,win,C] -> out [N,hout,wout,C]; C % 4 == 0. */
+int dfsfm_bilinear_up_nhwc_f32(const float* x, int N, int hin, int win, int C, int hout, int wout, float* out, void* stream);
 
 /* Separable resampling of NHWC patch feature maps:
  *   out[m, oy, ox, c] = sum_{qy,qx} By[oy, qy] * Bx[ox, qx] * y[m, qy, qx, c]

@@ -21,8 +21,8 @@ sys.path.insert(0, ROOT)
 from oracle import ref_import  # noqa: E402
 from detectorfreesfm_amd import synth  # noqa: E402
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config  # noqa: E402
-from detectorfreesfm_amd.params import (loftr_param_spec, multiview_param_spec, planted_loftr_state_dict,  # noqa: E402
-                                        random_state_dict)
+from detectorfreesfm_amd.params import (loftr_param_spec, matchformer_param_spec, multiview_param_spec,  # noqa: E402
+                                        planted_loftr_state_dict, planted_matchformer_state_dict, random_state_dict)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -208,6 +208,45 @@ def merge_golden():
     print("merge_keypoints.npz", {k: v.shape for k, v in out.items() if k.endswith("rows")})
 
 
+def matchformer_masks(n_pairs, h, w):
+    """Padding masks as the dataset's pad_to = -1 produces them (valid top-left rectangle per frame), coarse resolution."""
+    m0 = torch.ones((n_pairs, h, w), dtype=torch.bool)
+    m1 = torch.ones((n_pairs, h, w), dtype=torch.bool)
+    m0[0, h - 3:] = False
+    m0[0, :, w - 2:] = False
+    m1[0, h - 1:] = False
+    if n_pairs > 1:
+        m1[1, :, w - 4:] = False
+    return m0, m1
+
+
+def matchformer_golden():
+    """MatchFormer-LA coarse matcher: the real Matchformer module with planted seeded weights, two
+    pairs with per-pair scales, without and with padding masks -> tests/golden/matchformer_e2e.npz."""
+    from detectorfreesfm_amd.matchformer import matchformer_coarse_only_config
+    Matchformer = ref_import.import_matchformer()
+    c = dict(weight_seed=0, alpha=3.0, data_seed=1000, n_pairs=2, H=96, W=128, thr=0.2)
+    cfg = matchformer_coarse_only_config(c["thr"])
+    sd = planted_matchformer_state_dict(matchformer_param_spec(), c["weight_seed"], c["alpha"])
+    m = Matchformer(cfg).eval()
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    out = {}
+    with torch.no_grad():
+        for tag in ("plain", "masked"):
+            data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+            data["scale0"] = torch.tensor([[1.5, 2.0], [1.0, 1.0]])
+            data["scale1"] = torch.tensor([[1.0, 1.25], [0.5, 2.0]])
+            if tag == "masked":
+                data["mask0"], data["mask1"] = matchformer_masks(c["n_pairs"], c["H"] // 8, c["W"] // 8)
+            m(data)
+            assert data["i_ids"].numel() > 60
+            for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+                out[f"{tag}_{k}"] = data[k].numpy()
+            out["scale0"], out["scale1"] = data["scale0"].numpy(), data["scale1"].numpy()
+    np.savez(os.path.join(OUT, "matchformer_e2e.npz"), **out, **c)
+    print("matchformer_e2e.npz", {k: v.shape for k, v in out.items() if k.endswith("i_ids")})
+
+
 def bags_golden():
     """Host-side feeding: the reference's own MatchingMultiviewData on a seeded synthetic scene
     -> tests/golden/bags.npz (bag lists as JSON + the tensors of every bag, concatenated)."""
@@ -232,7 +271,10 @@ if __name__ == "__main__":
         merge_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "bags":
         bags_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "matchformer":
+        matchformer_golden()
     else:
         main()
         merge_golden()
         bags_golden()
+        matchformer_golden()

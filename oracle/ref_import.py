@@ -318,3 +318,28 @@ def import_matching_data():
     _compile_defs(os.path.join("src", "post_optimization", "matcher_model", "multiview_match_worker.py"),
                   ("UpdatedQueryPts",), ns2)
     return ns["MatchingMultiviewData"], ns2["UpdatedQueryPts"]
+
+
+def import_matchformer():
+    """Return the reference's ``Matchformer`` class (third_party/MatchFormer/model/matchformer.py) and its lower-cased
+    coarse_only config (third_party/MatchFormer/config/matchformer_coarse_only.py values).  ``timm.models.layers``
+    (DropPath with p = 0, to_2tuple, trunc_normal_) gets identity-level stand-ins; none of them computes on the
+    inference path."""
+    import torch
+    _ensure_path()
+    install_stubs()
+    if "timm.models.layers" not in sys.modules:
+        tl = _mod("timm.models.layers")
+
+        class DropPath(torch.nn.Module):
+            def __init__(self, drop_prob=0.0):
+                super().__init__()
+
+            def forward(self, x):
+                return x
+        tl.DropPath = DropPath
+        tl.to_2tuple = lambda x: x if isinstance(x, tuple) else (x, x)
+        tl.trunc_normal_ = lambda t, std=1.0: torch.nn.init.trunc_normal_(t, std=std)
+        sys.modules["timm.models"].layers = tl
+    from third_party.MatchFormer.model.matchformer import Matchformer
+    return Matchformer

@@ -28,14 +28,23 @@ def _la(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out
     if out_split:
         N, L, H, D = y.shape
         return _rows_split(y.reshape(N * L, H * D))
+    if out is not None:
+        out.copy_(y)
+        return out
     return y
 
 
-def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None, coarse_scale=8.0):
+def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None, coarse_scale=8.0,
+        mask0=None, mask1=None):
     from detectorfreesfm_amd.ops import SplitAct
     if isinstance(feat0, SplitAct):       # split planes carry the fp32 value to 2^-22: correlate what they hold
         feat0, feat1 = feat0.float(), feat1.float()
     hw0_i = (hw0_c[0] * coarse_scale, hw0_c[1] * coarse_scale)
+    if mask0 is not None:
+        from oracle import restate_matchformer as rmf
+        N = feat0.shape[0]
+        conf = rmf.dual_softmax_conf_masked(feat0, feat1, temperature, mask0.reshape(N, -1).bool(), mask1.reshape(N, -1).bool())
+        return restate.coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border, scale0, scale1)
     return restate.coarse_matching(feat0, feat1, hw0_c, hw1_c, hw0_i, thr, border, temperature, scale0, scale1)
 
 
@@ -145,7 +154,9 @@ def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None, out_split
         y = y + pw.bias
     if residual is not None:
         y = y + (residual.float() if isinstance(residual, SplitAct) else residual).reshape(y.shape)
-    if relu:
+    if relu == 2:
+        y = torch.nn.functional.leaky_relu(y, 0.01)
+    elif relu:
         y = torch.relu(y)
     if out_split:
         return _to_split(y)
@@ -190,6 +201,21 @@ def _resample(y, By, Bx, out=None):
     return out
 
 
+def _dwconv(x, w, bias, mode=0, out_split=False):
+    import torch.nn.functional as F
+    C = x.shape[-1]
+    w4 = w.reshape(C, 1, 3, 3) if w.dim() == 4 else w.t().reshape(C, 1, 3, 3)
+    xx = x.permute(0, 3, 1, 2)
+    y = F.conv2d(xx, w4, bias, 1, 1, 1, C)
+    y = (y, xx * torch.sigmoid(y), F.gelu(y))[mode].permute(0, 2, 3, 1).contiguous()
+    return _to_split(y) if out_split else y
+
+
+def _bilinear(x, hout, wout):
+    import torch.nn.functional as F
+    return F.interpolate(x.permute(0, 3, 1, 2), size=(hout, wout), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+
+
 def _merge(rows, img0, img1, n_images):
     """ops.merge_keypoints on the numpy restatement of the reference's consumer stage (oracle/restate_merge.py)."""
     from oracle import restate_merge as rm
@@ -203,12 +229,14 @@ def cpu_ops():
     from detectorfreesfm_amd import ops
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
-                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable")}
+                                          "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
+                                          "bilinear_up")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
     ops.split_rows, ops.linear_ln, ops.merge_keypoints = _split_rows, _linear_ln, _merge
     ops.resample_separable = _resample
+    ops.dwconv3x3, ops.bilinear_up = _dwconv, _bilinear
     try:
         yield
     finally:

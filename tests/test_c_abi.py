@@ -43,7 +43,8 @@ def test_workspace_queries(built_lib):
     L = built_lib
     assert L.dfsfm_linear_attention_workspace(1, 4800, 8, 32) > 0
     assert L.dfsfm_linear_attention_workspace(2000, 900, 8, 16) == ((2000 * 8 * 272 * 4 + 255) // 256) * 256
-    assert L.dfsfm_linear_attention_workspace(1, 4800, 8, 64) == 0        # unsupported head dim
+    assert L.dfsfm_linear_attention_workspace(1, 4800, 8, 64) > 0         # generic-D kernels (MatchFormer stage 4)
+    assert L.dfsfm_linear_attention_workspace(1, 4800, 8, 48) == 0        # unsupported head dim
     w1 = L.dfsfm_coarse_match_workspace(1, 4800, 4800)
     w8 = L.dfsfm_coarse_match_workspace(8, 4800, 4800)
     assert 0 < w1 < w8 <= 8 * w1 + 4096

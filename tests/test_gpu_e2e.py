@@ -411,3 +411,71 @@ def test_refine_scene_worker_vs_oracle(built_lib):
         assert len(flips) <= 3, flips           # each one already verified as a < 1e-5 score tie by check_refine
         n_rows += rows.shape[0]
     assert n_rows > 400
+
+
+# ---------------------------------------------------------------- MatchFormer-LA coarse matcher
+def _matchformer(thr=0.2):
+    from detectorfreesfm_amd import HipMatchformer, matchformer_coarse_only_config
+    from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
+    cfg = matchformer_coarse_only_config(thr)
+    sd = planted_matchformer_state_dict(matchformer_param_spec(), 0)
+    m = HipMatchformer(cfg)
+    m.load_state_dict(sd, strict=True)
+    return cfg, sd, m.eval().to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["plain", "masked"])
+def test_matchformer_e2e_golden(built_lib, golden, tag):
+    """Fixture written by the real Matchformer module (oracle/make_golden.py matchformer): 2 pairs, per-pair scales,
+    without / with padding masks; same per-entry rules as the LoFTR tests."""
+    from oracle import restate_matchformer as rmf
+    from oracle.make_golden import matchformer_masks
+    gz = golden("matchformer_e2e")
+    c = _case(gz)
+    cfg, sd, m = _matchformer(c["thr"])
+    data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    if tag == "masked":
+        data["mask0"], data["mask1"] = matchformer_masks(c["n_pairs"], c["H"] // 8, c["W"] // 8)
+    d = synth.to_device(data, DEV)
+    m(d)
+    with torch.no_grad():
+        o = rmf.matchformer_forward(sd, cfg, data, with_fine_backbone=False)
+    ref = {k: gz[f"{tag}_{k}"] for k in MATCH_KEYS}
+    ex = _strict_coarse(d, ref, o["conf_matrix"], c["thr"], f"matchformer_e2e {tag}")
+    assert len(ex) <= 1 and len(ref["i_ids"]) > 60 and (d["m_bids"] == d["b_ids"]).all()
+
+
+def test_matchformer_240x320_vs_oracle(built_lib):
+    """A larger frame (1200 coarse cells per image, all four stages with their real token counts: 19200 / 4800 / 1200 /
+    300): every match row identical to the oracle's."""
+    from oracle import restate_matchformer as rmf
+    cfg, sd, m = _matchformer(0.2)
+    data = synth.coarse_pair_batch(1, 240, 320, seed=7)
+    d = synth.to_device(data, DEV)
+    m(d)
+    with torch.no_grad():
+        o = rmf.matchformer_forward(sd, cfg, data, with_fine_backbone=False)
+    assert o["i_ids"].numel() > 500
+    ex = _strict_coarse(d, o, o["conf_matrix"], 0.2, "matchformer 240x320")
+    assert len(ex) <= 2
+
+
+def test_matchformer_plugin_surface(built_lib, tmp_path):
+    """build_model('matchformer_hip') from a bare state-dict checkpoint (coarse_match_worker.py:59-74) -> extract_matches."""
+    from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
+    from oracle import restate_matchformer as rmf
+    sd = planted_matchformer_state_dict(matchformer_param_spec(), 0)
+    ckpt = tmp_path / "matchformer.ckpt"
+    torch.save({"matcher." + k: v for k, v in sd.items()}, ckpt)
+    detector, matcher = plugin.build_model({"matcher": "matchformer_hip", "type": "coarse_only", "match_thr": 0.2, "seed": 666,
+                                            "matchformer_hip": {"weight_path": str(ckpt)}})
+    matcher.cuda()
+    data = synth.coarse_pair_batch(1, 96, 128, seed=1003)
+    d = {k: v.cuda() for k, v in data.items()}
+    mk0, mk1, mc = plugin.extract_matches(d, detector=detector, matcher=matcher)
+    with torch.no_grad():
+        o = rmf.matchformer_forward(sd, matcher.config, data, with_fine_backbone=False)
+    ex = _strict_coarse(d, o, o["conf_matrix"], 0.2, "matchformer plugin")
+    assert len(ex) == 0 and len(mc) > 30
+    assert np.array_equal(mk0, o["mkpts0_f"].numpy()) and np.abs(mc - o["mconf"].numpy()).max() <= parity.TOL_CONF

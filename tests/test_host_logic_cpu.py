@@ -180,3 +180,33 @@ def test_config0_example_scene_plumbing(tmp_path):
     kz, mz = np.load(tmp_path / "keypoints.npz"), np.load(tmp_path / "matches.npz")
     assert kz[names[0]].shape[1] == 2 and mz["-".join(names)].shape == (2, table.shape[0])
     assert (mz["-".join(names)][0] < len(kz[names[0]])).all() and (mz["-".join(names)][1] < len(kz[names[1]])).all()
+
+
+def test_matchformer_host_logic_with_cpu_standins():
+    """HipMatchformer's host logic (NHWC plumbing, weight packing, batch-half swap of the cross blocks, BN folding, FPN,
+    masks) with the exact split-GEMM algebra emulated on the CPU: the oracle's match rows, with and without padding masks."""
+    from detectorfreesfm_amd import HipMatchformer, matchformer_coarse_only_config
+    from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
+    from oracle import restate_matchformer as rmf
+    from oracle.make_golden import matchformer_masks
+    cfg = matchformer_coarse_only_config(0.2)
+    sd = planted_matchformer_state_dict(matchformer_param_spec(), 0)
+    m = HipMatchformer(cfg).eval()
+    m.load_state_dict({"matcher." + k: v for k, v in sd.items()}, strict=True)        # prefix stripped like matchformer.py:60-64
+    data = synth.coarse_pair_batch(2, 64, 96, seed=1000)
+    data["scale0"] = torch.tensor([[1.5, 2.0], [1.0, 1.0]])
+    for masked in (False, True):
+        if masked:
+            data["mask0"], data["mask1"] = matchformer_masks(2, 8, 12)
+        with cpu_ops(), torch.no_grad():
+            d = dict(data)
+            m(d)
+        with torch.no_grad():
+            o = rmf.matchformer_forward(sd, cfg, data, with_fine_backbone=False)
+        assert o["i_ids"].numel() > 30
+        for k in ("b_ids", "i_ids", "j_ids"):
+            assert torch.equal(d[k], o[k]), (masked, k)
+        assert torch.equal(d["mkpts0_f"], o["mkpts0_f"]) and torch.equal(d["mkpts1_f"], o["mkpts1_f"])
+        assert (d["mconf"] - o["mconf"]).abs().max().item() < 1e-4
+    with pytest.raises(NotImplementedError):
+        m({"image0": torch.zeros(1, 1, 64, 96), "image1": torch.zeros(1, 1, 64, 64)})

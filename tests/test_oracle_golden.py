@@ -188,3 +188,42 @@ def test_merge_oracle_vs_live_reference():
         assert np.array_equal(sc[off[i]:off[i + 1]], fs[n])
     for k, (lo, hi) in sl.items():
         assert np.array_equal(ids[lo:hi], upd[k].reshape(-1, 2))
+
+
+# ---------------------------------------------------------------- MatchFormer-LA
+def _mf_inputs(gz, tag):
+    from oracle.make_golden import matchformer_masks
+    c = _case(gz)
+    data = synth.coarse_pair_batch(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    if tag == "masked":
+        data["mask0"], data["mask1"] = matchformer_masks(c["n_pairs"], c["H"] // 8, c["W"] // 8)
+    return c, data
+
+
+@pytest.mark.parametrize("tag", ["plain", "masked"])
+def test_matchformer_e2e(golden, tag):
+    """oracle/restate_matchformer.py == the real Matchformer module (fixture), bit for bit, with and without padding masks."""
+    from detectorfreesfm_amd.matchformer import matchformer_coarse_only_config
+    from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
+    from oracle import restate_matchformer as rmf
+    gz = golden("matchformer_e2e")
+    c, data = _mf_inputs(gz, tag)
+    cfg = matchformer_coarse_only_config(c["thr"])
+    sd = planted_matchformer_state_dict(matchformer_param_spec(), c["weight_seed"], c["alpha"])
+    with torch.no_grad():
+        o = rmf.matchformer_forward(sd, cfg, data)
+    assert len(gz[f"{tag}_i_ids"]) > 60
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+        assert np.array_equal(o[k].numpy(), gz[f"{tag}_{k}"]), k
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference (build container only)")
+def test_matchformer_key_layout_vs_live_reference():
+    from detectorfreesfm_amd.matchformer import matchformer_coarse_only_config
+    from detectorfreesfm_amd.params import matchformer_param_spec
+    MF = ref_import.import_matchformer()
+    m = MF(matchformer_coarse_only_config(0.2)).eval()
+    spec = matchformer_param_spec()
+    assert [n for n, _, _ in spec] == list(m.state_dict().keys()) and len(spec) == 229
+    assert all(tuple(m.state_dict()[n].shape) == tuple(s) for n, s, _ in spec)
