@@ -13,6 +13,59 @@
 
 namespace {
 
+// C = 128 (the refinement transformer and MatchFormer stage 1, whose 300K-row maps stream from HBM): 32 lanes x 16 B per
+// row, two rows per wave pass, LN128_PASSES passes whose loads are all issued before the first reduction.
+constexpr int LN128_PASSES = 4;
+__global__ __launch_bounds__(256) void layernorm128_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const float* __restrict__ residual,
+                                                           const _Float16* __restrict__ resh,
+                                                           const _Float16* __restrict__ resl, int64_t ldr,
+                                                           float* __restrict__ out, int64_t ldo, int64_t rows,
+                                                           _Float16* __restrict__ outh, _Float16* __restrict__ outl,
+                                                           int64_t ldos) {
+    const int lane = threadIdx.x & 63, sub = lane >> 5, ch = (lane & 31) * 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * LN128_PASSES) + sub;
+    f32x4 v[LN128_PASSES];
+#pragma unroll
+    for (int p = 0; p < LN128_PASSES; ++p) {
+        const int64_t row = row0 + 2 * p;
+        v[p] = row < rows ? *reinterpret_cast<const f32x4*>(x + row * ldx + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + ch), bt = *reinterpret_cast<const f32x4*>(beta + ch);
+#pragma unroll
+    for (int p = 0; p < LN128_PASSES; ++p) {
+        const int64_t row = row0 + 2 * p;
+        float s = (v[p][0] + v[p][1]) + (v[p][2] + v[p][3]);
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        const float mean = s * (1.f / 128.f);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = v[p][e] - mean;
+        float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+        const float rstd = 1.f / sqrtf(q * (1.f / 128.f) + eps);
+        if (row >= rows) continue;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * g[e] + bt[e];
+        if (residual) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(residual + row * ldr + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = r[e] + o[e];
+        } else if (resh) {
+            const dfsfm::dfsfm_half4 rh = *reinterpret_cast<const dfsfm::dfsfm_half4*>(resh + row * ldr + ch);
+            const dfsfm::dfsfm_half4 rl = *reinterpret_cast<const dfsfm::dfsfm_half4*>(resl + row * ldr + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((float)rh[e] + (float)rl[e] * (1.f / 2048.f)) + o[e];
+        }
+        dfsfm::store4(out, outh, outl, row * ldo + ch, row * ldos + ch, o);
+    }
+}
+
 // One wave per row, VEC = C/64 contiguous floats per lane (C = 64*VEC).
 template <int VEC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
@@ -224,6 +277,14 @@ extern "C" int dfsfm_layernorm_f32(const float* x, int64_t ldx, const float* gam
             (out && ((ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))))
             return DFSFM_E_UNSUPPORTED;
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
+    } else if (C == 128 && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(gamma) & 15) &&
+               !(reinterpret_cast<uintptr_t>(beta) & 15) && (!out || (!(ldo & 3) && !(reinterpret_cast<uintptr_t>(out) & 15))) &&
+               (!oh || (!(ldo_s & 3) && !(reinterpret_cast<uintptr_t>(oh) & 7) && !(reinterpret_cast<uintptr_t>(ol) & 7))) &&
+               (!residual || (!(ldr & 3) && !(reinterpret_cast<uintptr_t>(residual) & 15))) &&
+               (!rh || (!(ldr & 3) && !(reinterpret_cast<uintptr_t>(rh) & 7) && !(reinterpret_cast<uintptr_t>(rl) & 7)))) {
+        const int64_t per_blk = 4 * 2 * LN128_PASSES;
+        hipLaunchKernelGGL(layernorm128_kernel, dim3((unsigned)((rows + per_blk - 1) / per_blk)), blk, 0, stream, x, ldx, gamma, beta, eps,
+                           residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 128) {
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, stream, x, ldx, gamma, beta, eps, residual, rh, rl, ldr, out, ldo, rows, oh, ol, ldo_s);
     } else if (C == 64) {
