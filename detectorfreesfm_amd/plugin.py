@@ -41,14 +41,14 @@ def build_model(args: dict):
     'loftr_hip': {'weight_path': path-or-None, 'cfg': optional lower-cased LoFTR config}}."""
     if "seed" in args:
         torch.manual_seed(args["seed"])
-    if args["matcher"] == "matchformer_hip":            # the 'matchformer' branch of the reference (:59-74)
+    if args["matcher"] == "matchformer_hip":            # the 'matchformer' branch of the reference (:62-76)
         if args.get("type", "coarse_only") != "coarse_only":
             raise NotImplementedError("matchformer_hip provides the coarse_only matcher")
         margs = args.get("matchformer_hip", {})
         cfg = margs.get("cfg") or matchformer_coarse_only_config(args["match_thr"])
         cfg["match_coarse"]["thr"] = args["match_thr"]
         matcher = HipMatchformer(config=cfg)
-        if margs.get("weight_path") is not None:            # the MatchFormer checkpoints are bare state dicts (:70)
+        if margs.get("weight_path") is not None:            # the MatchFormer checkpoints are bare state dicts (:72-73)
             matcher.load_state_dict(torch.load(margs["weight_path"], map_location="cpu"), strict=True)
         detector = DetectorWrapper()
         detector.eval()
