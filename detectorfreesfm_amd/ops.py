@@ -412,6 +412,43 @@ def bilinear_up(x, hout, wout):
 
 
 @_on_device
+def resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pad_hw=None, want_mask=False):
+    """PIL's 8-bit two-pass resampling of src [H,W] or [H,W,3] uint8 with the given int32 tables (images.py builds
+    them) -> (u8 [Hn,Wn(,3)] or None, fp32 [C,pad_h,pad_w] = lut[byte] or None, mask [pad_h,pad_w] or None)."""
+    _require_cuda(src, bounds_x, kk_x, bounds_y, kk_y)
+    if src.dtype != torch.uint8 or src.dim() not in (2, 3) or src.stride(-1) != 1 or (src.dim() == 3 and src.stride(1) != src.shape[2]):
+        raise _lib.DfsfmError("resample_u8: need a uint8 [H,W] or [H,W,3] image with dense rows")
+    for t in (bounds_x, kk_x, bounds_y, kk_y):
+        if t.dtype != torch.int32 or not t.is_contiguous() or t.dim() != 2:
+            raise _lib.DfsfmError("resample_u8: coefficient tables are contiguous int32 matrices")
+    H, W = src.shape[:2]
+    C = 1 if src.dim() == 2 else src.shape[2]
+    Wn, Hn = bounds_x.shape[0], bounds_y.shape[0]
+    if bounds_x.shape[1] != 2 or bounds_y.shape[1] != 2 or kk_x.shape[0] != Wn or kk_y.shape[0] != Hn:
+        raise _lib.DfsfmError("resample_u8: bounds are [out,2], coefficients [out,ksize]")
+    if not out_u8 and lut is None:
+        raise _lib.DfsfmError("resample_u8: no output requested")
+    dev = src.device
+    tmp = torch.empty((H * Wn * C,), dtype=torch.uint8, device=dev)
+    o8 = torch.empty((Hn, Wn) if src.dim() == 2 else (Hn, Wn, C), dtype=torch.uint8, device=dev) if out_u8 else None
+    of, mk, ph, pw = None, None, 0, 0
+    if lut is not None:
+        _require_cuda(lut)
+        if lut.dtype != torch.float32 or lut.numel() != 256 or not lut.is_contiguous():
+            raise _lib.DfsfmError("resample_u8: lut is 256 contiguous fp32 values")
+        ph, pw = (Hn, Wn) if pad_hw is None else (int(pad_hw[0]), int(pad_hw[1]))
+        of = torch.empty((C, ph, pw), dtype=torch.float32, device=dev)
+        mk = torch.empty((ph, pw), dtype=torch.float32, device=dev) if want_mask else None
+    elif want_mask:
+        raise _lib.DfsfmError("resample_u8: the mask comes with the fp32 output")
+    rc = _lib.lib().dfsfm_resample_u8(_ptr(src), src.stride(0), H, W, C, _ptr(bounds_x), _ptr(kk_x), kk_x.shape[1], Wn,
+                                      _ptr(bounds_y), _ptr(kk_y), kk_y.shape[1], Hn, _ptr(tmp), _ptr(o8), _ptr(of), _ptr(mk),
+                                      ph, pw, _ptr(lut), _stream())
+    _lib.check(rc, "dfsfm_resample_u8")
+    return o8, of, mk
+
+
+@_on_device
 def resample_separable(y, By, Bx, out=None):
     """out[m, oy*wout+ox, c] = sum By[oy,qy] Bx[ox,qx] y[m,qy,qx,c];  y [M,hin,win,C] fp32 contiguous (NHWC patches),
     By [hout,hin], Bx [wout,win] fp32 -> [M, hout*wout, C]."""

@@ -199,6 +199,22 @@ int dfsfm_dwconv3x3_nhwc_f32(const float* x, int N, int H, int W, int C, const f
  * x [N,hin,win,C] -> out [N,hout,wout,C]; C % 4 == 0. */
 int dfsfm_bilinear_up_nhwc_f32(const float* x, int N, int hin, int win, int C, int hout, int wout, float* out, void* stream);
 
+/* PIL's 8-bit fixed-point resampling (Image.resize on 'L' / 'RGB' images) + the tensor conversion of the reference's
+ * image readers.  Replaces, for an already decoded frame,
+ *   resize_image(image, (w_new, h_new), "pil_LANCZOS")           src/dataset/utils.py:160-177
+ *   pad_bottom_right / grayscale2tensor / rgb2tensor / mask2tensor  src/dataset/utils.py:30-62, as called at :108-121, :147-160
+ * Arithmetic (Pillow src/libImaging/Resample.c, ImagingResampleHorizontal_8bpc / Vertical_8bpc): a pixel is
+ *   clip8((2^21 + sum_x src[first + x] * kk[x]) >> 22) in int32; horizontal pass, rounded to 8 bits, then vertical.
+ * src [H,W,C] bytes with row pitch src_stride, C = 1 or 3.  bounds_x [Wn,2] / bounds_y [Hn,2] = (first source index, tap
+ * count) and kk_x [Wn,ksize_x] / kk_y [Hn,ksize_y] = the 22-bit coefficients of precompute_coeffs + normalize_coeffs_8bpc
+ * (any filter; identity tables skip a pass exactly).  tmp: H*Wn*C bytes of scratch.  Outputs, any subset:
+ *   out_u8 [Hn,Wn,C];   out_f32 [C,pad_h,pad_w] = lut256[byte] inside the image (lut256[v] = v / 255.f for the reference's
+ *   readers) and 0 in the bottom / right padding;   mask [pad_h,pad_w] = 1 inside, 0 in the padding (with out_f32 only). */
+int dfsfm_resample_u8(const uint8_t* src, int64_t src_stride, int H, int W, int C, const int32_t* bounds_x,
+                      const int32_t* kk_x, int ksize_x, int Wn, const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
+                      int Hn, uint8_t* tmp, uint8_t* out_u8, float* out_f32, float* mask, int pad_h, int pad_w,
+                      const float* lut256, void* stream);
+
 /* Separable resampling of NHWC patch feature maps:
  *   out[m, oy, ox, c] = sum_{qy,qx} By[oy, qy] * Bx[ox, qx] * y[m, qy, qx, c]
  * Replaces nn.Upsample(mode='bicubic', align_corners=True) followed by the centre-window crop of S2DNet's coarse

@@ -266,6 +266,43 @@ def bags_golden():
     print("bags.npz", len(bags), "bags")
 
 
+def read_image_cases():
+    """(name, colour?, H, W, kwargs of the reader) -- sizes as the pipelines use them: larger side to img_resize with
+    df = 8 (loftr), padded squares with masks (matchformer, pad_to = -1), an explicit (w, h), no resize at all."""
+    return [("gray_df8", False, 157, 203, dict(resize=(96,), df=8)),
+            ("gray_pad", False, 203, 157, dict(resize=(104,), df=8, pad_to=-1, ret_pad_mask=True)),
+            ("gray_wh", False, 90, 70, dict(resize=(112, 64), pad_to=128, ret_pad_mask=True)),
+            ("gray_keep", False, 48, 72, dict(resize=(100,), resize_no_larger_than=True, df=8)),
+            ("gray_up", False, 45, 60, dict(resize=(130,))),
+            ("rgb_df8", True, 157, 203, dict(resize=(96,), df=8)),
+            ("rgb_pad", True, 120, 90, dict(resize=(64,), pad_to=-1, ret_pad_mask=True))]
+
+
+def read_image_frame(name, color, H, W):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    smooth = rng.random((H // 8 + 2, W // 8 + 2) + ((3,) if color else ()))
+    big = np.kron(smooth, np.ones((8, 8) + ((1,) if color else ())))[:H, :W]              # blocky content + noise
+    return np.clip(big * 200 + rng.integers(0, 56, big.shape), 0, 255).astype(np.uint8)
+
+
+def read_image_golden():
+    """Host-side feeding (image part): the reference's own read_grayscale / read_rgb
+    (src/dataset/utils.py:80-160, real Pillow underneath) on seeded frames -> tests/golden/read_image.npz."""
+    frames, out = {}, {}
+    read_gray, read_rgb = ref_import.import_image_readers(frames)
+    for name, color, H, W, kw in read_image_cases():
+        frames[name] = read_image_frame(name, color, H, W)
+        ret = (read_rgb if color else read_gray)(name, ret_scales=True, **kw)
+        out[name + "/image"] = ret[0].numpy()
+        out[name + "/scales"] = ret[1].numpy()
+        out[name + "/original_hw"] = ret[2].numpy()
+        if kw.get("ret_pad_mask"):
+            out[name + "/mask"] = ret[3].numpy()
+    np.savez_compressed(os.path.join(OUT, "read_image.npz"), **out)
+    print("read_image.npz", {k: v.shape for k, v in out.items() if k.endswith("image")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "merge":
         merge_golden()
@@ -273,8 +310,11 @@ if __name__ == "__main__":
         bags_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "matchformer":
         matchformer_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "images":
+        read_image_golden()
     else:
         main()
         merge_golden()
         bags_golden()
         matchformer_golden()
+        read_image_golden()

@@ -343,3 +343,42 @@ def import_matchformer():
         sys.modules["timm.models"].layers = tl
     from third_party.MatchFormer.model.matchformer import Matchformer
     return Matchformer
+
+
+def import_image_readers(frames):
+    """Return the reference's own ``read_grayscale`` / ``read_rgb`` (src/dataset/utils.py:80-177, with the helpers they
+    call: process_resize, pad_bottom_right, grayscale2tensor, rgb2tensor, mask2tensor, resize_image), compiled unchanged.
+
+    The module imports cv2 / h5py / albumentations at the top, none installed here.  The readers use cv2 for exactly one
+    thing, the decode: ``frames`` maps a path to an already decoded uint8 array ([H,W] gray or [H,W,3] RGB) and the cv2
+    stand-in hands it out (as BGR for IMREAD_COLOR, so that the readers' own cvtColor(BGR2RGB) restores it).  Everything
+    after the decode -- the PIL LANCZOS resize included -- is the reference's code running on the real Pillow."""
+    import numpy as np
+    import PIL
+    import PIL.Image
+    import torch
+    _ensure_path()
+    install_stubs()
+
+    class _Cv2:
+        IMREAD_GRAYSCALE, IMREAD_COLOR, COLOR_BGR2RGB = 0, 1, 4
+
+        @staticmethod
+        def imread(path, flag):
+            a = frames[path]
+            if flag == _Cv2.IMREAD_COLOR:
+                assert a.ndim == 3
+                return np.ascontiguousarray(a[:, :, ::-1])
+            assert a.ndim == 2
+            return a
+
+        @staticmethod
+        def cvtColor(a, code):
+            assert code == _Cv2.COLOR_BGR2RGB
+            return np.ascontiguousarray(a[:, :, ::-1])
+
+    ns = {"np": np, "torch": torch, "PIL": PIL, "cv2": _Cv2, "logger": sys.modules["loguru"].logger}
+    _compile_defs(os.path.join("src", "dataset", "utils.py"),
+                  ("process_resize", "pad_bottom_right", "grayscale2tensor", "rgb2tensor", "mask2tensor", "read_rgb",
+                   "read_grayscale", "resize_image"), ns)
+    return ns["read_grayscale"], ns["read_rgb"]

@@ -216,6 +216,34 @@ def _bilinear(x, hout, wout):
     return F.interpolate(x.permute(0, 3, 1, 2), size=(hout, wout), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
 
 
+def _resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pad_hw=None, want_mask=False):
+    """ops.resample_u8 from the int32 tables alone (the arithmetic of csrc/image_resize.hip, in numpy)."""
+    import numpy as np
+    a = src.numpy()
+    a = a[:, :, None] if a.ndim == 2 else a
+
+    def one_pass(img, bounds, kk, axis):
+        s = np.moveaxis(img, axis, 0).astype(np.int64)
+        d = np.empty((bounds.shape[0],) + s.shape[1:], dtype=np.uint8)
+        for i in range(bounds.shape[0]):
+            lo, n = int(bounds[i, 0]), int(bounds[i, 1])
+            ss = (1 << 21) + np.tensordot(kk[i, :n].astype(np.int64), s[lo:lo + n], axes=(0, 0))
+            d[i] = np.clip(ss >> 22, 0, 255)
+        return np.moveaxis(d, 0, axis)
+    r = one_pass(one_pass(a, bounds_x.numpy(), kk_x.numpy(), 1), bounds_y.numpy(), kk_y.numpy(), 0)
+    o8 = torch.from_numpy(r[:, :, 0] if src.dim() == 2 else r) if out_u8 else None
+    of = mk = None
+    if lut is not None:
+        Hn, Wn, C = r.shape
+        ph, pw = (Hn, Wn) if pad_hw is None else pad_hw
+        of = torch.zeros((C, ph, pw), dtype=torch.float32)
+        of[:, :Hn, :Wn] = lut[torch.from_numpy(r.astype(np.int64))].permute(2, 0, 1)
+        if want_mask:
+            mk = torch.zeros((ph, pw), dtype=torch.float32)
+            mk[:Hn, :Wn] = 1
+    return o8, of, mk
+
+
 def _merge(rows, img0, img1, n_images):
     """ops.merge_keypoints on the numpy restatement of the reference's consumer stage (oracle/restate_merge.py)."""
     from oracle import restate_merge as rm
@@ -230,13 +258,14 @@ def cpu_ops():
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
-                                          "bilinear_up")}
+                                          "bilinear_up", "resample_u8")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
     ops.split_rows, ops.linear_ln, ops.merge_keypoints = _split_rows, _linear_ln, _merge
     ops.resample_separable = _resample
     ops.dwconv3x3, ops.bilinear_up = _dwconv, _bilinear
+    ops.resample_u8 = _resample_u8
     try:
         yield
     finally:
