@@ -57,6 +57,19 @@ SIGNATURES = [
     ("dfsfm_dwconv3x3_nhwc_f32", c_int,
      [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("dfsfm_bilinear_up_nhwc_f32", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("dfsfm_avgpool_nhwc_f32", c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    ("dfsfm_full_attention_f32", c_int,
+     [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+      c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    ("dfsfm_span_attention_f32", c_int,
+     [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+      c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    ("dfsfm_layernorm2d_f32", c_int,
+     [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+      c_int64, c_int, c_void_p]),
+    ("dfsfm_upsample_nhwc_f32", c_int,
+     [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("dfsfm_flow_decode_f32", c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p]),
     ("dfsfm_resample_u8", c_int,
      [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

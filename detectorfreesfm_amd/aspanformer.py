@@ -1,0 +1,312 @@
+"""MI355X ASpanFormer coarse matcher behind the reference's ``NEUSFM_coarse_matcher`` plugin surface.
+
+``HipASpanFormer`` is a drop-in for the reference's ``ASpanFormer`` module as src/coarse_match/coarse_match_worker.py:45-60
+builds it -- coarse_only config (configs/aspan/outdoor/aspan_test_coarse_only.py), ``online_resize=True`` -- with the same
+constructor arguments, the same 217-tensor ``state_dict`` layout (``matcher.`` prefix stripped, ``sample_offset`` entries of a
+checkpoint dropped, third_party/aspantransformer/src/ASpanFormer/aspanformer.py:110-117) and the same in-place
+``forward(data)`` contract: one pair per call (aspanformer.py:43); writes b_ids, i_ids, j_ids, m_bids, mconf, mkpts0_c/f,
+mkpts1_c/f, predict_flow and the offset_* visualisation entries.
+
+Paths below are relative to third_party/aspantransformer/src/ASpanFormer/.  The ResNet-FPN backbone is LoFTR's (identical
+file) and runs on the same split-plane convolution kernels; every 1x1 / 3x3 convolution of the transformer
+(aspan_module/transformer.py) is a launch of the same GEMM / conv kernels, with concatenations replaced by column slices
+of wider token buffers ([feat | upsampled], [x | flow feature | norm1(message)], the three-level fused message) and the
+positional part of ``v_proj(cat[x, pos])`` folded into a per-size constant that enters as the GEMM's residual.  New kernels
+(csrc/aspan_ops.hip): average pooling, softmax attention at the 1/32 level, the span attention of the two finer levels
+(flow statistics -> 8x8 bilinear K / V samples -> per-group softmax), ``layernorm2d``, bilinear / nearest up-sampling into
+column slices, the flow decoder's sigmoid.  The dual-softmax matching stage is K3-K5 of the LoFTR path.
+
+Not implemented (raises): frames whose sides are not multiples of 32 -- the reference resizes those with
+``torchvision.transforms.Resize`` (aspanformer.py:119-139), which this image does not have, so that branch could not be pinned
+-- padding masks (the reference's dataset path never pads for this matcher: src/coarse_match/coarse_match.py:88-90), and
+``fine.enable``.
+"""
+import math
+
+import torch
+
+from . import ops
+from .coarse import backbone_tokens_hip, fold_backbone, pack_backbone_hip
+from .params import ParamModule, aspanformer_param_spec
+
+
+def aspanformer_coarse_only_config(match_thr: float = 0.4) -> dict:
+    """``lower_config(get_cfg_defaults())['aspan']`` (src/config/default.py:5-51) merged with
+    configs/aspan/outdoor/aspan_test_coarse_only.py:7-12; coarse_match_worker.py:53 then overrides ``match_coarse.thr``."""
+    return {
+        "backbone_type": "ResNetFPN", "resolution": (8, 2), "fine_window_size": 5, "fine_concat_coarse_feat": True,
+        "resnetfpn": {"initial_dim": 128, "block_dims": [128, 196, 256]},
+        "coarse": {"d_model": 256, "d_ffn": 256, "d_flow": 128, "nhead": 8, "nlevel": 3, "ini_layer_num": 2, "layer_num": 4,
+                   "nsample": [2, 8], "radius_scale": 5, "coarsest_level": [36, 36], "train_res": [832, 832],
+                   "test_res": [1152, 1152]},
+        "match_coarse": {"thr": match_thr, "border_rm": 2, "match_type": "dual_softmax", "skh_iters": 3,
+                         "skh_init_bin_score": 1.0, "skh_prefilter": False, "train_coarse_percent": 0.3,
+                         "train_pad_num_gt_min": 200, "sparse_spvs": True, "learnable_ds_temp": True},
+        "fine": {"d_model": 128, "enable": False, "d_ffn": 128, "nhead": 8, "layer_names": ["self", "cross"],
+                 "attention": "linear"},
+    }
+
+
+def position_encoding(d_model, h, w, scaling):
+    """PositionEncodingSine.forward with an online ``scaling`` (utils/position_encoding.py:44-60), rows y*w + x -> [h*w, d_model]."""
+    y_position = torch.ones((h, w)).cumsum(0).float().unsqueeze(0) * scaling[0]
+    x_position = torch.ones((h, w)).cumsum(1).float().unsqueeze(0) * scaling[1]
+    div_term = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / (d_model // 2)))[:, None, None]
+    pe = torch.zeros((d_model, h, w))
+    pe[0::4] = torch.sin(x_position * div_term)
+    pe[1::4] = torch.cos(x_position * div_term)
+    pe[2::4] = torch.sin(y_position * div_term)
+    pe[3::4] = torch.cos(y_position * div_term)
+    return pe.permute(1, 2, 0).reshape(h * w, d_model).contiguous()
+
+
+class HipASpanFormer(ParamModule):
+    DS = 4            # aspanformer.py:76-77: with online_resize the coarsest level is always the 1/8 map pooled by 4
+
+    def __init__(self, config: dict, online_resize: bool = True):
+        super().__init__()
+        c = config["coarse"]
+        if not online_resize:
+            raise NotImplementedError("the reference builds ASpanFormer with online_resize=True (coarse_match_worker.py:54)")
+        if config["match_coarse"]["match_type"] != "dual_softmax":
+            raise NotImplementedError("only the dual_softmax coarse matcher is on the hot path")
+        if config["fine"]["enable"]:
+            raise NotImplementedError("HipASpanFormer implements the coarse_only configuration (ASPAN.FINE.ENABLE = False)")
+        if (c["d_model"], c["d_flow"], c["nhead"], list(c["nsample"]), c["nlevel"]) != (256, 128, 8, [2, 8], 3):
+            raise NotImplementedError("the kernels cover the released configuration (d_model 256, d_flow 128, 8 heads, nsample [2, 8])")
+        self.config = config
+        self.register_spec(aspanformer_param_spec(config))
+        self._packed = None
+        self._pos_cache = {}
+
+    # -- checkpoint compatibility (aspanformer.py:110-117) -----------------------------------------------------
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("matcher."):
+                if "sample_offset" in k:
+                    continue
+                k = k.replace("matcher.", "", 1)
+            sd[k] = v
+        self._packed, self._pos_cache = None, {}
+        for name in self._names:                           # the constant sampling pattern is not stored in checkpoints
+            if "sample_offset" in name and name not in sd:
+                sd[name] = self.p(name).detach().clone()
+        return super().load_state_dict(sd, *args, **kwargs)
+
+    def _apply(self, fn, *a, **kw):
+        self._packed, self._pos_cache = None, {}
+        return super()._apply(fn, *a, **kw)
+
+    # -- weight packing ---------------------------------------------------------------------------------------
+    def _pack(self):
+        g = self.p
+        c = self.config["coarse"]
+        d, dfl = c["d_model"], c["d_flow"]
+        PD = ops.PackedDense
+
+        def mat(name):                          # conv1d / 1x1 conv2d weight as a [Cout, Cin] matrix
+            return g(name).reshape(g(name).shape[0], -1)
+
+        def split_in(w, b=None, **kw):          # layer whose input arrives as split planes
+            return PD(w, b, cin_pad=w.shape[1], **kw)
+        P = {"bb": pack_backbone_hip(fold_backbone(g)), "pos_t": PD(mat("loftr_coarse.pos_transform.weight"))}
+
+        def qkv(q):
+            wv = mat(q + "v_proj.weight")
+            return {"qk": split_in(torch.cat([mat(q + "q_proj.weight"), mat(q + "k_proj.weight")], 0)),
+                    "vx": split_in(wv[:, :d].contiguous()), "vpos": PD(wv[:, d:].contiguous())}
+        P["ini"] = []
+        for i in range(c["ini_layer_num"]):
+            q = f"loftr_coarse.ini_layer.layers_coarse.{i}."
+            e = qkv(q)
+            e.update({"mh": PD(mat(q + "merge_head.weight")), "mf0": split_in(mat(q + "merge_f.0.weight")),
+                      "mf2": split_in(mat(q + "merge_f.2.weight")),
+                      "n1": (g(q + "norm1.affine"), g(q + "norm1.bias")), "n2": (g(q + "norm2.affine"), g(q + "norm2.bias"))})
+            P["ini"].append(e)
+        q = "loftr_coarse.ini_layer."
+        P["dec"] = split_in(mat(q + "decoupler.weight"), g(q + "decoupler.bias"))
+        P["upm"] = split_in(mat(q + "up_merge.weight"), g(q + "up_merge.bias"))
+        P["gla"] = []
+        for i in range(c["layer_num"]):
+            q = f"loftr_coarse.layers.{i}."
+            last = i == c["layer_num"] - 1
+            e = qkv(q)
+            fd2 = torch.zeros((64, dfl // 2), dtype=torch.float32, device=g(q + "flow_decoder.2.weight").device)
+            fd2[:4] = mat(q + "flow_decoder.2.weight")                   # 4 outputs in a 64-wide tile
+            mf0 = mat(q + "merge_f.0.weight")
+            if last:                                                     # input cat[x, norm1(msg)]: no flow-feature columns
+                mf0 = torch.cat([mf0[:, :d], torch.zeros((mf0.shape[0], dfl), dtype=mf0.dtype, device=mf0.device), mf0[:, d:]], 1)
+            e.update({"fd0": split_in(mat(q + "flow_decoder.0.weight")), "fd2": split_in(fd2),
+                      "mh0": split_in(mat(q + "attention.merge_head.0.weight")),
+                      "mh2": split_in(mat(q + "attention.merge_head.2.weight")),
+                      "mf0": split_in(mf0), "mf2": split_in(g(q + "merge_f.2.weight"), tap_padded=True),
+                      "n1": (g(q + "norm1.affine"), g(q + "norm1.bias")), "n2": (g(q + "norm2.affine"), g(q + "norm2.bias")),
+                      "temp": float(g(q + "attention.temp")), "so": g(q + "attention.sample_offset").float().contiguous(),
+                      "width": d if last else d + dfl})
+            P["gla"].append(e)
+        P["temperature"] = float(g("coarse_matching.temperature"))
+        self._packed = P
+        return P
+
+    def _positional(self, P, h, w, scaling, dev):
+        """Everything that depends only on the frame size: the encoding table, ``pos_transform(pe)``, its 1/4 pooling and the
+        positional part of every ``v_proj`` (transformer.py:52-56, 103-105, 222-224; avg_pool at :166-167)."""
+        key = (h, w, tuple(scaling))
+        hit = self._pos_cache.get(key)
+        if hit is not None:
+            return hit
+        c = self.config["coarse"]
+        pe = position_encoding(c["d_model"], h, w, scaling).to(dev)
+        pos = ops.linear(pe, P["pos_t"])                                                  # [L, d_flow]
+        sub = ops.avgpool(pos.view(1, h, w, -1), self.DS).view(-1, pos.shape[1])
+        out = {"pe": pe, "v_ini": [ops.linear(sub, e["vpos"]) for e in P["ini"]],
+               "v_gla": [ops.linear(pos, e["vpos"]) for e in P["gla"]]}
+        self._pos_cache[key] = out
+        return out
+
+    @staticmethod
+    def _qkv(x_split, e, vpos):
+        """[q | k | v] rows of one image: q, k from x; v = v_proj(cat[x, pos]) = x W_x^T + (pos W_pos^T, precomputed)."""
+        rows = x_split.hi.shape[0]
+        buf = torch.empty((rows, 768), dtype=torch.float32, device=x_split.hi.device)
+        ops.linear(x_split, e["qk"], out=buf[:, :512])
+        ops.linear(x_split, e["vx"], residual=vpos, out=buf[:, 512:])
+        return buf
+
+    # -- forward ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data: dict):
+        """Updates ``data`` in place like ASpanFormer.forward (aspanformer.py:31-108, fine.enable=False)."""
+        img0, img1 = data["image0"], data["image1"]
+        assert img0.shape[0] == 1 and img1.shape[1] == 1                                  # aspanformer.py:43
+        if "mask0" in data or "mask1" in data:
+            raise NotImplementedError("padding masks: the reference's dataset path does not pad frames for aspanformer")
+        for im in (img0, img1):
+            if im.shape[2] % 32 or im.shape[3] % 32:
+                raise NotImplementedError("frame sides must be multiples of 32 (the reference's torchvision online resize is not available)")
+        P = self._packed or self._pack()
+        c = self.config["coarse"]
+        d, dfl, nhead, DS = c["d_model"], c["d_flow"], c["nhead"], self.DS
+        dev = img0.device
+        tr = c["train_res"]
+        tr_h, tr_w = (tr, tr) if len(tr) == 1 else (tr[0], tr[1])
+        imgs = (img0, img1)
+        pos_scale = [[tr_h / im.shape[2], tr_w / im.shape[3]] for im in imgs]
+        data["pos_scale0"], data["pos_scale1"] = pos_scale
+        one = torch.ones((1, 2), device=dev)                                             # resize_input with unchanged sizes
+        data["online_resize_scale0"], data["online_resize_scale1"] = one, one.clone()
+        data.update({"bs": 1, "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
+        if img0.shape[2:] == img1.shape[2:]:
+            tok = backbone_tokens_hip(torch.cat([img0, img1], 0), P["bb"])
+            toks = (tok[0:1], tok[1:2])
+        else:
+            toks = (backbone_tokens_hip(img0, P["bb"]), backbone_tokens_hip(img1, P["bb"]))
+        hw = [tuple(t.shape[1:3]) for t in toks]
+        data.update({"hw0_c": torch.Size(hw[0]), "hw1_c": torch.Size(hw[1]),
+                     "hw0_f": torch.Size((img0.shape[2] // 2, img0.shape[3] // 2)),
+                     "hw1_f": torch.Size((img1.shape[2] // 2, img1.shape[3] // 2))})
+        L = [h * w for h, w in hw]
+        pc = [self._positional(P, hw[i][0], hw[i][1], pos_scale[i], dev) for i in (0, 1)]
+
+        # ---- flow_initializer (transformer.py:151-187): two softmax-attention layers on the 1/32 maps
+        X32, F, SB = [], [], []
+        for i in (0, 1):
+            x32 = torch.empty((L[i], d), dtype=torch.float32, device=dev)                # feat + pe
+            f = ops.SplitAct.empty_rows((L[i],), 2 * d, dev)                             # [feat + pe | upsampled update]
+            ops.split_rows(toks[i].reshape(L[i], d), add=pc[i]["pe"], out=x32, out_split=f.cols(0, d))
+            sub = ops.avgpool(x32.view(1, hw[i][0], hw[i][1], d), DS).view(-1, d)
+            sb = ops.SplitAct.empty_rows((sub.shape[0],), 2 * d, dev)                    # [sub feat | norm1(message)]
+            ops.split_rows(sub, out_split=sb.cols(0, d))
+            X32.append(x32), F.append(f), SB.append(sb)
+        for li, e in enumerate(P["ini"]):
+            qkv = [self._qkv(SB[i].cols(0, d), e, pc[i]["v_ini"][li]) for i in (0, 1)]
+            nxt = []
+            for a, b in ((0, 1), (1, 0)):
+                msg = ops.full_attention(qkv[a][None, :, :d], qkv[b][None, :, d:2 * d], qkv[b][None, :, 2 * d:], nhead,
+                                         1.0 / math.sqrt(d // nhead))[0]
+                ops.layernorm2d(ops.linear(msg, e["mh"]), *e["n1"], out_split=SB[a].cols(d, 2 * d), want_f32=False)
+                y = ops.linear(ops.linear(SB[a], e["mf0"], relu=True, out_split=True), e["mf2"])
+                sb = ops.SplitAct.empty_rows((SB[a].hi.shape[0],), 2 * d, dev)
+                ops.layernorm2d(y, *e["n2"], residual=SB[a].cols(0, d), out_split=sb.cols(0, d), want_f32=False)
+                nxt.append(sb)
+            SB = nxt
+        U = []
+        for i in (0, 1):
+            hs, ws = hw[i][0] // DS, hw[i][1] // DS
+            dec = ops.linear(SB[i].cols(0, d), P["dec"]).view(1, hs, ws, d + dfl)         # decoupler
+            u = ops.SplitAct.empty_rows((L[i],), 2 * d + dfl, dev)                       # [x | flow feature | norm1(message)]
+            ops.upsample(dec[..., :d], DS, True, out_split=F[i].cols(d, 2 * d), want_f32=False)
+            ops.upsample(dec[..., d:], DS, True, out_split=u.cols(d, d + dfl), want_f32=False)
+            ops.split_rows(ops.linear(F[i], P["upm"], residual=X32[i]), out_split=u.cols(0, d))   # feat + up_merge(cat[feat, upd])
+            U.append(u)
+
+        # ---- messageLayer_gla x layer_num (transformer.py:96-133, attention.py:42-133)
+        flows = [[], []]
+        feats = [None, None]
+        for e in P["gla"]:
+            width = e["width"]
+            qkv, pool2, pool4, flow = [], [], [], []
+            for i in (0, 1):
+                o = 1 - i
+                fd = ops.linear(ops.linear(U[i].cols(d, d + dfl), e["fd0"], relu=True, out_split=True), e["fd2"])
+                flow.append(ops.flow_decode(fd, hw[o][1], hw[o][0]))                      # decode_flow: target sized by the other map
+                t = self._qkv(U[i].cols(0, d), e, pc[i]["v_gla"][len(flows[0])])
+                t4 = t.view(1, hw[i][0], hw[i][1], 3 * d)
+                qkv.append(t)
+                pool2.append(ops.avgpool(t4, 2).view(-1, 3 * d))
+                pool4.append(ops.avgpool(t4, DS).view(-1, 3 * d))
+            nxt = []
+            for a, b in ((0, 1), (1, 0)):
+                (h, w), (hb, wb) = hw[a], hw[b]
+                m0 = ops.full_attention(pool4[a][None, :, :d], pool4[b][None, :, d:2 * d], pool4[b][None, :, 2 * d:], nhead,
+                                        e["temp"] / math.sqrt(d // nhead))[0]
+                m1 = ops.span_attention(pool2[a][:, :d], (h // 2, w // 2), pool2[b][:, d:2 * d], pool2[b][:, 2 * d:],
+                                        (hb // 2, wb // 2), flow[a], (h, w), e["so"], nhead, c["nsample"], c["radius_scale"])
+                m2 = ops.span_attention(qkv[a][:, :d], (h, w), qkv[b][:, d:2 * d], qkv[b][:, 2 * d:], (hb, wb), flow[a], (h, w),
+                                        e["so"], nhead, c["nsample"], c["radius_scale"])
+                am = ops.SplitAct.empty_rows((L[a],), 3 * d, dev)                         # the three levels side by side
+                ops.upsample(m0.view(1, h // DS, w // DS, d), DS, False, out_split=am.cols(0, d), want_f32=False)
+                ops.upsample(m1.view(1, h // 2, w // 2, d), 2, False, out_split=am.cols(d, 2 * d), want_f32=False)
+                ops.split_rows(m2, out_split=am.cols(2 * d, 3 * d))
+                msg = ops.linear(ops.linear(am, e["mh0"], relu=True, out_split=True), e["mh2"])
+                ops.layernorm2d(msg, *e["n1"], out_split=U[a].cols(d + dfl, 2 * d + dfl), want_f32=False)
+                hid = ops.linear(U[a], e["mf0"], relu=True, out_split=True)
+                hid4 = ops.SplitAct(hid.hi.view(1, h, w, -1), hid.lo.view(1, h, w, -1), hid.C)
+                y = ops.conv2d_nhwc(hid4, e["mf2"], 1, 1).view(L[a], width)
+                if width == d:                                                          # last layer: the final features
+                    feats[a] = ops.SplitAct.empty_rows((1, L[a]), d, dev)
+                    ops.layernorm2d(y, *e["n2"], residual=U[a].cols(0, d), out_split=ops.SplitAct(feats[a].hi[0], feats[a].lo[0], d),
+                                    want_f32=False)
+                    nxt.append(None)
+                else:
+                    u = ops.SplitAct.empty_rows((L[a],), 2 * d + dfl, dev)
+                    ops.layernorm2d(y, *e["n2"], residual=U[a].cols(0, width), out_split=u.cols(0, width), want_f32=False)
+                    nxt.append(u)
+            for i in (0, 1):
+                flows[i].append(flow[i].view(1, hw[i][0], hw[i][1], 4))
+            U = nxt
+
+        # ---- CoarseMatching (utils/coarse_matching.py:87-160, 226-262): sim = <f0, f1> / C * temperature
+        mc = self.config["match_coarse"]
+        m = ops.coarse_match(feats[0], feats[1], hw[0], hw[1], mc["thr"], mc["border_rm"], 1.0 / P["temperature"],
+                             data.get("scale0"), data.get("scale1"), img0.shape[2] / hw[0][0])
+        data.update(m)
+        data["m_bids"] = m["b_ids"]
+        data["gt_mask"] = m["mconf"] == 0
+        fl = [torch.stack(f, dim=0) for f in flows]                                       # [layer, 1, h, w, 4]
+        data["predict_flow"] = torch.stack(fl, dim=0) if hw[0] == hw[1] else fl
+        scale = img0.shape[2] / hw[0][0]
+        for side, f in (("left", fl[0]), ("right", fl[1])):                               # get_offset_match (:266-328)
+            off = f.reshape(f.shape[0], 1, -1, 4)
+            conf = off[..., 2:].mean(dim=-1)
+            keep = conf < 2
+            keep[:, :, 0] = True
+            l_ids, b_ids, i_ids = torch.where(keep)
+            j_coor = off[l_ids, b_ids, i_ids, :2] * scale
+            i_coor = torch.stack([i_ids % hw[0][1], i_ids // hw[0][1]], dim=1) * scale
+            data.update({"offset_bids_" + side: b_ids, "offset_lids_" + side: l_ids, "conf" + side: conf[keep]})
+            k0, k1 = (j_coor, i_coor) if side == "right" else (i_coor, j_coor)
+            data.update({"offset_kpts0_f_" + side: k0, "offset_kpts1_f_" + side: k1})
+        data.update({"mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})          # x online_resize_scale (= 1)
+        return data

@@ -154,6 +154,64 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
     return out_x
 
 
+def fold_backbone(g, with_fpn=False):
+    """ResNetFPN_8_2 weights (backbone/resnet_fpn.py:43-118) with eval-mode BatchNorm folded into (weight, bias) pairs;
+    ``g(name)`` fetches a tensor by its state_dict name.  Shared by HipLoFTR and HipASpanFormer (ASpanFormer's backbone file
+    is identical)."""
+    P = {}
+
+    def conv_bn(conv, bn):
+        return _fold_bn(g(conv + ".weight"), g(bn + ".weight"), g(bn + ".bias"),
+                        g(bn + ".running_mean"), g(bn + ".running_var"))
+    P["stem"] = conv_bn("backbone.conv1", "backbone.bn1")
+    for li in (1, 2, 3):
+        for bi in (0, 1):
+            q = f"backbone.layer{li}.{bi}"
+            blk = {"c1": conv_bn(q + ".conv1", q + ".bn1"), "c2": conv_bn(q + ".conv2", q + ".bn2"),
+                   "stride": 2 if (li > 1 and bi == 0) else 1}
+            if blk["stride"] != 1:
+                blk["down"] = conv_bn(q + ".downsample.0", q + ".downsample.1")
+            P[f"l{li}b{bi}"] = blk
+    P["l3out"] = g("backbone.layer3_outconv.weight")
+    if with_fpn:
+        P["l2out"] = g("backbone.layer2_outconv.weight")
+        P["l1out"] = g("backbone.layer1_outconv.weight")
+        for nm in ("layer2_outconv2", "layer1_outconv2"):
+            P[nm] = (conv_bn(f"backbone.{nm}.0", f"backbone.{nm}.1"), g(f"backbone.{nm}.3.weight"))
+    return P
+
+
+def pack_backbone_hip(P, same_conv=True):
+    """The folded backbone weights as split-plane operands of the conv kernels."""
+    def pk(wb, split_in=True, same=False):    # weights for a conv whose input arrives as a SplitAct
+        w, b = wb if isinstance(wb, tuple) else (wb, None)   # same: stride-1 3x3 -> activation-reuse kernel
+        return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
+                               tap_padded=same and same_conv)
+    H = {"stem": pk(P["stem"], split_in=False), "l3out": pk(P["l3out"])}
+    for li in (1, 2, 3):
+        for bi in (0, 1):
+            b = P[f"l{li}b{bi}"]
+            hb = {"c1": pk(b["c1"], same=b["stride"] == 1), "c2": pk(b["c2"], same=True), "stride": b["stride"]}
+            if "down" in b:
+                hb["down"] = pk(b["down"])
+            H[f"l{li}b{bi}"] = hb
+    return H
+
+
+def backbone_tokens_hip(x, H):
+    """x [N,1,H,W] -> coarse feature map as fp32 tokens [N, H/8, W/8, C] (NHWC == token-major): every conv is one launch
+    with folded BN, ReLU and the residual fused; activations between convolutions travel as split fp16 planes."""
+    t = x.permute(0, 2, 3, 1)                       # C=1: NCHW memory is already NHWC
+    t = ops.conv2d_nhwc(t, H["stem"], 2, 3, relu=True, out_split=True)
+    for li in (1, 2, 3):
+        for bi in (0, 1):
+            b = H[f"l{li}b{bi}"]
+            y = ops.conv2d_nhwc(t, b["c1"], b["stride"], 1, relu=True, out_split=True)
+            sc = ops.conv2d_nhwc(t, b["down"], b["stride"], 0, out_split=True) if "down" in b else t
+            t = ops.conv2d_nhwc(y, b["c2"], 1, 1, residual=sc, relu=True, out_split=True)
+    return ops.conv2d_nhwc(t, H["l3out"], 1, 0)     # fp32 tokens for the transformer
+
+
 class HipLoFTR(ParamModule):
     def __init__(self, config: dict, skip_dead_fpn: bool = True, dense_backend: str = "hip"):
         """dense_backend: "hip" (default) runs every convolution and linear layer on the hand-written
@@ -194,42 +252,11 @@ class HipLoFTR(ParamModule):
     # -- weight packing -----------------------------------------------------------------------
     def _pack(self):
         g = self.p
-        P = {}
-
-        def conv_bn(conv, bn):
-            return _fold_bn(g(conv + ".weight"), g(bn + ".weight"), g(bn + ".bias"),
-                            g(bn + ".running_mean"), g(bn + ".running_var"))
-        P["stem"] = conv_bn("backbone.conv1", "backbone.bn1")
-        for li in (1, 2, 3):
-            for bi in (0, 1):
-                q = f"backbone.layer{li}.{bi}"
-                blk = {"c1": conv_bn(q + ".conv1", q + ".bn1"), "c2": conv_bn(q + ".conv2", q + ".bn2"),
-                       "stride": 2 if (li > 1 and bi == 0) else 1}
-                if blk["stride"] != 1:
-                    blk["down"] = conv_bn(q + ".downsample.0", q + ".downsample.1")
-                P[f"l{li}b{bi}"] = blk
-        P["l3out"] = g("backbone.layer3_outconv.weight")
-        if not self.skip_dead_fpn:
-            P["l2out"] = g("backbone.layer2_outconv.weight")
-            P["l1out"] = g("backbone.layer1_outconv.weight")
-            for nm in ("layer2_outconv2", "layer1_outconv2"):
-                P[nm] = (conv_bn(f"backbone.{nm}.0", f"backbone.{nm}.1"), g(f"backbone.{nm}.3.weight"))
+        P = fold_backbone(g, with_fpn=not self.skip_dead_fpn)
         n_layers = len(self.config["coarse"]["layer_names"])
         P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.", self.dense_backend) for i in range(n_layers)]
         if self.dense_backend == "hip":
-            def pk(wb, split_in=True, same=False):    # weights for a conv whose input arrives as a SplitAct
-                w, b = wb if isinstance(wb, tuple) else (wb, None)   # same: stride-1 3x3 -> activation-reuse kernel
-                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
-                                       tap_padded=same and self.same_conv)
-            H = {"stem": pk(P["stem"], split_in=False), "l3out": pk(P["l3out"])}
-            for li in (1, 2, 3):
-                for bi in (0, 1):
-                    b = P[f"l{li}b{bi}"]
-                    hb = {"c1": pk(b["c1"], same=b["stride"] == 1), "c2": pk(b["c2"], same=True), "stride": b["stride"]}
-                    if "down" in b:
-                        hb["down"] = pk(b["down"])
-                    H[f"l{li}b{bi}"] = hb
-            P["hip"] = H
+            P["hip"] = pack_backbone_hip(P, self.same_conv)
         self._packed = P
         return P
 
@@ -238,16 +265,7 @@ class HipLoFTR(ParamModule):
         """x [N,1,H,W] -> coarse feature map as tokens [N, H/8, W/8, C] (NHWC == token-major).
         Activations between convolutions travel as split fp16 planes (ops.SplitAct): the producer's
         epilogue splits once, consumers DMA the planes straight into LDS."""
-        H = P["hip"]
-        t = x.permute(0, 2, 3, 1)                       # C=1: NCHW memory is already NHWC
-        t = ops.conv2d_nhwc(t, H["stem"], 2, 3, relu=True, out_split=True)
-        for li in (1, 2, 3):
-            for bi in (0, 1):
-                b = H[f"l{li}b{bi}"]
-                y = ops.conv2d_nhwc(t, b["c1"], b["stride"], 1, relu=True, out_split=True)
-                sc = ops.conv2d_nhwc(t, b["down"], b["stride"], 0, out_split=True) if "down" in b else t
-                t = ops.conv2d_nhwc(y, b["c2"], 1, 1, residual=sc, relu=True, out_split=True)
-        return ops.conv2d_nhwc(t, H["l3out"], 1, 0)     # fp32 tokens for the transformer
+        return backbone_tokens_hip(x, P["hip"])
 
     # -- K6, library control path: MIOpen fp32 convs (ResNetFPN_8_2.forward, resnet_fpn.py:100-118) ----
     def _backbone(self, x, P):

@@ -411,6 +411,140 @@ def bilinear_up(x, hout, wout):
     return out
 
 
+# ---------------------------------------------------------------- ASpanFormer pieces (csrc/aspan_ops.hip)
+def _split_out(out_split, rows, C, what):
+    if out_split is None:
+        return None, None, 0
+    rows_s, ldos = _rows_ld(out_split.hi, torch.float16)
+    if rows_s != rows or out_split.hi.shape[-1] != C or out_split.lo.stride() != out_split.hi.stride():
+        raise _lib.DfsfmError(f"{what}: split out shape mismatch")
+    return out_split.hi, out_split.lo, ldos
+
+
+@_on_device
+def avgpool(x, k, out=None):
+    """F.avg_pool2d(x, k, stride=k) of x [N,H,W,C] fp32 (token-pitched view OK) -> [N,H/k,W/k,C]."""
+    _require_cuda(x)
+    N, H, W, C = x.shape
+    rows, ldx = _rows_ld(x)
+    if out is None:
+        out = torch.empty((N, H // k, W // k, C), dtype=torch.float32, device=x.device)
+    rows_o, ldo = _rows_ld(out)
+    if H % k or W % k or rows_o != N * (H // k) * (W // k) or out.shape[-1] != C:
+        raise _lib.DfsfmError("avgpool: shape mismatch")
+    rc = _lib.lib().dfsfm_avgpool_nhwc_f32(_ptr(x), ldx, N, H, W, C, int(k), _ptr(out), ldo, _stream())
+    _lib.check(rc, "dfsfm_avgpool_nhwc_f32")
+    return out
+
+
+def _batched_rows(t, what):
+    """(pitch, batch stride) of a [N, L, C] fp32 view with dense channels."""
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
+        raise _lib.DfsfmError(f"{what}: need fp32 [N, L, C] views with dense channels")
+    return t.stride(1), t.stride(0)
+
+
+@_on_device
+def full_attention(q, k, v, nhead, scale, kv_swap=False):
+    """softmax(scale * q k^T) v per head; q [N,L,C], k / v [N,S,C] fp32 views; kv_swap pairs batch n with n ^ 1."""
+    _require_cuda(q, k, v)
+    N, L, C = q.shape
+    S = k.shape[1]
+    if k.shape != (N, S, C) or v.shape != (N, S, C) or C % nhead:
+        raise _lib.DfsfmError("full_attention: shape mismatch")
+    (ldq, sq), (ldk, sk), (ldv, sv) = (_batched_rows(t, "full_attention") for t in (q, k, v))
+    out = torch.empty((N, L, C), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().dfsfm_full_attention_f32(_ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv, _ptr(out), C, L * C, N, L, S,
+                                             int(nhead), C // nhead, 1 if kv_swap else 0, float(scale), _stream())
+    _lib.check(rc, "dfsfm_full_attention_f32")
+    return out
+
+
+@_on_device
+def span_attention(q, hw, k, v, hw_k, flow, hw0, sample_offset, nhead, nsample, radius_scale, temp=1.0):
+    """One level of ASpanFormer's hierarchical attention: q [h*w, C] (this image's level map), k / v [hk*wk, C] (the
+    other image's), flow [H0*W0, 4] (this image, full resolution) -> [h*w, C] in the reference's (group, member) order."""
+    _require_cuda(q, k, v, flow, sample_offset)
+    (rq, ldq), (rk, ldk), (rv, ldv) = _rows_ld(q), _rows_ld(k), _rows_ld(v)
+    C = q.shape[-1]
+    flow = flow.reshape(-1, 4)
+    if (rq != hw[0] * hw[1] or rk != hw_k[0] * hw_k[1] or rv != rk or not flow.is_contiguous() or flow.dtype != torch.float32
+            or flow.shape[0] != hw0[0] * hw0[1] or k.shape[-1] != C or v.shape[-1] != C):
+        raise _lib.DfsfmError("span_attention: shape mismatch")
+    so = sample_offset.to(torch.float32).contiguous()
+    if so.shape != (nsample[1] ** 2, 2):
+        raise _lib.DfsfmError("span_attention: sample_offset is [nsample1^2, 2]")
+    out = torch.empty((rq, C), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().dfsfm_span_attention_f32(_ptr(q), ldq, hw[0], hw[1], _ptr(k), ldk, _ptr(v), ldv, hw_k[0], hw_k[1], _ptr(flow),
+                                             hw0[0], hw0[1], _ptr(so), int(nhead), C, int(nsample[0]), int(nsample[1]),
+                                             float(radius_scale), float(temp), _ptr(out), C, _stream())
+    _lib.check(rc, "dfsfm_span_attention_f32")
+    return out
+
+
+@_on_device
+def layernorm2d(x, affine, bias, residual=None, out=None, out_split=None, want_f32=True):
+    """(residual or 0) + affine * (x - mean) / (std_unbiased + 1e-6) + bias over the last dim of fp32 rows (views OK);
+    residual: SplitAct view; results as fp32 (``out``, allocated when None and want_f32) and / or into ``out_split``."""
+    _require_cuda(x, affine, bias)
+    rows, ldx = _rows_ld(x)
+    C = x.shape[-1]
+    ldo = 0
+    if out is None and want_f32:
+        out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    if out is not None:
+        rows_o, ldo = _rows_ld(out)
+        if rows_o != rows or out.shape[-1] != C:
+            raise _lib.DfsfmError("layernorm2d: out shape mismatch")
+    oh, ol, ldos = _split_out(out_split, rows, C, "layernorm2d")
+    rh = rl = None
+    ldr = 0
+    if residual is not None:
+        rows_r, ldr = _rows_ld(residual.hi, torch.float16)
+        if rows_r != rows or residual.hi.shape[-1] != C or residual.lo.stride() != residual.hi.stride():
+            raise _lib.DfsfmError("layernorm2d: residual shape mismatch")
+        rh, rl = residual.hi, residual.lo
+    rc = _lib.lib().dfsfm_layernorm2d_f32(_ptr(x), ldx, _ptr(affine), _ptr(bias), _ptr(rh), _ptr(rl), ldr, _ptr(out), ldo,
+                                          _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
+    _lib.check(rc, "dfsfm_layernorm2d_f32")
+    if _debug_range and out_split is not None:
+        check_split_range(out_split, "layernorm2d")
+    return out
+
+
+@_on_device
+def upsample(x, scale, bilinear, out=None, out_split=None, want_f32=True):
+    """F.upsample(x, scale_factor=scale, mode='bilinear' | 'nearest') of x [N,hin,win,C] fp32 (token-pitched view OK) into
+    fp32 rows ``out`` [N*hin*scale*win*scale, C] (allocated dense when None and want_f32) and / or ``out_split`` rows."""
+    _require_cuda(x)
+    N, hin, win, C = x.shape
+    _, ldx = _rows_ld(x)
+    rows = N * hin * scale * win * scale
+    ldo = 0
+    if out is None and want_f32:
+        out = torch.empty((N, hin * scale, win * scale, C), dtype=torch.float32, device=x.device)
+    if out is not None:
+        rows_o, ldo = _rows_ld(out)
+        if rows_o != rows or out.shape[-1] != C:
+            raise _lib.DfsfmError("upsample: out shape mismatch")
+    oh, ol, ldos = _split_out(out_split, rows, C, "upsample")
+    rc = _lib.lib().dfsfm_upsample_nhwc_f32(_ptr(x), ldx, N, hin, win, C, int(scale), 1 if bilinear else 0, _ptr(out), ldo,
+                                            _ptr(oh), _ptr(ol), ldos, _stream())
+    _lib.check(rc, "dfsfm_upsample_nhwc_f32")
+    return out
+
+
+@_on_device
+def flow_decode(x, wk, hk):
+    """(sigmoid(x0) * wk, sigmoid(x1) * hk, x2, x3) of the first four columns of fp32 rows x -> [rows, 4]."""
+    _require_cuda(x)
+    rows, ldx = _rows_ld(x)
+    out = torch.empty((rows, 4), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dfsfm_flow_decode_f32(_ptr(x), ldx, rows, float(wk), float(hk), _ptr(out), _stream())
+    _lib.check(rc, "dfsfm_flow_decode_f32")
+    return out
+
+
 @_on_device
 def resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pad_hw=None, want_mask=False):
     """PIL's 8-bit two-pass resampling of src [H,W] or [H,W,3] uint8 with the given int32 tables (images.py builds

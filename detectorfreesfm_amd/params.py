@@ -39,8 +39,8 @@ def _encoder_layers(spec: Spec, p: str, n_layers: int, d: int):
             spec += [(q + nm + ".weight", (d,), "ones"), (q + nm + ".bias", (d,), "zeros")]
 
 
-def loftr_param_spec(cfg: dict) -> Spec:
-    s: Spec = []
+def _resnet_fpn_spec(s: Spec, cfg: dict):
+    """ResNetFPN_8_2 (backbone/resnet_fpn.py:43-98; the same file in third_party/LoFTR and third_party/aspantransformer)."""
     d0 = cfg["resnetfpn"]["initial_dim"]
     b1, b2, b3 = cfg["resnetfpn"]["block_dims"]
     p = "backbone."
@@ -68,6 +68,11 @@ def loftr_param_spec(cfg: dict) -> Spec:
     s.append((p + "layer1_outconv2.0.weight", (b2, b2, 3, 3), "kaiming_out"))
     _bn(s, p + "layer1_outconv2.1.", b2)
     s.append((p + "layer1_outconv2.3.weight", (b1, b2, 3, 3), "kaiming_out"))
+
+
+def loftr_param_spec(cfg: dict) -> Spec:
+    s: Spec = []
+    _resnet_fpn_spec(s, cfg)
     dc, df = cfg["coarse"]["d_model"], cfg["fine"]["d_model"]
     _encoder_layers(s, "loftr_coarse.", len(cfg["coarse"]["layer_names"]), dc)
     # fine-level modules: present in every LoFTR checkpoint, unused when fine.enable=False
@@ -76,6 +81,48 @@ def loftr_param_spec(cfg: dict) -> Spec:
           ("fine_preprocess.merge_feat.weight", (df, 2 * df), "kaiming_out"),
           ("fine_preprocess.merge_feat.bias", (df,), "zeros")]
     _encoder_layers(s, "loftr_fine.", len(cfg["fine"]["layer_names"]), df)
+    return s
+
+
+def aspanformer_param_spec(cfg: dict) -> Spec:
+    """ASpanFormer (217 tensors): third_party/aspantransformer/src/ASpanFormer/aspanformer.py:14-29 and its sub-modules
+    (aspan_module/transformer.py:8-32, 68-93, 138-149, 192-206; attention.py:21-39; utils/coarse_matching.py:72).  Transformer
+    matrices are xavier_uniform (transformer.py:208-212), ``temp`` 1, the dual-softmax temperature 10, ``sample_offset`` the
+    fixed 8x8 sampling pattern; the fine-level modules exist in every checkpoint and are unused in coarse_only mode."""
+    s: Spec = []
+    _resnet_fpn_spec(s, cfg)
+    c = cfg["coarse"]
+    d, df_, nl = c["d_model"], c["d_flow"], c["layer_num"]
+    p = "loftr_coarse."
+    s.append((p + "pos_transform.weight", (df_, d, 1, 1), "xavier"))
+    for i in range(c["ini_layer_num"]):
+        q = f"{p}ini_layer.layers_coarse.{i}."
+        s += [(q + "q_proj.weight", (d, d, 1), "xavier"), (q + "k_proj.weight", (d, d, 1), "xavier"),
+              (q + "v_proj.weight", (d, d + df_, 1), "xavier"), (q + "merge_head.weight", (d, d, 1), "xavier"),
+              (q + "merge_f.0.weight", (2 * d, 2 * d, 1, 1), "xavier"), (q + "merge_f.2.weight", (d, 2 * d, 1, 1), "xavier"),
+              (q + "norm1.affine", (d,), "ones"), (q + "norm1.bias", (d,), "zeros"),
+              (q + "norm2.affine", (d,), "ones"), (q + "norm2.bias", (d,), "zeros")]
+    s += [(p + "ini_layer.decoupler.weight", (d + df_, d, 1, 1), "xavier"),
+          (p + "ini_layer.decoupler.bias", (d + df_,), "torch_conv_b:%d" % d),
+          (p + "ini_layer.up_merge.weight", (d, 2 * d, 1, 1), "xavier"),
+          (p + "ini_layer.up_merge.bias", (d,), "torch_conv_b:%d" % (2 * d))]
+    for i in range(nl):
+        q = f"{p}layers.{i}."
+        extra = df_ if i < nl - 1 else 0                    # the last layer does not update the flow feature
+        s += [(q + "flow_decoder.0.weight", (df_ // 2, df_, 1), "xavier"), (q + "flow_decoder.2.weight", (4, df_ // 2, 1), "xavier"),
+              (q + "attention.temp", (), "const:1.0"), (q + "attention.sample_offset", (c["nsample"][1] ** 2, 2), "sample_offset"),
+              (q + "attention.merge_head.0.weight", (d, 3 * d, 1), "xavier"), (q + "attention.merge_head.2.weight", (d, d, 1), "xavier"),
+              (q + "q_proj.weight", (d, d, 1), "xavier"), (q + "k_proj.weight", (d, d, 1), "xavier"),
+              (q + "v_proj.weight", (d, d + df_, 1), "xavier"),
+              (q + "merge_f.0.weight", (d + df_, 2 * d + extra, 1, 1), "xavier"),
+              (q + "merge_f.2.weight", (d + extra, d + df_, 3, 3), "xavier"),
+              (q + "norm1.affine", (d,), "ones"), (q + "norm1.bias", (d,), "zeros"),
+              (q + "norm2.affine", (d + extra,), "ones"), (q + "norm2.bias", (d + extra,), "zeros")]
+    s.append(("coarse_matching.temperature", (), "const:10.0"))
+    dfine = cfg["fine"]["d_model"]
+    s += [("fine_preprocess.down_proj.weight", (dfine, d), "kaiming_out"), ("fine_preprocess.down_proj.bias", (dfine,), "zeros"),
+          ("fine_preprocess.merge_feat.weight", (dfine, 2 * dfine), "kaiming_out"), ("fine_preprocess.merge_feat.bias", (dfine,), "zeros")]
+    _encoder_layers(s, "loftr_fine.", len(cfg["fine"]["layer_names"]), dfine)
     return s
 
 
@@ -155,9 +202,17 @@ def random_state_dict(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
         if kind == "kaiming_out":          # nn.init.kaiming_normal_(mode='fan_out', relu)
             fan_out = shape[0] * (shape[2] * shape[3] if len(shape) == 4 else 1)
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
-        elif kind == "xavier":             # nn.init.xavier_uniform_
-            bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+        elif kind == "xavier":             # nn.init.xavier_uniform_ (fan = channels * receptive field)
+            rf = 1
+            for k in shape[2:]:
+                rf *= k
+            bound = math.sqrt(6.0 / ((shape[0] + shape[1]) * rf))
             t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind.startswith("const:"):
+            t = torch.full(shape, float(kind.split(":")[1]))
+        elif kind == "sample_offset":      # HierachicalAttention.__init__ (aspan_module/attention.py:38-39)
+            n = int(round(math.sqrt(shape[0])))
+            t = torch.tensor([[a - n / 2 + 0.5, b - n / 2 + 0.5] for a in range(n) for b in range(n)])
         elif kind == "tn02":               # timm trunc_normal_(std=.02) (match_LA_large.py:208-211)
             t = (torch.randn(shape, generator=g) * 0.02).clamp(-2.0, 2.0)
         elif kind.startswith("conv_fan_out"):   # normal_(0, sqrt(2 / (kh*kw*out / groups))) (:215-218)
@@ -232,6 +287,18 @@ def planted_matchformer_state_dict(spec: Spec, seed: int = 0, alpha: float = 3.0
     return sd
 
 
+
+def planted_aspanformer_state_dict(spec: Spec, seed: int = 0, alpha: float = 3.0) -> Dict[str, torch.Tensor]:
+    """Seeded ASpanFormer weights whose backbone is the planted LoFTR backbone (the two specs start with the same 107
+    backbone entries, so the seeded draws -- and the committed position mean -- are the same): on ``synth`` frames the
+    xavier-initialised span transformer then keeps enough content for real matches at thr 0.2."""
+    sd = random_state_dict(spec, seed)
+    n_bb = sum(1 for name, _, _ in spec if name.startswith("backbone."))
+    planted = planted_loftr_state_dict([e for e in spec[:n_bb]], seed, alpha)
+    for k, v in planted.items():
+        sd[k] = v
+    return sd
+
 class ParamModule(nn.Module):
     """nn.Module whose parameters/buffers carry the reference's dotted names.
 
@@ -255,6 +322,8 @@ class ParamModule(nn.Module):
                 mod.register_buffer(parts[-1], init)
             else:
                 init = torch.ones(shape) if kind in ("ones", "bn_w") else torch.zeros(shape)
+                if kind.startswith("const:") or kind == "sample_offset":      # constants the reference's constructors set
+                    init = random_state_dict([(name, shape, kind)], 0)[name]
                 mod.register_parameter(parts[-1], nn.Parameter(init, requires_grad=False))
             self._names.append(name)
 

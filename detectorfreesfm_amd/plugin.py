@@ -2,7 +2,7 @@
 
 coarse   ``build_model(args) -> (detector, matcher)``, ``extract_preds``, ``extract_matches``
          mirror src/coarse_match/coarse_match_worker.py:21-99; selected with the NEW matcher names
-         ``args['matcher'] == 'loftr_hip'`` / ``'matchformer_hip'`` (``neuralsfm.NEUSFM_coarse_matcher``), so the
+         ``args['matcher'] == 'loftr_hip'`` / ``'matchformer_hip'`` / ``'aspanformer_hip'`` (``neuralsfm.NEUSFM_coarse_matcher``), so the
          reference's own 'loftr_official' / 'aspanformer' / 'matchformer' branches stay intact.
 refine   ``build_refine_model(args, rewindow_size_factor, model_idx) -> matcher`` and
          ``extract_results`` mirror src/post_optimization/matcher_model/multiview_match_worker.py:16-82.
@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import ops
 from .coarse import HipLoFTR
 from .config import loftr_coarse_only_config, multiview_refinement_config
+from .aspanformer import HipASpanFormer, aspanformer_coarse_only_config
 from .matchformer import HipMatchformer, matchformer_coarse_only_config
 from .refine import HipMultiviewMatcher
 
@@ -50,6 +51,19 @@ def build_model(args: dict):
         matcher = HipMatchformer(config=cfg)
         if margs.get("weight_path") is not None:            # the MatchFormer checkpoints are bare state dicts (:72-73)
             matcher.load_state_dict(torch.load(margs["weight_path"], map_location="cpu"), strict=True)
+        detector = DetectorWrapper()
+        detector.eval()
+        matcher.eval()
+        return detector, matcher
+    if args["matcher"] == "aspanformer_hip":            # the 'aspanformer' branch of the reference (:45-60)
+        if args.get("type", "coarse_only") != "coarse_only":
+            raise NotImplementedError("aspanformer_hip provides the coarse_only matcher")
+        margs = args.get("aspanformer_hip", {})
+        cfg = margs.get("cfg") or aspanformer_coarse_only_config(args["match_thr"])
+        cfg["match_coarse"]["thr"] = args["match_thr"]
+        matcher = HipASpanFormer(config=cfg, online_resize=True)
+        if margs.get("weight_path") is not None:            # strict=False in the reference (:56): sample_offset is not stored
+            matcher.load_state_dict(torch.load(margs["weight_path"], map_location="cpu")["state_dict"], strict=True)
         detector = DetectorWrapper()
         detector.eval()
         matcher.eval()

@@ -199,6 +199,46 @@ int dfsfm_dwconv3x3_nhwc_f32(const float* x, int N, int H, int W, int C, const f
  * x [N,hin,win,C] -> out [N,hout,wout,C]; C % 4 == 0. */
 int dfsfm_bilinear_up_nhwc_f32(const float* x, int N, int hin, int win, int C, int hout, int wout, float* out, void* stream);
 
+/* ---- ASpanFormer coarse matcher (third_party/aspantransformer/src/ASpanFormer/) ------------------
+ * Maps are NHWC fp32 with a row (= token) pitch in floats, so column slices of wider buffers can be read and written. */
+
+/* F.avg_pool2d(x, k, stride=k): x [N,H,W,C] (pitch ldx) -> out [N,H/k,W/k,C] (pitch ldo); the window is summed in (ky, kx)
+ * order and divided by k*k like ATen.  aspan_module/transformer.py:163-167, attention.py:60-66. */
+int dfsfm_avgpool_nhwc_f32(const float* x, int64_t ldx, int N, int H, int W, int C, int k, float* out, int64_t ldo,
+                           void* stream);
+
+/* FullAttention.forward (aspan_module/attention.py:141-165): out[n,l,h,:] = softmax_s(scale * <q[n,l,h,:], k[n',s,h,:]>) v[n',s,h,:]
+ * with n' = n ^ kv_swap (kv_swap = 1 pairs image 0 with image 1 in a stacked batch).  q [N,L,H*D], k / v [N,S,H*D], pitches ld*
+ * and batch strides s* in floats; D = 32.  scale = temp / sqrt(D). */
+int dfsfm_full_attention_f32(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v,
+                             int64_t ldv, int64_t sv, float* out, int64_t ldo, int64_t so, int N, int L, int S, int H, int D,
+                             int kv_swap, float scale, void* stream);
+
+/* One level of HierachicalAttention (aspan_module/attention.py:49-53, 64-66, 92-133): for every 2x2 group of the query level map
+ * q [h*w, C] the mean flow offset / span of the group's full-resolution cells (flow [H0*W0, 4] = x, y, var_x, var_y; span =
+ * max(exp(var/2) * radius_scale * 2 / nsample1, 1)), nsample1^2 bilinear samples (grid_sample, zero padding, align_corners
+ * False) of the other image's level maps k, v [hk*wk, C] at offset + sample_offset * span, softmax attention of the group's 4
+ * queries over the samples per head.  out [h*w, C]: row g*4 + n, the order the reference's view() produces.
+ * C = 256, nhead = 8, nsample = (2, 8); no padding masks. */
+int dfsfm_span_attention_f32(const float* q, int64_t ldq, int h, int w, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                             int hk, int wk, const float* flow, int H0, int W0, const float* sample_offset, int nhead, int C,
+                             int nsample0, int nsample1, float radius_scale, float temp, float* out, int64_t ldo, void* stream);
+
+/* layernorm2d (aspan_module/attention.py:7-19) on token rows: res + affine * (x - mean) / (std_unbiased + 1e-6) + bias; the
+ * residual arrives as split planes (may be NULL); out fp32 and / or split planes.  C = 256 or 384. */
+int dfsfm_layernorm2d_f32(const float* x, int64_t ldx, const float* affine, const float* bias, const void* res_hi,
+                          const void* res_lo, int64_t ldr, float* out, int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s,
+                          int64_t rows, int C, void* stream);
+
+/* F.upsample(x, scale_factor=scale, mode='bilinear' (align_corners False) | 'nearest') of x [N,hin,win,C] (pitch ldx) into fp32
+ * and / or split-plane rows (pitches ldo, ldo_s).  aspan_module/transformer.py:177-180, attention.py:85-86. */
+int dfsfm_upsample_nhwc_f32(const float* x, int64_t ldx, int N, int hin, int win, int C, int scale, int bilinear, float* out,
+                            int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, void* stream);
+
+/* messageLayer_gla.decode_flow after the flow_decoder convs (aspan_module/transformer.py:125-133):
+ * out[r] = (sigmoid(x[r,0]) * wk, sigmoid(x[r,1]) * hk, x[r,2], x[r,3]). */
+int dfsfm_flow_decode_f32(const float* x, int64_t ldx, int64_t rows, float wk, float hk, float* out, void* stream);
+
 /* PIL's 8-bit fixed-point resampling (Image.resize on 'L' / 'RGB' images) + the tensor conversion of the reference's
  * image readers.  Replaces, for an already decoded frame,
  *   resize_image(image, (w_new, h_new), "pil_LANCZOS")           src/dataset/utils.py:160-177

@@ -266,6 +266,47 @@ def bags_golden():
     print("bags.npz", len(bags), "bags")
 
 
+def aspanformer_cases():
+    """(tag, (H0, W0), (H1, W1)): one pair of equal frames, one of different sizes (two backbone calls, cross-size spans)."""
+    return [("same", (96, 128), (96, 128)), ("sizes", (96, 128), (64, 160))]
+
+
+def aspanformer_inputs(c, hw0, hw1):
+    data = synth.coarse_pair_batch(1, hw0[0], hw0[1], c["data_seed"])
+    if hw1 != hw0:
+        data["image1"] = synth.coarse_pair_batch(1, hw1[0], hw1[1], c["data_seed"] + 1)["image0"]
+        data["scale1"] = torch.ones(1, 2)
+    data["scale0"] = torch.tensor([[1.5, 2.0]])
+    return data
+
+
+def aspanformer_golden():
+    """ASpanFormer coarse matcher: the real ASpanFormer module (online_resize=True, coarse_only
+    config) with seeded weights on a planted backbone -> tests/golden/aspanformer_e2e.npz."""
+    from detectorfreesfm_amd.aspanformer import aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    A = ref_import.import_aspanformer()
+    c = dict(weight_seed=0, alpha=3.0, data_seed=1000, thr=0.2)
+    cfg = aspanformer_coarse_only_config(c["thr"])
+    sd = planted_aspanformer_state_dict(aspanformer_param_spec(cfg), c["weight_seed"], c["alpha"])
+    m = A(config=cfg, online_resize=True).eval()
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    out = {}
+    with torch.no_grad(), ref_import.cpu_cuda_calls():
+        for tag, hw0, hw1 in aspanformer_cases():
+            data = aspanformer_inputs(c, hw0, hw1)
+            m(data)
+            assert data["i_ids"].numel() > 10
+            for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f", "conf_matrix", "offset_bids_left",
+                      "offset_lids_left", "confleft", "offset_kpts0_f_left", "offset_kpts1_f_left", "offset_bids_right",
+                      "offset_lids_right", "confright", "offset_kpts0_f_right", "offset_kpts1_f_right"):
+                out[f"{tag}_{k}"] = data[k].numpy()
+            pf = data["predict_flow"]
+            out[f"{tag}_flow0"], out[f"{tag}_flow1"] = pf[0].numpy(), pf[1].numpy()
+    np.savez_compressed(os.path.join(OUT, "aspanformer_e2e.npz"), **out, **c)
+    print("aspanformer_e2e.npz", {k: v.shape for k, v in out.items() if k.endswith("i_ids")})
+
+
 def read_image_cases():
     """(name, colour?, H, W, kwargs of the reader) -- sizes as the pipelines use them: larger side to img_resize with
     df = 8 (loftr), padded squares with masks (matchformer, pad_to = -1), an explicit (w, h), no resize at all."""
@@ -312,9 +353,12 @@ if __name__ == "__main__":
         matchformer_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "images":
         read_image_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aspanformer":
+        aspanformer_golden()
     else:
         main()
         merge_golden()
         bags_golden()
         matchformer_golden()
         read_image_golden()
+        aspanformer_golden()

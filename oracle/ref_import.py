@@ -382,3 +382,52 @@ def import_image_readers(frames):
                   ("process_resize", "pad_bottom_right", "grayscale2tensor", "rgb2tensor", "mask2tensor", "read_rgb",
                    "read_grayscale", "resize_image"), ns)
     return ns["read_grayscale"], ns["read_rgb"]
+
+
+def aspanformer_coarse_only_config(match_thr=0.4):
+    """Lower-cased ``aspan`` node of third_party/aspantransformer/src/config/default.py:5-51 with the overrides of
+    configs/aspan/outdoor/aspan_test_coarse_only.py:7-12 and the threshold override of coarse_match_worker.py:53."""
+    _ensure_path()
+    install_stubs()
+    cfgmod = importlib.import_module("third_party.aspantransformer.src.config.default")
+    cfg = cfgmod.get_cfg_defaults()
+
+    def lower(c):
+        return {k.lower(): lower(v) for k, v in c.items()} if isinstance(c, dict) else c
+    a = lower(cfg)["aspan"]
+    a["coarse"].update(coarsest_level=[36, 36], train_res=[832, 832], test_res=[1152, 1152])
+    a["match_coarse"].update(match_type="dual_softmax", thr=match_thr, train_coarse_percent=0.3)
+    a["fine"]["enable"] = False
+    return a
+
+
+class cpu_cuda_calls:
+    """ASpanFormer hard-codes ``.cuda()`` on three small constant tensors inside forward (aspan_module/transformer.py:128,
+    attention.py:103, aspanformer.py:129).  This container has no GPU: inside this context ``Tensor.cuda`` is the identity,
+    which leaves every value the module computes unchanged."""
+
+    def __enter__(self):
+        import torch
+        self._saved = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+
+    def __exit__(self, *exc):
+        import torch
+        torch.Tensor.cuda = self._saved
+
+
+def import_aspanformer():
+    """Return the reference's ``ASpanFormer`` class (third_party/aspantransformer/src/ASpanFormer/aspanformer.py), imported
+    unchanged.  ``torchvision.transforms.Resize`` (online resize of frames whose sides are not multiples of 32,
+    aspanformer.py:131-139) is NOT available here: the stand-in raises, so fixtures only use sides that are multiples of 32,
+    for which the reference skips the resize."""
+    _ensure_path()
+    install_stubs()
+    tvt = sys.modules["torchvision.transforms"]
+    if not hasattr(tvt, "Resize"):
+        class Resize:
+            def __init__(self, *a, **k):
+                raise RuntimeError("torchvision is not installed: use frame sides that are multiples of 32")
+        tvt.Resize = Resize
+    from third_party.aspantransformer.src.ASpanFormer.aspanformer import ASpanFormer
+    return ASpanFormer

@@ -244,6 +244,78 @@ def _resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pa
     return o8, of, mk
 
 
+# ---------------------------------------------------------------- ASpanFormer pieces (csrc/aspan_ops.hip)
+def _avgpool(x, k, out=None):
+    import torch.nn.functional as F
+    y = F.avg_pool2d(x.permute(0, 3, 1, 2).contiguous(), k, stride=k).permute(0, 2, 3, 1).contiguous()
+    if out is not None:
+        out.copy_(y.view(out.shape))
+        return out
+    return y
+
+
+def _full_attention(q, k, v, nhead, scale, kv_swap=False):
+    from oracle import restate_aspanformer as ra
+    N = q.shape[0]
+    outs = []
+    for n in range(N):
+        o = n ^ 1 if kv_swap else n
+        y = ra.full_attention(q[n:n + 1].transpose(1, 2).contiguous(), k[o:o + 1].transpose(1, 2).contiguous(),
+                              v[o:o + 1].transpose(1, 2).contiguous(), nhead, temp=scale * (q.shape[2] // nhead) ** .5)
+        outs.append(y.transpose(1, 2))
+    return torch.cat(outs, 0).contiguous()
+
+
+def _span_attention(q, hw, k, v, hw_k, flow, hw0, sample_offset, nhead, nsample, radius_scale, temp=1.0):
+    """One level of HierachicalAttention with the reference's own operations (aspan_module/attention.py:49-66, 92-133)."""
+    import torch.nn.functional as F
+    from oracle import restate_aspanformer as ra
+    (h, w), (hk, wk), (H0, W0) = hw, hw_k, hw0
+    s = H0 // h
+    C = q.shape[-1]
+    fl = flow.reshape(1, H0, W0, 4)
+    variance = torch.exp(0.5 * fl[..., 2:]) * radius_scale
+    span_scale = torch.clamp(variance * 2 / nsample[1], min=1)
+    ker = s * nsample[0]
+    off = F.avg_pool2d(fl[..., :2].permute(0, 3, 1, 2), kernel_size=ker, stride=ker).permute(0, 2, 3, 1) / s
+    span = F.avg_pool2d(span_scale.permute(0, 3, 1, 2), kernel_size=ker, stride=ker).permute(0, 2, 3, 1)
+    nchw = lambda t, hh, ww: t.reshape(1, hh, ww, C).permute(0, 3, 1, 2).contiguous()
+    sd = {"sample_offset": sample_offset}
+    qq, kk, vv, _ = ra.partition_token(sd, "", nchw(q, h, w), nchw(k, hk, wk), nchw(v, hk, wk), off, span, None, nhead, nsample)
+    y = ra.group_attention(qq, kk, vv, temp, C)                               # [1, C, h*w] in (group, member) order
+    return y[0].transpose(0, 1).contiguous()
+
+
+def _layernorm2d(x, affine, bias, residual=None, out=None, out_split=None, want_f32=True):
+    mean, std = x.mean(dim=-1, keepdim=True), x.std(dim=-1, keepdim=True)
+    y = affine * (x - mean) / (std + 1e-6) + bias
+    if residual is not None:
+        y = residual.float() + y
+    if out_split is not None:
+        _put_split(out_split, y)
+    if out is not None:
+        out.copy_(y.view(out.shape))
+        return out
+    return y.contiguous() if want_f32 else None
+
+
+def _upsample(x, scale, bilinear, out=None, out_split=None, want_f32=True):
+    import torch.nn.functional as F
+    xc = x.permute(0, 3, 1, 2).contiguous()
+    y = F.interpolate(xc, scale_factor=scale, mode="bilinear") if bilinear else F.interpolate(xc, scale_factor=scale, mode="nearest")
+    y = y.permute(0, 2, 3, 1).contiguous()
+    if out_split is not None:
+        _put_split(out_split, y.reshape(-1, y.shape[-1]))
+    if out is not None:
+        out.copy_(y.view(out.shape))
+        return out
+    return y if want_f32 else None
+
+
+def _flow_decode(x, wk, hk):
+    return torch.cat([torch.sigmoid(x[:, :2]) * torch.tensor([float(wk), float(hk)]), x[:, 2:4]], dim=1).contiguous()
+
+
 def _merge(rows, img0, img1, n_images):
     """ops.merge_keypoints on the numpy restatement of the reference's consumer stage (oracle/restate_merge.py)."""
     from oracle import restate_merge as rm
@@ -258,7 +330,8 @@ def cpu_ops():
     saved = {n: getattr(ops, n) for n in ("linear_attention", "coarse_match", "roi_align", "fine_match",
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
-                                          "bilinear_up", "resample_u8")}
+                                          "bilinear_up", "resample_u8", "avgpool", "full_attention",
+                                          "span_attention", "layernorm2d", "upsample", "flow_decode")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
@@ -266,6 +339,8 @@ def cpu_ops():
     ops.resample_separable = _resample
     ops.dwconv3x3, ops.bilinear_up = _dwconv, _bilinear
     ops.resample_u8 = _resample_u8
+    ops.avgpool, ops.full_attention, ops.span_attention = _avgpool, _full_attention, _span_attention
+    ops.layernorm2d, ops.upsample, ops.flow_decode = _layernorm2d, _upsample, _flow_decode
     try:
         yield
     finally:

@@ -1,0 +1,192 @@
+"""ASpanFormer coarse matcher on the GPU: every new kernel of csrc/aspan_ops.hip through the C ABI against
+the reference's own operations (torch CPU), then HipASpanFormer end to end against the fixture written by the real module and
+against the oracle, with the per-entry parity rules of tests/parity.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import parity
+from cpu_standins import _span_attention as span_reference
+from detectorfreesfm_amd import ops, plugin, synth
+from oracle import restate_aspanformer as ra
+from oracle.make_golden import aspanformer_cases, aspanformer_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(npz):
+    return {k: npz[k].item() for k in npz.files if npz[k].ndim == 0}
+
+
+@pytest.mark.parametrize("N,H,W,C,k", [(1, 60, 80, 768, 4), (2, 24, 32, 256, 2), (1, 12, 16, 128, 4)])
+def test_avgpool_vs_torch(built_lib, N, H, W, C, k):
+    g = torch.Generator().manual_seed(H + k)
+    wide = torch.randn((N, H, W, C + 64), generator=g)
+    x = wide[..., 32:32 + C]                                         # a column slice of a wider token buffer
+    ref = F.avg_pool2d(x.permute(0, 3, 1, 2).contiguous(), k, stride=k).permute(0, 2, 3, 1)
+    out = ops.avgpool(wide.to(DEV)[..., 32:32 + C], k).cpu()
+    assert torch.equal(out, ref)                                     # same summation order, exact division
+
+
+@pytest.mark.parametrize("L,S,swap", [(300, 300, False), (300, 117, False), (70, 676, True)])
+def test_full_attention_vs_reference(built_lib, L, S, swap):
+    g = torch.Generator().manual_seed(L + S)
+    N = 2 if swap else 1
+    q = torch.randn((N, L, 768), generator=g)[..., :256]
+    kv = torch.randn((N, S, 768), generator=g)
+    k, v = kv[..., 256:512], kv[..., 512:]
+    scale = 1.3 / math.sqrt(32)
+    outs = []
+    for n in range(N):
+        o = n ^ 1 if swap else n
+        outs.append(ra.full_attention(q[n:n + 1].double().transpose(1, 2).contiguous(), k[o:o + 1].double().transpose(1, 2).contiguous(),
+                                      v[o:o + 1].double().transpose(1, 2).contiguous(), 8, temp=1.3).transpose(1, 2))
+    ref = torch.cat(outs, 0)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    out = ops.full_attention(qd, kvd[..., 256:512], kvd[..., 512:], 8, scale, kv_swap=swap).cpu().double()
+    assert (out - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("hw,hw_k,s", [((12, 16), (12, 16), 1), ((6, 8), (6, 8), 2), ((30, 40), (24, 52), 2), ((60, 80), (60, 80), 1)])
+def test_span_attention_vs_reference(built_lib, hw, hw_k, s):
+    """Random maps and flows whose spans reach far outside the key map (zero padding) and whose centres sit on the border."""
+    g = torch.Generator().manual_seed(hw[0] * 7 + s)
+    h, w = hw
+    hk, wk = hw_k
+    H0, W0 = h * s, w * s
+    q = torch.randn((h * w, 768), generator=g)[:, :256]
+    kv = torch.randn((hk * wk, 768), generator=g)
+    flow = torch.cat([torch.rand((H0 * W0, 1), generator=g) * (wk * s + 6) - 3, torch.rand((H0 * W0, 1), generator=g) * (hk * s + 6) - 3,
+                      torch.randn((H0 * W0, 2), generator=g) * 1.5 - 1.0], 1).contiguous()
+    so = torch.tensor([[a - 3.5, b - 3.5] for a in range(8) for b in range(8)])
+    ref = span_reference(q.double(), hw, kv[:, 256:512].double(), kv[:, 512:].double(), hw_k, flow.double(), (H0, W0), so.double(),
+                         8, [2, 8], 5, 1.0)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    out = ops.span_attention(qd, hw, kvd[:, 256:512], kvd[:, 512:], hw_k, flow.to(DEV), (H0, W0), so.to(DEV), 8, [2, 8], 5).cpu().double()
+    # a sample that lands within fp32 rounding of a cell edge may take the neighbouring cell: compare in the mean and bound the max
+    err = (out - ref).abs()
+    assert err.mean().item() < 1e-6 and err.max().item() < 5e-4
+
+
+@pytest.mark.parametrize("C", [256, 384])
+def test_layernorm2d_vs_reference(built_lib, C):
+    g = torch.Generator().manual_seed(C)
+    rows = 1003
+    x = torch.randn((rows, C + 32), generator=g)[:, :C] * 3 + 0.5
+    aff, b = torch.randn((C,), generator=g), torch.randn((C,), generator=g)
+    res = ops.SplitAct.empty_rows((rows,), 640, DEV)
+    r32 = torch.randn((rows, C), generator=g)
+    ops.split_rows(r32.to(DEV), out_split=res.cols(0, C))
+    xd = x.double()
+    ref = aff.double() * (xd - xd.mean(1, keepdim=True)) / (xd.std(1, keepdim=True) + 1e-6) + b.double()
+    xg = torch.randn((rows, C + 32)).to(DEV)
+    xg[:, :C] = x.to(DEV)
+    out = ops.layernorm2d(xg[:, :C], aff.to(DEV), b.to(DEV)).cpu().double()
+    assert (out - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+    dst = ops.SplitAct.empty_rows((rows,), 640, DEV)
+    ops.layernorm2d(xg[:, :C], aff.to(DEV), b.to(DEV), residual=res.cols(0, C), out_split=dst.cols(128, 128 + C), want_f32=False)
+    got = dst.cols(128, 128 + C).float().cpu().double()
+    want = res.cols(0, C).float().cpu().double() + ref
+    assert (got - want).abs().max().item() < 3e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("bilinear,scale", [(True, 4), (False, 4), (False, 2), (False, 1)])
+def test_upsample_vs_torch(built_lib, bilinear, scale):
+    g = torch.Generator().manual_seed(scale)
+    x = torch.randn((1, 15, 20, 384), generator=g)
+    xs = x[..., 128:384]
+    xc = xs.permute(0, 3, 1, 2).contiguous()
+    ref = (F.interpolate(xc, scale_factor=scale, mode="bilinear") if bilinear else F.interpolate(xc, scale_factor=scale, mode="nearest"))
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, 256)
+    xd = x.to(DEV)[..., 128:384]
+    out = ops.upsample(xd, scale, bilinear).cpu().reshape(-1, 256)
+    assert (out - ref).abs().max().item() < (2e-6 if bilinear else 0.0) + 1e-30
+    dst = ops.SplitAct.empty_rows((ref.shape[0],), 768, DEV)
+    ops.upsample(xd, scale, bilinear, out_split=dst.cols(256, 512), want_f32=False)
+    assert (dst.cols(256, 512).float().cpu() - ref).abs().max().item() < 4e-6
+
+
+def test_flow_decode_vs_reference(built_lib):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((4800, 64), generator=g) * 3
+    ref = torch.cat([torch.sigmoid(x[:, :2].double()) * torch.tensor([80.0, 60.0], dtype=torch.float64), x[:, 2:4].double()], 1)
+    out = ops.flow_decode(x.to(DEV), 80, 60).cpu().double()
+    assert (out - ref).abs().max().item() < 1e-5
+
+
+# ---------------------------------------------------------------- end to end
+def _aspan(thr=0.2):
+    from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    cfg = aspanformer_coarse_only_config(thr)
+    sd = planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0)
+    m = HipASpanFormer(cfg)
+    m.load_state_dict(sd, strict=True)
+    return cfg, sd, m.eval().to(DEV)
+
+
+def _strict(d, ref, conf, thr, what, max_exempt):
+    ex = parity.check_coarse(d, ref, conf, thr)
+    parity.check_coarse_rows(d, ref, ex)
+    print(f"[{what}] {len(ref['i_ids'])} reference matches, {len(d['i_ids'])} on the GPU, exempted entries: {ex}")
+    assert len(ex) <= max_exempt
+    return ex
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_aspanformer_e2e_golden(built_lib, golden, case):
+    """Fixture written by the real ASpanFormer module: equal frames, and two frame sizes (cross-size span attention)."""
+    gz = golden("aspanformer_e2e")
+    c = _case(gz)
+    tag, hw0, hw1 = aspanformer_cases()[case]
+    cfg, sd, m = _aspan(c["thr"])
+    data = aspanformer_inputs(c, hw0, hw1)
+    d = synth.to_device(data, DEV)
+    m(d)
+    ref = {k: gz[f"{tag}_{k}"] for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f")}
+    _strict(d, ref, gz[f"{tag}_conf_matrix"], c["thr"], f"aspanformer_e2e {tag}", 1)
+    assert len(ref["i_ids"]) > 10 and (d["m_bids"] == d["b_ids"]).all()
+    pf = d["predict_flow"]
+    for i in (0, 1):                                                  # the predicted flows: sigmoid * size, 12 x 16 cells
+        assert np.abs(pf[i].cpu().numpy() - gz[f"{tag}_flow{i}"]).max() < 2e-3
+    for k in ("offset_bids_left", "offset_lids_left", "offset_bids_right", "offset_lids_right"):
+        assert np.array_equal(d[k].cpu().numpy(), gz[f"{tag}_{k}"]), k
+    assert np.abs(d["offset_kpts1_f_left"].cpu().numpy() - gz[f"{tag}_offset_kpts1_f_left"]).max() < 2e-2   # x8 pixels
+
+
+def test_aspanformer_480x640_vs_oracle(built_lib):
+    """configs[1] frame size: 4800 tokens per image, levels of 300 / 1200 / 4800 tokens."""
+    cfg, sd, m = _aspan(0.2)
+    data = synth.coarse_pair_batch(1, 480, 640, seed=7)
+    d = synth.to_device(data, DEV)
+    m(d)
+    with torch.no_grad():
+        o = ra.aspanformer_forward(sd, cfg, data, with_fine_backbone=False)
+    assert o["i_ids"].numel() > 300
+    _strict(d, o, o["conf_matrix"], 0.2, "aspanformer 480x640", 3)
+    assert (d["predict_flow"][0].cpu() - o["predict_flow"][0]).abs().max().item() < 2e-2
+
+
+def test_aspanformer_plugin_surface(built_lib, tmp_path):
+    """build_model('aspanformer_hip') from a {'state_dict': ...} checkpoint (coarse_match_worker.py:45-60) -> extract_matches."""
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    from detectorfreesfm_amd.aspanformer import aspanformer_coarse_only_config
+    sd = planted_aspanformer_state_dict(aspanformer_param_spec(aspanformer_coarse_only_config(0.2)), 0)
+    ckpt = tmp_path / "aspan.ckpt"
+    torch.save({"state_dict": {"matcher." + k: v for k, v in sd.items()}}, ckpt)
+    detector, matcher = plugin.build_model({"matcher": "aspanformer_hip", "type": "coarse_only", "match_thr": 0.2, "seed": 666,
+                                            "aspanformer_hip": {"weight_path": str(ckpt)}})
+    matcher.cuda()
+    data = synth.coarse_pair_batch(1, 96, 128, seed=1003)
+    d = {k: v.cuda() for k, v in data.items()}
+    mk0, mk1, mc = plugin.extract_matches(d, detector=detector, matcher=matcher)
+    with torch.no_grad():
+        o = ra.aspanformer_forward(sd, matcher.config, data, with_fine_backbone=False)
+    _strict(d, o, o["conf_matrix"], 0.2, "aspanformer plugin", 1)
+    assert len(mc) > 10 and np.abs(mc - o["mconf"].numpy()).max() <= parity.TOL_CONF
+    with pytest.raises(NotImplementedError):
+        matcher({"image0": torch.zeros(1, 1, 100, 128, device=DEV), "image1": torch.zeros(1, 1, 96, 128, device=DEV)})

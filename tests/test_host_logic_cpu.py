@@ -210,3 +210,38 @@ def test_matchformer_host_logic_with_cpu_standins():
         assert (d["mconf"] - o["mconf"]).abs().max().item() < 1e-4
     with pytest.raises(NotImplementedError):
         m({"image0": torch.zeros(1, 1, 64, 96), "image1": torch.zeros(1, 1, 64, 64)})
+
+
+def test_aspanformer_host_logic_with_cpu_standins():
+    """HipASpanFormer's host logic (weight packing incl. the folded positional part of v_proj and the zero block of the last
+    layer's merge_f, the [x | flow | message] token buffers, level pooling, the (group, member) order of the span levels,
+    both directions from the pre-update state, flow bookkeeping) with the kernels emulated on the CPU: the oracle's rows."""
+    from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    from oracle import restate_aspanformer as ra
+    cfg = aspanformer_coarse_only_config(0.2)
+    sd = planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0)
+    m = HipASpanFormer(cfg).eval()
+    m.load_state_dict({"matcher." + k: v for k, v in sd.items()}, strict=True)        # prefix stripped, sample_offset dropped
+    for hw1 in ((96, 128), (64, 160)):                                                # same and different frame sizes
+        data = synth.coarse_pair_batch(1, 96, 128, seed=1000)
+        if hw1 != (96, 128):
+            data["image1"] = synth.coarse_pair_batch(1, hw1[0], hw1[1], seed=1001)["image0"]
+        data["scale0"] = torch.tensor([[1.5, 2.0]])
+        o = ra.aspanformer_forward(sd, cfg, dict(data))
+        with cpu_ops():
+            d = m(dict(data))
+        assert o["b_ids"].numel() > 10
+        for k in ("b_ids", "i_ids", "j_ids"):
+            assert torch.equal(d[k], o[k]), (hw1, k)
+        assert torch.equal(d["mkpts0_f"], o["mkpts0_f"]) and torch.equal(d["mkpts1_f"], o["mkpts1_f"])
+        assert (d["mconf"] - o["mconf"]).abs().max().item() < 1e-4
+        fl_d = d["predict_flow"] if isinstance(d["predict_flow"], list) else list(d["predict_flow"])
+        fl_o = o["predict_flow"] if isinstance(o["predict_flow"], list) else list(o["predict_flow"])
+        for a, b in zip(fl_d, fl_o):
+            assert a.shape == b.shape and (a - b).abs().max().item() < 1e-3
+        for k in ("offset_bids_left", "offset_lids_left", "offset_bids_right", "offset_lids_right"):
+            assert torch.equal(d[k], o[k]), k
+        assert (d["offset_kpts1_f_left"] - o["offset_kpts1_f_left"]).abs().max().item() < 1e-2
+    with pytest.raises(NotImplementedError):
+        m({"image0": torch.zeros(1, 1, 100, 128), "image1": torch.zeros(1, 1, 96, 128)})

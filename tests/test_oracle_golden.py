@@ -227,3 +227,46 @@ def test_matchformer_key_layout_vs_live_reference():
     spec = matchformer_param_spec()
     assert [n for n, _, _ in spec] == list(m.state_dict().keys()) and len(spec) == 229
     assert all(tuple(m.state_dict()[n].shape) == tuple(s) for n, s, _ in spec)
+
+
+# ---------------------------------------------------------------- ASpanFormer
+ASPAN_KEYS = ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f", "conf_matrix", "offset_bids_left", "offset_lids_left",
+              "confleft", "offset_kpts0_f_left", "offset_kpts1_f_left", "offset_bids_right", "offset_lids_right", "confright",
+              "offset_kpts0_f_right", "offset_kpts1_f_right")
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_aspanformer_e2e(golden, case):
+    """oracle/restate_aspanformer.py == the real ASpanFormer module (fixture), bit for bit: equal frames and two sizes."""
+    from detectorfreesfm_amd.aspanformer import aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    from oracle import restate_aspanformer as ra
+    from oracle.make_golden import aspanformer_cases, aspanformer_inputs
+    gz = golden("aspanformer_e2e")
+    c = _case(gz)
+    tag, hw0, hw1 = aspanformer_cases()[case]
+    cfg = aspanformer_coarse_only_config(c["thr"])
+    sd = planted_aspanformer_state_dict(aspanformer_param_spec(cfg), c["weight_seed"], c["alpha"])
+    with torch.no_grad():
+        o = ra.aspanformer_forward(sd, cfg, aspanformer_inputs(c, hw0, hw1))
+    assert len(gz[f"{tag}_i_ids"]) > 10
+    for k in ASPAN_KEYS:
+        assert np.array_equal(o[k].numpy(), gz[f"{tag}_{k}"]), k
+    pf = o["predict_flow"]
+    assert np.array_equal(pf[0].numpy(), gz[f"{tag}_flow0"]) and np.array_equal(pf[1].numpy(), gz[f"{tag}_flow1"])
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference (build container only)")
+def test_aspanformer_layout_and_config_vs_live_reference():
+    from detectorfreesfm_amd.aspanformer import aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec
+    A = ref_import.import_aspanformer()
+    cfg = aspanformer_coarse_only_config(0.4)
+    ref_cfg = ref_import.aspanformer_coarse_only_config(0.4)                # yacs defaults + aspan_test_coarse_only.py
+    for sect in ("coarse", "match_coarse", "fine", "resnetfpn"):
+        for k, v in cfg[sect].items():
+            assert list(ref_cfg[sect][k]) == list(v) if isinstance(v, (list, tuple)) else ref_cfg[sect][k] == v, (sect, k)
+    m = A(config=cfg, online_resize=True).eval()
+    spec = aspanformer_param_spec(cfg)
+    assert [n for n, _, _ in spec] == list(m.state_dict().keys()) and len(spec) == 217
+    assert all(tuple(m.state_dict()[n].shape) == tuple(s) for n, s, _ in spec)
