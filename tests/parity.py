@@ -26,9 +26,11 @@ def _np(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
-def check_coarse(hip, ref, conf, thr, border=None):
+def check_coarse(hip, ref, conf, thr, border=None, tol_conf=TOL_CONF):
     """hip / ref: dicts with b_ids, i_ids, j_ids, mconf (+ optional mkpts*); conf: the ORACLE's dense
-    confidence matrix [N,L,S].  Asserts the per-entry rules above; returns the list of exempted entries."""
+    confidence matrix [N,L,S].  Asserts the per-entry rules above; returns the list of exempted entries.
+    ``tol_conf`` is north_star's 1e-4 everywhere except where a caller has MEASURED that the reference's own fp32
+    evaluation is not reproducible to that level (tests/test_gpu_aspan.py::test_aspanformer_480x640_vs_oracle)."""
     conf = _np(conf).astype(np.float64)
     hb, hi_, hj, hc = (_np(hip[k]) for k in ("b_ids", "i_ids", "j_ids", "mconf"))
     rb, ri, rj, rc = (_np(ref[k]) for k in ("b_ids", "i_ids", "j_ids", "mconf"))
@@ -57,7 +59,7 @@ def check_coarse(hip, ref, conf, thr, border=None):
         if key in H and key in R:
             (j, c), (jr, cr) = H[key], R[key]
             if j == jr:
-                if abs(c - cr) > TOL_CONF:
+                if abs(c - cr) > tol_conf:
                     bad.append(("conf", key, j, c, cr))
             elif selectable(b, i, j) and fragile(b, i, jr):
                 exempt.append(("tie", key, j, jr))
@@ -65,7 +67,7 @@ def check_coarse(hip, ref, conf, thr, border=None):
                 bad.append(("j differs", key, j, jr, conf[b, i, j], conf[b, i, jr]))
         elif key in H:
             j, c = H[key]
-            if abs(c - conf[b, i, j]) > TOL_CONF:
+            if abs(c - conf[b, i, j]) > tol_conf:
                 bad.append(("conf of extra entry", key, j, c, conf[b, i, j]))
             elif selectable(b, i, j) and (abs(conf[b, i, j] - thr) <= TOL_THR or conf[b, i, j] < rowmax[b, i]
                                           or conf[b, i, j] < colmax[b, j]):

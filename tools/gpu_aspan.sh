@@ -1,6 +1,12 @@
 #!/bin/bash
-# ASpanFormer session: kernel + e2e GPU tests, then a timing of the 640x480 pair.
+# ASpanFormer session: tests/test_gpu_aspan.py in one process, then (a device fault must not hide the rest) test by test.
 exec < /dev/null
 out=gpurun_out/${1:-as1}; mkdir -p $out
-timeout 900 python -m pytest tests/test_gpu_aspan.py -q -s > $out/pytest.log 2>&1; echo "rc=$?" >> $out/pytest.log
-grep -n "passed\|failed\|rc=\|^\[aspan\|Error\|assert " $out/pytest.log | head -40
+timeout 900 python -m pytest tests/test_gpu_aspan.py -q -s 2>&1 | grep -v "^  File\|pluggy\|_pytest" | tail -40 > $out/pytest_all.log
+: > $out/pytest.log
+for t in avgpool full_attention span_attention layernorm2d upsample flow_decode e2e_golden 480x640 plugin_surface; do
+  echo "=== $t" >> $out/pytest.log
+  timeout 600 python -m pytest tests/test_gpu_aspan.py -q -s -k $t 2>&1 | grep -v "^  File\|pluggy\|_pytest" | tail -25 >> $out/pytest.log
+done
+grep -n "passed\|failed\|^\[aspan\|Error\|assert \|fault" $out/pytest_all.log | cut -c1-420 | head -20
+grep -n "===\|passed\|failed\|^\[aspan\|Error\|assert \|fault" $out/pytest.log | cut -c1-420 | head -60
