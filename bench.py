@@ -51,17 +51,22 @@ MATCH_FLOP_PER_PAIR = 11.8e9           # 2*L*S*C, counted once
 REFINE_FLOP_PER_TRACK = 6.6e9          # S2DNet 5.1 G + transformer 1.47 G + fine correlation 0.011 G
 
 
-def event_time_ms(fn, iters=10, warmup=2):
-    """Average duration of fn() with events on the current (= launch) stream."""
+def event_time_ms(fn, iters=10, warmup=2, rounds=3):
+    """Average duration of fn() with events on the current (= launch) stream: the median of ``rounds`` averages over
+    ``iters`` launches each, so that one allocator / page-fault hiccup (seen once: 60 ms inside a 10-launch window) does not
+    become a kernel's reported time."""
     for _ in range(warmup):
         fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    e.synchronize()
-    return s.elapsed_time(e) / iters
+    avgs = []
+    for _ in range(rounds):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        e.synchronize()
+        avgs.append(s.elapsed_time(e) / iters)
+    return sorted(avgs)[len(avgs) // 2]
 
 
 def timed_steps(step, steps, warmup, distributed):

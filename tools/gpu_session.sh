@@ -1,5 +1,6 @@
 #!/bin/bash
 # One gpurun call: GPU tests, smoke, bench; logs under gpurun_out/<tag>/
+exec < /dev/null
 tag=${1:-s1}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -12,3 +13,4 @@ timeout 600 python bench.py --steps 10 --warmup 2 > $out/bench.json 2> $out/benc
 echo "bench rc=$?" >> $out/bench.err
 tail -5 $out/pytest.log
 tail -3 $out/smoke.log
+grep -o "\"value\": [0-9.]*\|\"ms_per_step\": [0-9.]*\|\"secondary\": {[^}]*}" $out/bench.json | head -5; tail -2 $out/bench.err
