@@ -69,6 +69,7 @@ SIGNATURES = [
       c_int64, c_int, c_void_p]),
     ("dfsfm_upsample_nhwc_f32", c_int,
      [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("dfsfm_resize_bilinear_f32", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("dfsfm_flow_decode_f32", c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p]),
     ("dfsfm_resample_u8", c_int,
      [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,

@@ -16,10 +16,11 @@ positional part of ``v_proj(cat[x, pos])`` folded into a per-size constant that 
 (flow statistics -> 8x8 bilinear K / V samples -> per-group softmax), ``layernorm2d``, bilinear / nearest up-sampling into
 column slices, the flow decoder's sigmoid.  The dual-softmax matching stage is K3-K5 of the LoFTR path.
 
-Not implemented (raises): frames whose sides are not multiples of 32 -- the reference resizes those with
-``torchvision.transforms.Resize`` (aspanformer.py:119-139), which this image does not have, so that branch could not be pinned
--- padding masks (the reference's dataset path never pads for this matcher: src/coarse_match/coarse_match.py:88-90), and
-``fine.enable``.
+Frames whose sides are not multiples of 32 are resized on the device like the reference's ``resize_input``
+(aspanformer.py:119-139): the pinned torchvision 0.9.1 (environment.yaml) implements ``transforms.Resize`` on a float tensor as
+``F.interpolate(size, mode='bilinear', align_corners=False)``; torchvision itself is not installed here, so this one step is
+pinned against torch's ``F.interpolate``, not against torchvision.  Not implemented (raises): padding masks (the reference's
+dataset path never pads for this matcher: src/coarse_match/coarse_match.py:88-90) and ``fine.enable``.
 """
 import math
 
@@ -182,20 +183,26 @@ class HipASpanFormer(ParamModule):
         assert img0.shape[0] == 1 and img1.shape[1] == 1                                  # aspanformer.py:43
         if "mask0" in data or "mask1" in data:
             raise NotImplementedError("padding masks: the reference's dataset path does not pad frames for aspanformer")
-        for im in (img0, img1):
-            if im.shape[2] % 32 or im.shape[3] % 32:
-                raise NotImplementedError("frame sides must be multiples of 32 (the reference's torchvision online resize is not available)")
         P = self._packed or self._pack()
         c = self.config["coarse"]
         d, dfl, nhead, DS = c["d_model"], c["d_flow"], c["nhead"], self.DS
         dev = img0.device
         tr = c["train_res"]
         tr_h, tr_w = (tr, tr) if len(tr) == 1 else (tr[0], tr[1])
-        imgs = (img0, img1)
+        # resize_input / resize_df (aspanformer.py:119-139): sides rounded down to multiples of 32 by torchvision 0.9.1's
+        # transforms.Resize on a float tensor = F.interpolate(size, 'bilinear', align_corners=False); identity when they already are
+        orig = [(im.shape[2], im.shape[3]) for im in (img0, img1)]
+        imgs = []
+        for im in (img0, img1):
+            h, w = im.shape[2], im.shape[3]
+            h_new, w_new = h // 32 * 32, w // 32 * 32
+            imgs.append(ops.resize_bilinear(im, h_new, w_new) if (h_new, w_new) != (h, w) else im)
+        img0, img1 = imgs
+        data["image0"], data["image1"] = img0, img1
         pos_scale = [[tr_h / im.shape[2], tr_w / im.shape[3]] for im in imgs]
         data["pos_scale0"], data["pos_scale1"] = pos_scale
-        one = torch.ones((1, 2), device=dev)                                             # resize_input with unchanged sizes
-        data["online_resize_scale0"], data["online_resize_scale1"] = one, one.clone()
+        rs = [torch.tensor([orig[i][1] / imgs[i].shape[3], orig[i][0] / imgs[i].shape[2]])[None].to(dev) for i in (0, 1)]
+        data["online_resize_scale0"], data["online_resize_scale1"] = rs
         data.update({"bs": 1, "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
         if img0.shape[2:] == img1.shape[2:]:
             tok = backbone_tokens_hip(torch.cat([img0, img1], 0), P["bb"])
@@ -308,5 +315,8 @@ class HipASpanFormer(ParamModule):
             data.update({"offset_bids_" + side: b_ids, "offset_lids_" + side: l_ids, "conf" + side: conf[keep]})
             k0, k1 = (j_coor, i_coor) if side == "right" else (i_coor, j_coor)
             data.update({"offset_kpts0_f_" + side: k0, "offset_kpts1_f_" + side: k1})
-        data.update({"mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})          # x online_resize_scale (= 1)
+        # mkpts*_f are the SAME tensors as mkpts*_c in the reference and are scaled in place (aspanformer.py:96-108)
+        data["mkpts0_c"] = data["mkpts0_c"] * rs[0]
+        data["mkpts1_c"] = data["mkpts1_c"] * rs[1]
+        data.update({"mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
         return data

@@ -311,6 +311,28 @@ __global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __re
     store4(out, outh, outl, row * ldo + c4 * 4, row * ldos + c4 * 4, r);
 }
 
+// F.interpolate(x, size=(hout, wout), mode='bilinear', align_corners=False) of single-channel planes: what
+// torchvision 0.9.1's transforms.Resize does to a float tensor (aspanformer.py:131-139).  ATen's arithmetic: scale = in / out in
+// fp32, src = max(scale * (dst + 0.5) - 0.5, 0), weights (1 - l, l), rows combined as wy0 * (wx0 a + wx1 b) + wy1 * (...).
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, int hin, int win, int hout, int wout,
+                                                              float sy, float sx, float* __restrict__ out, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int ox = (int)(e % wout);
+    int64_t t = e / wout;
+    const int oy = (int)(t % hout);
+    const int64_t n = t / hout;
+    const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)fy, hin - 1), x0 = min((int)fx, win - 1);
+    const int y1 = min(y0 + 1, hin - 1), x1 = min(x0 + 1, win - 1);
+    const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* b = x + n * hin * win;
+    const float v00 = b[(int64_t)y0 * win + x0], v01 = b[(int64_t)y0 * win + x1];
+    const float v10 = b[(int64_t)y1 * win + x0], v11 = b[(int64_t)y1 * win + x1];
+    out[e] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+}
+
 __global__ __launch_bounds__(256) void flow_decode_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, float wk,
                                                           float hk, float* __restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -421,4 +443,14 @@ extern "C" int dfsfm_flow_decode_f32(const float* x, int64_t ldx, int64_t rows, 
     hipLaunchKernelGGL(flow_decode_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        x, ldx, rows, wk, hk, out);
     return dfsfm::check_launch("dfsfm_flow_decode_f32");
+}
+
+extern "C" int dfsfm_resize_bilinear_f32(const float* x, int N, int hin, int win, int hout, int wout, float* out, void* stream_) {
+    if (N == 0) return DFSFM_OK;
+    if (!x || !out || N < 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) return DFSFM_E_BADARG;
+    const float sy = (float)hin / (float)hout, sx = (float)win / (float)wout;        // area_pixel_compute_scale, size given
+    const int64_t total = (int64_t)N * hout * wout;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       x, hin, win, hout, wout, sy, sx, out, total);
+    return dfsfm::check_launch("dfsfm_resize_bilinear_f32");
 }

@@ -535,6 +535,21 @@ def upsample(x, scale, bilinear, out=None, out_split=None, want_f32=True):
 
 
 @_on_device
+def resize_bilinear(x, hout, wout):
+    """F.interpolate(x, size=(hout, wout), mode='bilinear', align_corners=False) of fp32 planes x [..., hin, win]."""
+    _require_cuda(x)
+    if x.dtype != torch.float32 or x.dim() < 2:
+        raise _lib.DfsfmError("resize_bilinear: need fp32 planes [..., H, W]")
+    x = x.contiguous()
+    hin, win = x.shape[-2:]
+    N = x.numel() // (hin * win)
+    out = torch.empty((*x.shape[:-2], int(hout), int(wout)), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dfsfm_resize_bilinear_f32(_ptr(x), N, hin, win, int(hout), int(wout), _ptr(out), _stream())
+    _lib.check(rc, "dfsfm_resize_bilinear_f32")
+    return out
+
+
+@_on_device
 def flow_decode(x, wk, hk):
     """(sigmoid(x0) * wk, sigmoid(x1) * hk, x2, x3) of the first four columns of fp32 rows x -> [rows, 4]."""
     _require_cuda(x)

@@ -239,6 +239,11 @@ int dfsfm_upsample_nhwc_f32(const float* x, int64_t ldx, int N, int hin, int win
  * out[r] = (sigmoid(x[r,0]) * wk, sigmoid(x[r,1]) * hk, x[r,2], x[r,3]). */
 int dfsfm_flow_decode_f32(const float* x, int64_t ldx, int64_t rows, float wk, float hk, float* out, void* stream);
 
+/* F.interpolate(x, size=(hout, wout), mode='bilinear', align_corners=False) of fp32 planes x [N,hin,win] -> out [N,hout,wout]:
+ * the online resize of frames whose sides are not multiples of 32 (torchvision 0.9.1 transforms.Resize on a float tensor,
+ * third_party/aspantransformer/src/ASpanFormer/aspanformer.py:131-139). */
+int dfsfm_resize_bilinear_f32(const float* x, int N, int hin, int win, int hout, int wout, float* out, void* stream);
+
 /* PIL's 8-bit fixed-point resampling (Image.resize on 'L' / 'RGB' images) + the tensor conversion of the reference's
  * image readers.  Replaces, for an already decoded frame,
  *   resize_image(image, (w_new, h_new), "pil_LANCZOS")           src/dataset/utils.py:160-177

@@ -267,8 +267,9 @@ def bags_golden():
 
 
 def aspanformer_cases():
-    """(tag, (H0, W0), (H1, W1)): one pair of equal frames, one of different sizes (two backbone calls, cross-size spans)."""
-    return [("same", (96, 128), (96, 128)), ("sizes", (96, 128), (64, 160))]
+    """(tag, (H0, W0), (H1, W1)): one pair of equal frames, one of different sizes (two backbone calls, cross-size spans), one
+    whose first frame is not a multiple of 32 (online resize; that step runs on a torchvision stand-in, see ref_import)."""
+    return [("same", (96, 128), (96, 128)), ("sizes", (96, 128), (64, 160)), ("resized", (100, 140), (96, 128))]
 
 
 def aspanformer_inputs(c, hw0, hw1):

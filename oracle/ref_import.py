@@ -419,15 +419,21 @@ class cpu_cuda_calls:
 def import_aspanformer():
     """Return the reference's ``ASpanFormer`` class (third_party/aspantransformer/src/ASpanFormer/aspanformer.py), imported
     unchanged.  ``torchvision.transforms.Resize`` (online resize of frames whose sides are not multiples of 32,
-    aspanformer.py:131-139) is NOT available here: the stand-in raises, so fixtures only use sides that are multiples of 32,
-    for which the reference skips the resize."""
+    aspanformer.py:131-139) is NOT available here: the stand-in restates torchvision 0.9.1's tensor path (bilinear
+    ``F.interpolate``, align_corners=False) -- builder-written, like the kornia stand-ins; the fixture case that uses it is
+    labelled "resized"."""
     _ensure_path()
     install_stubs()
     tvt = sys.modules["torchvision.transforms"]
     if not hasattr(tvt, "Resize"):
-        class Resize:
-            def __init__(self, *a, **k):
-                raise RuntimeError("torchvision is not installed: use frame sides that are multiples of 32")
+        import torch.nn.functional as F
+
+        class Resize:                      # NOT the reference's code: torchvision 0.9.1 functional_tensor.resize, restated
+            def __init__(self, size):
+                self.size = list(size)
+
+            def forward(self, img):
+                return F.interpolate(img, size=self.size, mode="bilinear", align_corners=False)
         tvt.Resize = Resize
     from third_party.aspantransformer.src.ASpanFormer.aspanformer import ASpanFormer
     return ASpanFormer

@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- functional fp32 torch-CPU restatement of the ASpanFormer coarse matcher (SURVEY.md 8(f)
 rank 4) on a plain ``state_dict``: third_party/aspantransformer/src/ASpanFormer/aspanformer.py:31-111 with
 ``fine.enable = False`` and ``online_resize = True`` (how src/coarse_match/coarse_match_worker.py:45-60 builds it), for
-frames whose sides are multiples of 32 (the online resize, aspanformer.py:119-139, is then the identity; it needs
-torchvision, which this image does not have).
+any frame size: the online resize of sides that are not multiples of 32 (aspanformer.py:119-139) is restated from
+torchvision 0.9.1's source (``resize_df`` below) because torchvision is not installed here -- PARITY UNPINNED for that one
+step; everything else is pinned.
 
 Each function cites the reference lines it follows (paths relative to third_party/aspantransformer/src/ASpanFormer/).
 PINNED: tests/test_oracle_golden.py compares it bit for bit with the real module (imported unchanged through
@@ -31,6 +32,18 @@ def position_encoding(d_model, scaling, max_shape=(256, 256)):
     pe[2::4] = torch.sin(y_position * div_term)
     pe[3::4] = torch.cos(y_position * div_term)
     return pe.unsqueeze(0)
+
+
+def resize_df(image, df=32):
+    """ASpanFormer.resize_df (aspanformer.py:131-139).  ``transforms.Resize([h, w]).forward(tensor)`` of the pinned
+    torchvision 0.9.1 (environment.yaml:9) is functional_tensor.resize: ``interpolate(img, size=[h, w], mode='bilinear',
+    align_corners=False)`` (the antialias option only exists from 0.10).  torchvision is not installed here, so this line is a
+    restatement of that published source, NOT checked against torchvision itself."""
+    h, w = image.shape[2], image.shape[3]
+    h_new, w_new = h // df * df, w // df * df
+    if h != h_new or w != w_new:
+        return F.interpolate(image, size=[h_new, w_new], mode="bilinear", align_corners=False)
+    return image
 
 
 def layernorm2d(sd, p, x):
@@ -235,16 +248,18 @@ def offset_matches(flow, conf_mask, hw_c, hw_i0, side):
 
 
 def aspanformer_forward(sd, cfg, data, with_fine_backbone=True):
-    """ASpanFormer.forward, fine disabled, online_resize=True, frame sides multiples of 32 -- aspanformer.py:31-111.
+    """ASpanFormer.forward, fine disabled, online_resize=True -- aspanformer.py:31-111.
     Returns the keys the reference writes into ``data`` (+ the transformer outputs for kernel-level checks)."""
     img0, img1 = data["image0"], data["image1"]
     assert img0.shape[0] == 1 and img1.shape[1] == 1                                  # aspanformer.py:43
-    for im in (img0, img1):
-        assert im.shape[2] % 32 == 0 and im.shape[3] % 32 == 0, "online resize (torchvision) is not restated"
+    orig = [(im.shape[2], im.shape[3]) for im in (img0, img1)]
+    img0, img1 = resize_df(img0), resize_df(img1)                                          # aspanformer.py:119-121
     tr = cfg["coarse"]["train_res"]
     tr_h, tr_w = (tr, tr) if len(tr) == 1 else (tr[0], tr[1])
     pos_scale0 = [tr_h / img0.shape[2], tr_w / img0.shape[3]]
     pos_scale1 = [tr_h / img1.shape[2], tr_w / img1.shape[3]]
+    rs0 = torch.tensor([orig[0][1] / img0.shape[3], orig[0][0] / img0.shape[2]])[None]     # online_resize_scale (:128-129)
+    rs1 = torch.tensor([orig[1][1] / img1.shape[3], orig[1][0] / img1.shape[2]])[None]
     bs = img0.size(0)
     hw0_i, hw1_i = tuple(img0.shape[2:]), tuple(img1.shape[2:])
     if hw0_i == hw1_i:
@@ -278,7 +293,7 @@ def aspanformer_forward(sd, cfg, data, with_fine_backbone=True):
         out["predict_flow"] = flows
     out.update(offset_matches(flows[0], mask0, hw0_c, hw0_i, "left"))
     out.update(offset_matches(flows[1], mask1, hw0_c, hw0_i, "right"))
-    s0 = torch.tensor([img0.shape[3] / img0.shape[3], img0.shape[2] / img0.shape[2]])[None]   # online_resize_scale = 1
-    out.update({"feat_c0": f0, "feat_c1": f1, "hw0_c": hw0_c, "hw1_c": hw1_c, "mkpts0_f": out["mkpts0_c"] * s0,
-                "mkpts1_f": out["mkpts1_c"] * s0})
+    out["mkpts0_c"], out["mkpts1_c"] = out["mkpts0_c"] * rs0, out["mkpts1_c"] * rs1     # in place on the shared tensors (:104-108)
+    out.update({"feat_c0": f0, "feat_c1": f1, "hw0_c": hw0_c, "hw1_c": hw1_c, "mkpts0_f": out["mkpts0_c"],
+                "mkpts1_f": out["mkpts1_c"], "image0": img0, "image1": img1})
     return out

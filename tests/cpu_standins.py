@@ -312,6 +312,12 @@ def _upsample(x, scale, bilinear, out=None, out_split=None, want_f32=True):
     return y if want_f32 else None
 
 
+def _resize_bilinear(x, hout, wout):
+    import torch.nn.functional as F
+    return F.interpolate(x.reshape(-1, 1, *x.shape[-2:]), size=[hout, wout], mode="bilinear", align_corners=False).reshape(
+        *x.shape[:-2], hout, wout)
+
+
 def _flow_decode(x, wk, hk):
     return torch.cat([torch.sigmoid(x[:, :2]) * torch.tensor([float(wk), float(hk)]), x[:, 2:4]], dim=1).contiguous()
 
@@ -331,7 +337,7 @@ def cpu_ops():
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
                                           "bilinear_up", "resample_u8", "avgpool", "full_attention",
-                                          "span_attention", "layernorm2d", "upsample", "flow_decode")}
+                                          "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
@@ -341,6 +347,7 @@ def cpu_ops():
     ops.resample_u8 = _resample_u8
     ops.avgpool, ops.full_attention, ops.span_attention = _avgpool, _full_attention, _span_attention
     ops.layernorm2d, ops.upsample, ops.flow_decode = _layernorm2d, _upsample, _flow_decode
+    ops.resize_bilinear = _resize_bilinear
     try:
         yield
     finally:

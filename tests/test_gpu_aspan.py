@@ -110,6 +110,18 @@ def test_upsample_vs_torch(built_lib, bilinear, scale):
     assert (dst.cols(256, 512).float().cpu() - ref).abs().max().item() < 4e-6
 
 
+@pytest.mark.parametrize("hw,out", [((100, 140), (96, 128)), ((900, 1200), (896, 1184)), ((37, 53), (32, 32)), ((64, 64), (64, 64))])
+def test_resize_bilinear_vs_torch(built_lib, hw, out):
+    """The online resize of ASpanFormer.resize_df: F.interpolate(size, bilinear, align_corners=False) on [1,1,H,W] frames."""
+    g = torch.Generator().manual_seed(hw[0])
+    x = torch.rand((1, 1, *hw), generator=g)
+    ref = F.interpolate(x, size=list(out), mode="bilinear", align_corners=False)
+    got = ops.resize_bilinear(x.to(DEV), *out).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-6
+    ref64 = F.interpolate(x.double(), size=list(out), mode="bilinear", align_corners=False)
+    assert (got.double() - ref64).abs().max().item() < 2e-5          # fp32 source coordinates on both sides
+
+
 def test_flow_decode_vs_reference(built_lib):
     g = torch.Generator().manual_seed(0)
     x = torch.randn((4800, 64), generator=g) * 3
@@ -137,9 +149,10 @@ def _strict(d, ref, conf, thr, what, max_exempt):
     return ex
 
 
-@pytest.mark.parametrize("case", [0, 1])
+@pytest.mark.parametrize("case", [0, 1, 2])
 def test_aspanformer_e2e_golden(built_lib, golden, case):
-    """Fixture written by the real ASpanFormer module: equal frames, and two frame sizes (cross-size span attention)."""
+    """Fixture written by the real ASpanFormer module: equal frames, two frame sizes (cross-size span attention), and a
+    100x140 frame that the online resize turns into 96x128 first."""
     gz = golden("aspanformer_e2e")
     c = _case(gz)
     tag, hw0, hw1 = aspanformer_cases()[case]
@@ -213,4 +226,5 @@ def test_aspanformer_plugin_surface(built_lib, tmp_path):
     _strict(d, o, o["conf_matrix"], 0.2, "aspanformer plugin", 1)
     assert len(mc) > 10 and np.abs(mc - o["mconf"].numpy()).max() <= parity.TOL_CONF
     with pytest.raises(NotImplementedError):
-        matcher({"image0": torch.zeros(1, 1, 100, 128, device=DEV), "image1": torch.zeros(1, 1, 96, 128, device=DEV)})
+        matcher({"image0": torch.zeros(1, 1, 96, 128, device=DEV), "image1": torch.zeros(1, 1, 96, 128, device=DEV),
+                 "mask0": torch.ones(1, 12, 16, device=DEV), "mask1": torch.ones(1, 12, 16, device=DEV)})

@@ -223,9 +223,9 @@ def test_aspanformer_host_logic_with_cpu_standins():
     sd = planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0)
     m = HipASpanFormer(cfg).eval()
     m.load_state_dict({"matcher." + k: v for k, v in sd.items()}, strict=True)        # prefix stripped, sample_offset dropped
-    for hw1 in ((96, 128), (64, 160)):                                                # same and different frame sizes
-        data = synth.coarse_pair_batch(1, 96, 128, seed=1000)
-        if hw1 != (96, 128):
+    for hw0, hw1 in (((96, 128), (96, 128)), ((96, 128), (64, 160)), ((100, 140), (96, 128))):   # same / different / resized frames
+        data = synth.coarse_pair_batch(1, hw0[0], hw0[1], seed=1000)
+        if hw1 != hw0:
             data["image1"] = synth.coarse_pair_batch(1, hw1[0], hw1[1], seed=1001)["image0"]
         data["scale0"] = torch.tensor([[1.5, 2.0]])
         o = ra.aspanformer_forward(sd, cfg, dict(data))
@@ -233,7 +233,7 @@ def test_aspanformer_host_logic_with_cpu_standins():
             d = m(dict(data))
         assert o["b_ids"].numel() > 10
         for k in ("b_ids", "i_ids", "j_ids"):
-            assert torch.equal(d[k], o[k]), (hw1, k)
+            assert torch.equal(d[k], o[k]), (hw0, hw1, k)
         assert torch.equal(d["mkpts0_f"], o["mkpts0_f"]) and torch.equal(d["mkpts1_f"], o["mkpts1_f"])
         assert (d["mconf"] - o["mconf"]).abs().max().item() < 1e-4
         fl_d = d["predict_flow"] if isinstance(d["predict_flow"], list) else list(d["predict_flow"])
@@ -243,5 +243,8 @@ def test_aspanformer_host_logic_with_cpu_standins():
         for k in ("offset_bids_left", "offset_lids_left", "offset_bids_right", "offset_lids_right"):
             assert torch.equal(d[k], o[k]), k
         assert (d["offset_kpts1_f_left"] - o["offset_kpts1_f_left"]).abs().max().item() < 1e-2
+        assert tuple(d["image0"].shape[2:]) == (hw0[0] // 32 * 32, hw0[1] // 32 * 32)     # resize_input replaces the frames
+        assert torch.equal(d["online_resize_scale0"], torch.tensor([[hw0[1] / (hw0[1] // 32 * 32), hw0[0] / (hw0[0] // 32 * 32)]]))
     with pytest.raises(NotImplementedError):
-        m({"image0": torch.zeros(1, 1, 100, 128), "image1": torch.zeros(1, 1, 96, 128)})
+        m({"image0": torch.zeros(1, 1, 96, 128), "image1": torch.zeros(1, 1, 96, 128), "mask0": torch.ones(1, 12, 16),
+           "mask1": torch.ones(1, 12, 16)})

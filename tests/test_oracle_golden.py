@@ -235,9 +235,10 @@ ASPAN_KEYS = ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f", "conf_
               "offset_kpts0_f_right", "offset_kpts1_f_right")
 
 
-@pytest.mark.parametrize("case", [0, 1])
+@pytest.mark.parametrize("case", [0, 1, 2])
 def test_aspanformer_e2e(golden, case):
-    """oracle/restate_aspanformer.py == the real ASpanFormer module (fixture), bit for bit: equal frames and two sizes."""
+    """oracle/restate_aspanformer.py == the real ASpanFormer module (fixture), bit for bit: equal frames, two sizes, and a frame
+    that goes through the online resize (whose torchvision call is a stand-in on both sides, see ref_import)."""
     from detectorfreesfm_amd.aspanformer import aspanformer_coarse_only_config
     from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
     from oracle import restate_aspanformer as ra
