@@ -119,7 +119,7 @@ def test_resize_bilinear_vs_torch(built_lib, hw, out):
     got = ops.resize_bilinear(x.to(DEV), *out).cpu()
     assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-6
     ref64 = F.interpolate(x.double(), size=list(out), mode="bilinear", align_corners=False)
-    assert (got.double() - ref64).abs().max().item() < 2e-5          # fp32 source coordinates on both sides
+    assert (got.double() - ref64).abs().max().item() < 3e-4          # fp32 source coordinates (ulp 1.2e-4 at x = 1200) on both fp32 sides
 
 
 def test_flow_decode_vs_reference(built_lib):
