@@ -14,7 +14,8 @@ on 127.0.0.1; under the driver's own torchrun it just reads RANK / LOCAL_RANK / 
 
 Other workloads (explicit, not the headline): ``--workload scene300`` = configs[3] (300 images, 44 850 exhaustive
 pairs sharded over the ranks, backbone once per image, all-gather of the tables, keypoint merge on rank 0);
-``--workload hires832`` = configs[4] (832x832 pairs + one 16 000-track refinement chunk).
+``--workload hires832`` = configs[4] (832x832 pairs + one 16 000-track refinement chunk);
+``--workload matchformer`` / ``aspanformer`` = the alternative coarse matchers of SURVEY 8(f) at the configs[1] frame size.
 
 Extra objects: ``roofline`` (dominant hand-written kernel, measured live with events on the launch stream),
 ``rooflines`` (all hand-written kernels), ``step_roofline`` (whole-step algorithmic flops), ``breakdown`` (stage
@@ -457,6 +458,49 @@ def run_hires(args, dev, rank, world, distributed, out_fd):
                           "workload": "configs[4]: one 16 000-track x 5-view chunk, 832x832 RGB frames"}})
 
 
+def run_alt_matcher(args, dev, rank, world, distributed, out_fd):
+    """The reference's two alternative coarse matchers at the configs[1] frame size.  MatchFormer-LA
+    takes a batch of pairs per step; ASpanFormer takes one pair per call like the reference (aspanformer.py:43), a step is
+    ``--batch`` calls."""
+    if args.workload == "matchformer":
+        from detectorfreesfm_amd.matchformer import HipMatchformer, matchformer_coarse_only_config
+        from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
+        cfg = matchformer_coarse_only_config(0.4)
+        m = HipMatchformer(cfg)
+        m.load_state_dict(planted_matchformer_state_dict(matchformer_param_spec(), 0), strict=True)
+        per_call, name = args.batch, "MatchFormer-LA large, coarse_only, thr 0.4"
+    else:
+        from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+        from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+        cfg = aspanformer_coarse_only_config(0.4)
+        m = HipASpanFormer(cfg)
+        m.load_state_dict(planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0), strict=True)
+        per_call, name = 1, "ASpanFormer, coarse_only, online_resize, thr 0.4, one pair per call"
+    m = m.eval().to(dev)
+    calls = args.batch // per_call
+    batches = [[synth.to_device(synth.coarse_pair_batch(per_call, 480, 640, seed=1000 + 1000 * rank + 100 * k + c), dev)
+                for c in range(calls)] for k in range(N_RESIDENT)]
+    n_matches = [0]
+
+    def step(i):
+        n = 0
+        for b in batches[i % N_RESIDENT]:
+            d = dict(b)
+            m(d)
+            n += int(d["mconf"].shape[0])
+        n_matches[0] = n
+    dt = timed_steps(step, args.steps, args.warmup, distributed)
+    if rank == 0:
+        _emit(out_fd, {
+            "metric": "coarse_image_pairs_per_sec", "value": args.batch * world * args.steps / dt, "unit": "image-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"{name}; 640x480, {args.batch} pairs per GPU per step, {N_RESIDENT} distinct resident batches "
+                                   "rotating, seeded weights on a planted backbone", "parallelism": f"{world} rank(s), weak"},
+            "matches_last_step": n_matches[0]})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -464,7 +508,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--tracks", type=int, default=2000, help="tracks per refinement bag (configs[2]: 2000)")
-    ap.add_argument("--workload", choices=("pairs", "scene300", "hires832"), default="pairs")
+    ap.add_argument("--workload", choices=("pairs", "scene300", "hires832", "matchformer", "aspanformer"), default="pairs")
     ap.add_argument("--scene-images", type=int, default=300)
     ap.add_argument("--scene-pairs", type=int, default=0, help="truncate the exhaustive pair list (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -501,6 +545,8 @@ def main():
         run_pairs(args, dev, rank, world, distributed, out_fd)
     elif args.workload == "scene300":
         run_scene(args, dev, rank, world, distributed, out_fd)
+    elif args.workload in ("matchformer", "aspanformer"):
+        run_alt_matcher(args, dev, rank, world, distributed, out_fd)
     else:
         run_hires(args, dev, rank, world, distributed, out_fd)
     if distributed:

@@ -46,17 +46,20 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- softmax attention, D = 32
-// One lane = one query row of one head; keys / values of the head go through LDS in blocks of 64 rows and are read
-// as broadcasts; online softmax (running maximum, rescaled sums).
+// 256 threads = 32 queries x 8 key splits of one head.  Keys / values of the head pass through LDS in 64-row tiles (row
+// pitch 33 floats: the 8 splits of a query read 8 different rows conflict-free, the queries of a split share a broadcast);
+// every lane keeps an online-softmax partial (running maximum, rescaled sums) over its keys j = split, split + 8, ...; the 8
+// partials of a query are merged with three xor-butterfly steps and each lane stores 4 of the 32 output channels.
 template <int D>
-__global__ __launch_bounds__(64) void full_attention_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq,
-                                                            const float* __restrict__ k, int64_t ldk, int64_t sk,
-                                                            const float* __restrict__ v, int64_t ldv, int64_t sv,
-                                                            float* __restrict__ out, int64_t ldo, int64_t so, int L, int S,
-                                                            int kv_swap, float scale) {
-    __shared__ float ks[64][D], vs[64][D];
-    const int lane = threadIdx.x, h = blockIdx.y, n = blockIdx.z, nk = n ^ kv_swap;
-    const int l = blockIdx.x * 64 + lane;
+__global__ __launch_bounds__(256) void full_attention_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq,
+                                                             const float* __restrict__ k, int64_t ldk, int64_t sk,
+                                                             const float* __restrict__ v, int64_t ldv, int64_t sv,
+                                                             float* __restrict__ out, int64_t ldo, int64_t so, int L, int S,
+                                                             int kv_swap, float scale) {
+    constexpr int LD = D + 1;
+    __shared__ float ks[64 * LD], vs[64 * LD];
+    const int tid = threadIdx.x, split = tid & 7, h = blockIdx.y, n = blockIdx.z, nk = n ^ kv_swap;
+    const int l = blockIdx.x * 32 + (tid >> 3);
     float qr[D], acc[D];
     const float* qp = q + n * sq + (int64_t)min(l, L - 1) * ldq + h * D;
 #pragma unroll
@@ -68,40 +71,52 @@ __global__ __launch_bounds__(64) void full_attention_kernel(const float* __restr
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     float m = -INFINITY, lsum = 0.f;
+    const int lrow = tid >> 2, lq = (tid & 3) * (D / 4);           // tile loader: 4 threads per key row, D/4 floats each
     for (int s0 = 0; s0 < S; s0 += 64) {
-        const int row = min(s0 + lane, S - 1);
-        const float* kp = k + nk * sk + (int64_t)row * ldk + h * D;
-        const float* vp = v + nk * sv + (int64_t)row * ldv + h * D;
+        const int row = min(s0 + lrow, S - 1);
+        const float* kp = k + nk * sk + (int64_t)row * ldk + h * D + lq;
+        const float* vp = v + nk * sv + (int64_t)row * ldv + h * D + lq;
 #pragma unroll
-        for (int d = 0; d < D; d += 4) {
-            *reinterpret_cast<f32x4*>(&ks[lane][d]) = *reinterpret_cast<const f32x4*>(kp + d);
-            *reinterpret_cast<f32x4*>(&vs[lane][d]) = *reinterpret_cast<const f32x4*>(vp + d);
+        for (int d = 0; d < D / 4; d += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(kp + d), b = *reinterpret_cast<const f32x4*>(vp + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ks[lrow * LD + lq + d + e] = a[e];
+                vs[lrow * LD + lq + d + e] = b[e];
+            }
         }
         __syncthreads();
         const int cnt = min(64, S - s0);
-        for (int j = 0; j < cnt; ++j) {
+        for (int j = split; j < cnt; j += 8) {
             float dot = 0.f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) dot = fmaf(qr[d], ks[j][d], dot);
+            for (int d = 0; d < D; ++d) dot = fmaf(qr[d], ks[j * LD + d], dot);
             const float sc = dot * scale;
             const float mn = fmaxf(m, sc);
             const float corr = expf(m - mn), p = expf(sc - mn);
             lsum = lsum * corr + p;
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] = fmaf(p, vs[j][d], acc[d] * corr);
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(p, vs[j * LD + d], acc[d] * corr);
             m = mn;
         }
         __syncthreads();
     }
-    if (l >= L) return;
-    float* op = out + n * so + (int64_t)l * ldo + h * D;
 #pragma unroll
-    for (int d = 0; d < D; d += 4) {
-        f32x4 t;
+    for (int off = 1; off < 8; off <<= 1) {                          // merge the 8 key splits of a query
+        const float mo = __shfl_xor(m, off), lo = __shfl_xor(lsum, off);
+        const float mn = fmaxf(m, mo);
+        const float ca = m == -INFINITY ? 0.f : expf(m - mn), cb = mo == -INFINITY ? 0.f : expf(mo - mn);
+        lsum = lsum * ca + lo * cb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = acc[d + e] / lsum;
-        *reinterpret_cast<f32x4*>(op + d) = t;
+        for (int d = 0; d < D; ++d) acc[d] = acc[d] * ca + __shfl_xor(acc[d], off) * cb;
+        m = mn;
     }
+    if (l >= L) return;
+    f32x4 t;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if ((d >> 2) == split) t[d & 3] = acc[d] / lsum;             // D = 32: split s owns channels 4s .. 4s + 3
+    *reinterpret_cast<f32x4*>(out + n * so + (int64_t)l * ldo + h * D + split * 4) = t;
 }
 
 // ---------------------------------------------------------------- span (group) attention, one level
@@ -131,18 +146,26 @@ __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
     __shared__ float grp[4];                     // offset x, y, span x, y of the group
     const int tid = threadIdx.x, g = blockIdx.x, gw = a.w / 2;
     const int gy = g / gw, gx = g % gw;
+    // avg_pool2d(offset, win) / s and avg_pool2d(span_scale, win) over the group's full-resolution cells: the per-cell terms
+    // (two exps each) in parallel, the window sums in the reference's (ky, kx) order by one thread
+    float* cell = att;                           // [win*win][4] scratch (att is not live yet)
+    if (tid < a.win * a.win) {
+        const float* f = a.flow + ((int64_t)(gy * a.win + tid / a.win) * a.W0 + gx * a.win + tid % a.win) * 4;
+        const float vx = expf(0.5f * f[2]) * a.radius_scale, vy = expf(0.5f * f[3]) * a.radius_scale;
+        cell[tid * 4 + 0] = f[0];
+        cell[tid * 4 + 1] = f[1];
+        cell[tid * 4 + 2] = fmaxf(vx * 2.f / a.nsample1, 1.f);
+        cell[tid * 4 + 3] = fmaxf(vy * 2.f / a.nsample1, 1.f);
+    }
+    __syncthreads();
     if (tid == 0) {
-        // avg_pool2d(offset, win) / s and avg_pool2d(span_scale, win) over the group's full-resolution cells
         float ox = 0.f, oy = 0.f, sx = 0.f, sy = 0.f;
-        for (int ky = 0; ky < a.win; ++ky)
-            for (int kx = 0; kx < a.win; ++kx) {
-                const float* f = a.flow + ((int64_t)(gy * a.win + ky) * a.W0 + gx * a.win + kx) * 4;
-                ox += f[0];
-                oy += f[1];
-                const float vx = expf(0.5f * f[2]) * a.radius_scale, vy = expf(0.5f * f[3]) * a.radius_scale;
-                sx += fmaxf(vx * 2.f / a.nsample1, 1.f);
-                sy += fmaxf(vy * 2.f / a.nsample1, 1.f);
-            }
+        for (int c = 0; c < a.win * a.win; ++c) {
+            ox += cell[c * 4 + 0];
+            oy += cell[c * 4 + 1];
+            sx += cell[c * 4 + 2];
+            sy += cell[c * 4 + 3];
+        }
         const float d = (float)(a.win * a.win);
         grp[0] = ox / d * a.inv_s;
         grp[1] = oy / d * a.inv_s;
@@ -177,6 +200,7 @@ __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
     }
     __syncthreads();
     auto gather = [&](const float* src, int64_t ld) {
+#pragma unroll 1      // measured: deeper unrolling (more gathers in flight per lane) is 7 % slower end to end
         for (int m = 0; m < SP_M; ++m) {
             float r = src[(int64_t)si[m * 4 + 0] * ld + tid] * sw[m * 4 + 0];
             r += src[(int64_t)si[m * 4 + 1] * ld + tid] * sw[m * 4 + 1];
@@ -197,17 +221,23 @@ __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
         }
     }
     __syncthreads();
-    if (tid < 32) {   // softmax over the 64 samples of (n, head) = tid
-        float* p = att + tid * SP_M;
-        float mx = p[0];
-        for (int m = 1; m < SP_M; ++m) mx = fmaxf(mx, p[m]);
-        float s = 0.f;
-        for (int m = 0; m < SP_M; ++m) {
-            const float e = expf(p[m] - mx);
-            p[m] = e;
-            s += e;
+    {   // softmax over the 64 samples of (n, head) = tid >> 3: 8 lanes x 8 samples, xor butterflies inside the 8-lane group
+        float* p = att + (tid >> 3) * SP_M + (tid & 7) * 8;
+        float e[8], mx = p[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mx = fmaxf(mx, p[i]);
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            e[i] = expf(p[i] - mx);
+            sum += e[i];
         }
-        for (int m = 0; m < SP_M; ++m) p[m] = p[m] / s;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) sum += __shfl_xor(sum, off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = e[i] / sum;
     }
     gather(a.v, a.ldv);      // rows <- sampled values (the keys are no longer needed; att is a different region)
     __syncthreads();
@@ -372,7 +402,7 @@ extern "C" int dfsfm_full_attention_f32(const float* q, int64_t ldq, int64_t sq,
     if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (sq & 3) || (sk & 3) || (sv & 3) || (so & 3) || !al16(q) || !al16(k) ||
         !al16(v) || !al16(out))
         return DFSFM_E_UNSUPPORTED;
-    hipLaunchKernelGGL(full_attention_kernel<32>, dim3((unsigned)((L + 63) / 64), (unsigned)H, (unsigned)N), dim3(64), 0,
+    hipLaunchKernelGGL(full_attention_kernel<32>, dim3((unsigned)((L + 31) / 32), (unsigned)H, (unsigned)N), dim3(256), 0,
                        static_cast<hipStream_t>(stream_), q, ldq, sq, k, ldk, sk, v, ldv, sv, out, ldo, so, L, S, kv_swap, scale);
     return dfsfm::check_launch("dfsfm_full_attention_f32");
 }
