@@ -168,6 +168,9 @@ def merge_match_tables(matches: dict, names: list, pair_name_split: str, device=
     updated_matches {pair: [N,2] int}) exactly like the reference's three dictionaries."""
     index = {n: i for i, n in enumerate(names)}
     keys = list(matches.keys())
+    for k in keys:                                  # match_worker's tables are float32 (.cpu().numpy() of fp32 tensors, :139-141);
+        if np.asarray(matches[k]).dtype == np.float64:   # float64 rows would be averaged differently by the reference
+            raise TypeError(f"merge_match_tables: table {k!r} is float64; the device merge reproduces the reference on float32 tables")
     tabs = [np.asarray(matches[k], dtype=np.float32).reshape(-1, 5) for k in keys]
     lens = [t.shape[0] for t in tabs]
     if sum(lens) == 0:

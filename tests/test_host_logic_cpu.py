@@ -248,3 +248,9 @@ def test_aspanformer_host_logic_with_cpu_standins():
     with pytest.raises(NotImplementedError):
         m({"image0": torch.zeros(1, 1, 96, 128), "image1": torch.zeros(1, 1, 96, 128), "mask0": torch.ones(1, 12, 16),
            "mask1": torch.ones(1, 12, 16)})
+
+
+def test_merge_match_tables_rejects_float64():
+    """The device merge reproduces the reference's float32 arithmetic; float64 tables must not be cast silently."""
+    with pytest.raises(TypeError):
+        plugin.merge_match_tables({"a b": np.zeros((3, 5), dtype=np.float64)}, ["a", "b"], " ", device="cpu")
