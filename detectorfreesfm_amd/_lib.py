@@ -54,6 +54,8 @@ SIGNATURES = [
     ("dfsfm_split_rows_f32", c_int,
      [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
       c_void_p]),
+    ("dfsfm_split_rows_blocked_f32", c_int,
+     [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     ("dfsfm_dwconv3x3_nhwc_f32", c_int,
      [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("dfsfm_bilinear_up_nhwc_f32", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -906,48 +906,68 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
     *reinterpret_cast<f32x4*>(y + ((n * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
 }
 
-// max pooling on split activations: reconstruct hi + lo/2048, take the max, split again
+// max pooling on split activations: reconstruct hi + lo/2048, take the max, split again.  One thread = 8 channels of one
+// output COLUMN of a strip of MP_R output rows: the 2*MP_R + 1 input rows are streamed once (row maxima over the three
+// kx taps, then the running 3-row window), 6 loads per input row instead of 18 per output; workgroups are dealt to the
+// XCDs in contiguous bands so the columns a strip shares with its neighbours meet in one L2.  max is exact and order-free:
+// the result is bit-identical to the one-thread-per-output form.
+constexpr int MP_R = 9;
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_sf_kernel(const _Float16* __restrict__ xh,
                                                                    const _Float16* __restrict__ xl,
                                                                    _Float16* __restrict__ yh, _Float16* __restrict__ yl,
-                                                                   int H, int W, int C, int Ho, int Wo, int64_t total8) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total8) return;
+                                                                   int H, int W, int C, int Ho, int Wo, int nstrips,
+                                                                   int64_t total, int64_t nblk) {
+    const int64_t per_xcd = (nblk + 7) >> 3;
+    const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t e = blk * 256 + threadIdx.x;
+    if (blk >= nblk || e >= total) return;
     const int c8 = (int)(e % (C / 8));
     int64_t t = e / (C / 8);
     const int ox = (int)(t % Wo);
     t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int64_t n = t / Ho;
-    float m[8];
+    const int oy0 = (int)(t % nstrips) * MP_R;
+    const int64_t n = t / nstrips;
+    const int noy = min(MP_R, Ho - oy0);
+    float prev[8], cur[8];                       // row maxima of input rows iy - 2 and iy - 1
 #pragma unroll
-    for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+    for (int q = 0; q < 8; ++q) prev[q] = cur[q] = -INFINITY;
+    const int iy_begin = oy0 * 2 - 1, iy_end = (oy0 + noy - 1) * 2 + 1;      // inclusive
+    for (int iy = iy_begin; iy <= iy_end; ++iy) {
+        float rm[8];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 - 1 + ky;
-        if (iy < 0 || iy >= H) continue;
+        for (int q = 0; q < 8; ++q) rm[q] = -INFINITY;
+        if (iy >= 0 && iy < H) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * 2 - 1 + kx;
-            if (ix < 0 || ix >= W) continue;
-            const int64_t o = ((n * H + iy) * W + ix) * C + c8 * 8;
-            const half8 h = *reinterpret_cast<const half8*>(xh + o);
-            const half8 l = *reinterpret_cast<const half8*>(xl + o);
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const int64_t o = ((n * H + iy) * W + ix) * C + c8 * 8;
+                const half8 h = *reinterpret_cast<const half8*>(xh + o);
+                const half8 l = *reinterpret_cast<const half8*>(xl + o);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)h[q] + (float)l[q] * (1.f / 2048.f));
+                for (int q = 0; q < 8; ++q) rm[q] = fmaxf(rm[q], (float)h[q] + (float)l[q] * (1.f / 2048.f));
+            }
+        }
+        const int k = iy - iy_begin;             // rows k = 2, 4, ... close an output row: window (iy - 2, iy - 1, iy)
+        if (k >= 2 && (k & 1) == 0) {
+            half8 oh, ol;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                _Float16 a, b;
+                split1(fmaxf(fmaxf(prev[q], cur[q]), rm[q]), a, b);
+                oh[q] = a;
+                ol[q] = b;
+            }
+            const int64_t o = ((n * Ho + oy0 + (k >> 1) - 1) * Wo + ox) * C + c8 * 8;
+            *reinterpret_cast<half8*>(yh + o) = oh;
+            *reinterpret_cast<half8*>(yl + o) = ol;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            prev[q] = cur[q];
+            cur[q] = rm[q];
         }
     }
-    half8 oh, ol;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        _Float16 a, b;
-        split1(m[q], a, b);
-        oh[q] = a;
-        ol[q] = b;
-    }
-    const int64_t o = ((n * Ho + oy) * Wo + ox) * C + c8 * 8;
-    *reinterpret_cast<half8*>(yh + o) = oh;
-    *reinterpret_cast<half8*>(yl + o) = ol;
 }
 
 template <int BN_>
@@ -1100,10 +1120,12 @@ extern "C" int dfsfm_maxpool3x3s2_nhwc_f32(const float* x, const void* x_hi, con
     if (x_hi) {
         if (!x_lo || !out_hi || !out_lo) return DFSFM_E_BADARG;
         if (C % 8 != 0) return DFSFM_E_UNSUPPORTED;
-        const int64_t total8 = (int64_t)Nimg * Ho * Wo * (C / 8);
-        hipLaunchKernelGGL(maxpool3x3s2_nhwc_sf_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+        const int nstrips = (Ho + MP_R - 1) / MP_R;
+        const int64_t total = (int64_t)Nimg * nstrips * Wo * (C / 8), nblk = (total + 255) / 256;
+        if (((nblk + 7) >> 3) * 8 > 0x7fffffff) return DFSFM_E_UNSUPPORTED;
+        hipLaunchKernelGGL(maxpool3x3s2_nhwc_sf_kernel, dim3((unsigned)(((nblk + 7) >> 3) * 8)), dim3(256), 0, stream,
                            static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
-                           static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), H, W, C, Ho, Wo, total8);
+                           static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), H, W, C, Ho, Wo, nstrips, total, nblk);
         return dfsfm::check_launch("dfsfm_maxpool3x3s2_nhwc_f32(split)");
     }
     if (!x || !out) return DFSFM_E_BADARG;

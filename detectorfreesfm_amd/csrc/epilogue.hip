@@ -158,6 +158,21 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     dfsfm::store4(out, outh, outl, r * ldo + c, r * ldos + c, v);
 }
 
+// The same from a two-level source: row r lives at x + (r / blk_rows) * blk_stride + (r % blk_rows) * ldx (e.g. the tokens of
+// views 1..Vq of every track inside a [T, V, WW, C] feature tensor) -- no intermediate contiguous copy.
+__global__ __launch_bounds__(256) void split_rows_blocked_kernel(const float* __restrict__ x, int64_t blk_rows,
+                                                                 int64_t blk_stride, int64_t ldx,
+                                                                 _Float16* __restrict__ outh, _Float16* __restrict__ outl,
+                                                                 int64_t ldos, int64_t rows, int C4) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * C4) return;
+    const int64_t r = e / C4;
+    const int c = (int)(e - r * C4) * 4;
+    const int64_t b = r / blk_rows;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + b * blk_stride + (r - b * blk_rows) * ldx + c);
+    dfsfm::store4(nullptr, outh, outl, 0, r * ldos + c, v);
+}
+
 // dst[slot[m], p, c] = a[m, c, p] (+ b[m, c, p]);  one workgroup per patch, 32-channel slabs
 // transposed through LDS so both the reads (p fastest) and the writes (c fastest) are coalesced.
 __global__ __launch_bounds__(256) void add_scatter_tokens_kernel(const float* __restrict__ a,
@@ -325,4 +340,18 @@ extern "C" int dfsfm_split_rows_f32(const float* x, int64_t ldx, const float* ad
                        static_cast<hipStream_t>(stream_), x, ldx, add, add_rows, out, ldo,
                        static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), ldo_s, rows, C / 4);
     return dfsfm::check_launch("dfsfm_split_rows_f32");
+}
+
+extern "C" int dfsfm_split_rows_blocked_f32(const float* x, int64_t blk_rows, int64_t blk_stride, int64_t ldx, void* out_hi,
+                                            void* out_lo, int64_t ldo_s, int64_t rows, int C, void* stream_) {
+    if (rows == 0) return DFSFM_OK;
+    if (!x || !out_hi || !out_lo || rows < 0 || C <= 0 || blk_rows <= 0 || ldx < C || ldo_s < C) return DFSFM_E_BADARG;
+    if ((C & 3) || (ldx & 3) || (blk_stride & 3) || (ldo_s & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+        (reinterpret_cast<uintptr_t>(out_hi) & 7) || (reinterpret_cast<uintptr_t>(out_lo) & 7))
+        return DFSFM_E_UNSUPPORTED;
+    const int64_t total = rows * (C / 4);
+    hipLaunchKernelGGL(split_rows_blocked_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), x, blk_rows, blk_stride, ldx, static_cast<_Float16*>(out_hi),
+                       static_cast<_Float16*>(out_lo), ldo_s, rows, C / 4);
+    return dfsfm::check_launch("dfsfm_split_rows_blocked_f32");
 }

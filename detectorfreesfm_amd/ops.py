@@ -351,8 +351,20 @@ def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None,
 def split_rows(x, add=None, out=None, out_split=None):
     """out / out_split = x (+ add broadcast over row blocks); x [..., C] fp32 rows, add [R, C] contiguous."""
     _require_cuda(x)
-    rows, ldx = _rows_ld(x)
     C = x.shape[-1]
+    if (x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1 and x.shape[0] > 1 and x.stride(0) != x.stride(1) * x.shape[1]
+            and add is None and out is None and out_split is not None):
+        # [B, R, C] blocks with their own outer stride (e.g. the tokens of some views of every track): no contiguous copy
+        rows_s, ldos = _rows_ld(out_split.hi, torch.float16)
+        if rows_s != x.shape[0] * x.shape[1] or out_split.hi.shape[-1] != C:
+            raise _lib.DfsfmError("split_rows: split out shape mismatch")
+        rc = _lib.lib().dfsfm_split_rows_blocked_f32(_ptr(x), x.shape[1], x.stride(0), x.stride(1), _ptr(out_split.hi),
+                                                     _ptr(out_split.lo), ldos, rows_s, C, _stream())
+        _lib.check(rc, "dfsfm_split_rows_blocked_f32")
+        if _debug_range:
+            check_split_range(out_split, "split_rows")
+        return
+    rows, ldx = _rows_ld(x)
     ldo = ldos = 0
     if out is not None:
         _, ldo = _rows_ld(out)

@@ -299,8 +299,8 @@ class HipMultiviewMatcher(ParamModule):
                 # split planes [., ., 2C] = [x | norm1(message)], ping-pong; fp32 only for the last layer's output
                 rs = [ops.SplitAct.empty_rows((nt, WW), 2 * C, dev) for _ in range(2)]
                 qs = [ops.SplitAct.empty_rows((nt, Vq * WW), 2 * C, dev) for _ in range(2)]
-                ops.split_rows(feats[sl, 0].contiguous(), None, out_split=rs[0].cols(0, C))
-                ops.split_rows(feats[sl, 1:cv].contiguous().view(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
+                ops.split_rows(feats[sl, 0], None, out_split=rs[0].cols(0, C))            # strided [nt, WW, C] blocks: no copy
+                ops.split_rows(feats[sl, 1:cv].reshape(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
                 ref = qry = None
                 for li, (w, name) in enumerate(zip(P["layers"], names)):   # matcher_module/transformer.py:158-172
                     last = li == len(names) - 1

@@ -186,6 +186,12 @@ int dfsfm_split_rows_f32(const float* x, int64_t ldx, const float* add, int64_t 
                          int64_t ldo, void* out_hi, void* out_lo, int64_t ldo_s, int64_t rows, int C,
                          void* stream);
 
+/* Split planes of rows that sit in uniformly strided BLOCKS of a larger tensor: row r is read at
+ * x + (r / blk_rows) * blk_stride + (r % blk_rows) * ldx.  Used to hand the per-track token groups of the [T,V,WW,C] feature
+ * tensor (src/MultiviewMatcher/MultiviewMatcher.py:240-270) to the first encoder layer without a contiguous copy. */
+int dfsfm_split_rows_blocked_f32(const float* x, int64_t blk_rows, int64_t blk_stride, int64_t ldx, void* out_hi, void* out_lo,
+                                 int64_t ldo_s, int64_t rows, int C, void* stream);
+
 /* Depth-wise 3x3 convolution (groups = C, stride 1, pad 1, bias) on an NHWC fp32 map with its consumer fused:
  *   mode 0: dw(x) + b      mode 1: x * sigmoid(dw(x) + b)      mode 2: GELU(dw(x) + b)   (erf form)
  * Replaces Positional (pa_conv + sigmoid gate) and the DWConv + GELU of Mlp of MatchFormer-LA
