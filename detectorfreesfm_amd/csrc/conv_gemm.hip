@@ -400,6 +400,12 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
             }
         }
     }
+    if (g.relu == 2) {     // nn.LeakyReLU() (one MatchFormer FPN conv): its own pass, so that the ReLU / linear epilogues of
+#pragma unroll         // every other layer keep their instruction stream (a per-element mode select cost 2 % of both steps)
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[it][q] = v[it][q] > 0.f ? v[it][q] : 0.01f * v[it][q];
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int64_t m = m0 + it * RPI + rr;
@@ -408,7 +414,6 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
         for (int q = 0; q < 8; ++q) {
             float x = v[it][q];
             if (g.relu == 1) x = fmaxf(x, 0.f);
-            else if (g.relu == 2) x = x > 0.f ? x : 0.01f * x;      // nn.LeakyReLU() (MatchFormer FPN)
             v[it][q] = (full || n + q < g.Cout) ? x : 0.f;    // padded split channels are zeros
         }
 #ifdef DFSFM_ABL_NOSTORE

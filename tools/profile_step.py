@@ -1,6 +1,6 @@
 """One warm forward of each plugin (for rocprofv3 --kernel-trace --stats): python tools/profile_step.py [coarse|refine] [n]"""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, synth
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config
 from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, planted_loftr_state_dict, random_state_dict
