@@ -139,6 +139,13 @@ __device__ __forceinline__ void store_slab(char* st, int tid, int c4, const f32x
     *reinterpret_cast<uint4*>(st + 3 * TILE_B + tile_off(rb + 64, c)) = bl1;
 }
 
+// the LDS-staged epilogue shared with the split-input kernels (defined below)
+template <int BN_, int BM_, int NT>
+__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * BM_ / (32 * NT)],
+                                            f32x16 (&accx)[2][BN_ * BM_ / (32 * NT)], int64_t m0, int n0, int tid,
+                                            int wr, int wc, int col, int kgrp);
+constexpr int V1_EPI_BYTES = BM * (BN + 4) * 4;     // its fp32 staging tile: 66 KB (> the 64 KB operand ring)
+
 template <bool VEC_A>   // VEC_A: Cin % 4 == 0 -> 16-byte activation loads; else scalar gathers
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,34 +238,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g) {
 
 #undef GLOAD
 #undef LSTORE
-    // ---- epilogue: combine, bias (folded BN), residual, ReLU; 128-byte row segments per store ----
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wc * 64 + j * 32 + col;
-            const float b = (g.bias && n < g.Cout) ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, kgrp);
-                if (m >= g.M) continue;
-                float v = 0.f;
-                if (n < g.Cout) {
-                    v = accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f) + b;
-                    if (g.res) v += g.res[m * g.ldr + n];
-                    if (g.resh) v += (float)g.resh[m * g.ldr + n] + (float)g.resl[m * g.ldr + n] * (1.f / 2048.f);
-                    if (g.relu == 1) v = fmaxf(v, 0.f);
-                    else if (g.relu == 2) v = v > 0.f ? v : 0.01f * v;
-                    if (g.out) g.out[m * g.ldo + n] = v;
-                }
-                if (g.outh && n < g.Cout_s) {
-                    _Float16 h, l;
-                    split1(v, h, l);
-                    g.outh[m * g.ldo_s + n] = h;
-                    g.outl[m * g.ldo_s + n] = l;
-                }
-            }
-        }
+    // ---- epilogue: the tile goes through LDS (the operand ring is dead) so that every thread owns 8 consecutive
+    // channels of a row: bias (folded BN), residual, ReLU, 32-byte fp32 / 16+16-byte split stores.  The per-element form
+    // this replaces wrote the split planes of the 7x7 stem (629 MB per step) two bytes per lane.
+    sf_epilogue<BN, BM, 256>(g, smem, accm, accx, m0, n0, tid, wr, wc, col, kgrp);
 }
 
 // =================================================================================================
@@ -410,11 +393,13 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
     for (int it = 0; it < IT; ++it) {
         const int64_t m = m0 + it * RPI + rr;
         if (m >= g.M) continue;
+        if (g.relu == 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float x = v[it][q];
-            if (g.relu == 1) x = fmaxf(x, 0.f);
-            v[it][q] = (full || n + q < g.Cout) ? x : 0.f;    // padded split channels are zeros
+            for (int q = 0; q < 8; ++q) v[it][q] = fmaxf(v[it][q], 0.f);
+        }
+        if (!full) {          // only the chunk that straddles Cout (196 = 24 * 8 + 4): padded split channels are zeros
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[it][q] = n + q < g.Cout ? v[it][q] : 0.f;
         }
 #ifdef DFSFM_ABL_NOSTORE
         if (v[it][0] != 12345.678f) continue;
@@ -1107,12 +1092,15 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
                      !(reinterpret_cast<uintptr_t>(x) & 15);
     const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((Cout + BN - 1) / BN)), blk(256);
     static dfsfm::SmemAttr smem_attr[2];
+    // operand ring (+ the k-table of the scalar-gather path) during the main loop, the epilogue's staging tile afterwards
+    constexpr int smem_vec = SMEM_BYTES > V1_EPI_BYTES ? SMEM_BYTES : V1_EPI_BYTES;
+    constexpr int smem_lut = SMEM_BYTES + LUT_MAX * 4 > V1_EPI_BYTES ? SMEM_BYTES + LUT_MAX * 4 : V1_EPI_BYTES;
     if (vec) {
-        smem_attr[0].ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<true>), SMEM_BYTES);
-        hipLaunchKernelGGL(conv_gemm_kernel<true>, grid, blk, SMEM_BYTES, stream, g);
+        smem_attr[0].ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<true>), smem_vec);
+        hipLaunchKernelGGL(conv_gemm_kernel<true>, grid, blk, smem_vec, stream, g);
     } else {
-        smem_attr[1].ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<false>), SMEM_BYTES + LUT_MAX * 4);
-        hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, blk, SMEM_BYTES + LUT_MAX * 4, stream, g);
+        smem_attr[1].ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<false>), smem_lut);
+        hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, blk, smem_lut, stream, g);
     }
     return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32");
 }
