@@ -51,16 +51,18 @@ __device__ __forceinline__ float elu_plus_one(float x) {
     return (x > 0.f ? x : expm1f(x)) + 1.f;
 }
 
-// fp16x2 split of an fp32 value: v = hi + lo/2048 (22 significant bits); values below the fp16 normal
-// range go entirely to lo so the matrix cores never see an fp16 subnormal (csrc/conv_gemm.hip).
+// fp16x2 split of an fp32 value: v = hi + lo/2048 (22 significant bits).
 // The value saturates at the largest finite fp16 (65504) instead of overflowing to inf: an out-of-range activation
 // yields a finite, wrong value (hi = +-65504, lo = 0) that `hi == +-65504` flags (ops.check_split_range), never an
 // inf - inf = NaN that would spread through the matches.  One v_med3 on the input covers both planes: with
 // |xc| <= 65504 the remainder (xc - hi) * 2048 is at most 2^15, so lo needs no clamp of its own (a second one
 // measured 0.7 % of both steps together with this one).  In-range values split exactly as before.
+// Values below the fp16 normal range simply get a subnormal hi: gfx950's MFMA keeps fp16 subnormal operands exactly
+// (tools/probe_mfma_denorm.py: 5.96e-8 in, 5.96e-8 out), so the compare-and-select that used to route them to lo alone
+// was two VALU operations per output element for nothing (the GEMM epilogue is VALU-bound).
 __device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
     const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-    const _Float16 h = fabsf(x) >= 6.103515625e-05f ? (_Float16)xc : (_Float16)0.f;
+    const _Float16 h = (_Float16)xc;
     hi = h;
     lo = (_Float16)((xc - (float)h) * 2048.f);
 }
