@@ -78,7 +78,8 @@ class HipMultiviewMatcher(ParamModule):
             # equals the reference's pad-2 convolution of the full map only while that halo stays inside the patch
             raise NotImplementedError(f"window_size {W} too close to crop_size {crop}: need crop >= window + 6")
         self.config = config
-        self.max_backbone_patches = max_backbone_patches
+        # patches per S2DNet pass; DFSFM_BACKBONE_PATCHES overrides it for A/B runs of the chunk size
+        self.max_backbone_patches = int(os.environ.get("DFSFM_BACKBONE_PATCHES", max_backbone_patches))
         self.register_spec(multiview_param_spec(config))
         self.register_buffer("_mean", torch.tensor(IMAGENET_MEAN), persistent=False)
         self.register_buffer("_std", torch.tensor(IMAGENET_STD), persistent=False)
