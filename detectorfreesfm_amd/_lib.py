@@ -64,8 +64,8 @@ SIGNATURES = [
      [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
       c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     ("dfsfm_span_attention_f32", c_int,
-     [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
-      c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int64, c_void_p]),
+     [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p,
+      c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     ("dfsfm_layernorm2d_f32", c_int,
      [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
       c_int64, c_int, c_void_p]),

@@ -14,7 +14,8 @@ of wider token buffers ([feat | upsampled], [x | flow feature | norm1(message)],
 positional part of ``v_proj(cat[x, pos])`` folded into a per-size constant that enters as the GEMM's residual.  New kernels
 (csrc/aspan_ops.hip): average pooling, softmax attention at the 1/32 level, the span attention of the two finer levels
 (flow statistics -> 8x8 bilinear K / V samples -> per-group softmax), ``layernorm2d``, bilinear / nearest up-sampling into
-column slices, the flow decoder's sigmoid.  The dual-softmax matching stage is K3-K5 of the LoFTR path.
+column slices, the flow decoder's sigmoid.  The dual-softmax matching stage is K3-K5 of the LoFTR path.  Two frames of one
+size are processed as one stream of row-stacked images (half the launches); different sizes as two streams.
 
 Frames whose sides are not multiples of 32 are resized on the device like the reference's ``resize_input``
 (aspanformer.py:119-139): the pinned torchvision 0.9.1 (environment.yaml) implements ``transforms.Resize`` on a float tensor as
@@ -204,6 +205,7 @@ class HipASpanFormer(ParamModule):
         rs = [torch.tensor([orig[i][1] / imgs[i].shape[3], orig[i][0] / imgs[i].shape[2]])[None].to(dev) for i in (0, 1)]
         data["online_resize_scale0"], data["online_resize_scale1"] = rs
         data.update({"bs": 1, "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
+        tok = None
         if img0.shape[2:] == img1.shape[2:]:
             tok = backbone_tokens_hip(torch.cat([img0, img1], 0), P["bb"])
             toks = (tok[0:1], tok[1:2])
@@ -216,83 +218,98 @@ class HipASpanFormer(ParamModule):
         L = [h * w for h, w in hw]
         pc = [self._positional(P, hw[i][0], hw[i][1], pos_scale[i], dev) for i in (0, 1)]
 
+        # Every layer shares its weights between the two directions and updates both images from the pre-update pair
+        # (transformer.py:34-41, 96-107), so two frames of one size travel as ONE stream of 2 row-stacked images (half the
+        # launches; attention pairs image n with n ^ 1); frames of different sizes are two streams of one image each.
+        stacked = hw[0] == hw[1] and pos_scale[0] == pos_scale[1]
+        streams = [{"ids": (0, 1)}] if stacked else [{"ids": (0,)}, {"ids": (1,)}]
+        for st in streams:
+            i0 = st["ids"][0]
+            st.update(nb=len(st["ids"]), h=hw[i0][0], w=hw[i0][1], L=L[i0], pc=pc[i0])
+        other = (lambda st: st) if stacked else (lambda st: streams[1] if st is streams[0] else streams[0])
+
+        def rep(t, nb):                      # a per-size constant for every image of the stream
+            return t if nb == 1 else t.repeat(nb, 1)
+
         # ---- flow_initializer (transformer.py:151-187): two softmax-attention layers on the 1/32 maps
-        X32, F, SB = [], [], []
-        for i in (0, 1):
-            x32 = torch.empty((L[i], d), dtype=torch.float32, device=dev)                # feat + pe
-            f = ops.SplitAct.empty_rows((L[i],), 2 * d, dev)                             # [feat + pe | upsampled update]
-            ops.split_rows(toks[i].reshape(L[i], d), add=pc[i]["pe"], out=x32, out_split=f.cols(0, d))
-            sub = ops.avgpool(x32.view(1, hw[i][0], hw[i][1], d), DS).view(-1, d)
-            sb = ops.SplitAct.empty_rows((sub.shape[0],), 2 * d, dev)                    # [sub feat | norm1(message)]
-            ops.split_rows(sub, out_split=sb.cols(0, d))
-            X32.append(x32), F.append(f), SB.append(sb)
+        for st in streams:
+            nb, h, w, Ls = st["nb"], st["h"], st["w"], st["L"]
+            tk = tok if stacked else toks[st["ids"][0]]
+            st["x32"] = torch.empty((nb * Ls, d), dtype=torch.float32, device=dev)            # feat + pe
+            st["F"] = ops.SplitAct.empty_rows((nb * Ls,), 2 * d, dev)                         # [feat + pe | upsampled update]
+            ops.split_rows(tk.reshape(nb * Ls, d), add=st["pc"]["pe"], out=st["x32"], out_split=st["F"].cols(0, d))
+            sub = ops.avgpool(st["x32"].view(nb, h, w, d), DS).view(-1, d)
+            st["SB"] = ops.SplitAct.empty_rows((sub.shape[0],), 2 * d, dev)                   # [sub feat | norm1(message)]
+            ops.split_rows(sub, out_split=st["SB"].cols(0, d))
+            st["Ls"] = sub.shape[0] // nb
         for li, e in enumerate(P["ini"]):
-            qkv = [self._qkv(SB[i].cols(0, d), e, pc[i]["v_ini"][li]) for i in (0, 1)]
-            nxt = []
-            for a, b in ((0, 1), (1, 0)):
-                msg = ops.full_attention(qkv[a][None, :, :d], qkv[b][None, :, d:2 * d], qkv[b][None, :, 2 * d:], nhead,
-                                         1.0 / math.sqrt(d // nhead))[0]
-                ops.layernorm2d(ops.linear(msg, e["mh"]), *e["n1"], out_split=SB[a].cols(d, 2 * d), want_f32=False)
-                y = ops.linear(ops.linear(SB[a], e["mf0"], relu=True, out_split=True), e["mf2"])
-                sb = ops.SplitAct.empty_rows((SB[a].hi.shape[0],), 2 * d, dev)
-                ops.layernorm2d(y, *e["n2"], residual=SB[a].cols(0, d), out_split=sb.cols(0, d), want_f32=False)
-                nxt.append(sb)
-            SB = nxt
-        U = []
-        for i in (0, 1):
-            hs, ws = hw[i][0] // DS, hw[i][1] // DS
-            dec = ops.linear(SB[i].cols(0, d), P["dec"]).view(1, hs, ws, d + dfl)         # decoupler
-            u = ops.SplitAct.empty_rows((L[i],), 2 * d + dfl, dev)                       # [x | flow feature | norm1(message)]
-            ops.upsample(dec[..., :d], DS, True, out_split=F[i].cols(d, 2 * d), want_f32=False)
-            ops.upsample(dec[..., d:], DS, True, out_split=u.cols(d, d + dfl), want_f32=False)
-            ops.split_rows(ops.linear(F[i], P["upm"], residual=X32[i]), out_split=u.cols(0, d))   # feat + up_merge(cat[feat, upd])
-            U.append(u)
+            for st in streams:
+                st["qkv"] = self._qkv(st["SB"].cols(0, d), e, rep(st["pc"]["v_ini"][li], st["nb"])).view(st["nb"], st["Ls"], 3 * d)
+            for st in streams:
+                kv = other(st)["qkv"]
+                msg = ops.full_attention(st["qkv"][..., :d], kv[..., d:2 * d], kv[..., 2 * d:], nhead, 1.0 / math.sqrt(d // nhead),
+                                         kv_swap=stacked).view(-1, d)
+                ops.layernorm2d(ops.linear(msg, e["mh"]), *e["n1"], out_split=st["SB"].cols(d, 2 * d), want_f32=False)
+                y = ops.linear(ops.linear(st["SB"], e["mf0"], relu=True, out_split=True), e["mf2"])
+                st["SBn"] = ops.SplitAct.empty_rows((st["SB"].hi.shape[0],), 2 * d, dev)
+                ops.layernorm2d(y, *e["n2"], residual=st["SB"].cols(0, d), out_split=st["SBn"].cols(0, d), want_f32=False)
+            for st in streams:
+                st["SB"] = st.pop("SBn")
+        for st in streams:
+            nb, h, w = st["nb"], st["h"], st["w"]
+            dec = ops.linear(st["SB"].cols(0, d), P["dec"]).view(nb, h // DS, w // DS, d + dfl)    # decoupler
+            st["U"] = ops.SplitAct.empty_rows((nb * st["L"],), 2 * d + dfl, dev)              # [x | flow feature | norm1(message)]
+            ops.upsample(dec[..., :d], DS, True, out_split=st["F"].cols(d, 2 * d), want_f32=False)
+            ops.upsample(dec[..., d:], DS, True, out_split=st["U"].cols(d, d + dfl), want_f32=False)
+            ops.split_rows(ops.linear(st["F"], P["upm"], residual=st["x32"]), out_split=st["U"].cols(0, d))   # feat + up_merge(cat[feat, upd])
 
         # ---- messageLayer_gla x layer_num (transformer.py:96-133, attention.py:42-133)
         flows = [[], []]
         feats = [None, None]
-        for e in P["gla"]:
+        for lj, e in enumerate(P["gla"]):
             width = e["width"]
-            qkv, pool2, pool4, flow = [], [], [], []
-            for i in (0, 1):
-                o = 1 - i
-                fd = ops.linear(ops.linear(U[i].cols(d, d + dfl), e["fd0"], relu=True, out_split=True), e["fd2"])
-                flow.append(ops.flow_decode(fd, hw[o][1], hw[o][0]))                      # decode_flow: target sized by the other map
-                t = self._qkv(U[i].cols(0, d), e, pc[i]["v_gla"][len(flows[0])])
-                t4 = t.view(1, hw[i][0], hw[i][1], 3 * d)
-                qkv.append(t)
-                pool2.append(ops.avgpool(t4, 2).view(-1, 3 * d))
-                pool4.append(ops.avgpool(t4, DS).view(-1, 3 * d))
-            nxt = []
-            for a, b in ((0, 1), (1, 0)):
-                (h, w), (hb, wb) = hw[a], hw[b]
-                m0 = ops.full_attention(pool4[a][None, :, :d], pool4[b][None, :, d:2 * d], pool4[b][None, :, 2 * d:], nhead,
-                                        e["temp"] / math.sqrt(d // nhead))[0]
-                m1 = ops.span_attention(pool2[a][:, :d], (h // 2, w // 2), pool2[b][:, d:2 * d], pool2[b][:, 2 * d:],
-                                        (hb // 2, wb // 2), flow[a], (h, w), e["so"], nhead, c["nsample"], c["radius_scale"])
-                m2 = ops.span_attention(qkv[a][:, :d], (h, w), qkv[b][:, d:2 * d], qkv[b][:, 2 * d:], (hb, wb), flow[a], (h, w),
-                                        e["so"], nhead, c["nsample"], c["radius_scale"])
-                am = ops.SplitAct.empty_rows((L[a],), 3 * d, dev)                         # the three levels side by side
-                ops.upsample(m0.view(1, h // DS, w // DS, d), DS, False, out_split=am.cols(0, d), want_f32=False)
-                ops.upsample(m1.view(1, h // 2, w // 2, d), 2, False, out_split=am.cols(d, 2 * d), want_f32=False)
-                ops.split_rows(m2, out_split=am.cols(2 * d, 3 * d))
+            for st in streams:
+                nb, h, w, o = st["nb"], st["h"], st["w"], other(st)
+                fd = ops.linear(ops.linear(st["U"].cols(d, d + dfl), e["fd0"], relu=True, out_split=True), e["fd2"])
+                st["flow"] = ops.flow_decode(fd, o["w"], o["h"]).view(nb, st["L"], 4)          # decode_flow: sized by the other map
+                t = self._qkv(st["U"].cols(0, d), e, rep(st["pc"]["v_gla"][lj], nb))
+                t4 = t.view(nb, h, w, 3 * d)
+                st["qkv"] = t.view(nb, st["L"], 3 * d)
+                st["p2"] = ops.avgpool(t4, 2).view(nb, -1, 3 * d)
+                st["p4"] = ops.avgpool(t4, DS).view(nb, -1, 3 * d)
+            for st in streams:
+                nb, h, w, o = st["nb"], st["h"], st["w"], other(st)
+                hb, wb = o["h"], o["w"]
+                m0 = ops.full_attention(st["p4"][..., :d], o["p4"][..., d:2 * d], o["p4"][..., 2 * d:], nhead,
+                                        e["temp"] / math.sqrt(d // nhead), kv_swap=stacked)
+                m1 = ops.span_attention(st["p2"][..., :d], (h // 2, w // 2), o["p2"][..., d:2 * d], o["p2"][..., 2 * d:],
+                                        (hb // 2, wb // 2), st["flow"], (h, w), e["so"], nhead, c["nsample"], c["radius_scale"],
+                                        kv_swap=stacked)
+                m2 = ops.span_attention(st["qkv"][..., :d], (h, w), o["qkv"][..., d:2 * d], o["qkv"][..., 2 * d:], (hb, wb),
+                                        st["flow"], (h, w), e["so"], nhead, c["nsample"], c["radius_scale"], kv_swap=stacked)
+                am = ops.SplitAct.empty_rows((nb * st["L"],), 3 * d, dev)                     # the three levels side by side
+                ops.upsample(m0.view(nb, h // DS, w // DS, d), DS, False, out_split=am.cols(0, d), want_f32=False)
+                ops.upsample(m1.view(nb, h // 2, w // 2, d), 2, False, out_split=am.cols(d, 2 * d), want_f32=False)
+                ops.split_rows(m2.view(-1, d), out_split=am.cols(2 * d, 3 * d))
                 msg = ops.linear(ops.linear(am, e["mh0"], relu=True, out_split=True), e["mh2"])
-                ops.layernorm2d(msg, *e["n1"], out_split=U[a].cols(d + dfl, 2 * d + dfl), want_f32=False)
-                hid = ops.linear(U[a], e["mf0"], relu=True, out_split=True)
-                hid4 = ops.SplitAct(hid.hi.view(1, h, w, -1), hid.lo.view(1, h, w, -1), hid.C)
-                y = ops.conv2d_nhwc(hid4, e["mf2"], 1, 1).view(L[a], width)
+                ops.layernorm2d(msg, *e["n1"], out_split=st["U"].cols(d + dfl, 2 * d + dfl), want_f32=False)
+                hid = ops.linear(st["U"], e["mf0"], relu=True, out_split=True)
+                hid4 = ops.SplitAct(hid.hi.view(nb, h, w, -1), hid.lo.view(nb, h, w, -1), hid.C)
+                y = ops.conv2d_nhwc(hid4, e["mf2"], 1, 1).view(nb * st["L"], width)
                 if width == d:                                                          # last layer: the final features
-                    feats[a] = ops.SplitAct.empty_rows((1, L[a]), d, dev)
-                    ops.layernorm2d(y, *e["n2"], residual=U[a].cols(0, d), out_split=ops.SplitAct(feats[a].hi[0], feats[a].lo[0], d),
-                                    want_f32=False)
-                    nxt.append(None)
+                    fe = ops.SplitAct.empty_rows((nb, st["L"]), d, dev)
+                    ops.layernorm2d(y, *e["n2"], residual=st["U"].cols(0, d),
+                                    out_split=ops.SplitAct(fe.hi.view(-1, d), fe.lo.view(-1, d), d), want_f32=False)
+                    for k, i in enumerate(st["ids"]):
+                        feats[i] = fe[k:k + 1]
                 else:
-                    u = ops.SplitAct.empty_rows((L[a],), 2 * d + dfl, dev)
-                    ops.layernorm2d(y, *e["n2"], residual=U[a].cols(0, width), out_split=u.cols(0, width), want_f32=False)
-                    nxt.append(u)
-            for i in (0, 1):
-                flows[i].append(flow[i].view(1, hw[i][0], hw[i][1], 4))
-            U = nxt
+                    st["Un"] = ops.SplitAct.empty_rows((nb * st["L"],), 2 * d + dfl, dev)
+                    ops.layernorm2d(y, *e["n2"], residual=st["U"].cols(0, width), out_split=st["Un"].cols(0, width), want_f32=False)
+            for st in streams:
+                for k, i in enumerate(st["ids"]):
+                    flows[i].append(st["flow"][k].view(1, st["h"], st["w"], 4))
+                if "Un" in st:
+                    st["U"] = st.pop("Un")
 
         # ---- CoarseMatching (utils/coarse_matching.py:87-160, 226-262): sim = <f0, f1> / C * temperature
         mc = self.config["match_coarse"]

@@ -134,6 +134,8 @@ struct SpanArgs {
     float* out; int64_t ldo;              // [h*w, 256]; row g*4 + n (the reference views (g, n) as a raster index)
     int h, w, hk, wk, W0, win;            // level map sizes; full-resolution width; win = 2*s full-resolution cells per group side
     float inv_s, radius_scale, nsample1, scale;
+    int64_t sq, sk, sv, sflow, so;        // batch strides (floats); blockIdx.y = image, its keys / values come from image ^ kv_swap
+    int kv_swap;
 };
 
 __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
@@ -144,6 +146,10 @@ __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
     float* sw = att + 4 * 8 * SP_M;              // [64][4] bilinear weights (nw, ne, sw, se; 0 where the corner is outside)
     int* si = reinterpret_cast<int*>(sw + SP_M * 4);   // [64][4] corner row indices (clamped)
     __shared__ float grp[4];                     // offset x, y, span x, y of the group
+    {
+        const int nb = blockIdx.y, nk = nb ^ a.kv_swap;
+        a.q += nb * a.sq; a.k += nk * a.sk; a.v += nk * a.sv; a.flow += nb * a.sflow; a.out += nb * a.so;
+    }
     const int tid = threadIdx.x, g = blockIdx.x, gw = a.w / 2;
     const int gy = g / gw, gx = g % gw;
     // avg_pool2d(offset, win) / s and avg_pool2d(span_scale, win) over the group's full-resolution cells: the per-cell terms
@@ -407,13 +413,15 @@ extern "C" int dfsfm_full_attention_f32(const float* q, int64_t ldq, int64_t sq,
     return dfsfm::check_launch("dfsfm_full_attention_f32");
 }
 
-extern "C" int dfsfm_span_attention_f32(const float* q, int64_t ldq, int h, int w, const float* k, int64_t ldk, const float* v,
-                                        int64_t ldv, int hk, int wk, const float* flow, int H0, int W0,
-                                        const float* sample_offset, int nhead, int C, int nsample0, int nsample1,
-                                        float radius_scale, float temp, float* out, int64_t ldo, void* stream_) {
-    if (!q || !k || !v || !flow || !sample_offset || !out || h <= 0 || w <= 0 || hk <= 0 || wk <= 0 || H0 <= 0 || W0 <= 0)
+extern "C" int dfsfm_span_attention_f32(const float* q, int64_t ldq, int64_t sq, int h, int w, const float* k, int64_t ldk,
+                                        int64_t sk, const float* v, int64_t ldv, int64_t sv, int hk, int wk, const float* flow,
+                                        int H0, int W0, const float* sample_offset, int nhead, int C, int nsample0, int nsample1,
+                                        float radius_scale, float temp, float* out, int64_t ldo, int N, int kv_swap,
+                                        void* stream_) {
+    if (N == 0) return DFSFM_OK;
+    if (!q || !k || !v || !flow || !sample_offset || !out || h <= 0 || w <= 0 || hk <= 0 || wk <= 0 || H0 <= 0 || W0 <= 0 || N < 0)
         return DFSFM_E_BADARG;
-    if (ldq < C || ldk < C || ldv < C || ldo < C) return DFSFM_E_BADARG;
+    if (ldq < C || ldk < C || ldv < C || ldo < C || (kv_swap != 0 && kv_swap != 1) || (kv_swap && (N & 1))) return DFSFM_E_BADARG;
     if (C != SP_C || nhead != 8 || nsample0 != 2 || nsample1 != 8) return DFSFM_E_UNSUPPORTED;   // the released configuration
     if (h % 2 || w % 2 || H0 % h || W0 % w || H0 / h != W0 / w) return DFSFM_E_UNSUPPORTED;
     const int s = H0 / h;
@@ -422,10 +430,11 @@ extern "C" int dfsfm_span_attention_f32(const float* q, int64_t ldq, int h, int 
     a.out = out; a.ldo = ldo; a.h = h; a.w = w; a.hk = hk; a.wk = wk; a.W0 = W0; a.win = 2 * s;
     a.inv_s = 1.f / (float)s; a.radius_scale = radius_scale; a.nsample1 = (float)nsample1;
     a.scale = temp / sqrtf((float)(C / nhead));
+    a.sq = sq; a.sk = sk; a.sv = sv; a.sflow = (int64_t)H0 * W0 * 4; a.so = (int64_t)h * w * ldo; a.kv_swap = kv_swap;
     const int smem = (SP_M * SP_LD + 4 * SP_C + 4 * 8 * SP_M + SP_M * 4 + SP_M * 4) * 4;
     static dfsfm::SmemAttr attr;
     attr.ensure(reinterpret_cast<const void*>(span_attention_kernel), smem);
-    hipLaunchKernelGGL(span_attention_kernel, dim3((unsigned)((h / 2) * (w / 2))), dim3(256), smem,
+    hipLaunchKernelGGL(span_attention_kernel, dim3((unsigned)((h / 2) * (w / 2)), (unsigned)N), dim3(256), smem,
                        static_cast<hipStream_t>(stream_), a);
     return dfsfm::check_launch("dfsfm_span_attention_f32");
 }

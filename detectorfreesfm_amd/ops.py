@@ -473,25 +473,29 @@ def full_attention(q, k, v, nhead, scale, kv_swap=False):
 
 
 @_on_device
-def span_attention(q, hw, k, v, hw_k, flow, hw0, sample_offset, nhead, nsample, radius_scale, temp=1.0):
-    """One level of ASpanFormer's hierarchical attention: q [h*w, C] (this image's level map), k / v [hk*wk, C] (the
-    other image's), flow [H0*W0, 4] (this image, full resolution) -> [h*w, C] in the reference's (group, member) order."""
+def span_attention(q, hw, k, v, hw_k, flow, hw0, sample_offset, nhead, nsample, radius_scale, temp=1.0, kv_swap=False):
+    """One level of ASpanFormer's hierarchical attention for N images: q [N, h*w, C] (level maps), k / v [N, hk*wk, C] (image
+    n takes those of image n ^ kv_swap), flow [N, H0*W0, 4] (full resolution) -> [N, h*w, C] in the reference's (group, member)
+    order.  2-D q / k / v / flow are one image."""
     _require_cuda(q, k, v, flow, sample_offset)
-    (rq, ldq), (rk, ldk), (rv, ldv) = _rows_ld(q), _rows_ld(k), _rows_ld(v)
-    C = q.shape[-1]
-    flow = flow.reshape(-1, 4)
-    if (rq != hw[0] * hw[1] or rk != hw_k[0] * hw_k[1] or rv != rk or not flow.is_contiguous() or flow.dtype != torch.float32
-            or flow.shape[0] != hw0[0] * hw0[1] or k.shape[-1] != C or v.shape[-1] != C):
+    single = q.dim() == 2
+    if single:
+        q, k, v, flow = q[None], k[None], v[None], flow.reshape(1, -1, 4)
+    N, rq, C = q.shape
+    (ldq, sq), (ldk, sk), (ldv, sv) = (_batched_rows(t, "span_attention") for t in (q, k, v))
+    flow = flow.reshape(N, -1, 4)
+    if (rq != hw[0] * hw[1] or k.shape != (N, hw_k[0] * hw_k[1], C) or v.shape != k.shape or not flow.is_contiguous()
+            or flow.dtype != torch.float32 or flow.shape[1] != hw0[0] * hw0[1]):
         raise _lib.DfsfmError("span_attention: shape mismatch")
     so = sample_offset.to(torch.float32).contiguous()
     if so.shape != (nsample[1] ** 2, 2):
         raise _lib.DfsfmError("span_attention: sample_offset is [nsample1^2, 2]")
-    out = torch.empty((rq, C), dtype=torch.float32, device=q.device)
-    rc = _lib.lib().dfsfm_span_attention_f32(_ptr(q), ldq, hw[0], hw[1], _ptr(k), ldk, _ptr(v), ldv, hw_k[0], hw_k[1], _ptr(flow),
-                                             hw0[0], hw0[1], _ptr(so), int(nhead), C, int(nsample[0]), int(nsample[1]),
-                                             float(radius_scale), float(temp), _ptr(out), C, _stream())
+    out = torch.empty((N, rq, C), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().dfsfm_span_attention_f32(_ptr(q), ldq, sq, hw[0], hw[1], _ptr(k), ldk, sk, _ptr(v), ldv, sv, hw_k[0], hw_k[1],
+                                             _ptr(flow), hw0[0], hw0[1], _ptr(so), int(nhead), C, int(nsample[0]), int(nsample[1]),
+                                             float(radius_scale), float(temp), _ptr(out), C, N, 1 if kv_swap else 0, _stream())
     _lib.check(rc, "dfsfm_span_attention_f32")
-    return out
+    return out[0] if single else out
 
 
 @_on_device

@@ -220,15 +220,17 @@ int dfsfm_full_attention_f32(const float* q, int64_t ldq, int64_t sq, const floa
                              int64_t ldv, int64_t sv, float* out, int64_t ldo, int64_t so, int N, int L, int S, int H, int D,
                              int kv_swap, float scale, void* stream);
 
-/* One level of HierachicalAttention (aspan_module/attention.py:49-53, 64-66, 92-133): for every 2x2 group of the query level map
- * q [h*w, C] the mean flow offset / span of the group's full-resolution cells (flow [H0*W0, 4] = x, y, var_x, var_y; span =
- * max(exp(var/2) * radius_scale * 2 / nsample1, 1)), nsample1^2 bilinear samples (grid_sample, zero padding, align_corners
- * False) of the other image's level maps k, v [hk*wk, C] at offset + sample_offset * span, softmax attention of the group's 4
- * queries over the samples per head.  out [h*w, C]: row g*4 + n, the order the reference's view() produces.
+/* One level of HierachicalAttention (aspan_module/attention.py:49-53, 64-66, 92-133) for N images: for every 2x2 group of the
+ * query level map q [N, h*w, C] the mean flow offset / span of the group's full-resolution cells (flow [N, H0*W0, 4] = x, y,
+ * var_x, var_y, dense; span = max(exp(var/2) * radius_scale * 2 / nsample1, 1)), nsample1^2 bilinear samples (grid_sample, zero
+ * padding, align_corners False) of the level maps k, v [N, hk*wk, C] of image n ^ kv_swap at offset + sample_offset * span,
+ * softmax attention of the group's 4 queries over the samples per head.  Row pitches ld*, batch strides s* in floats.
+ * out [N, h*w, C] (dense batches of pitch ldo): row g*4 + n, the order the reference's view() produces.
  * C = 256, nhead = 8, nsample = (2, 8); no padding masks. */
-int dfsfm_span_attention_f32(const float* q, int64_t ldq, int h, int w, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                             int hk, int wk, const float* flow, int H0, int W0, const float* sample_offset, int nhead, int C,
-                             int nsample0, int nsample1, float radius_scale, float temp, float* out, int64_t ldo, void* stream);
+int dfsfm_span_attention_f32(const float* q, int64_t ldq, int64_t sq, int h, int w, const float* k, int64_t ldk, int64_t sk,
+                             const float* v, int64_t ldv, int64_t sv, int hk, int wk, const float* flow, int H0, int W0,
+                             const float* sample_offset, int nhead, int C, int nsample0, int nsample1, float radius_scale,
+                             float temp, float* out, int64_t ldo, int N, int kv_swap, void* stream);
 
 /* layernorm2d (aspan_module/attention.py:7-19) on token rows: res + affine * (x - mean) / (std_unbiased + 1e-6) + bias; the
  * residual arrives as split planes (may be NULL); out fp32 and / or split planes.  C = 256 or 384. */

@@ -266,10 +266,16 @@ def _full_attention(q, k, v, nhead, scale, kv_swap=False):
     return torch.cat(outs, 0).contiguous()
 
 
-def _span_attention(q, hw, k, v, hw_k, flow, hw0, sample_offset, nhead, nsample, radius_scale, temp=1.0):
-    """One level of HierachicalAttention with the reference's own operations (aspan_module/attention.py:49-66, 92-133)."""
+def _span_attention(q, hw, k, v, hw_k, flow, hw0, sample_offset, nhead, nsample, radius_scale, temp=1.0, kv_swap=False):
+    """One level of HierachicalAttention with the reference's own operations (aspan_module/attention.py:49-66, 92-133);
+    batched [N, rows, C] inputs pair image n with the keys / values of image n ^ kv_swap."""
     import torch.nn.functional as F
     from oracle import restate_aspanformer as ra
+    if q.dim() == 3:
+        N = q.shape[0]
+        fl = flow.reshape(N, -1, 4)
+        return torch.stack([_span_attention(q[n], hw, k[n ^ 1 if kv_swap else n], v[n ^ 1 if kv_swap else n], hw_k, fl[n], hw0,
+                                            sample_offset, nhead, nsample, radius_scale, temp) for n in range(N)], 0)
     (h, w), (hk, wk), (H0, W0) = hw, hw_k, hw0
     s = H0 // h
     C = q.shape[-1]
