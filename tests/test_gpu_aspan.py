@@ -72,6 +72,25 @@ def test_span_attention_vs_reference(built_lib, hw, hw_k, s):
     assert err.mean().item() < 1e-6 and err.max().item() < 5e-4
 
 
+def test_span_attention_batched_swap(built_lib):
+    """Two row-stacked images in one launch, image n sampling the keys / values of image n ^ 1 (how a pair of equal frames runs)."""
+    g = torch.Generator().manual_seed(11)
+    hw, s = (12, 16), 2
+    H0, W0 = hw[0] * s, hw[1] * s
+    q = torch.randn((2, hw[0] * hw[1], 768), generator=g)
+    flow = torch.cat([torch.rand((2, H0 * W0, 1), generator=g) * 36 - 2, torch.rand((2, H0 * W0, 1), generator=g) * 28 - 2,
+                      torch.randn((2, H0 * W0, 2), generator=g) - 1.0], 2).contiguous()
+    so = torch.tensor([[a - 3.5, b - 3.5] for a in range(8) for b in range(8)])
+    qd = q.to(DEV)
+    out = ops.span_attention(qd[..., :256], hw, qd[..., 256:512], qd[..., 512:], hw, flow.to(DEV), (H0, W0), so.to(DEV), 8, [2, 8], 5,
+                             kv_swap=True).cpu().double()
+    for n in (0, 1):
+        ref = span_reference(q[n, :, :256].double(), hw, q[1 - n, :, 256:512].double(), q[1 - n, :, 512:].double(), hw, flow[n].double(),
+                             (H0, W0), so.double(), 8, [2, 8], 5, 1.0)
+        err = (out[n] - ref).abs()
+        assert err.mean().item() < 1e-6 and err.max().item() < 5e-4
+
+
 @pytest.mark.parametrize("C", [256, 384])
 def test_layernorm2d_vs_reference(built_lib, C):
     g = torch.Generator().manual_seed(C)
