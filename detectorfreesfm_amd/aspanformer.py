@@ -64,6 +64,7 @@ def position_encoding(d_model, h, w, scaling):
 
 class HipASpanFormer(ParamModule):
     DS = 4            # aspanformer.py:76-77: with online_resize the coarsest level is always the 1/8 map pooled by 4
+    POS_CACHE_SIZES = 8   # per-frame-size positional constants kept (least recently used evicted)
 
     def __init__(self, config: dict, online_resize: bool = True):
         super().__init__()
@@ -155,9 +156,12 @@ class HipASpanFormer(ParamModule):
         """Everything that depends only on the frame size: the encoding table, ``pos_transform(pe)``, its 1/4 pooling and the
         positional part of every ``v_proj`` (transformer.py:52-56, 103-105, 222-224; avg_pool at :166-167)."""
         key = (h, w, tuple(scaling))
-        hit = self._pos_cache.get(key)
+        hit = self._pos_cache.pop(key, None)
         if hit is not None:
+            self._pos_cache[key] = hit             # most recently used last
             return hit
+        while len(self._pos_cache) >= self.POS_CACHE_SIZES:   # an entry is ~25 MB at 640x480: keep a handful of frame sizes
+            self._pos_cache.pop(next(iter(self._pos_cache)))
         c = self.config["coarse"]
         pe = position_encoding(c["d_model"], h, w, scaling).to(dev)
         pos = ops.linear(pe, P["pos_t"])                                                  # [L, d_flow]

@@ -245,6 +245,12 @@ def test_aspanformer_host_logic_with_cpu_standins():
         assert (d["offset_kpts1_f_left"] - o["offset_kpts1_f_left"]).abs().max().item() < 1e-2
         assert tuple(d["image0"].shape[2:]) == (hw0[0] // 32 * 32, hw0[1] // 32 * 32)     # resize_input replaces the frames
         assert torch.equal(d["online_resize_scale0"], torch.tensor([[hw0[1] / (hw0[1] // 32 * 32), hw0[0] / (hw0[0] // 32 * 32)]]))
+    assert 0 < len(m._pos_cache) <= m.POS_CACHE_SIZES
+    m.POS_CACHE_SIZES = 2                                  # the per-size constants are an LRU: a third frame size evicts the oldest
+    with cpu_ops():
+        for hw_ in ((64, 96), (96, 96), (64, 128)):
+            m(dict(synth.coarse_pair_batch(1, hw_[0], hw_[1], seed=3)))
+            assert len(m._pos_cache) <= 2
     with pytest.raises(NotImplementedError):
         m({"image0": torch.zeros(1, 1, 96, 128), "image1": torch.zeros(1, 1, 96, 128), "mask0": torch.ones(1, 12, 16),
            "mask1": torch.ones(1, 12, 16)})
