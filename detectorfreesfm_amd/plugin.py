@@ -258,6 +258,74 @@ def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", b
     return matches, kp, sc, upd
 
 
+# dataset rules of detector_free_coarse_matching per matcher (src/coarse_match/coarse_match.py:82-90)
+_DATA_RULES = {"loftr_hip": {"df": 8, "pad_to": None}, "matchformer_hip": {"df": 8, "pad_to": -1},
+               "aspanformer_hip": {"df": None, "pad_to": None}}
+
+
+@torch.no_grad()
+def match_worker(subset_ids, image_lists, covis_pairs_out, cfgs, device="cuda", frames=None, models=None):
+    """``match_worker`` (src/coarse_match/coarse_match_worker.py:101-145) for any of the three HIP matchers, with
+    ``CoarseMatchingDataset`` (src/dataset/coarse_matching_dataset.py:10-100) folded in: every frame of the subset is read
+    once (the reference's ``img_preload``), resized / padded / converted on the device (``images.read_grayscale``, rules of
+    coarse_match.py:82-90), then every pair goes through ``extract_matches``.  ``cfgs`` is the reference's dictionary
+    (``cfgs['matcher']['model']`` -> ``build_model``, ``cfgs['data']['img_resize']``, ``cfgs['matcher']['pair_name_split']``).
+    covis_pairs_out: list of "path0 path1" strings or a file of such lines.  ``frames``: optional {path: decoded uint8
+    array} to skip the file decode.  Returns {path0<split>path1: ndarray [N,5]} like the reference.  Only the coarse_only
+    model type exists here, so the grid rounding of :131-133 never applies."""
+    from . import images
+    margs = cfgs["matcher"]["model"]
+    detector, matcher = models if models is not None else build_model(margs)
+    matcher.to(device)
+    rule = dict(_DATA_RULES[margs["matcher"]])
+    resize = cfgs["data"].get("img_resize")
+    if isinstance(covis_pairs_out, (list, tuple)):
+        pair_list = list(covis_pairs_out)
+    else:
+        with open(covis_pairs_out, "r") as f:
+            pair_list = f.read().rstrip("\n").split("\n")
+    split = cfgs["matcher"].get("pair_name_split", " ")
+    cache, matches = {}, {}
+
+    def read(path):
+        if path not in cache:
+            src = frames[path] if frames is not None else path
+            cache[path] = images.read_grayscale(src, (resize,) if resize is not None else None, df=rule["df"],
+                                                pad_to=rule["pad_to"], ret_scales=True, device=device)
+        return cache[path]
+    for pair_idx in subset_ids:
+        p0, p1 = pair_list[pair_idx].split(" ")
+        (img0, scale0, _), (img1, scale1, _) = read(p0), read(p1)
+        data = {"image0": img0[None], "image1": img1[None], "scale0": scale0[None].to(device), "scale1": scale1[None].to(device),
+                "pair_key": ([p0], [p1]), "frameID": pair_idx}
+        mkpts0, mkpts1, mconfs = extract_matches(data, detector=detector, matcher=matcher)
+        matches[split.join([p0, p1])] = np.concatenate([mkpts0, mkpts1, mconfs[:, None]], -1)
+    return matches
+
+
+@torch.no_grad()
+def match_worker_sharded(image_lists, covis_pairs_out, cfgs, device="cuda", frames=None, models=None, group=None):
+    """The reference's Ray fan-out of ``match_worker`` over chunks of the pair list (coarse_match.py:127-140) as one process
+    per GPU: rank r matches its contiguous shard, ONE all-gather (``dist.all_gather_tables``) hands every rank the scene's
+    table dictionary in pair order."""
+    from . import dist as ddist
+    import torch.distributed as tdist
+    if isinstance(covis_pairs_out, (list, tuple)):
+        pair_list = list(covis_pairs_out)
+    else:
+        with open(covis_pairs_out, "r") as f:
+            pair_list = f.read().rstrip("\n").split("\n")
+    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
+    rank = tdist.get_rank(group) if world > 1 else 0
+    lo, hi = ddist.shard_range(len(pair_list), rank, world)
+    mine = match_worker(list(range(lo, hi)), image_lists, pair_list, cfgs, device=device, frames=frames, models=models)
+    split = cfgs["matcher"].get("pair_name_split", " ")
+    keys = [split.join(p.split(" ")) for p in pair_list]
+    tables = ddist.all_gather_tables([torch.from_numpy(mine[k]).to(torch.float32).to(device) for k in keys[lo:hi]], group=group)
+    assert len(tables) == len(keys)
+    return {k: t.cpu().numpy() for k, t in zip(keys, tables)}
+
+
 def _batched(bag: dict, device):
     """What the reference's DataLoader(batch_size=1) + dict_to_cuda hand to the matcher: a leading batch dimension on
     every tensor (multiview_match_worker.py:115,126)."""
