@@ -479,3 +479,23 @@ def test_matchformer_plugin_surface(built_lib, tmp_path):
     ex = _strict_coarse(d, o, o["conf_matrix"], 0.2, "matchformer plugin")
     assert len(ex) == 0 and len(mc) > 30
     assert np.array_equal(mk0, o["mkpts0_f"].numpy()) and np.abs(mc - o["mconf"].numpy()).max() <= parity.TOL_CONF
+
+
+@pytest.mark.parametrize("which", ["loftr_hip", "matchformer_hip", "aspanformer_hip"])
+def test_match_worker_from_frames(built_lib, which):
+    """plugin.match_worker on the device: decoded uint8 frames -> device LANCZOS resize / pad (per-matcher rule of
+    coarse_match.py:82-90) -> matcher -> per-pair tables, against the oracle readers + oracle matcher on the same frames."""
+    import test_match_worker_cpu as mw
+    frames = mw.scene_frames()
+    cfgs, models, oracle = mw.build(which)
+    got = plugin.match_worker([0, 1, 2], list(frames), mw.PAIRS, cfgs, device=DEV, frames=frames, models=models)
+    exp = mw.expected_tables(which, oracle, frames)
+    n = 0
+    for p in mw.PAIRS:
+        t, (m0, m1, mc) = got[p], exp[p]
+        assert t.shape == (len(mc), 5), (p, t.shape, len(mc))
+        assert np.array_equal(t[:, :2], m0) and np.array_equal(t[:, 2:4], m1)
+        assert np.abs(t[:, 4] - mc).max(initial=0) <= parity.TOL_CONF
+        n += len(mc)
+    print(f"[match_worker {which}] {n} rows over {len(mw.PAIRS)} pairs identical to the oracle path")
+    assert n > 30
