@@ -5,7 +5,7 @@ point is absent, importing this module's ``lib()`` raises, and every op built on
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, c_char_p
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DFSFM_LIB_PATH lets kernel A/B experiments point at an alternative build of the same ABI.

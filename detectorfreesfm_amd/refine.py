@@ -29,7 +29,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .coarse import EncoderLayerWeights, encoder_layer, encoder_layer_split, _fold_bn
+from .coarse import EncoderLayerWeights, encoder_layer, encoder_layer_split
 from .params import ParamModule, multiview_param_spec
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)   # S2DNet.mean / .std, backbone/S2DNet/s2dnet.py:66-67
