@@ -126,3 +126,17 @@ def test_match_worker_sharded_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("which", ["loftr_hip", "matchformer_hip", "aspanformer_hip"])
+def test_match_worker_empty_tables(which):
+    """A threshold nothing passes: every pair still gets its key, with an empty float32 [0,5] table (what the reference's
+    np.concatenate of empty predictions gives), and the matchers' data dicts stay well-formed."""
+    frames = scene_frames()
+    cfgs, (detector, matcher), _ = build(which)
+    matcher.config["match_coarse"]["thr"] = 2.0                       # confidences are products of two probabilities: <= 1
+    with cpu_ops():
+        got = plugin.match_worker([0, 2], list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=(detector, matcher))
+    assert list(got) == [PAIRS[0], PAIRS[2]]
+    for t in got.values():
+        assert t.shape == (0, 5) and t.dtype == np.float32
