@@ -7,13 +7,13 @@ all ranks.  The same run also times the refinement head (configs[2]: 2000 tracks
 ``secondary``.  Four distinct resident batches rotate through the steps; the weights are the seeded "planted" set
 (params.planted_loftr_state_dict), so every step ends with a real match table (~3600 rows per pair at thr 0.2).
 Pairs / track bags shard across ranks with no data-path collective (weak scaling: every rank runs its own batch);
-with N>1 every step ends with the path's one real exchange, the all-gather of the match tables (RCCL over xGMI).
+with N>1 every step ends with the path's one real exchange, the gather of the match tables to the merging rank (RCCL over xGMI).
 
 ``--gpus N`` without a launcher (WORLD_SIZE unset) re-executes itself under ``torch.distributed.run`` with N ranks
 on 127.0.0.1; under the driver's own torchrun it just reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 Other workloads (explicit, not the headline): ``--workload scene300`` = configs[3] (300 images, 44 850 exhaustive
-pairs sharded over the ranks, backbone once per image, all-gather of the tables, keypoint merge on rank 0);
+pairs sharded over the ranks, backbone once per image, gather-to-root of the tables, keypoint merge on rank 0);
 ``--workload hires832`` = configs[4] (832x832 pairs + one 16 000-track refinement chunk);
 ``--workload matchformer`` / ``aspanformer`` = the alternative coarse matchers of SURVEY 8(f) at the configs[1] frame size.
 
@@ -175,33 +175,57 @@ def kernel_rooflines(dev, batch):
     return out
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU port of the reference PyTorch path, same weights/inputs) on the host cores:
-    a bounded sample -- 640x480 pairs one at a time (the reference runs batch 1) and one bag of
-    64 tracks x 5 views."""
+def cpu_baseline():
+    """The oracle (CPU port of the reference PyTorch path, same weights / inputs) on the host cores, BASELINE.md section 2
+    protocol: 1 warm-up + >= 5 timed 640x480 pairs one at a time (the reference runs batch 1) and one bag of 200 tracks x 5
+    views.  The thread count is swept first (a 128-thread pool is slower than 16-32 threads on these shapes: the convolutions
+    of one pair do not feed that many cores) and the fastest setting is the one reported, with its core count."""
     from oracle import restate
-    cores = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
+    cand = sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads})
     cfg = loftr_coarse_only_config(0.2)
     sd = planted_loftr_state_dict(loftr_param_spec(cfg), 0)
     data = synth.coarse_pair_batch(1, 480, 640, seed=1000)
-    with torch.no_grad():
-        restate.loftr_coarse_forward(sd, cfg, data)      # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < 5 and (time.perf_counter() - t0) < seconds_budget * 0.6:
-            restate.loftr_coarse_forward(sd, cfg, data)
-            n += 1
-        pairs_per_s = n / (time.perf_counter() - t0)
-        rcfg = multiview_refinement_config()
-        rsd = random_state_dict(multiview_param_spec(rcfg), 1)
-        rdata = synth.refine_bag(T=64, V=5, H=480, W=640, seed=2000)
+    rcfg = multiview_refinement_config()
+    rsd = random_state_dict(multiview_param_spec(rcfg), 1)
+    rprobe = synth.refine_bag(T=24, V=5, H=480, W=640, seed=2001)
+    rdata = synth.refine_bag(T=200, V=5, H=480, W=640, seed=2000)
+
+    def timed(fn):
         t0 = time.perf_counter()
-        restate.multiview_matcher_forward(rsd, rcfg, rdata)
-        tracks_per_s = 64 / (time.perf_counter() - t0)
-    return {"value": pairs_per_s, "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} single 640x480 pairs through oracle.restate.loftr_coarse_forward (incl. the FPN "
-                      "branch the reference computes and discards)",
-            "secondary": {"value": tracks_per_s, "unit": "tracks/s",
-                          "sample": "1 bag of 64 tracks x 5 views through oracle.restate.multiview_matcher_forward"}}
+        fn()
+        return time.perf_counter() - t0
+    sweep_c, sweep_r = {}, {}
+    try:
+        with torch.no_grad():
+            restate.loftr_coarse_forward(sd, cfg, data)                          # warm-up (allocator, thread pool)
+            for t in cand:
+                torch.set_num_threads(t)
+                sweep_c[t] = timed(lambda: restate.loftr_coarse_forward(sd, cfg, data))
+            best_c = min(sweep_c, key=sweep_c.get)
+            torch.set_num_threads(best_c)
+            n, t0 = 0, time.perf_counter()
+            while n < 5:
+                restate.loftr_coarse_forward(sd, cfg, data)
+                n += 1
+            pairs_per_s = n / (time.perf_counter() - t0)
+            restate.multiview_matcher_forward(rsd, rcfg, rprobe)
+            for t in cand:
+                torch.set_num_threads(t)
+                sweep_r[t] = timed(lambda: restate.multiview_matcher_forward(rsd, rcfg, rprobe))
+            best_r = min(sweep_r, key=sweep_r.get)
+            torch.set_num_threads(best_r)
+            tracks_per_s = 200 / timed(lambda: restate.multiview_matcher_forward(rsd, rcfg, rdata))
+    finally:
+        torch.set_num_threads(all_threads)
+    return {"value": pairs_per_s, "unit": "image-pairs/s", "cores": best_c, "kind": "port",
+            "sample": f"{n} single 640x480 pairs through oracle.restate.loftr_coarse_forward (incl. the FPN branch the "
+                      f"reference computes and discards) at the fastest of {cand} threads; 1 warm-up",
+            "thread_sweep_s_per_pair": {str(k): round(v, 3) for k, v in sweep_c.items()}, "host_threads": all_threads,
+            "secondary": {"value": tracks_per_s, "unit": "tracks/s", "cores": best_r,
+                          "sample": "1 bag of 200 tracks x 5 views through oracle.restate.multiview_matcher_forward "
+                                    f"at the fastest of {cand} threads (swept on a 24-track bag)",
+                          "thread_sweep_s_per_24_tracks": {str(k): round(v, 3) for k, v in sweep_r.items()}}}
 
 
 def _claim_stdout():
@@ -282,9 +306,9 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         d = dict(batches[i % N_RESIDENT])
         matcher(d)
         table = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1)
-        if distributed:
-            gathered = ddist.all_gather_tables([table])
-            n_matches[0] = sum(t.shape[0] for t in gathered)
+        if distributed:       # the path's one exchange: the tables go to the merging rank (gather-to-root)
+            gathered = ddist.collect_tables([table], root=0)
+            n_matches[0] = sum(t.shape[0] for t in gathered) if gathered is not None else table.shape[0]
         else:
             n_matches[0] = table.shape[0]
 
@@ -319,7 +343,7 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         refiner(d)
         if distributed:
             rows = torch.cat([d["query_points_refined"][0], d["reference_points_refined"][-1][0].reshape(-1, 2)], 0)
-            ddist.all_gather_tables([rows])
+            ddist.collect_tables([rows], root=0)
 
     r_steps = max(2, args.steps // 2)
     rdt = timed_steps(refine_step, r_steps, min(args.warmup, 2), distributed)
@@ -333,8 +357,9 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"configs[1]: LoFTR coarse_only, 640x480, batch {args.batch} pairs per GPU per step, "
                                f"{N_RESIDENT} distinct resident batches rotating, seeded planted weights (real match tables "
-                               "at thr 0.2), inputs resident in HBM; match-table all-gather per step when N>1",
-                   "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
+                               "at thr 0.2), inputs resident in HBM; match-table gather to rank 0 per step when N>1",
+                   "parallelism": f"pairs sharded over {world} rank(s), no data-path collective",
+                   "rccl_ranks": world if distributed else 0},
         "secondary": {"metric": "refinement_tracks_per_sec", "value": tracks_per_s, "unit": "tracks/s",
                       "steps": r_steps, "ms_per_step": 1000.0 * rdt / r_steps,
                       "workload": f"configs[2]: MultiviewMatcher, {args.tracks} tracks x 5 views, 640x480 RGB, W=15, crop 35, "
@@ -370,7 +395,7 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
 def run_scene(args, dev, rank, world, distributed, out_fd):
     """configs[3]: ETH3D-shaped scene, exhaustive pairs sharded over the ranks (the analogue of
     src/coarse_match/coarse_match.py:127-140): backbone once per image on every rank, the rank's contiguous shard of
-    the pair list matched from the cached tokens, ONE all-gather of the tables, keypoint merge on rank 0."""
+    the pair list matched from the cached tokens, ONE gather-to-root of the tables, keypoint merge on rank 0."""
     n_img = args.scene_images
     matcher = build_coarse(dev)
     g = torch.Generator().manual_seed(4242)
@@ -390,10 +415,10 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
     torch.cuda.synchronize()
     t_match = time.perf_counter() - t0
     flat = [tables[p] for p in pairs[lo:hi]]
-    gathered = ddist.all_gather_tables(flat) if distributed else flat
+    gathered = ddist.collect_tables(flat, root=0) if distributed else flat        # merge runs on rank 0 only
     torch.cuda.synchronize()
     t_gather = time.perf_counter() - t0 - t_match
-    n_rows, n_kpts = sum(int(t.shape[0]) for t in gathered), 0
+    n_rows, n_kpts = (sum(int(t.shape[0]) for t in gathered) if gathered is not None else 0), 0
     if rank == 0:
         rows = torch.cat(gathered, 0)
         lens = torch.tensor([t.shape[0] for t in gathered])
@@ -415,9 +440,10 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
             "steps": 1, "warmup": 0, "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"configs[3]: {n_img} images 640x480, {len(pairs)} exhaustive pairs, backbone once per image, "
-                                   "tables all-gathered once, keypoint merge on rank 0",
-                       "parallelism": f"contiguous pair shards over {world} rank(s); one all-gather of match tables"},
-            "phases_s": {"match_rank0": t_match, "all_gather_rank0": t_gather, "total_max_over_ranks": dt},
+                                   "tables gathered to rank 0 once, keypoint merge on rank 0",
+                       "parallelism": f"contiguous pair shards over {world} rank(s); one gather-to-root of match tables",
+                       "rccl_ranks": world if distributed else 0},
+            "phases_s": {"match_rank0": t_match, "gather_rank0": t_gather, "total_max_over_ranks": dt},
             "match_rows": n_rows, "keypoints": n_kpts})
 
 

@@ -283,10 +283,14 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     }
 }
 
+// dynamic LDS of one workgroup: reference planes (hi, lo) + grid + per-view results + 4 waves x 3 stages x 8 KB of DMA ring
+inline size_t fine_smem_bytes(int C, int Vq) {
+    return (size_t)MAXL * C * 4 + MAXWW * 8 + (((size_t)Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + 4 * 3 * 32 * 256;
+}
+
 template <int C, bool FAST>
 void launch(const FineArgs& g, hipStream_t stream) {
-    // reference planes (hi, lo) + grid + per-view results + 4 waves x 3 stages x 8 KB of DMA ring
-    const size_t smem = (size_t)MAXL * C * 4 + MAXWW * 8 + (((size_t)g.Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + 4 * 3 * 32 * 256;
+    const size_t smem = fine_smem_bytes(C, g.Vq);
     static dfsfm::SmemAttr smem_attr;
     smem_attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C, FAST>), 160 * 1024);
     hipLaunchKernelGGL((fine_match_kernel<C, FAST>), dim3(g.T), dim3(256), smem, stream, g);
@@ -306,7 +310,8 @@ extern "C" int dfsfm_fine_match_f32(const float* ref, const float* qry, const ui
     if (query_refined && (!query_pts || !scale_q)) return DFSFM_E_BADARG;
     if (ref_refined && (!ref_pts || !scale_r)) return DFSFM_E_BADARG;
     if (left > W || left * left > MAXL || W * W > MAXWW || (left & 1) == 0 || (W & 1) == 0) return DFSFM_E_UNSUPPORTED;
-    if (Vq > 64) return DFSFM_E_UNSUPPORTED;   // s_res LDS budget
+    if (C != 128 && C != 64) return DFSFM_E_UNSUPPORTED;
+    if (fine_smem_bytes(C, Vq) > 160 * 1024) return DFSFM_E_UNSUPPORTED;   // LDS budget: Vq <= 39 at C = 128, <= 60 at C = 64
     if ((reinterpret_cast<uintptr_t>(ref) & 15) || (reinterpret_cast<uintptr_t>(qry) & 15)) return DFSFM_E_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     FineArgs g{ref, qry, track_mask, movable, T, Vq, W, left, query_pts, scale_q, ref_pts, scale_r,

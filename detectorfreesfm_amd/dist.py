@@ -4,8 +4,10 @@ collective of the path: an all-gather of variable-length match tables (SURVEY.md
 The reference fans pairs / tracks out over Ray tasks and merges pickled numpy results through the
 object store (src/coarse_match/coarse_match.py:127-140, src/post_optimization/matcher_model/
 multiview_match.py:39-62).  Here every rank takes a static contiguous shard (no data-path
-collective), and the tables are collected with ``torch.distributed`` all-gathers (table count, row
-counts, then one padded payload) -- RCCL over xGMI with backend "nccl" on MI355X, gloo on CPU for the tests.
+collective), and the tables are collected with ``collect_tables``: a three-integer metadata all-gather plus ONE payload
+collective -- a flat ``all_gather_into_tensor`` when every rank needs the scene's tables, an exact-size gather-to-root
+(``all_to_all_single`` with uneven splits) when only the merging rank does -- RCCL over xGMI with backend "nccl" on MI355X,
+gloo on CPU for the tests.
 """
 from typing import List, Sequence, Tuple
 
@@ -45,39 +47,84 @@ def exhaustive_pairs(n_images: int) -> List[Tuple[int, int]]:
     return [(i, j) for i in range(n_images) for j in range(i + 1, n_images)]
 
 
-def all_gather_tables(tables: List[torch.Tensor], group=None) -> List[torch.Tensor]:
-    """Gather every rank's list of [M_k, W] float32 tables; returns the concatenated list in rank
-    order on every rank.  Three small-to-one-large collectives regardless of the number of tables:
-    (0) all-gather of (table count, width), (1) all-gather of the row counts (padded to the max table count),
-    (2) all-gather of one flat payload per rank padded to the largest payload."""
+def _group_device(tables, group):
+    if tables:
+        return tables[0].device
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _as_words(t: torch.Tensor) -> torch.Tensor:
+    """A [M, W] table of a 4-byte dtype (float32 / int32) as int32 words, bit for bit."""
+    if t.dtype not in (torch.float32, torch.int32):
+        raise TypeError(f"collect_tables: tables travel as 4-byte words (float32 / int32), got {t.dtype}")
+    return t.contiguous().view(torch.int32)
+
+
+def collect_tables(tables: List[torch.Tensor], group=None, root=None, dtype=torch.float32):
+    """Collect every rank's list of [M_k, W] tables (float32 or int32; all of one width) in rank order.
+
+    root=None: every rank receives the full list (ONE metadata all-gather of three integers per rank, then ONE
+    ``all_gather_into_tensor`` of a flat word buffer that carries the row counts in-band; a single [world, len] receive
+    buffer, no per-rank Python lists, two host reads in total).
+    root=r: gather-to-root -- the merge of a scene runs on one rank ("a gather-to-root suffices"), so only rank r
+    allocates a receive buffer, of exactly the summed size (``all_to_all_single`` with uneven splits: nothing is padded to the
+    largest rank and the other ranks receive nothing); they get ``None``.
+    The reference moves the same tables as pickled numpy arrays through Ray's object store
+    (src/coarse_match/coarse_match.py:127-140; multiview_match.py:39-62)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return list(tables)
-    ws = dist.get_world_size(group)
-    dev = tables[0].device if tables else torch.device(
-        "cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _group_device(tables, group)
     width = tables[0].shape[1] if tables else 0
-    meta = torch.tensor([len(tables), width], dtype=torch.int64, device=dev)
-    metas = [torch.zeros_like(meta) for _ in range(ws)]
-    dist.all_gather(metas, meta, group=group)
-    max_tables = max(int(m[0]) for m in metas)
-    width = max(int(m[1]) for m in metas)
-    rows = torch.zeros(max(max_tables, 1), dtype=torch.int64, device=dev)
-    if tables:
-        rows[:len(tables)] = torch.tensor([t.shape[0] for t in tables], dtype=torch.int64, device=dev)
-    all_rows = [torch.zeros_like(rows) for _ in range(ws)]
-    dist.all_gather(all_rows, rows, group=group)
-    totals = [int(r.sum()) for r in all_rows]
-    max_total = max(max(totals), 1)
-    payload = torch.zeros((max_total, max(width, 1)), dtype=torch.float32, device=dev)
-    if tables and totals[dist.get_rank(group)] > 0:
-        payload[:totals[dist.get_rank(group)]] = torch.cat([t.to(torch.float32) for t in tables], 0)
-    gathered = [torch.zeros_like(payload) for _ in range(ws)]
-    dist.all_gather(gathered, payload, group=group)
-    out = []
-    for r in range(ws):
-        off = 0
-        for k in range(int(metas[r][0])):
-            n = int(all_rows[r][k])
-            out.append(gathered[r][off:off + n, :width])
-            off += n
-    return out
+    total = sum(t.shape[0] for t in tables)
+    meta = torch.tensor([len(tables), width, total], dtype=torch.int64, device=dev)
+    metas = torch.empty((ws * 3,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(ws, 3).tolist()                                            # host read 1: three integers per rank
+    width = max(m[1] for m in metas)
+    # this rank's words: [row counts (n_tables) | rows (total x width)]
+    counts = torch.tensor([t.shape[0] for t in tables], dtype=torch.int32, device=dev)
+    words = torch.cat([counts] + [_as_words(t).reshape(-1) for t in tables if t.shape[0]]) if tables else \
+        torch.empty((0,), dtype=torch.int32, device=dev)
+    lens = [m[0] + m[2] * m[1] for m in metas]
+    assert words.numel() == lens[rank]
+
+    def unpack(buf, offs):
+        cnt = torch.cat([buf[offs[r]:offs[r] + metas[r][0]] for r in range(ws)]).tolist() if sum(m[0] for m in metas) else []
+        out, k = [], 0                                                # host read 2: the row counts
+        for r in range(ws):
+            o = offs[r] + metas[r][0]
+            for _ in range(metas[r][0]):
+                n = cnt[k]
+                k += 1
+                out.append(buf[o:o + n * metas[r][1]].view(dtype).view(n, metas[r][1]) if metas[r][1] else
+                           torch.empty((n, width), dtype=dtype, device=dev))
+                o += n * metas[r][1]
+        return out
+
+    if root is None:
+        pitch = max(max(lens), 1)
+        send = torch.zeros((pitch,), dtype=torch.int32, device=dev)
+        send[:words.numel()] = words
+        recv = torch.empty((ws * pitch,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        return unpack(recv, [r * pitch for r in range(ws)])
+    in_split = [words.numel() if r == root else 0 for r in range(ws)]
+    out_split = lens if rank == root else [0] * ws
+    recv = torch.empty((sum(out_split),), dtype=torch.int32, device=dev)
+    send = words if words.numel() else torch.empty((0,), dtype=torch.int32, device=dev)
+    dist.all_to_all_single(recv, send, out_split, in_split, group=group)
+    if rank != root:
+        return None
+    offs, o = [], 0
+    for n in lens:
+        offs.append(o)
+        o += n
+    return unpack(recv, offs)
+
+
+def all_gather_tables(tables: List[torch.Tensor], group=None) -> List[torch.Tensor]:
+    """``collect_tables(..., root=None)`` for float32 tables (the name the round-1/2 callers and tests use)."""
+    return collect_tables(tables, group=group, root=None, dtype=torch.float32)

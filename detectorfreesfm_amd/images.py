@@ -111,10 +111,39 @@ def resize_lanczos(image_u8, size, device=None):
     return ops.resample_u8(img, bx, kx, by, ky, out_u8=True)[0]
 
 
+_warned_pil_decode = False
+
+
 def _decode(path, color: bool):
-    """Host decode for callers that pass a file name (the reference uses cv2.imread; PIL is what this image has)."""
-    from PIL import Image
+    """Host entropy decode for callers that pass a file name.  The reference decodes with ``cv2.imread(path,
+    IMREAD_GRAYSCALE)`` / ``IMREAD_COLOR`` + BGR->RGB (src/dataset/utils.py:92-96, 150-153): OpenCV applies the EXIF
+    orientation, decodes JPEG luma directly for gray and uses its own rounding for colour->gray.  With cv2 importable the
+    same calls are made here.  Without it (this image) Pillow decodes -- EXIF orientation is applied to match cv2, but
+    gray / colour bytes of a JPEG can differ by an LSB from OpenCV's decoder, so this branch is NOT parity-pinned; it warns
+    once and INTEGRATION.md says so.  Everything after the decode is byte-exact (tests pass decoded frames)."""
+    try:
+        import cv2
+    except ImportError:
+        cv2 = None
+    if cv2 is not None:
+        if color:
+            im = cv2.imread(str(path), cv2.IMREAD_COLOR)
+            if im is None:
+                raise FileNotFoundError(str(path))
+            return np.ascontiguousarray(im[:, :, ::-1])
+        im = cv2.imread(str(path), cv2.IMREAD_GRAYSCALE)
+        if im is None:
+            raise FileNotFoundError(str(path))
+        return im
+    global _warned_pil_decode
+    if not _warned_pil_decode:
+        import warnings
+        warnings.warn("detectorfreesfm_amd.images: cv2 is not installed, decoding files with Pillow -- the decode step is not "
+                      "parity-pinned to the reference's cv2.imread (pass decoded frames, or install OpenCV)", RuntimeWarning)
+        _warned_pil_decode = True
+    from PIL import Image, ImageOps
     with Image.open(str(path)) as im:
+        im = ImageOps.exif_transpose(im)                     # cv2.imread honours the EXIF orientation
         return np.asarray(im.convert("RGB" if color else "L"))
 
 

@@ -23,6 +23,9 @@ from .matchformer import HipMatchformer, matchformer_coarse_only_config
 from .refine import HipMultiviewMatcher
 
 
+_COARSE_ONLY = "coarse_only"      # the literal of coarse_match_worker.py:134 (interned: identical to any literal 'coarse_only')
+
+
 class DetectorWrapper(nn.Module):
     """No-op 'OnGrid' detector (src/coarse_match/utils/detector_wrapper.py:4-22)."""
 
@@ -62,8 +65,17 @@ def build_model(args: dict):
         cfg = margs.get("cfg") or aspanformer_coarse_only_config(args["match_thr"])
         cfg["match_coarse"]["thr"] = args["match_thr"]
         matcher = HipASpanFormer(config=cfg, online_resize=True)
-        if margs.get("weight_path") is not None:            # strict=False in the reference (:56): sample_offset is not stored
-            matcher.load_state_dict(torch.load(margs["weight_path"], map_location="cpu")["state_dict"], strict=True)
+        if margs.get("weight_path") is not None:
+            # strict=False like the reference (:56) -- but a drop-in must not silently run on half-loaded weights, so what
+            # strict=False let through is checked: only the constant sampling pattern may be missing (it is not stored in
+            # checkpoints), and unexpected keys are tolerated only outside the matcher (Lightning bookkeeping, loss buffers)
+            res = matcher.load_state_dict(torch.load(margs["weight_path"], map_location="cpu")["state_dict"], strict=False)
+            missing = [k for k in res.missing_keys if "sample_offset" not in k]
+            unexpected = [k for k in res.unexpected_keys if k.startswith(("backbone.", "loftr_coarse.", "coarse_matching.",
+                                                                             "pos_encoding.", "fine_", "loftr_fine."))]
+            if missing or unexpected:
+                raise RuntimeError(f"aspanformer_hip: checkpoint does not fit the matcher (missing {missing[:5]}"
+                                   f"{'...' if len(missing) > 5 else ''}, unexpected {unexpected[:5]})")
         detector = DetectorWrapper()
         detector.eval()
         matcher.eval()
@@ -235,14 +247,19 @@ def match_scene_cached(matcher: HipLoFTR, images, pairs, batch=8, scales=None, t
 
 
 @torch.no_grad()
-def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", batch=8, scales=None, pairs=None, group=None):
+def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", batch=8, scales=None, pairs=None, group=None,
+                        root=0):
     """One scene on all ranks of the process group -- the analogue of the reference's Ray fan-out + merge
     (src/coarse_match/coarse_match.py:127-140, 203-237): every rank matches a contiguous shard of the pair list
-    (``match_scene_cached``: backbone once per image), the match tables are collected with ONE all-gather
-    (``dist.all_gather_tables``: RCCL over xGMI, gloo in the CPU tests), and the keypoint merge runs on the device.
+    (``match_scene_cached``: backbone once per image), the match tables are collected with ONE payload collective
+    (``dist.collect_tables``: RCCL over xGMI, gloo in the CPU tests), and the keypoint merge runs on the device.
+
+    root=r (default 0): gather-to-root -- like the reference, whose driver process alone merges and writes the h5 files
+    (coarse_match.py:203-254), only rank r receives the tables (an exact-size buffer) and runs the merge; the other ranks
+    return None.  root=None: every rank receives the tables and merges (the round-1/2 behaviour).
 
     images [n_images,1,H,W]; names: image names in the same order; pairs: list of (i, j) (default: exhaustive, in the
-    order of src/construct_pairs/pairs_exhaustive.py).  Returns on EVERY rank the reference's dictionaries
+    order of src/construct_pairs/pairs_exhaustive.py).  Returns the reference's dictionaries
     (matches {"name0<split>name1": [M,5]}, final_keypoints, final_scores, updated_matches)."""
     from . import dist as ddist
     import torch.distributed as tdist
@@ -251,7 +268,9 @@ def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", b
     rank = tdist.get_rank(group) if world > 1 else 0
     lo, hi = ddist.shard_range(len(pairs), rank, world)
     mine = match_scene_cached(matcher, images, pairs[lo:hi], batch=batch, scales=scales, to_host=False)
-    tables = ddist.all_gather_tables([mine[p] for p in pairs[lo:hi]], group=group)      # rank order == pair order
+    tables = ddist.collect_tables([mine[p] for p in pairs[lo:hi]], group=group, root=root)   # rank order == pair order
+    if tables is None:
+        return None
     assert len(tables) == len(pairs)
     matches = {f"{names[i]}{pair_name_split}{names[j]}": t.cpu().numpy() for (i, j), t in zip(pairs, tables)}
     kp, sc, upd = merge_match_tables(matches, names, pair_name_split, device=next(matcher.parameters()).device)
@@ -271,10 +290,15 @@ def match_worker(subset_ids, image_lists, covis_pairs_out, cfgs, device="cuda", 
     coarse_match.py:82-90), then every pair goes through ``extract_matches``.  ``cfgs`` is the reference's dictionary
     (``cfgs['matcher']['model']`` -> ``build_model``, ``cfgs['data']['img_resize']``, ``cfgs['matcher']['pair_name_split']``).
     covis_pairs_out: list of "path0 path1" strings or a file of such lines.  ``frames``: optional {path: decoded uint8
-    array} to skip the file decode.  Returns {path0<split>path1: ndarray [N,5]} like the reference.  Only the coarse_only
-    model type exists here, so the grid rounding of :131-133 never applies."""
+    array} to skip the file decode.  Returns {path0<split>path1: ndarray [N,5]} like the reference.
+    Grid rounding (:133-136): the reference's guard is ``args['model']['type'] is not 'coarse_only'`` -- a string IDENTITY
+    test.  It is False for a type string that is the interned literal (a Python-level config) and True for an equal string
+    that comes out of YAML / hydra, in which case the reference rounds even in coarse_only mode whenever
+    ``round_matches_ratio`` is set.  The same identity test and the same rounding expression are used here, so a config
+    behaves as it does in the reference either way (the shipped coarse_only configs set the ratio to null)."""
     from . import images
     margs = cfgs["matcher"]["model"]
+    ratio = cfgs["matcher"].get("round_matches_ratio")
     detector, matcher = models if models is not None else build_model(margs)
     matcher.to(device)
     rule = dict(_DATA_RULES[margs["matcher"]])
@@ -299,15 +323,19 @@ def match_worker(subset_ids, image_lists, covis_pairs_out, cfgs, device="cuda", 
         data = {"image0": img0[None], "image1": img1[None], "scale0": scale0[None].to(device), "scale1": scale1[None].to(device),
                 "pair_key": ([p0], [p1]), "frameID": pair_idx}
         mkpts0, mkpts1, mconfs = extract_matches(data, detector=detector, matcher=matcher)
+        if margs.get("type", _COARSE_ONLY) is not _COARSE_ONLY and ratio is not None:      # identity, as in the reference
+            sc0, sc1 = scale0[None].cpu().numpy()[:, [1, 0]], scale1[None].cpu().numpy()[:, [1, 0]]
+            mkpts0 = np.round((mkpts0 / sc0) / ratio) * ratio * sc0
+            mkpts1 = np.round((mkpts1 / sc1) / ratio) * ratio * sc1
         matches[split.join([p0, p1])] = np.concatenate([mkpts0, mkpts1, mconfs[:, None]], -1)
     return matches
 
 
 @torch.no_grad()
-def match_worker_sharded(image_lists, covis_pairs_out, cfgs, device="cuda", frames=None, models=None, group=None):
+def match_worker_sharded(image_lists, covis_pairs_out, cfgs, device="cuda", frames=None, models=None, group=None, root=0):
     """The reference's Ray fan-out of ``match_worker`` over chunks of the pair list (coarse_match.py:127-140) as one process
-    per GPU: rank r matches its contiguous shard, ONE all-gather (``dist.all_gather_tables``) hands every rank the scene's
-    table dictionary in pair order."""
+    per GPU: rank r matches its contiguous shard, ONE payload collective (``dist.collect_tables``) hands rank ``root`` (every
+    rank with root=None) the scene's table dictionary in pair order; the other ranks return None."""
     from . import dist as ddist
     import torch.distributed as tdist
     if isinstance(covis_pairs_out, (list, tuple)):
@@ -321,7 +349,10 @@ def match_worker_sharded(image_lists, covis_pairs_out, cfgs, device="cuda", fram
     mine = match_worker(list(range(lo, hi)), image_lists, pair_list, cfgs, device=device, frames=frames, models=models)
     split = cfgs["matcher"].get("pair_name_split", " ")
     keys = [split.join(p.split(" ")) for p in pair_list]
-    tables = ddist.all_gather_tables([torch.from_numpy(mine[k]).to(torch.float32).to(device) for k in keys[lo:hi]], group=group)
+    tables = ddist.collect_tables([torch.from_numpy(mine[k]).to(torch.float32).to(device) for k in keys[lo:hi]], group=group,
+                                  root=root)
+    if tables is None:
+        return None
     assert len(tables) == len(keys)
     return {k: t.cpu().numpy() for k, t in zip(keys, tables)}
 
@@ -367,12 +398,15 @@ def match_tracks_worker(colmap_dataset, matcher, subset_track_idxs=None, dataset
 
 
 @torch.no_grad()
-def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, device="cuda", group=None):
+def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, device="cuda", group=None, root=0):
     """One scene's feature tracks on all ranks of the process group -- the analogue of ``multiview_matcher`` with Ray
     (src/post_optimization/matcher_model/multiview_match.py:39-62): tracks are dealt to the ranks by index
     (``dist.shard_tracks``: all bags of one track on one rank), every rank runs ``match_tracks_worker`` on its subset,
-    and the [M,4] result rows are collected with ONE all-gather of variable-length tables (RCCL over xGMI / gloo).
-    Returns the concatenated list of per-bag arrays, identical on every rank (rank order, then bag order)."""
+    and the [M,4] result rows are collected with ONE payload collective of variable-length tables (RCCL over xGMI / gloo)
+    as 16-byte rows: the two coordinates are fp32 values already (``.cpu().numpy()`` of fp32 tensors, widened to float64 only
+    by the reference's ``np.concatenate`` with the integer columns, multiview_match_worker.py:136-139), so they travel as
+    their fp32 bits, and the image id / keypoint index as int32.  Returns the concatenated list of per-bag float64 arrays
+    (rank order, then bag order) on rank ``root`` (default 0; None elsewhere) or on every rank with root=None."""
     from . import dist as ddist
     import torch.distributed as tdist
     world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
@@ -382,8 +416,19 @@ def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, devic
     if world == 1:
         return mine
     dev = torch.device(device)
-    # ids fit float64 exactly; the reference's own rows are float64 for the same reason (np.concatenate with int columns)
-    hi = [torch.from_numpy(a.astype(np.float32)).to(dev) for a in mine]
-    lo = [torch.from_numpy((a - a.astype(np.float32).astype(np.float64)).astype(np.float32)).to(dev) for a in mine]
-    tabs = ddist.all_gather_tables([torch.cat([h, l], 1) for h, l in zip(hi, lo)], group=group)
-    return [(t[:, :4].double() + t[:, 4:].double()).cpu().numpy() for t in tabs]
+    words = []
+    for a in mine:
+        xy = a[:, :2].astype(np.float32)
+        ids = a[:, 2:]
+        if not (np.array_equal(xy.astype(np.float64), a[:, :2]) and np.array_equal(np.rint(ids), ids) and
+                (np.abs(ids) < 2 ** 31).all()):
+            raise ValueError("refine_scene_sharded: result rows are not (fp32 x, fp32 y, int32 image id, int32 keypoint index)")
+        words.append(torch.from_numpy(np.concatenate([xy.view(np.int32), ids.astype(np.int32)], 1)).to(dev))
+    tabs = ddist.collect_tables(words, group=group, root=root, dtype=torch.int32)
+    if tabs is None:
+        return None
+    out = []
+    for t in tabs:
+        w = t.cpu().numpy()
+        out.append(np.concatenate([w[:, :2].copy().view(np.float32).astype(np.float64), w[:, 2:].astype(np.float64)], 1))
+    return out

@@ -31,6 +31,16 @@ def _worker(rank, world, port, q):
     ok = len(got) == 10 and all(torch.equal(a, b) for a, b in zip(got, all_tables))
     empty = ddist.all_gather_tables([] if rank == 0 else [torch.ones(2, 4)])
     ok = ok and len(empty) == 1 and torch.equal(empty[0], torch.ones(2, 4))
+    # gather-to-root: only the root receives (an exact-size buffer); int32 tables travel bit for bit
+    for root in (0, 1):
+        got = ddist.collect_tables(all_tables[lo:hi], root=root)
+        ok = ok and ((got is None) if rank != root else
+                     (len(got) == 10 and all(torch.equal(a, b) for a, b in zip(got, all_tables))))
+    ints = [torch.arange(12, dtype=torch.int32).view(3, 4) * (rank + 1) - 7, torch.zeros((0, 4), dtype=torch.int32)]
+    gi = ddist.collect_tables(ints, root=None, dtype=torch.int32)
+    ok = ok and len(gi) == 4 and gi[0].dtype == torch.int32 and torch.equal(gi[2], torch.arange(12, dtype=torch.int32).view(3, 4) * 2 - 7)
+    none = ddist.collect_tables([], root=0)
+    ok = ok and (none == [] if rank == 0 else none is None)
     q.put((rank, ok, len(pairs)))
     dist.barrier()
     dist.destroy_process_group()
@@ -67,9 +77,12 @@ def _scene_worker(rank, world, port, q):
     images = torch.cat([base["image0"], base["image1"]], 0)            # 4 images -> 6 exhaustive pairs, 3 per rank
     names = [f"scene/img{k}.jpg" for k in range(4)]
     with cpu_ops(), torch.no_grad():
-        matches, kp, sc, upd = plugin.match_scene_sharded(m, images, names, " ", batch=2)
-        ok = len(matches) == 6 and list(matches) == [f"{names[i]} {names[j]}" for i, j in ddist.exhaustive_pairs(4)]
+        on_root = plugin.match_scene_sharded(m, images, names, " ", batch=2)          # default: gather-to-root 0
+        ok = (on_root is None) == (rank != 0)
+        matches, kp, sc, upd = plugin.match_scene_sharded(m, images, names, " ", batch=2, root=None)
+        ok = ok and len(matches) == 6 and list(matches) == [f"{names[i]} {names[j]}" for i, j in ddist.exhaustive_pairs(4)]
         if rank == 0:          # the same scene in one process
+            ok = ok and all(np.array_equal(on_root[0][k], matches[k]) for k in matches)
             full = plugin.match_scene_cached(m, images, ddist.exhaustive_pairs(4), batch=2)
             ref = {f"{names[i]} {names[j]}": t for (i, j), t in full.items()}
             kp1, sc1, upd1 = plugin.merge_match_tables(ref, names, " ", device="cpu")
@@ -118,11 +131,16 @@ def _refine_worker(rank, world, port, q):
         rows = np.concatenate(results, 0)
         return {(int(r[2]), int(r[3])): r[:2] for r in rows}, rows.shape[0]
     with cpu_ops(), torch.no_grad():
-        got, n_got = table(plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu"))
-        ok = True
+        res_all = plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu", root=None)
+        got, n_got = table(res_all)
+        res_root = plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu")              # default: gather-to-root 0
+        ok = (res_root is None) == (rank != 0)
+        if rank == 0:
+            ok = ok and len(res_root) == len(res_all) and all(a.dtype == np.float64 and np.array_equal(a, b)
+                                                              for a, b in zip(res_root, res_all))
         if rank == 0:
             ref, n_ref = table(plugin.match_tracks_worker(scene, m, None, dcfg, device="cpu"))
-            ok = n_got == n_ref and set(got) == set(ref) and all(np.abs(got[k] - ref[k]).max() < 1e-3 for k in ref)
+            ok = ok and n_got == n_ref and set(got) == set(ref) and all(np.abs(got[k] - ref[k]).max() < 1e-3 for k in ref)
     q.put((rank, bool(ok), n_got))
     dist.barrier()
     dist.destroy_process_group()

@@ -97,14 +97,38 @@ def test_match_worker_tables_equal_oracle(which):
     assert list(sub) == [PAIRS[2]] and np.array_equal(sub[PAIRS[2]], got[PAIRS[2]])
 
 
+def test_round_matches_ratio_follows_the_reference_identity_test():
+    """coarse_match_worker.py:134 guards the grid rounding with ``type is not 'coarse_only'`` (identity).  A literal type string
+    is that very object -> no rounding (the case above, ratio 4 set); an equal string built at run time (what YAML / hydra
+    hands over) is another object -> the reference rounds, and so does this worker, with the reference's expression."""
+    frames = scene_frames()
+    cfgs, models, _ = build("loftr_hip")
+    with cpu_ops():
+        plain = plugin.match_worker([0], list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)[PAIRS[0]]
+        cfgs["matcher"]["model"]["type"] = "".join(["coarse", "_only"])            # equal, not identical
+        assert cfgs["matcher"]["model"]["type"] == "coarse_only" and cfgs["matcher"]["model"]["type"] is not plugin._COARSE_ONLY
+        cfgs["matcher"]["round_matches_ratio"] = 12          # coarse cells sit on multiples of 8: ratio 4 would change nothing
+        rounded = plugin.match_worker([0], list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)[PAIRS[0]]
+        cfgs["matcher"]["round_matches_ratio"] = None
+        unrounded = plugin.match_worker([0], list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)[PAIRS[0]]
+    assert np.array_equal(unrounded, plain) and len(plain) > 10
+    sc = np.array([[2.0, 2.0]], dtype=np.float32)                                  # 256x192 frames read at 128
+    for c in (slice(0, 2), slice(2, 4)):
+        assert np.array_equal(rounded[:, c], np.round((plain[:, c] / sc) / 12) * 12 * sc)
+    assert np.array_equal(rounded[:, 4], plain[:, 4]) and not np.array_equal(rounded[:, :4], plain[:, :4])
+
+
 def _sharded(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = scene_frames()
     cfgs, models, _ = build("loftr_hip")
     with cpu_ops():
-        got = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)
+        on_root = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)
+        assert (on_root is None) == (rank != 0)                    # default: gather-to-root 0
+        got = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models, root=None)
         if rank == 0:
+            assert list(on_root) == PAIRS and all(np.array_equal(on_root[p], got[p]) for p in PAIRS)
             ref = plugin.match_worker([0, 1, 2], list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)
             ok = list(got) == PAIRS and all(np.array_equal(got[p], ref[p]) for p in PAIRS) and sum(len(v) for v in got.values()) > 30
         else:
