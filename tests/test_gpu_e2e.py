@@ -168,6 +168,21 @@ def test_loftr_832_config5_batch_invariance(built_lib):
         assert n > 5000
 
 
+def test_loftr_832_config5_vs_oracle(built_lib):
+    """BASELINE configs[4] frame size against the ORACLE (not only against itself): one planted 832x832 pair end to end
+    under the per-entry rules -- L = S = 10816, the 117 M-entry confidence matrix of
+    third_party/LoFTR/src/loftr/utils/coarse_matching.py:103-116 and the mutual-NN selection :171-193 at the size where a
+    row has the most competitors."""
+    cfg, sd, m = _loftr(0.2)
+    data = synth.coarse_pair_batch(1, 832, 832, seed=51)
+    d = synth.to_device(data, DEV)
+    m(d)
+    o, conf = _oracle_coarse(sd, cfg, data)
+    assert tuple(d["hw0_c"]) == (104, 104) and o["i_ids"].numel() > 6000
+    ex = _strict_coarse(d, o, conf, 0.2, "832x832 planted")
+    assert len(ex) <= 3
+
+
 def test_loftr_batch_equals_singles(built_lib):
     """Batch of 4 pairs == 4 single-pair calls (pairs are independent units of work)."""
     cfg, sd, m = _loftr(0.2)
@@ -349,6 +364,80 @@ def test_refine_plugin_surface(built_lib, tmp_path):
     m2 = plugin.build_refine_model({"weight_path": [None]}, rewindow_size_factor=2)
     assert m2.config["multiview_transform"]["window_size"] == 11
     assert m2.config["multiview_matching_test"]["left_point_movement_window_size"] == 3
+
+
+def test_multiview_16_views_ragged_vs_oracle(built_lib):
+    """The production track length: ``max_track_length: 16`` (src/post_optimization/post_optimization.py:25) => one
+    reference view + up to 15 query views per track.  A ragged bag with lengths 2..16 (so every view-count group of
+    MultiviewMatcher.py:117-133 from 15 query views down to 1 occurs) through the whole head, against the oracle."""
+    cfg, sd, m = _refiner(1)
+    data = synth.refine_bag(T=40, V=16, H=240, W=320, seed=2200, variable_lengths=True)
+    lens = data["track_valid_mask"][0].sum(0) + 1
+    assert int(lens.max()) == 16 and int(lens.min()) <= 4
+    g = torch.Generator().manual_seed(9)
+    data["scales"] = 0.75 + 0.5 * torch.rand((1, 16, 2), generator=g)
+    d = synth.to_device(data, DEV)
+    m(d)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data)
+    flips = _strict_refine(d, o, data, 7, "16 views, ragged")
+    assert len(flips) <= 2
+    assert d["reference_points_refined"][-1].shape == (1, 15, 40, 2)
+
+
+def test_multiview_second_iteration_window_vs_oracle(built_lib):
+    """The matcher of the second refinement iteration: ``build_model(args, rewindow_size_factor=2)`` shrinks the search window
+    to W = 11 and the left-point window to 3 (multiview_match_worker.py:20-34; crop 35 kept, so S2DNet's centre slice, the
+    bicubic window, K1's 121-token groups and K11's 9 candidates all change shape)."""
+    sd = random_state_dict(multiview_param_spec(multiview_refinement_config()), 1)
+    m = plugin.build_refine_model({"weight_path": [None], "seed": 1}, rewindow_size_factor=2)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    cfg = m.config
+    assert cfg["multiview_transform"]["window_size"] == 11 and cfg["multiview_matching_test"]["left_point_movement_window_size"] == 3
+    data = synth.refine_bag(T=48, V=5, H=240, W=320, seed=2300, variable_lengths=True)
+    g = torch.Generator().manual_seed(4)
+    data["query_movable_mask"] = torch.rand((1, 48), generator=g) > 0.15
+    d = synth.to_device(data, DEV)
+    m(d)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data)
+    assert o["cand_score"].shape[-1] == 9
+    flips = _strict_refine(d, o, data, 3, "W=11 / left=3")
+    assert len(flips) <= 2
+    # refined references stay inside the shrunk window
+    dr = (d["reference_points_refined"][-1].cpu() - data["reference_points_coarse"]).abs()
+    assert dr[data["track_valid_mask"]].max().item() <= 5.5
+
+
+def test_multiview_padded_image_tensor_vs_oracle(built_lib):
+    """``data['images']`` as ONE padded tensor [1, N, 3, h, w] (MultiviewMatcher.py:60-62, 201-203: the reference slices
+    ``images[:, img_idx]``) instead of a list: frames of different sizes padded bottom / right with zeros, tracks placed so
+    that crops run across the frame border into the padding (RoIAlign then normalises by the PADDED size)."""
+    cfg, sd, m = _refiner(1)
+    T, V, hp, wp = 36, 4, 200, 264
+    data = synth.refine_bag(T=T, V=V, H=hp, W=wp, seed=2400, variable_lengths=True)
+    sizes = [(200, 264), (168, 264), (200, 216), (152, 200)]
+    imgs = torch.zeros((1, V, 3, hp, wp))
+    for v, (h, w) in enumerate(sizes):
+        imgs[0, v, :, :h, :w] = data["images"][v][0, :, :h, :w]
+    g = torch.Generator().manual_seed(12)
+    for v, (h, w) in enumerate(sizes):                     # a third of the points of every view hug its own frame border
+        pts = data["query_points"][0] if v == 0 else data["reference_points_coarse"][0, v - 1]
+        sel = torch.rand(T, generator=g) < 0.34
+        pts[sel, 0] = w - 1 - 6 * torch.rand(int(sel.sum()), generator=g)
+        pts[sel, 1] = torch.minimum(pts[sel, 1], torch.tensor(float(h - 1)))
+    data_t = dict(data)
+    data_t["images"] = imgs
+    d = synth.to_device({k: v for k, v in data_t.items()}, DEV)
+    assert isinstance(d["images"], torch.Tensor) and d["images"].shape == (1, V, 3, hp, wp)
+    m(d)
+    data_l = dict(data)
+    data_l["images"] = [imgs[:, v].contiguous() for v in range(V)]
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data_l)
+    flips = _strict_refine(d, o, data_l, 7, "padded image tensor")
+    assert len(flips) <= 2
 
 
 def test_scene_matching_cached_tokens_equals_pairwise(built_lib):
