@@ -9,8 +9,7 @@ dict), same ``state_dict`` layout (``load_state_dict(strict=True)`` of the offic
 Every kernel of the path is hand-written HIP (``libdfsfm_hip.so``): the ResNet convolutions and all ``nn.Linear``
 GEMMs on the fp16x2-split MFMA implicit-GEMM kernels (folded BN, ReLU, residual, LayerNorm in the epilogue), linear
 attention (K1) inside every encoder layer, and the fused correlation / dual-softmax / mutual-NN / keypoint stage
-(K3-K5).  ``dense_backend="library"`` (MIOpen / hipBLASLt fp32 through PyTorch) exists only as an explicit
-measurement control.  Output-identical work the reference wastes is skipped:
+(K3-K5).  There is no library (MIOpen / hipBLASLt) path in this package.  Output-identical work the reference wastes is skipped:
 the FPN top-down branch (dead when fine.enable=False, resnet_fpn.py:110-116) and the dense
 ``conf_matrix`` (never read by an inference caller).
 """
@@ -19,7 +18,6 @@ import math
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .params import ParamModule, loftr_param_spec
@@ -44,79 +42,33 @@ def position_encoding_sine(d_model: int, max_shape=(256, 256), temp_bug_fix: boo
 
 
 def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
-    """conv -> eval BatchNorm == conv with scaled weights + bias."""
-    s = bn_w / torch.sqrt(var + eps)
-    return (w * s[:, None, None, None]).contiguous(), (bn_b - mean * s).contiguous()
+    """conv -> eval BatchNorm == conv with scaled weights + bias.  Folded in float64: the products w*s are then split
+    into the fp16 hi/lo planes (ops.PackedDense) from their exact values instead of from an fp32 rounding of them -- the
+    fold adds no rounding of its own to the 22-bit weight representation (tools/studies/aspan_noise_study.py: every
+    backbone layer's rounding is amplified ~500x by ASpanFormer's transformer)."""
+    s = bn_w.double() / torch.sqrt(var.double() + eps)
+    return (w.double() * s[:, None, None, None]).contiguous(), (bn_b.double() - mean.double() * s).contiguous()
 
 
 class EncoderLayerWeights:
-    """Packed weights of one LoFTREncoderLayer (transformer.py:7-33)."""
+    """Packed weights of one LoFTREncoderLayer (transformer.py:7-33): fp16x2-split operands of dfsfm_conv2d_nhwc_f32 (1x1 case)."""
 
-    def __init__(self, get, prefix, backend="hip"):
+    def __init__(self, get, prefix):
         wq, wk, wv = get(prefix + "q_proj.weight"), get(prefix + "k_proj.weight"), get(prefix + "v_proj.weight")
-        self.backend = backend
-        self.wq = wq.contiguous()
-        self.wkv = torch.cat([wk, wv], 0).contiguous()
-        self.wqkv = torch.cat([wq, wk, wv], 0).contiguous()
-        self.merge = get(prefix + "merge.weight").contiguous()
-        self.w1t = get(prefix + "mlp.0.weight").t()          # [2C_in, 2C_out] view for addmm
-        self.b1 = torch.zeros(self.w1t.shape[1], dtype=wq.dtype, device=wq.device)
-        self.w2 = get(prefix + "mlp.2.weight").contiguous()
+        self.pq, self.pkv = ops.PackedDense(wq), ops.PackedDense(torch.cat([wk, wv], 0))
+        self.pqkv = ops.PackedDense(torch.cat([wq, wk, wv], 0))
+        self.pmerge, self.p2 = ops.PackedDense(get(prefix + "merge.weight")), ops.PackedDense(get(prefix + "mlp.2.weight"))
+        self.p1 = ops.PackedDense(get(prefix + "mlp.0.weight"))
         self.n1 = (get(prefix + "norm1.weight").contiguous(), get(prefix + "norm1.bias").contiguous())
         self.n2 = (get(prefix + "norm2.weight").contiguous(), get(prefix + "norm2.bias").contiguous())
-        if backend == "hip":     # fp16x2-split packed weights for dfsfm_conv2d_nhwc_f32 (1x1 case)
-            self.pq, self.pkv, self.pqkv = ops.PackedDense(self.wq), ops.PackedDense(self.wkv), ops.PackedDense(self.wqkv)
-            self.pmerge, self.p2 = ops.PackedDense(self.merge), ops.PackedDense(self.w2)
-            self.p1 = ops.PackedDense(get(prefix + "mlp.0.weight"))
-
-
-def encoder_layer(w: EncoderLayerWeights, xm, source, out, nhead, x_mask=None, source_mask=None,
-                  q_group=1, kv_group=1, is_self=False):
-    """LoFTREncoderLayer.forward (LoFTR transformer.py:35-58; multiview copy
-    src/MultiviewMatcher/matcher_module/transformer.py:66-95), concat-free:
-
-    ``xm`` [N,L,2C] holds x in ``xm[..., :C]``; its second half is where norm1(message) lands, so
-    ``torch.cat([x, message])`` never happens -- the MLP GEMM reads ``xm`` as is.  ``source``
-    [N,S,C] and ``out`` [N,L,C] may be row-strided views (e.g. the first half of another
-    [.., 2C] buffer); ``out`` receives ``x + norm2(mlp(...))``.
-
-    GEMMs (q|k|v fused for self, k|v for cross; ReLU as GEMM epilogue): backend "hip" = the
-    hand-written fp16x2-split MFMA kernel (dfsfm_conv2d_nhwc_f32, 1x1 case); backend "library" =
-    hipBLASLt fp32 through torch (measurement control).  K1, both LayerNorms and the residual add
-    are hand-written HIP either way."""
-    N, L, C2 = xm.shape
-    C = C2 // 2
-    D = C // nhead
-    S = source.shape[1]
-    xm2 = xm.view(N * L, C2)
-    x2 = xm2[:, :C]                                        # [rows, C] view, row stride 2C: no copy
-    hip = w.backend == "hip"
-    if is_self:
-        qkv = (ops.linear(x2, w.pqkv) if hip else F.linear(x2, w.wqkv)).view(N, L, 3 * C)
-        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    else:
-        src2 = source.reshape(N * S, C)
-        q = (ops.linear(x2, w.pq) if hip else F.linear(x2, w.wq)).view(N, L, C)
-        kv = (ops.linear(src2, w.pkv) if hip else F.linear(src2, w.wkv)).view(N, S, 2 * C)
-        k, v = kv[..., :C], kv[..., C:]
-    msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
-                               v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group)
-    msg2 = msg.view(N * L, C)
-    merged = ops.linear(msg2, w.pmerge) if hip else F.linear(msg2, w.merge)
-    ops.layernorm(merged, w.n1[0], w.n1[1], out=xm2[:, C:])                   # norm1 -> [x | message]
-    if hip:
-        h = ops.linear(xm2, w.p1, relu=True)                                  # relu(mlp.0([x|message]))
-        o = ops.linear(h, w.p2)
-    else:
-        h = torch._addmm_activation(w.b1, xm2, w.w1t)
-        o = F.linear(h, w.w2)
-    ops.layernorm(o.view(N, L, C), w.n2[0], w.n2[1], residual=xm[..., :C], out=out)   # x + norm2(.)
-    return out
 
 
 def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
                         q_group=1, kv_group=1, is_self=False):
-    """The same layer with every GEMM on the split-plane LDS-DMA kernels: the token state lives ONLY as split
+    """LoFTREncoderLayer.forward (LoFTR transformer.py:35-58; multiview copy
+    src/MultiviewMatcher/matcher_module/transformer.py:66-95) with every GEMM on the split-plane LDS-DMA kernels, concat-free
+    (``torch.cat([x, message])`` never happens: norm1(message) lands in the second half of the [x | message] buffer the MLP
+    GEMM reads), q|k|v fused for self attention, k|v for cross, ReLU in the GEMM epilogue: the token state lives ONLY as split
     fp16 planes (ops.SplitAct, value = hi + lo/2048), written by the epilogue of whichever kernel computes it
     (LayerNorm, attention apply, GEMM) -- no conversion pass, no concat, no fp32 copy of the residual chain.
 
@@ -154,7 +106,7 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
     return out_x
 
 
-def fold_backbone(g, with_fpn=False):
+def fold_backbone(g):
     """ResNetFPN_8_2 weights (backbone/resnet_fpn.py:43-118) with eval-mode BatchNorm folded into (weight, bias) pairs;
     ``g(name)`` fetches a tensor by its state_dict name.  Shared by HipLoFTR and HipASpanFormer (ASpanFormer's backbone file
     is identical)."""
@@ -173,11 +125,6 @@ def fold_backbone(g, with_fpn=False):
                 blk["down"] = conv_bn(q + ".downsample.0", q + ".downsample.1")
             P[f"l{li}b{bi}"] = blk
     P["l3out"] = g("backbone.layer3_outconv.weight")
-    if with_fpn:
-        P["l2out"] = g("backbone.layer2_outconv.weight")
-        P["l1out"] = g("backbone.layer1_outconv.weight")
-        for nm in ("layer2_outconv2", "layer1_outconv2"):
-            P[nm] = (conv_bn(f"backbone.{nm}.0", f"backbone.{nm}.1"), g(f"backbone.{nm}.3.weight"))
     return P
 
 
@@ -213,14 +160,8 @@ def backbone_tokens_hip(x, H):
 
 
 class HipLoFTR(ParamModule):
-    def __init__(self, config: dict, skip_dead_fpn: bool = True, dense_backend: str = "hip"):
-        """dense_backend: "hip" (default) runs every convolution and linear layer on the hand-written
-        fp16x2-split MFMA kernel; "library" routes them to MIOpen / hipBLASLt fp32 through PyTorch and
-        exists as an explicit measurement control, never as a silent fallback."""
+    def __init__(self, config: dict):
         super().__init__()
-        if dense_backend not in ("hip", "library"):
-            raise ValueError(dense_backend)
-        self.dense_backend = dense_backend
         self.same_conv = os.environ.get("DFSFM_SAME_CONV", "1") != "0"   # A/B switch for the tap-reuse conv kernel
         if config["match_coarse"]["match_type"] != "dual_softmax":
             raise NotImplementedError("only the dual_softmax coarse matcher is on the hot path")
@@ -230,7 +171,6 @@ class HipLoFTR(ParamModule):
         if config["coarse"]["attention"] != "linear":
             raise NotImplementedError("only linear attention")
         self.config = config
-        self.skip_dead_fpn = skip_dead_fpn
         self.register_spec(loftr_param_spec(config))
         self.register_buffer("pe", position_encoding_sine(config["coarse"]["d_model"],
                                                           temp_bug_fix=config["coarse"]["temp_bug_fix"]),
@@ -252,11 +192,10 @@ class HipLoFTR(ParamModule):
     # -- weight packing -----------------------------------------------------------------------
     def _pack(self):
         g = self.p
-        P = fold_backbone(g, with_fpn=not self.skip_dead_fpn)
+        P = fold_backbone(g)
         n_layers = len(self.config["coarse"]["layer_names"])
-        P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.", self.dense_backend) for i in range(n_layers)]
-        if self.dense_backend == "hip":
-            P["hip"] = pack_backbone_hip(P, self.same_conv)
+        P["enc"] = [EncoderLayerWeights(g, f"loftr_coarse.layers.{i}.") for i in range(n_layers)]
+        P["hip"] = pack_backbone_hip(P, self.same_conv)
         self._packed = P
         return P
 
@@ -267,45 +206,18 @@ class HipLoFTR(ParamModule):
         epilogue splits once, consumers DMA the planes straight into LDS."""
         return backbone_tokens_hip(x, P["hip"])
 
-    # -- K6, library control path: MIOpen fp32 convs (ResNetFPN_8_2.forward, resnet_fpn.py:100-118) ----
-    def _backbone(self, x, P):
-        def block(t, b):
-            y = F.relu_(F.conv2d(t, b["c1"][0], b["c1"][1], b["stride"], 1))
-            y = F.conv2d(y, b["c2"][0], b["c2"][1], 1, 1)
-            if "down" in b:
-                t = F.conv2d(t, b["down"][0], b["down"][1], b["stride"], 0)
-            return F.relu_(y.add_(t))
-        x0 = F.relu_(F.conv2d(x, P["stem"][0], P["stem"][1], 2, 3))
-        x1 = block(block(x0, P["l1b0"]), P["l1b1"])
-        x2 = block(block(x1, P["l2b0"]), P["l2b1"])
-        x3 = block(block(x2, P["l3b0"]), P["l3b1"])
-        x3_out = F.conv2d(x3, P["l3out"])
-        if self.skip_dead_fpn:
-            return x3_out, None
-
-        def outconv2(q, t):
-            (w0, b0), w3 = P[q]
-            return F.conv2d(F.leaky_relu_(F.conv2d(t, w0, b0, 1, 1), 0.01), w3, None, 1, 1)
-        x3_2x = F.interpolate(x3_out, scale_factor=2.0, mode="bilinear", align_corners=True)
-        x2_out = outconv2("layer2_outconv2", F.conv2d(x2, P["l2out"]) + x3_2x)
-        x2_2x = F.interpolate(x2_out, scale_factor=2.0, mode="bilinear", align_corners=True)
-        x1_out = outconv2("layer1_outconv2", F.conv2d(x1, P["l1out"]) + x2_2x)
-        return x3_out, x1_out
-
     # -- K2/K1: LocalFeatureTransformer.forward (transformer.py:80-101) -------------------------
     def _transformer(self, f0, f1, P, pe0=None, pe1=None):
         """f0 [N,L,C], f1 [N,S,C] (+ optional positional-encoding tables added on the way in) -> updated
         features (contiguous fp32).  When both images have the same grid they share buffers so that
-        self layers run as ONE batch of 2N sequences.
-        backend "hip": split planes [.,.,2C] = [x | norm1(message)] ping-pong, fp32 only for the result
-        (encoder_layer_split); backend "library": fp32 [.,.,2C] buffers (encoder_layer)."""
+        self layers run as ONE batch of 2N sequences.  Split planes [.,.,2C] = [x | norm1(message)] ping-pong, fp32 only
+        for the result (encoder_layer_split)."""
         nhead = self.config["coarse"]["nhead"]
         names = self.config["coarse"]["layer_names"]
         N, L, C = f0.shape
         S = f1.shape[1]
         same = L == S
         dev = f0.device
-        hip = self.dense_backend == "hip"
 
         def new_f32(width):
             if same:
@@ -320,83 +232,44 @@ class HipLoFTR(ParamModule):
                 return big, big[:N], big[N:]
             return None, ops.SplitAct.empty_rows((N, L), width, dev), ops.SplitAct.empty_rows((N, S), width, dev)
 
-        if hip:
-            XS, XSn = new_split(2 * C), new_split(2 * C)
-            ops.split_rows(f0, pe0, out_split=XS[1].cols(0, C))
-            ops.split_rows(f1, pe1, out_split=XS[2].cols(0, C))
-            fin = new_split(C)      # the final features as contiguous split planes: operands of the correlation
-            out = (None, None, None)
-            for li, (w, name) in enumerate(zip(P["enc"], names)):
-                last = li == len(names) - 1
-                oxs = fin if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
-                if last:
-                    out = new_f32(C)            # fp32 copy of the final features only
-                if name == "self":
-                    if same:   # both images through one batched call
-                        encoder_layer_split(w, XS[0], XS[0].cols(0, C), out[0], oxs[0], nhead, is_self=True)
-                    else:
-                        for i in (1, 2):
-                            encoder_layer_split(w, XS[i], XS[i].cols(0, C), out[i], oxs[i], nhead, is_self=True)
-                elif name == "cross":
-                    encoder_layer_split(w, XS[1], XS[2].cols(0, C), out[1], oxs[1], nhead)
-                    encoder_layer_split(w, XS[2], oxs[1], out[2], oxs[2], nhead)         # sees the updated feat0 (:96-97)
-                else:
-                    raise KeyError(name)
-                XS, XSn = XSn, XS
-            self._feat_split = (fin[1], fin[2])
-            return out[1], out[2]
-
-        cur = new_f32(2 * C)
-        nxt = new_f32(2 * C)
-        cur[1][..., :C] = f0 if pe0 is None else f0 + pe0
-        cur[2][..., :C] = f1 if pe1 is None else f1 + pe1
+        XS, XSn = new_split(2 * C), new_split(2 * C)
+        ops.split_rows(f0, pe0, out_split=XS[1].cols(0, C))
+        ops.split_rows(f1, pe1, out_split=XS[2].cols(0, C))
+        fin = new_split(C)      # the final features as contiguous split planes: operands of the correlation
+        out = (None, None, None)
         for li, (w, name) in enumerate(zip(P["enc"], names)):
             last = li == len(names) - 1
-            dst = new_f32(C) if last else tuple(None if b is None else b[..., :C] for b in nxt)
+            oxs = fin if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
+            if last:
+                out = new_f32(C)            # fp32 copy of the final features only
             if name == "self":
-                if same:
-                    encoder_layer(w, cur[0], cur[0][..., :C], dst[0], nhead, is_self=True)
+                if same:   # both images through one batched call
+                    encoder_layer_split(w, XS[0], XS[0].cols(0, C), out[0], oxs[0], nhead, is_self=True)
                 else:
-                    encoder_layer(w, cur[1], cur[1][..., :C], dst[1], nhead, is_self=True)
-                    encoder_layer(w, cur[2], cur[2][..., :C], dst[2], nhead, is_self=True)
+                    for i in (1, 2):
+                        encoder_layer_split(w, XS[i], XS[i].cols(0, C), out[i], oxs[i], nhead, is_self=True)
             elif name == "cross":
-                encoder_layer(w, cur[1], cur[2][..., :C], dst[1], nhead)
-                encoder_layer(w, cur[2], dst[1], dst[2], nhead)       # sees the UPDATED feat0 (:96-97)
+                encoder_layer_split(w, XS[1], XS[2].cols(0, C), out[1], oxs[1], nhead)
+                encoder_layer_split(w, XS[2], oxs[1], out[2], oxs[2], nhead)         # sees the updated feat0 (:96-97)
             else:
                 raise KeyError(name)
-            if last:
-                return dst[1], dst[2]
-            cur, nxt = nxt, cur
-        return cur[1][..., :C].contiguous(), cur[2][..., :C].contiguous()
+            XS, XSn = XSn, XS
+        self._feat_split = (fin[1], fin[2])
+        return out[1], out[2]
 
     def coarse_features(self, image0, image1):
         """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c)."""
         P = self._packed or self._pack()
         bs = image0.size(0)
         same = image0.shape[2:] == image1.shape[2:]
-        if self.dense_backend == "hip":
-            if not self.skip_dead_fpn:
-                raise NotImplementedError("the dead FPN branch is only available with dense_backend='library'")
-            if same:
-                c = self._backbone_hip(torch.cat([image0, image1], 0), P)
-                c0, c1 = c[:bs], c[bs:]
-            else:
-                c0, c1 = self._backbone_hip(image0, P), self._backbone_hip(image1, P)
-            hw0_c, hw1_c = tuple(c0.shape[1:3]), tuple(c1.shape[1:3])
-            f0, f1 = self._transformer(c0.flatten(1, 2), c1.flatten(1, 2), P, self._pe_tokens(hw0_c),
-                                       self._pe_tokens(hw1_c))     # pos-enc added while splitting
-            return f0, f1, hw0_c, hw1_c
+        if same:
+            c = self._backbone_hip(torch.cat([image0, image1], 0), P)
+            c0, c1 = c[:bs], c[bs:]
         else:
-            if same:
-                c, _ = self._backbone(torch.cat([image0, image1], 0), P)
-                c0, c1 = c[:bs], c[bs:]
-            else:
-                c0, _ = self._backbone(image0, P)
-                c1, _ = self._backbone(image1, P)
-            hw0_c, hw1_c = tuple(c0.shape[2:]), tuple(c1.shape[2:])
-            f0 = (c0 + self.pe[:, :, :hw0_c[0], :hw0_c[1]]).flatten(2).transpose(1, 2).contiguous()
-            f1 = (c1 + self.pe[:, :, :hw1_c[0], :hw1_c[1]]).flatten(2).transpose(1, 2).contiguous()
-        f0, f1 = self._transformer(f0, f1, P)
+            c0, c1 = self._backbone_hip(image0, P), self._backbone_hip(image1, P)
+        hw0_c, hw1_c = tuple(c0.shape[1:3]), tuple(c1.shape[1:3])
+        f0, f1 = self._transformer(c0.flatten(1, 2), c1.flatten(1, 2), P, self._pe_tokens(hw0_c),
+                                   self._pe_tokens(hw1_c))     # pos-enc added while splitting
         return f0, f1, hw0_c, hw1_c
 
     # -- "backbone once per image" (SURVEY 8(f) rank 1: the reference re-runs the CNN for every pair an image is in)
@@ -404,8 +277,6 @@ class HipLoFTR(ParamModule):
     def image_tokens(self, images):
         """[B,1,H,W] -> (coarse backbone tokens [B, h*w, C] fp32, (h, w)).  Per-image results do not depend on what
         else is in the batch, so they can be cached and paired freely (``match_tokens``)."""
-        if self.dense_backend != "hip":
-            raise NotImplementedError("token caching is implemented for dense_backend='hip'")
         P = self._packed or self._pack()
         c = self._backbone_hip(images, P)
         return c.flatten(1, 2), tuple(c.shape[1:3])
@@ -417,9 +288,8 @@ class HipLoFTR(ParamModule):
         P = self._packed or self._pack()
         self._feat_split = None
         f0, f1 = self._transformer(tok0, tok1, P, self._pe_tokens(tuple(hw0_c)), self._pe_tokens(tuple(hw1_c)))
-        if self._feat_split is not None:
-            f0, f1 = self._feat_split
-            self._feat_split = None
+        f0, f1 = self._feat_split
+        self._feat_split = None
         mc = self.config["match_coarse"]
         return ops.coarse_match(f0, f1, tuple(hw0_c), tuple(hw1_c), mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
                                 scale0, scale1, hw0_i[0] / hw0_c[0])
@@ -441,9 +311,8 @@ class HipLoFTR(ParamModule):
         data.update({"bs": img0.size(0), "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
         self._feat_split = None
         f0, f1, hw0_c, hw1_c = self.coarse_features(img0, img1)
-        if self._feat_split is not None:       # hip backend: correlate the split planes the last LayerNorm wrote
-            f0, f1 = self._feat_split
-            self._feat_split = None
+        f0, f1 = self._feat_split              # correlate the split planes the last LayerNorm wrote
+        self._feat_split = None
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
                      "hw0_f": torch.Size((img0.shape[2] // 2, img0.shape[3] // 2)),
                      "hw1_f": torch.Size((img1.shape[2] // 2, img1.shape[3] // 2))})

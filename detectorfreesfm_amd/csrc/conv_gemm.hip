@@ -24,7 +24,7 @@
 //                                    (ky,kx,ci), 3-stage LDS-DMA ring of whole slabs, lock-step waves
 //   conv_gemm_kernel<VEC_A>          fp32 inputs (image stem): splits in registers while staging, 128x128 tile
 // All share sf_epilogue-style fusion of bias (folded BN), residual, ReLU, optional LayerNorm, fp32 / split stores.
-// Ablation builds (-DDFSFM_ABL_*, tools/abl_conv.sh) switch single resources off for measurements.
+// (The -DDFSFM_ABL_* ablation switches of rounds 1-2 are gone from these sources; their measurements are in DESIGN.md section 3.)
 #include "common.h"
 #include "sf_gemm.h"
 #include <cstdlib>
@@ -278,13 +278,6 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
     constexpr int TILE_LD_ = BN_ + 4;                        // fp32 staging-tile row (floats)
     constexpr int NJ = BN_ * BM_ / (32 * NT);                // 32-wide column blocks per wave (waves: BM_/64 x NT/BM_)
     constexpr int WCOLS = NJ * 32;                            // columns per wave
-#ifdef DFSFM_ABL_NOEPI
-#if defined(__HIP_DEVICE_COMPILE__)
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(accm[i][j]), "v"(accx[i][j]));
-#endif
-    return;
-#endif
     __syncthreads();
     float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -401,9 +394,6 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[it][q] = n + q < g.Cout ? v[it][q] : 0.f;
         }
-#ifdef DFSFM_ABL_NOSTORE
-        if (v[it][0] != 12345.678f) continue;
-#endif
         if (g.out) {
             if (full) {
                 *reinterpret_cast<f32x4*>(g.out + m * g.ldo + n) = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
@@ -506,10 +496,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
         }
     };
     // pieces of a slab: A rows group `wave + 8q`, plane hi/lo (4 pieces), then the weight pieces
-#ifdef DFSFM_ABL_NODMA
-#define DMA_A(q, lo, stage) ((void)0)
-#define DMA_B(j, stage) ((void)0)
-#else
 #define DMA_A(q, lo, stage)                                                                                   \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((lo) ? rxl : rxh,                                                \
                                              (lds_void*)(smem + (stage) * T::STAGE + (lo) * T::A_PLANE +      \
@@ -524,7 +510,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
                                                              plane_ * T::B_PLANE + grp_ * 1024),              \
                                                  16, offB[j], 0, 0, 0);                                       \
     } while (0)
-#endif
     auto issue_all = [&](int stage) __attribute__((always_inline)) {
         addr();
         DMA_A(0, 0, stage);
@@ -550,9 +535,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     half8 a0h[2], a0l[2], b0h[NJ], b0l[NJ], a1h[2], a1l[2], b1h[NJ], b1l[NJ];
     auto read_frags = [&](const char* st, int ks, half8 (&ah)[2], half8 (&al)[2], half8 (&bh)[NJ],
                           half8 (&bl)[NJ]) __attribute__((always_inline)) {
-#ifdef DFSFM_ABL_NOREAD
-        if (ks >= 0) return;
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int off = tile_off(wr * 64 + i * 32 + col, ks * 2 + kgrp);
@@ -568,10 +550,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     };
     auto mma = [&](const half8 (&ah)[2], const half8 (&al)[2], const half8 (&bh)[NJ], const half8 (&bl)[NJ])
                    __attribute__((always_inline)) {
-#ifdef DFSFM_ABL_NOMMA
-        asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(bh[0]), "v"(bl[0]), "v"(ah[1]), "v"(al[1]));
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -596,10 +574,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     read_frags(smem, 0, a0h, a0l, b0h, b0l);
     auto mma3 = [&](const half8& ah, const half8& al, const half8& bh, const half8& bl, f32x16& m, f32x16& x)
                     __attribute__((always_inline)) {
-#ifdef DFSFM_ABL_NOMMA
-        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
-        return;
-#endif
         m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, m, 0, 0, 0);
         x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, x, 0, 0, 0);
         x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, x, 0, 0, 0);
@@ -743,28 +717,12 @@ __global__ __launch_bounds__(256, 2) void linear_gemm_sf_kernel(ConvArgs g) {
     auto addrA = [&](int t) __attribute__((always_inline)) {
         const bool in = t < nk && t * BK + lslot * 8 < g.Cin;
 #pragma unroll
-#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBA)
-        for (int q = 0; q < 2; ++q) offA[q] = g.xbytes + (in ? 0u : 16u);      // ablation: A pieces zero-fill (no traffic)
-#elif defined(DFSFM_ABL_ROW128)
-        // timing-only ablation (results are wrong): a piece reads 8 rows x 128 contiguous bytes instead of 16 rows x 64
-        for (int q = 0; q < 2; ++q) {
-            const int64_t row = m0 + (wave + 4 * q) * 8 + (lane >> 3);
-            offA[q] = (row < g.M && in) ? (unsigned)((row * g.ldx + (t >> 1) * 64 + (lane & 7) * 8) * 2) : g.xbytes;
-        }
-#else
         for (int q = 0; q < 2; ++q) offA[q] = (aok[q] && in) ? (unsigned)((abase[q] + t * BK) * 2) : g.xbytes;
-#endif
     };
     auto addrB = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBB)
-            offB[q] = g.wbytes + (t < nk ? 0u : 16u);
-#elif defined(DFSFM_ABL_ROW128)
-            offB[q] = t < nk ? (unsigned)((((int64_t)(n0 + (wave + 4 * q) * 8 + (lane >> 3)) * g.Kpad) + (t >> 1) * 64 + (lane & 7) * 8) * 2) : g.wbytes;
-#else
             offB[q] = t < nk ? bbase + (unsigned)(wave + 4 * q) * 16u * (unsigned)g.Kpad * 2u + (unsigned)(t * BK * 2) : g.wbytes;
-#endif
     };
 #define LDMA_A(stage)                                                                                                  \
     do {                                                                                                                \

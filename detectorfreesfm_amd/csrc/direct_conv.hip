@@ -97,9 +97,6 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectArgs g) {
                 for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
             }
             const int ch = c0 + c8 * 8;
-#ifdef DFSFM_ABL_NOSTORE
-            if (v[0] != 12345.678f) continue;
-#endif
             if (!valid) continue;
             if (g.out) {
                 *reinterpret_cast<f32x4*>(g.out + m * g.ldo + ch) = f32x4{v[0], v[1], v[2], v[3]};

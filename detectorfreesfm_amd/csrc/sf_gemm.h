@@ -49,11 +49,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // tiles that read the same activation rows (the ky halo of neighbouring M tiles, the N tiles of one M tile)
 // run on one XCD at about the same time and meet in its L2 instead of each fetching from HBM.
 __device__ __forceinline__ unsigned xcd_band_tile(unsigned b, unsigned per_xcd) {
-#ifdef DFSFM_ABL_NOXCD
-    return b;
-#else
     return (b & 7u) * per_xcd + (b >> 3);
-#endif
 }
 
 
@@ -84,11 +80,7 @@ struct VS {
     static constexpr int B_STAGE = 2 * B_PLANE;
     static constexpr int BN_I = (BN_ / 16) * 2 / 8;         // weight pieces per wave per slab (2 or 1)
     static constexpr int NA = KW == 1 ? 3 : 2;              // A ring depth (super-slabs)
-#ifndef DFSFM_SAME_NB4
-#define DFSFM_SAME_NB4 0
-#endif
-    // B ring depth (slabs): 4 where it fits beside a 2-deep A ring (one more slab of lead for the weight stream)
-    static constexpr int NB = (DFSFM_SAME_NB4 && KW > 1 && NA * A_STAGE + 4 * B_STAGE + 1024 <= 160 * 1024) ? 4 : 3;
+    static constexpr int NB = 3;                            // B ring depth (slabs); 4 measured +-1 %
     static constexpr int OFF_B = NA * A_STAGE;
     static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;  // 1 KB sink for the padding pieces
     static constexpr int RING = OFF_DUMMY + 1024;
@@ -122,11 +114,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     const int col = lane & 31, kgrp = lane >> 5;
     const int wr = wave / WN, wc = wave % WN;
     const int Cin_p = g.Kpad / (KW * KW);                    // tap-padded channel count (multiple of 32)
-#ifdef DFSFM_ABL_NOLOOP
-    const int nchunk = Cin_p / BK, nS = 0;
-#else
     const int nchunk = Cin_p / BK, nS = KW * nchunk;
-#endif
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
@@ -142,11 +130,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int grp = q < 2 ? wave + 8 * q : 16;
-#ifdef DFSFM_ABL_TILE0
-        const int64_t pix = (int64_t)(blockIdx.x & 7) * BM2 - PAD + grp * 16 + lrow;   // ablation: L2-resident A
-#else
         const int64_t pix = m0 - PAD + grp * 16 + lrow;      // flattened pixel of LDS row grp*16 + lrow
-#endif
         aok[q] = pix >= 0 && pix < g.M && (q < 2 || wave < 2);
         const int64_t pp = aok[q] ? pix : 0;
         const int ox = (int)(pp % g.W);
@@ -165,11 +149,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             const int iy = ay[q] + ky - PAD;
             const bool ok = aok[q] & in & (iy >= 0) & (iy < g.H);
             const int64_t off = (abase[q] + (int64_t)(ky - PAD) * g.sxh + chunk * BK) * 2;
-#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBA)
-            offA[q] = g.xbytes + (ok ? 0u : 16u);                // ablation: every piece zero-fills (no memory traffic)
-#else
             offA[q] = ok ? (unsigned)off : g.xbytes;
-#endif
         }
     };
     const unsigned bbase = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);
@@ -181,17 +161,9 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
 #pragma unroll
         for (int j = 0; j < BNI; ++j) {
             const int grp = (wave + 8 * j) % (BN_ / 16);
-#if defined(DFSFM_ABL_OOB) || defined(DFSFM_ABL_OOBB)
-            offB[j] = g.wbytes + (Sn < nS ? 0u : 16u);
-#else
             offB[j] = Sn < nS ? bbase + koff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
-#endif
         }
     };
-#ifdef DFSFM_ABL_NODMA
-#define SDMA_A(p, astage) ((void)0)
-#define SDMA_B(j, bstage) ((void)0)
-#else
     // A piece p of a super-slab: 0,1 = group wave (hi, lo); 2,3 = group wave+8 (hi, lo); 4 = group 16 (wave 0: hi,
     // wave 1: lo, other waves: an out-of-range piece into the 1-KB sink so every wave issues the same count)
 #define SDMA_A(p, astage)                                                                                          \
@@ -217,7 +189,6 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
                                                              plane_ * S_::B_PLANE + grp_ * 1024),                   \
                                                  16, offB[j], 0, 0, 0);                                             \
     } while (0)
-#endif
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -342,13 +313,9 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- COMPUTE segment of slab t ----
-#ifndef DFSFM_ABL_NOPRIO
             __builtin_amdgcn_s_setprio(1);
-#endif
             compute_slab();
-#ifndef DFSFM_ABL_NOPRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
             if (grp == 0) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 0-3 publish slab t+1 here
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();

@@ -710,15 +710,17 @@ class PackedDense:
         self.Cout, self.Cin, self.kh, self.kw = Cout, cp, kh, kw
         self.Kpad = (K + 31) // 32 * 32
         npad = (Cout + 127) // 128 * 128
-        wk = torch.zeros((Cout, kh, kw, cp), dtype=torch.float32, device=w.device)
-        wk[..., :Cin] = w.detach().float().permute(0, 2, 3, 1)
-        full = torch.zeros((npad, self.Kpad), dtype=torch.float32, device=w.device)
+        # float64 weights (a BN fold done in double) are split from their exact values; fp32 weights are unchanged by this
+        wd = torch.float64 if w.dtype == torch.float64 else torch.float32
+        wk = torch.zeros((Cout, kh, kw, cp), dtype=wd, device=w.device)
+        wk[..., :Cin] = w.detach().to(wd).permute(0, 2, 3, 1)
+        full = torch.zeros((npad, self.Kpad), dtype=wd, device=w.device)
         full[:Cout, :K] = wk.reshape(Cout, K)
         if not bool(torch.isfinite(full).all()) or float(full.abs().max()) >= FP16_MAX:
             raise _lib.DfsfmError(f"PackedDense: weights must be finite with |w| < {FP16_MAX:.0f} (split-plane range)")
         hi = torch.where(full.abs() >= 2.0 ** -14, full, torch.zeros_like(full)).half()
         self.hi = hi.contiguous()
-        self.lo = ((full - hi.float()) * 2048.0).half().contiguous()
+        self.lo = ((full - hi.to(wd)) * 2048.0).half().contiguous()
         self.bias = None if bias is None else bias.detach().float().contiguous()
         # first layers (K = kh*kw*Cin of 49 / 27): fp32 weights [K][Cout] for the direct FMA kernel
         self.w32 = None

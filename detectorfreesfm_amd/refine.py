@@ -12,8 +12,7 @@ Hand-written HIP: RoIAlign patch extraction (K8, with the ImageNet normalisation
 output in (track, view) order), the S2DNet patch CNN (K9) and every nn.Linear (K10) on the
 fp16x2-split MFMA implicit-GEMM kernel with fused bias/BN/ReLU/residual, max pooling, linear
 attention (K1, D=16), LayerNorm + residual, and the fused fine correlation / softmax expectation /
-candidate argmin / refined keypoints (K11+K12).  ``dense_backend="library"`` keeps an explicit
-MIOpen / hipBLASLt fp32 control path for measurement.
+candidate argmin / refined keypoints (K11+K12).  No library (MIOpen / hipBLASLt) path exists in this package.
 
 Output-identical work the reference wastes is skipped ("dead work"):
 * only the centre (W+4)^2 of relu1_2 feeds adaptation layer 0 (the reference convolves the full
@@ -26,10 +25,10 @@ Output-identical work the reference wastes is skipped ("dea
 import os
 
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F      # _bicubic_rows: PyTorch's own interpolation coefficients, on the host
 
 from . import ops
-from .coarse import EncoderLayerWeights, encoder_layer, encoder_layer_split
+from .coarse import EncoderLayerWeights, encoder_layer_split
 from .params import ParamModule, multiview_param_spec
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)   # S2DNet.mean / .std, backbone/S2DNet/s2dnet.py:66-67
@@ -45,14 +44,8 @@ def _bicubic_rows(n_in: int, n_out: int, lo: int, hi: int) -> torch.Tensor:
 
 
 class HipMultiviewMatcher(ParamModule):
-    def __init__(self, config: dict, test: bool = True, max_backbone_patches: int = 16384,
-                 dense_backend: str = "hip", **_unused):
-        """dense_backend: "hip" (default) = hand-written fp16x2-split MFMA conv / linear kernels on NHWC
-        patches; "library" = MIOpen / hipBLASLt fp32 through PyTorch (explicit measurement control)."""
+    def __init__(self, config: dict, test: bool = True, max_backbone_patches: int = 16384, **_unused):
         super().__init__()
-        if dense_backend not in ("hip", "library"):
-            raise ValueError(dense_backend)
-        self.dense_backend = dense_backend
         self.same_conv = os.environ.get("DFSFM_SAME_CONV", "1") != "0"   # A/B switch for the tap-reuse conv kernel
         if not test:
             raise NotImplementedError("training path is out of scope; build with test=True")
@@ -101,23 +94,22 @@ class HipMultiviewMatcher(ParamModule):
         for i in (0, 1):
             q = f"backbone.adaptation_layers.adap_layer_{i}."
             w5, b5 = g(q + "2.weight"), g(q + "2.bias")
-            s = g(q + "3.weight") / torch.sqrt(g(q + "3.running_var") + 1e-5)
-            # conv(+bias) -> eval BN folded: w*s, (b - mean)*s + beta
-            P[f"adap{i}"] = (g(q + "0.weight"), g(q + "0.bias"), (w5 * s[:, None, None, None]).contiguous(),
-                             ((b5 - g(q + "3.running_mean")) * s + g(q + "3.bias")).contiguous())
+            s = g(q + "3.weight").double() / torch.sqrt(g(q + "3.running_var").double() + 1e-5)
+            # conv(+bias) -> eval BN folded: w*s, (b - mean)*s + beta -- in float64, split from the exact products (coarse._fold_bn)
+            P[f"adap{i}"] = (g(q + "0.weight"), g(q + "0.bias"), (w5.double() * s[:, None, None, None]).contiguous(),
+                             ((b5.double() - g(q + "3.running_mean").double()) * s + g(q + "3.bias").double()).contiguous())
         mt = self.config["multiview_transform"]
         n_layers = len(mt["layer_names"]) * mt["layer_iter_n"]
-        P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.", self.dense_backend)
-                       for i in range(n_layers)]
-        if self.dense_backend == "hip":
-            def pk(w, b, split_in=True, same=False):    # same: stride-1 'same' conv -> activation-reuse kernel
-                return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
-                                       tap_padded=same and split_in and self.same_conv)
-            H = {"enc": {i: pk(*P["enc"][i], split_in=(i != 0), same=True) for i in P["enc"]}}   # conv1_1 reads fp32 patches
-            for i in (0, 1):
-                a = P[f"adap{i}"]
-                H[f"adap{i}"] = (pk(a[0], a[1]), pk(a[2], a[3], same=(i == 1)))   # adap1's 5x5 is pad 2, adap0's pad 0
-            P["hip"] = H
+        P["layers"] = [EncoderLayerWeights(g, f"fine_transformer.layers.{i}.") for i in range(n_layers)]
+
+        def pk(w, b, split_in=True, same=False):    # same: stride-1 'same' conv -> activation-reuse kernel
+            return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
+                                   tap_padded=same and split_in and self.same_conv)
+        H = {"enc": {i: pk(*P["enc"][i], split_in=(i != 0), same=True) for i in P["enc"]}}   # conv1_1 reads fp32 patches
+        for i in (0, 1):
+            a = P[f"adap{i}"]
+            H[f"adap{i}"] = (pk(a[0], a[1]), pk(a[2], a[3], same=(i == 1)))   # adap1's 5x5 is pad 2, adap0's pad 0
+        P["hip"] = H
         self._packed = P
         return P
 
@@ -146,33 +138,6 @@ class HipMultiviewMatcher(ParamModule):
         a0 = ops.conv2d_nhwc(f0, H["adap0"][0], 1, 0, **S)                        # [m,W+4,W+4,64]
         ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out=dst)           # + hypercolumn sum, fused
         return dst
-
-    # -- K9: S2DNet._forward on normalised patches (s2dnet.py:127-193) ----------------------------
-    def _s2dnet(self, x, P, W):
-        crop = x.shape[-1]
-
-        def conv(i, t):
-            return F.relu_(F.conv2d(t, P["enc"][i][0], P["enc"][i][1], 1, 1))
-        x = conv(2, conv(0, x))
-        c, r = crop // 2, W // 2
-        f0 = x[..., c - r - 2:c + r + 3, c - r - 2:c + r + 3]      # centre (W+4)^2 of relu1_2
-        x = F.max_pool2d(x, 3, 2, 1)
-        x = conv(7, conv(5, x))
-        x = F.max_pool2d(x, 3, 2, 1)
-        f1 = conv(14, conv(12, conv(10, x)))                        # relu3_3, 1/4 resolution
-
-        a0 = P["adap0"]
-        y0 = F.conv2d(F.relu_(F.conv2d(f0, a0[0], a0[1])), a0[2], a0[3], 1, 0)      # [M,od,W,W]
-        a1 = P["adap1"]
-        y1 = F.conv2d(F.relu_(F.conv2d(f1, a1[0], a1[1])), a1[2], a1[3], 1, 2)      # [M,od,h4,w4]
-        key = (y1.shape[-1], crop, W)
-        if P.get("bicubic_key") != key:
-            B = _bicubic_rows(y1.shape[-1], crop, c - r, c + r + 1)
-            P["bicubic"] = torch.kron(B, B).contiguous().to(y1.device)   # separable -> one [WW, h4*w4] map
-            P["bicubic_key"] = key
-        K = P["bicubic"]                                             # [W*W, h4*w4]
-        up = torch.matmul(y1.flatten(2), K.t())                     # one GEMM for the whole batch: [M,od,W*W]
-        return y0.flatten(2), up                                    # summed by the scatter kernel
 
     @torch.no_grad()
     def forward(self, data: dict, chunk_track: int = 1000, chunk_backbone_img: bool = True):
@@ -235,46 +200,30 @@ class HipMultiviewMatcher(ParamModule):
         r = crop // 2
         boxes = torch.cat([flat_pts - r, flat_pts + r], dim=-1)[order].contiguous()     # fine_preprocess.py:101-104
         slot = (order % T) * V + order // T                                            # (v t) -> (t v)
-        hip = self.dense_backend == "hip"
-        if hip:
-            # patch m of the compact list goes to position rank(slot): the CNN then emits features
-            # already in (track, view) order -- no gather afterwards (MultiviewMatcher.py:264-270)
-            by_slot = torch.argsort(slot)
-            pos = torch.empty_like(by_slot)
-            pos[by_slot] = torch.arange(M, device=dev)
-            patches = torch.empty((M, crop, crop, 3), dtype=torch.float32, device=dev)
-        else:
-            pos = None
-            patches = torch.empty((M, 3, crop, crop), dtype=torch.float32, device=dev)
+        # patch m of the compact list goes to position rank(slot): the CNN then emits features
+        # already in (track, view) order -- no gather afterwards (MultiviewMatcher.py:264-270)
+        by_slot = torch.argsort(slot)
+        pos = torch.empty_like(by_slot)
+        pos[by_slot] = torch.arange(M, device=dev)
+        patches = torch.empty((M, crop, crop, 3), dtype=torch.float32, device=dev)
         start = 0
         for ii in range(n_img):
             n = per_img[ii]
             if n == 0:
                 continue
-            if hip:
-                ops.roi_align(images[ii], boxes[start:start + n], crop, crop, out_slot=pos[start:start + n],
-                              mean=self._mean, std=self._std, out=patches, channels_last=True)
-            else:
-                ops.roi_align(images[ii], boxes[start:start + n], crop, crop, mean=self._mean, std=self._std,
-                              out=patches[start:start + n])
+            ops.roi_align(images[ii], boxes[start:start + n], crop, crop, out_slot=pos[start:start + n],
+                          mean=self._mean, std=self._std, out=patches, channels_last=True)
             start += n
-        if hip:
-            dense = n_pad == 0                      # every (track, view) slot is valid: write in place
-            feats = torch.empty((T * V, WW, C), dtype=torch.float32, device=dev) if dense else \
-                torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
-            comp = feats if dense else torch.empty((M, WW, C), dtype=torch.float32, device=dev)
-            for s in range(0, M, self.max_backbone_patches):
-                e = min(M, s + self.max_backbone_patches)
-                self._s2dnet_hip(patches[s:e], P, W, comp[s:e])
-            if not dense:
-                feats.index_copy_(0, slot[by_slot], comp)
-                del comp
-        else:
-            feats = torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
-            for s in range(0, M, self.max_backbone_patches):
-                e = min(M, s + self.max_backbone_patches)
-                y0, up = self._s2dnet(patches[s:e], P, W)                               # 2 x [m,C,WW]
-                ops.add_scatter_tokens(y0, up, slot[s:e], feats)      # (y0+up) 'm c p -> slot p c'
+        dense = n_pad == 0                      # every (track, view) slot is valid: write in place
+        feats = torch.empty((T * V, WW, C), dtype=torch.float32, device=dev) if dense else \
+            torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
+        comp = feats if dense else torch.empty((M, WW, C), dtype=torch.float32, device=dev)
+        for s in range(0, M, self.max_backbone_patches):
+            e = min(M, s + self.max_backbone_patches)
+            self._s2dnet_hip(patches[s:e], P, W, comp[s:e])
+        if not dense:
+            feats.index_copy_(0, slot[by_slot], comp)
+            del comp
         del patches
         feats = feats.view(T, V, WW, C)
 
@@ -296,7 +245,7 @@ class HipMultiviewMatcher(ParamModule):
                 i += nt
                 continue
             qm = tmask[sl, :Vq].contiguous()
-            if mt["enable"] and hip:
+            if mt["enable"]:
                 # split planes [., ., 2C] = [x | norm1(message)], ping-pong; fp32 only for the last layer's output
                 rs = [ops.SplitAct.empty_rows((nt, WW), 2 * C, dev) for _ in range(2)]
                 qs = [ops.SplitAct.empty_rows((nt, Vq * WW), 2 * C, dev) for _ in range(2)]
@@ -319,31 +268,6 @@ class HipMultiviewMatcher(ParamModule):
                     else:
                         raise NotImplementedError(name)
                     rs.reverse(); qs.reverse()
-            elif mt["enable"]:
-                # library control: fp32 [., ., 2C] buffers (x | norm1(message)), see encoder_layer
-                rb = [torch.empty((nt, WW, 2 * C), dtype=torch.float32, device=dev) for _ in range(2)]
-                qb = [torch.empty((nt, Vq * WW, 2 * C), dtype=torch.float32, device=dev) for _ in range(2)]
-                rb[0][..., :C] = feats[sl, 0]
-                qb[0].view(nt, Vq, WW, 2 * C)[..., :C] = feats[sl, 1:cv]
-                ref = qry = None
-                for li, (w, name) in enumerate(zip(P["layers"], names)):   # matcher_module/transformer.py:158-172
-                    last = li == len(names) - 1
-                    if last:
-                        ref = torch.empty((nt, WW, C), dtype=torch.float32, device=dev)
-                        qry = torch.empty((nt, Vq * WW, C), dtype=torch.float32, device=dev)
-                        dr, dq = ref, qry
-                    else:
-                        dr, dq = rb[1][..., :C], qb[1][..., :C]
-                    if name == "self":
-                        encoder_layer(w, rb[0], rb[0][..., :C], dr, nhead, is_self=True)
-                        encoder_layer(w, qb[0], qb[0][..., :C], dq, nhead, qm, qm, WW, WW, is_self=True)
-                    elif name == "cross":                 # both sides from the PRE-update tensors (:163)
-                        encoder_layer(w, qb[0], rb[0][..., :C], dq, nhead, qm, None, WW, 1)
-                        encoder_layer(w, rb[0], qb[0][..., :C], dr, nhead, None, qm, 1, WW)
-                    else:
-                        raise NotImplementedError(name)
-                    rb.reverse()
-                    qb.reverse()
             else:
                 ref = feats[sl, 0].contiguous()
                 qry = feats[sl, 1:cv].reshape(nt, Vq * WW, C)

@@ -12,14 +12,12 @@ from detectorfreesfm_amd.params import loftr_param_spec, multiview_param_spec, r
 from oracle import restate
 
 
-@pytest.mark.parametrize("backend,skip_dead_fpn", [("hip", True), ("library", True), ("library", False)])
-def test_coarse_host_logic(backend, skip_dead_fpn):
-    """backend 'hip': every conv / linear goes through the (emulated) fp16x2-split kernel algebra with
-    the packed NHWC weights -- checks packing order, NHWC plumbing and that the split leaves the
-    matches unchanged; 'library': the MIOpen/hipBLASLt control path."""
+def test_coarse_host_logic():
+    """Every conv / linear goes through the (emulated) fp16x2-split kernel algebra with the packed NHWC weights -- checks
+    packing order, NHWC plumbing, the float64 BatchNorm fold and that the split leaves the matches unchanged."""
     cfg = loftr_coarse_only_config(1e-3)
     sd = random_state_dict(loftr_param_spec(cfg), 0)
-    m = HipLoFTR(cfg, skip_dead_fpn=skip_dead_fpn, dense_backend=backend).eval()
+    m = HipLoFTR(cfg).eval()
     m.load_state_dict({"matcher." + k: v for k, v in sd.items()}, strict=True)   # checkpoint prefix (loftr.py:83-87)
     data = synth.coarse_pair_batch(2, 96, 128, seed=1000)
     data["scale0"] = torch.tensor([[1.5, 2.0], [1.0, 1.0]])
@@ -50,14 +48,13 @@ def test_coarse_different_image_sizes():
     assert torch.allclose(d["mkpts1_f"], o["mkpts1_f"])
 
 
-@pytest.mark.parametrize("factor,backend,varlen", [(None, "hip", True), (2, "hip", False), (None, "library", True),
-                                                   (2, "library", True)])
-def test_refine_host_logic(factor, backend, varlen):
+@pytest.mark.parametrize("factor,varlen", [(None, True), (2, False), (2, True)])
+def test_refine_host_logic(factor, varlen):
     cfg = multiview_refinement_config(factor)
     assert (cfg["multiview_transform"]["window_size"], cfg["multiview_matching_test"]["left_point_movement_window_size"]) == \
         ((15, 7) if factor is None else (11, 3))
     sd = random_state_dict(multiview_param_spec(cfg), 1)
-    m = HipMultiviewMatcher(cfg, test=True, dense_backend=backend).eval()
+    m = HipMultiviewMatcher(cfg, test=True).eval()
     m.load_state_dict(sd, strict=True)
     data = synth.refine_bag(T=40, V=4, H=120, W=160, seed=2000, variable_lengths=varlen)
     data["scales"] = torch.tensor([[[1.0, 1.0], [1.25, 1.5], [1.0, 2.0], [0.5, 0.75]]])
