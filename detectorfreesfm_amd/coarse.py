@@ -50,6 +50,10 @@ def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
     return (w.double() * s[:, None, None, None]).contiguous(), (bn_b.double() - mean.double() * s).contiguous()
 
 
+# DFSFM_FUSED_ENCODER=0 keeps d_model-128 layers on the five-GEMM path as well (same-box A/B switch, read once at import)
+FUSED_ENCODER = os.environ.get("DFSFM_FUSED_ENCODER", "1") != "0"
+
+
 class EncoderLayerWeights:
     """Packed weights of one LoFTREncoderLayer (transformer.py:7-33): fp16x2-split operands of dfsfm_conv2d_nhwc_f32 (1x1 case)."""
 
@@ -61,6 +65,11 @@ class EncoderLayerWeights:
         self.p1 = ops.PackedDense(get(prefix + "mlp.0.weight"))
         self.n1 = (get(prefix + "norm1.weight").contiguous(), get(prefix + "norm1.bias").contiguous())
         self.n2 = (get(prefix + "norm2.weight").contiguous(), get(prefix + "norm2.bias").contiguous())
+        # d_model 128 (the refinement head): the whole layer runs as two fused kernels (csrc/encoder_fused.hip)
+        self.fused = None
+        if wq.shape == (ops.ENC_C, ops.ENC_C) and FUSED_ENCODER:
+            self.fused = ops.EncoderFusedWeights(wq, wk, wv, get(prefix + "merge.weight"), get(prefix + "mlp.0.weight"),
+                                                 get(prefix + "mlp.2.weight"), self.n1, self.n2)
 
 
 def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
@@ -81,6 +90,12 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
     D = C // nhead
     S = src.hi.shape[1]
     xs_x = xs.cols(0, C)
+    if w.fused is not None and nhead == 8 and L >= 32 and (out_x is not None or out_xs is not None):
+        # two launches: source tokens -> per-sequence attention state; x tokens -> layer output.  q, k, v, the message, the
+        # merged message and the MLP's hidden layer never reach memory (the second half of ``xs`` stays unused)
+        state = ops.encoder_kv(src, w.fused, source_mask, kv_group)
+        ops.encoder_apply(xs_x, w.fused, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
+        return out_x
     if is_self:
         qkv = ops.linear(xs_x, w.pqkv).view(N, L, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]

@@ -1,0 +1,766 @@
+// K2 + K1 + K10 fused -- one LoFTREncoderLayer application in TWO kernels, for gfx950 (MI355X), d_model 128, 8 heads.
+//
+// Replaces, for the refinement head's transformer (and any d_model-128 LoFTR encoder layer),
+//   LoFTREncoderLayer.forward   src/MultiviewMatcher/matcher_module/transformer.py:66-95
+//                               (third_party/LoFTR/src/loftr/loftr_module/transformer.py:35-58)
+//   LinearAttention.forward     src/MultiviewMatcher/matcher_module/linear_attention.py:28-60
+// which the unfused path runs as five GEMM launches + three attention launches that round-trip every activation of the
+// 2.25 M-row token matrix through HBM (q|k|v, message, merged message, the 256-wide MLP hidden: ~9 KB per row and layer).
+// Here a token row is read once per kernel (512 B as fp16x2 split planes) and written once (512 B):
+//
+//   enc_kv_kernel     source tokens -> k|v = W_kv x (never stored) -> per sequence  KV = sum phi(k)^T (v/S), Ksum = sum phi(k)
+//                     written as the "apply image": KV^T already in MFMA A-fragment order (fp16 hi/lo) + Ksum.
+//   enc_apply_kernel  x tokens -> q = W_q x -> phi(q) KV Z S -> merge -> LayerNorm1 -> mlp.0([x | m]) -> ReLU -> mlp.2
+//                     -> LayerNorm2 -> x + .   Every intermediate lives in registers.
+//
+// Arithmetic is the repository's fp16x2 split (value = hi + lo/2048, three v_mfma_f32_32x32x16_f16 per product, fp32
+// accumulation): fp32-class, lo*lo (2^-22) dropped.
+//
+// enc_apply_kernel is TOKEN-STATIONARY and TRANSPOSED: it computes out^T[channel][token] = W[channel][k] x^T[k][token], so the
+// MFMA result of a 32x32 block has lane = token, registers = 16 channels -- and the B operand of the next GEMM wants
+// lane = token, 8 k-values per lane: the accumulator of one GEMM becomes the operand of the next after an fp32 -> fp16x2
+// conversion in registers, with no LDS round trip and no cross-lane traffic.  The price is a fixed permutation of the k index
+// inside every 16-wide k-step (reg r of a block holds channel (r&3) + 8(r>>2) + 4*half), which the host applies to the weight
+// columns once (ops.EncoderFusedWeights).  A wave owns 32 tokens; the 4 waves of a workgroup share only the weight stream,
+// which the host lays out as a sequence of 16-KB "slabs" of ready-made A fragments (1 KB each, lane-linear): the kernel
+// streams them global -> LDS with buffer_load ... lds through a 4-deep ring (one s_barrier per slab) and reads them with
+// conflict-free ds_read_b128.  One wave per SIMD (512-register budget): accumulators + operands of a whole layer stay resident.
+//
+// enc_kv_kernel uses the classic orientation (lane = channel, registers = tokens) so that the contraction over tokens of
+// phi(k)^T v is again an MFMA fed from accumulator registers; a workgroup owns one sequence, its 4 waves take every fourth
+// 32-token block, partial sums are combined in a fixed order (run-to-run deterministic, independent of the batch).
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+using namespace dfsfm;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int EC = 128;                  // d_model
+constexpr int NBLK = EC / 32;            // 32-channel blocks
+constexpr int NKS = EC / 16;             // k-steps over d_model
+constexpr int SLAB = 16384;              // bytes of one weight slab: 16 A fragments of 1 KB
+constexpr int NSTG = 4;                  // ring depth (slabs)
+constexpr int RING = NSTG * SLAB;
+constexpr int STG = 16384;               // per-wave staging tile: 32 tokens x 128 channels, hi + lo planes
+constexpr int SMEM_BYTES = RING + 4 * STG;
+constexpr int NSLAB_APPLY = 32;          // q 4, merge 4, 4 x (mlp.0 chunk 4 + mlp.2 chunk 2)
+constexpr int NSLAB_KV = 8;              // 4 head pairs x 2
+constexpr int KVIMG = 16 * 1024 + 512;   // bytes per sequence: 16 KV^T fragments + Ksum[128]
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ f32x16 mfma(const half8 a, const half8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// phi(x) = elu(x) + 1 = exp(x) for x <= 0, x + 1 otherwise.  The reference evaluates expm1(x) + 1 in fp32; here exp(x) comes
+// from the hardware exp2 with the argument's rounding error compensated (x * log2(e) carried as hi + lo), which stays within
+// ~2 ulp of it -- below the 2^-22 of the split operands this value is converted to next -- at a fifth of the instructions.
+__device__ __forceinline__ float phi_fast(float x) {
+    const float L2E = 1.4426950408889634f;
+    const float hi = x * L2E;
+    const float lo = __builtin_fmaf(x, L2E, -hi) + x * 1.925963033500853e-8f;      // rounding of x * L2E + (log2(e) - L2E)
+    const float e = __builtin_amdgcn_exp2f(hi);
+    const float r = __builtin_fmaf(e * 0.6931471805599453f, lo, e);                 // 2^(hi + lo) ~ 2^hi (1 + lo ln 2)
+    return x > 0.f ? x + 1.f : r;
+}
+
+// channel (within a 32-channel block) that accumulator register r of lane half h holds
+__device__ __forceinline__ int dch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// fp32 accumulator block -> the two B (or A) fragments it becomes for the next MFMA: k-step t of the block = registers 8t..8t+7.
+// Same split as split_f32 (common.h) with the saturation expressed on the fp16 side: fp16(v) overflows to +-inf for
+// |v| >= 65520, which one v_pk_min / v_pk_max pair per two values brings back to +-65504; lo is then finite as well.
+__device__ __forceinline__ void to_frags(const float (&v)[16], half8& h0, half8& l0, half8& h1, half8& l1) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const half2_t big = {(_Float16)65504.f, (_Float16)65504.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        half2_t h = {(_Float16)v[r], (_Float16)v[r + 1]};
+        h = __builtin_elementwise_max(__builtin_elementwise_min(h, big), -big);
+        const half2_t l = {(_Float16)((v[r] - (float)h[0]) * 2048.f), (_Float16)((v[r + 1] - (float)h[1]) * 2048.f)};
+        if (r < 8) {
+            h0[r] = h[0]; h0[r + 1] = h[1]; l0[r] = l[0]; l0[r + 1] = l[1];
+        } else {
+            h1[r - 8] = h[0]; h1[r - 7] = h[1]; l1[r - 8] = l[0]; l1[r - 7] = l[1];
+        }
+    }
+}
+
+// byte offset of 16-byte chunk c of token row t inside a staging plane (32 rows x 256 B): XOR swizzle so that the
+// fragment-shaped 8/16-byte reads of 32 different rows spread over all banks
+__device__ __forceinline__ int stg_off(int t, int c) { return t * 256 + ((c ^ (t & 15)) << 4); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight-slab ring shared by both kernels: slab g of the cyclic stream lives in stage g % NSTG
+// ---------------------------------------------------------------------------------------------------------------------
+struct SlabRing {
+    char* ring;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lane_off;       // wave * 4096 + lane * 16
+    int wave, nslab;
+    unsigned next;           // next slab index to consume (monotonic)
+
+    __device__ __forceinline__ void issue(unsigned g) const {
+        const unsigned src = (g % (unsigned)nslab) * SLAB + lane_off;
+        char* dst = ring + (g % NSTG) * SLAB + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + i * 1024), 16, src + i * 1024, 0, 0, 0);
+    }
+    __device__ __forceinline__ void prologue() {
+#pragma unroll
+        for (int g = 0; g < NSTG - 1; ++g) issue(g);
+        next = 0;
+    }
+    // make slab `next` readable by every wave and refill the stage the previous slab occupied; returns its LDS address.
+    // Loads complete in issue order, so "at most (NSTG-2)*4 outstanding" means this wave's pieces of the slab have landed
+    // (anything issued in between -- other loads, or stores, which may complete out of order with respect to loads but
+    // only ever add to the count -- makes the wait more conservative, never less).
+    __device__ __forceinline__ const char* acquire() {
+        wait_vmcnt<(NSTG - 2) * 4>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(next + NSTG - 1);
+        const char* p = ring + (next % NSTG) * SLAB;
+        ++next;
+        return p;
+    }
+};
+
+// one slab = KPS k-steps x NB blocks of (hi, lo) fragments; acc[b] += W(b, ks) * B[ks] with the 3-MFMA split product:
+// am += W_hi B_hi, ax += W_lo B_hi, ay += W_hi B_lo (callers with NB = 4 pass ax for ay: an accumulator is then reused
+// after four other MFMAs; with NB = 2 a third accumulator keeps every MFMA independent of its two predecessors).
+template <int NB, int KPS>
+__device__ __forceinline__ void slab_mma(const char* slab, int lane, f32x16 (&am)[NB], f32x16 (&ax)[NB], f32x16 (&ay)[NB],
+                                         const half8* bh, const half8* bl) {
+    static_assert(NB * KPS == 8, "a slab holds 16 fragments");
+#pragma unroll
+    for (int ks = 0; ks < KPS; ++ks) {
+        half8 wh[NB], wl[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 0) * 1024 + lane * 16);
+            wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 1) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) am[b] = mfma(wh[b], bh[ks], am[b]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ax[b] = mfma(wl[b], bh[ks], ax[b]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ay[b] = mfma(wh[b], bl[ks], ay[b]);
+    }
+}
+
+struct ApplyArgs {
+    const _Float16 *xh, *xl;     // x rows as split planes, row stride ldx (elements)
+    int64_t ldx;
+    unsigned xbytes;
+    const char* wstream;         // NSLAB_APPLY slabs
+    const char* kvimg;           // [N][KVIMG]
+    const uint8_t* qmask;        // [N][qm_per_seq] or null
+    int q_group, qm_per_seq;
+    const float *g1, *b1, *g2, *b2;
+    float eps1, eps2, attn_eps;
+    _Float16 *oh, *ol;           // out rows as split planes (or null)
+    int64_t ldo;
+    float* o32;                  // out rows fp32 (or null)
+    int64_t ldo32;
+    int64_t M;                   // rows = N * L
+    int L, N, S;                 // tokens per sequence on the x side, sequences, tokens per sequence on the source side
+    int ntiles;                  // ceil(M / 128)
+    float* dbg;                  // [M][128] fp32 dump of one intermediate (tests), or null
+    int dbg_stage;               // 1 q, 2 message, 3 norm1(merge), 4 mlp output (before norm2)
+    int stagger;                 // start delay per (blockIdx % 8), in s_sleep(127) units (~8 K cycles each... see the entry point)
+};
+
+// D-layout values of one block (lane = token, v[r] = channel 32 b + dch(r, half)) -> dbg rows.  Must stay inlined: a real call
+// from this 512-register kernel (256 VGPRs + 256 AGPRs live) corrupted caller state on gfx950 / ROCm 7.2 -- outputs of later
+// blocks saturated, another build faulted -- so nothing in this file is ever __noinline__.
+__device__ __forceinline__ void dump(const ApplyArgs& g, const float (&v)[16], int b, int64_t row, bool valid, int half) {
+    if (!valid) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g.dbg[row * EC + 32 * b + dch(r, half)] = v[r];
+}
+
+__global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    char* stg = smem + RING + wave * STG;
+
+    SlabRing ring;
+    ring.ring = smem;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.wstream, 0, NSLAB_APPLY * SLAB, 0x00020000);
+    ring.lane_off = (unsigned)(wave * 4096 + lane * 16);
+    ring.wave = wave;
+    ring.nslab = NSLAB_APPLY;
+    ring.prologue();
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const float Sf = (float)g.S;
+
+    // All workgroups run the same instruction stream on equal tiles: left alone they stay in phase and hit HBM together
+    // (every CU loading its x tiles, then every CU storing).  A one-off start delay of blockIdx % 8 eighths of a tile time
+    // spreads the memory phases of the chip over the whole tile period.
+    if (g.stagger > 0)
+        for (int i = 0; i < (int)(blockIdx.x & 7) * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    // dbg_stage 100: wave 0 of every workgroup records s_memtime at the stage boundaries of each of its tiles
+    // (dbg[(tile * 16 + k)] as two floats per stamp: low 24 bits, next 24 bits) -- the profile behind DESIGN.md's stage table
+    const bool stamp = g.dbg && g.dbg_stage == 100 && tid == 0;
+#define ENC_STAMP(k)                                                                    \
+    if (stamp) {                                                                        \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();                               \
+        g.dbg[((int64_t)tile * 16 + (k)) * 2] = (float)(t_ & 0xFFFFFF);                 \
+        g.dbg[((int64_t)tile * 16 + (k)) * 2 + 1] = (float)((t_ >> 24) & 0xFFFFFF);     \
+    }
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        ENC_STAMP(0)
+        const int64_t row0 = ((int64_t)tile * 4 + wave) * 32;
+        const int64_t row = row0 + tok;
+        const bool valid = row < g.M;
+        // ---- S0: this wave's 32 token rows -> staging (row-major, swizzled) -> B fragments of x --------------------------
+        {
+            const int trow = lane >> 4, p = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = 4 * i + trow;
+                const int64_t rr = row0 + t;
+                const unsigned off = rr < g.M ? (unsigned)((rr * g.ldx + ((p ^ (t & 15)) << 3)) * 2) : g.xbytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + 8192 + i * 1024), 16, off, 0, 0, 0);
+            }
+        }
+        // sequence of this lane's token; the tile touches at most two sequences (L >= 32)
+        const int n_first = (int)(row0 / g.L);
+        const int64_t bound = (int64_t)(n_first + 1) * g.L;
+        const int n_tok = min(row >= bound ? n_first + 1 : n_first, g.N - 1);
+        const int l_tok = (int)(row - (int64_t)n_tok * g.L);
+        float qm = valid ? 1.f : 0.f;
+        if (g.qmask && valid) qm = (float)g.qmask[(int64_t)n_tok * g.qm_per_seq + l_tok / g.q_group];
+        const bool two = __builtin_amdgcn_readfirstlane((int)(row0 + 31 >= bound && n_first + 1 < g.N)) != 0;
+
+        wait_vmcnt<0>();        // the x tile has landed (this also waits for the slabs in flight: once per tile)
+        ENC_STAMP(1)
+        // B fragments of x are re-read from the staging tile where they are needed (q GEMM, every mlp.0 chunk) instead of
+        // occupying 64 registers for the whole layer; the tile stays intact until the output overwrites it in place
+        auto xfrags = [&](int s0, half8 (&fh)[4], half8 (&fl)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = s0 + i;
+                const half4 a0 = *reinterpret_cast<const half4*>(stg + stg_off(tok, 2 * s) + 8 * half);
+                const half4 a1 = *reinterpret_cast<const half4*>(stg + stg_off(tok, 2 * s + 1) + 8 * half);
+                const half4 c0 = *reinterpret_cast<const half4*>(stg + 8192 + stg_off(tok, 2 * s) + 8 * half);
+                const half4 c1 = *reinterpret_cast<const half4*>(stg + 8192 + stg_off(tok, 2 * s + 1) + 8 * half);
+                fh[i] = half8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                fl[i] = half8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            }
+        };
+
+        // KV^T fragments of the tile's first sequence: requested now, consumed after the q GEMM.  Fragment (b, t) is non-zero
+        // only in the rows of head 2b + t (lanes with (tok >> 4) == t): the other lanes neither load nor are stored
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        half8 kvh[NKS], kvl[NKS];
+        {
+            const char* img = g.kvimg + (int64_t)min(n_first, g.N - 1) * KVIMG + lane * 16;
+#pragma unroll
+            for (int f = 0; f < NKS; ++f) {
+                const bool on = (tok >> 4) == (f & 1);
+                kvh[f] = on ? *reinterpret_cast<const half8*>(img + (f * 2 + 0) * 1024) : zero8;
+                kvl[f] = on ? *reinterpret_cast<const half8*>(img + (f * 2 + 1) * 1024) : zero8;
+            }
+        }
+        half8 ah[NKS], al[NKS];          // operand of the next GEMM: phi(q), then the message, then norm1(merge)
+        // LayerNorm statistics of the 128 channels of this lane's token, straight from accumulator blocks (three cheap
+        // passes over the accumulators instead of a 64-register copy of the row)
+#define ENC_ROWSTATS(VAL, EPS, MEAN, RSTD)                                                                            \
+        float MEAN, RSTD;                                                                                             \
+        {                                                                                                             \
+            float sum_ = 0.f;                                                                                         \
+            _Pragma("unroll") for (int b = 0; b < NBLK; ++b) _Pragma("unroll") for (int r = 0; r < 16; ++r) sum_ += VAL(b, r); \
+            sum_ += __shfl_xor(sum_, 32);                                                                             \
+            MEAN = sum_ / (float)EC;                                                                                  \
+            float sq_ = 0.f;                                                                                          \
+            _Pragma("unroll") for (int b = 0; b < NBLK; ++b) _Pragma("unroll") for (int r = 0; r < 16; ++r)           \
+                sq_ += (VAL(b, r) - MEAN) * (VAL(b, r) - MEAN);                                                       \
+            sq_ += __shfl_xor(sq_, 32);                                                                               \
+            RSTD = 1.f / sqrtf(sq_ / (float)EC + (EPS));                                                              \
+        }
+        float Z[2 * NBLK];
+        // ---- S1: q = W_q x, phi(q), Z ------------------------------------------------------------------------------------
+        {
+            f32x16 am[NBLK], ax[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) am[b] = ax[b] = f32x16{0};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8 th[4], tl[4];
+                xfrags(4 * s2, th, tl);
+                slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, th, tl);
+                slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, th + 2, tl + 2);
+            }
+            ENC_STAMP(2)
+            const float* ks = reinterpret_cast<const float*>(g.kvimg + (int64_t)n_tok * KVIMG + 16384);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = am[b][r] + ax[b][r] * (1.f / 2048.f);
+                if (g.dbg && g.dbg_stage == 1) dump(g, v, b, row, valid, half);
+                float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(ks + 32 * b + 8 * q4 + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float f = phi_fast(v[4 * q4 + e]) * qm;
+                        v[4 * q4 + e] = f;
+                        if (q4 < 2) z0 += f * k4[e]; else z1 += f * k4[e];
+                    }
+                }
+                z0 += __shfl_xor(z0, 32);
+                z1 += __shfl_xor(z1, 32);
+                Z[2 * b] = 1.f / (z0 + g.attn_eps);
+                Z[2 * b + 1] = 1.f / (z1 + g.attn_eps);
+                to_frags(v, ah[2 * b], al[2 * b], ah[2 * b + 1], al[2 * b + 1]);
+            }
+        }
+        ENC_STAMP(3)
+        // ---- S2: message^T = KV^T phi(q)^T per head (block-diagonal: block b holds heads 2b, 2b+1) ------------------------
+        {
+            f32x16 am[NBLK], ax[NBLK], ay[NBLK];      // a block's three products are consecutive here: three accumulators
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) am[b] = ax[b] = ay[b] = f32x16{0};
+            {
+                const bool mine = n_tok == min(n_first, g.N - 1);   // tokens of the other sequence contribute zero columns
+#pragma unroll
+                for (int f = 0; f < NKS; ++f) {
+                    const half8 qh = mine ? ah[f] : zero8, ql = mine ? al[f] : zero8;
+                    am[f >> 1] = mfma(kvh[f], qh, am[f >> 1]);
+                    ax[f >> 1] = mfma(kvl[f], qh, ax[f >> 1]);
+                    ay[f >> 1] = mfma(kvh[f], ql, ay[f >> 1]);
+                }
+            }
+            if (two) {                                               // the tile's second sequence (uniform branch)
+                const bool mine = n_tok == n_first + 1;
+                const char* img = g.kvimg + (int64_t)(n_first + 1) * KVIMG + lane * 16;
+#pragma unroll
+                for (int f = 0; f < NKS; ++f) {
+                    const bool on = (tok >> 4) == (f & 1);
+                    const half8 kh = on ? *reinterpret_cast<const half8*>(img + (f * 2 + 0) * 1024) : zero8;
+                    const half8 kl = on ? *reinterpret_cast<const half8*>(img + (f * 2 + 1) * 1024) : zero8;
+                    const half8 qh = mine ? ah[f] : zero8, ql = mine ? al[f] : zero8;
+                    am[f >> 1] = mfma(kh, qh, am[f >> 1]);
+                    ax[f >> 1] = mfma(kl, qh, ax[f >> 1]);
+                    ay[f >> 1] = mfma(kh, ql, ay[f >> 1]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    v[r] = ((am[b][r] + (ax[b][r] + ay[b][r]) * (1.f / 2048.f)) * Z[2 * b + (r >> 3)]) * Sf;
+                if (g.dbg && g.dbg_stage == 2) dump(g, v, b, row, valid, half);
+                to_frags(v, ah[2 * b], al[2 * b], ah[2 * b + 1], al[2 * b + 1]);
+            }
+        }
+        ENC_STAMP(4)
+        // ---- S3: merge, LayerNorm1 ------------------------------------------------------------------------------------------
+        {
+            f32x16 am[NBLK], ax[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) am[b] = ax[b] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, ah + 2 * s, al + 2 * s);
+            ENC_STAMP(5)
+#define ENC_V3(b, r) (am[b][r] + ax[b][r] * (1.f / 2048.f))
+            ENC_ROWSTATS(ENC_V3, g.eps1, mean, rstd)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                float v[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.g1 + 32 * b + 8 * q4 + 4 * half);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(g.b1 + 32 * b + 8 * q4 + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q4 + e] = (ENC_V3(b, 4 * q4 + e) - mean) * rstd * gm[e] + bt[e];
+                }
+                if (g.dbg && g.dbg_stage == 3) dump(g, v, b, row, valid, half);
+                to_frags(v, ah[2 * b], al[2 * b], ah[2 * b + 1], al[2 * b + 1]);
+            }
+#undef ENC_V3
+        }
+        ENC_STAMP(6)
+        // ---- S4: mlp.2(relu(mlp.0([x | m]))) in four 64-channel chunks of the hidden layer; S5: x + LayerNorm2(.) ----------
+        {
+            f32x16 om[NBLK], ox[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) om[b] = ox[b] = f32x16{0};
+#pragma unroll 1
+            for (int hc = 0; hc < 4; ++hc) {
+                f32x16 hm[2], hx[2], hy[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) hm[b] = hx[b] = hy[b] = f32x16{0};
+                {
+                    half8 th[4], tl[4];
+                    xfrags(0, th, tl);
+                    slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, th, tl);          // k-steps 0-3: x channels 0-63
+                    xfrags(4, th, tl);
+                    slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, th, tl);          // 4-7
+                }
+                slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, ah, al);              // 8-11: norm1(merge) channels 0-63
+                slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, ah + 4, al + 4);      // 12-15
+                half8 hh[4], hl[4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float hv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hm[b][r] + (hx[b][r] + hy[b][r]) * (1.f / 2048.f), 0.f);
+                    to_frags(hv, hh[2 * b], hl[2 * b], hh[2 * b + 1], hl[2 * b + 1]);
+                }
+                slab_mma<NBLK, 2>(ring.acquire(), lane, om, ox, ox, hh, hl);
+                slab_mma<NBLK, 2>(ring.acquire(), lane, om, ox, ox, hh + 2, hl + 2);
+            }
+            ENC_STAMP(7)
+#define ENC_V5(b, r) (om[b][r] + ox[b][r] * (1.f / 2048.f))
+            ENC_ROWSTATS(ENC_V5, g.eps2, mean, rstd)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                float v[16];
+                if (g.dbg && g.dbg_stage == 4) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = ENC_V5(b, r);
+                    dump(g, v, b, row, valid, half);
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.g2 + 32 * b + 8 * q4 + 4 * half);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(g.b2 + 32 * b + 8 * q4 + 4 * half);
+                    // residual x: this lane's 4 channels of chunk 4b + q4 sit where its output goes (read, then overwritten below)
+                    const half4 xrh = *reinterpret_cast<const half4*>(stg + stg_off(tok, 4 * b + q4) + 8 * half);
+                    const half4 xrl = *reinterpret_cast<const half4*>(stg + 8192 + stg_off(tok, 4 * b + q4) + 8 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q4 + e;
+                        const float xr = (float)xrh[e] + (float)xrl[e] * (1.f / 2048.f);
+                        v[r] = xr + ((ENC_V5(b, r) - mean) * rstd * gm[e] + bt[e]);
+                    }
+                }
+                // split planes -> staging, in place of the x values just read (same swizzled row-major layout)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    half4 h4, l4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, c;
+                        split_f32(v[4 * q4 + e], a, c);
+                        h4[e] = a;
+                        l4[e] = c;
+                    }
+                    const int o = stg_off(tok, 4 * b + q4) + 8 * half;
+                    *reinterpret_cast<half4*>(stg + o) = h4;
+                    *reinterpret_cast<half4*>(stg + 8192 + o) = l4;
+                }
+            }
+#undef ENC_V5
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ENC_STAMP(8)
+            {
+                // whole-row stores; the fp32 form (last layer: features for the fine matcher, which splits them the same
+                // way again) is the exact value of the planes, hi + lo / 2048
+                const int trow = lane >> 4, p = lane & 15;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 4 * i + trow;
+                    const int64_t rr = row0 + t;
+                    const uint4 dh = *reinterpret_cast<const uint4*>(stg + t * 256 + p * 16);
+                    const uint4 dl = *reinterpret_cast<const uint4*>(stg + 8192 + t * 256 + p * 16);
+                    if (rr < g.M) {
+                        const int cc = (p ^ (t & 15)) << 3;
+                        if (g.oh) {
+                            *reinterpret_cast<uint4*>(g.oh + rr * g.ldo + cc) = dh;
+                            *reinterpret_cast<uint4*>(g.ol + rr * g.ldo + cc) = dl;
+                        }
+                        if (g.o32) {
+                            const half8 h8 = *reinterpret_cast<const half8*>(&dh), l8 = *reinterpret_cast<const half8*>(&dl);
+                            float* o32 = g.o32 + rr * g.ldo32 + cc;
+                            f32x4 f0, f1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                f0[e] = (float)h8[e] + (float)l8[e] * (1.f / 2048.f);
+                                f1[e] = (float)h8[4 + e] + (float)l8[4 + e] * (1.f / 2048.f);
+                            }
+                            *reinterpret_cast<f32x4*>(o32) = f0;
+                            *reinterpret_cast<f32x4*>(o32 + 4) = f1;
+                        }
+                    }
+                }
+            }
+            // staging reads done before the next tile's DMA lands; the stores themselves may stay in flight: a counted
+            // vmcnt wait only becomes more conservative with stores in the queue (SlabRing::acquire)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ENC_STAMP(9)
+        }
+#undef ENC_ROWSTATS
+    }
+#undef ENC_STAMP
+    wait_vmcnt<0>();        // prefetched slabs still in flight must land before the LDS allocation is released
+}
+
+// =====================================================================================================================
+// enc_kv_kernel: one workgroup per sequence; wave w takes token blocks w, w+4, ... of the sequence.
+// Classic orientation: D[token][channel] = x[token][k] W[channel][k]: lane = channel, registers = 16 tokens, so that
+// KV[d][d'] = sum_tokens phi(k)[token][d] v[token][d'] is an MFMA whose A and B fragments are the k / v accumulators.
+// Weight stream: 8 slabs; slab 2 p + u = rows [k channels of head pair p | v channels of head pair p] (2 blocks) x k-steps 4u..4u+3.
+// =====================================================================================================================
+struct KvArgs {
+    const _Float16 *xh, *xl;     // source rows as split planes
+    int64_t ldx;
+    unsigned xbytes;
+    const char* wstream;         // NSLAB_KV slabs
+    const uint8_t* kvmask;       // [N][km_per_seq] or null
+    int kv_group, km_per_seq;
+    char* kvimg;                 // [N][KVIMG] out
+    int S, N;
+};
+
+__global__ __launch_bounds__(256) void enc_kv_kernel(KvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    char* stg = smem + RING + wave * STG;
+    const int n = blockIdx.x;
+
+    SlabRing ring;
+    ring.ring = smem;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.wstream, 0, NSLAB_KV * SLAB, 0x00020000);
+    ring.lane_off = (unsigned)(wave * 4096 + lane * 16);
+    ring.wave = wave;
+    ring.nslab = NSLAB_KV;
+    ring.prologue();
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const float Sf = (float)g.S;
+    const int nblocks = (g.S + 31) / 32;
+    const int niter = (nblocks + 3) / 4;            // every wave runs the same number of rounds (shared weight stream)
+
+    f32x16 kvm[NBLK], kvx[NBLK];                    // KV of head pair p: rows = k channel, cols = v channel (lane)
+    float ksum[NBLK];
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p) {
+        kvm[p] = kvx[p] = f32x16{0};
+        ksum[p] = 0.f;
+    }
+
+    for (int it = 0; it < niter; ++it) {
+        const int blk = it * 4 + wave;
+        const int s0 = blk * 32;                    // first token of this wave's block (may be past the sequence: all masked)
+        {
+            const int trow = lane >> 4, pp = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = 4 * i + trow;
+                const int s = s0 + t;
+                const unsigned off = s < g.S ? (unsigned)((((int64_t)n * g.S + s) * g.ldx + ((pp ^ (t & 15)) << 3)) * 2) : g.xbytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + 8192 + i * 1024), 16, off, 0, 0, 0);
+            }
+        }
+        // mask of the 16 tokens this lane's accumulator registers hold: token s0 + dch(r, half)
+        float tm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = s0 + dch(r, half);
+            float m = s < g.S ? 1.f : 0.f;
+            if (g.kvmask && s < g.S) m = (float)g.kvmask[(int64_t)n * g.km_per_seq + s / g.kv_group];
+            tm[r] = m;
+        }
+        wait_vmcnt<0>();
+        // A fragments of x: lane = token, natural k order (16 bytes = channels 16 s + 8 half ..)
+        half8 xh[NKS], xl[NKS];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            xh[s] = *reinterpret_cast<const half8*>(stg + stg_off(col, 2 * s + half));
+            xl[s] = *reinterpret_cast<const half8*>(stg + 8192 + stg_off(col, 2 * s + half));
+        }
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p) {
+            f32x16 dm[2], dx[2], dy[2];             // block 0 = k channels of head pair p, block 1 = v channels
+#pragma unroll
+            for (int b = 0; b < 2; ++b) dm[b] = dx[b] = dy[b] = f32x16{0};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const char* slab = ring.acquire();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    half8 wh[2], wl[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * 2 + b) * 2 + 0) * 1024 + lane * 16);
+                        wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * 2 + b) * 2 + 1) * 1024 + lane * 16);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) dm[b] = mfma(xh[4 * u + ks], wh[b], dm[b]);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) dx[b] = mfma(xh[4 * u + ks], wl[b], dx[b]);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) dy[b] = mfma(xl[4 * u + ks], wh[b], dy[b]);
+                }
+            }
+            float kf[16], vf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                kf[r] = phi_fast(dm[0][r] + (dx[0][r] + dy[0][r]) * (1.f / 2048.f)) * tm[r];
+                vf[r] = ((dm[1][r] + (dx[1][r] + dy[1][r]) * (1.f / 2048.f)) * tm[r]) / Sf;
+                ksum[p] += kf[r];
+            }
+            half8 kh0, kl0, kh1, kl1, vh0, vl0, vh1, vl1;
+            to_frags(kf, kh0, kl0, kh1, kl1);
+            to_frags(vf, vh0, vl0, vh1, vl1);
+            // KV[d][d'] += sum over the 16 + 16 tokens: A = phi(k) (lane = d), B = v (lane = d'); same token order on both
+            kvm[p] = mfma(kh0, vh0, kvm[p]);
+            kvx[p] = mfma(kl0, vh0, kvx[p]);
+            kvm[p] = mfma(kh1, vh1, kvm[p]);
+            kvx[p] = mfma(kh0, vl0, kvx[p]);
+            kvx[p] = mfma(kl1, vh1, kvx[p]);
+            kvx[p] = mfma(kh1, vl1, kvx[p]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                                // ring and staging are free: reuse them for the cross-wave sums
+    // every wave parks its partial KV (fp32) in its staging tile: [p][r][lane], and its Ksum in the ring area
+    float* part = reinterpret_cast<float*>(stg);
+    float* ksp = reinterpret_cast<float*>(smem);    // [wave][p][lane]
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(p * 16 + r) * 64 + lane] = kvm[p][r] + kvx[p][r] * (1.f / 2048.f);
+        ksp[(wave * NBLK + p) * 64 + lane] = ksum[p];
+    }
+    __syncthreads();
+    // wave w finishes head pair w: fixed summation order over the waves (deterministic)
+    {
+        const int p = wave;
+        float kv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += reinterpret_cast<const float*>(smem + RING + w * STG)[(p * 16 + r) * 64 + lane];
+            kv[r] = a;
+        }
+        float ks = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) ks += ksp[(w * NBLK + p) * 64 + lane];
+        ks += __shfl_xor(ks, 32);                   // the two lane halves hold the two token halves of every block
+        char* img = g.kvimg + (int64_t)n * KVIMG;
+        // apply image: fragment (b = p, t) of KV^T for enc_apply_kernel = this lane's registers 8t..8t+7, rows of the other
+        // head zeroed (block-diagonal): lane = v channel d' (row of KV^T), slot j = k channel 16 t + dch(j, half)
+        half8 h0, l0, h1, l1;
+        to_frags(kv, h0, l0, h1, l1);
+        if ((col >> 4) == 0) {                      // rows of head 2p: fragment t = 0; the other lanes' slots stay unwritten
+            *reinterpret_cast<half8*>(img + ((p * 2 + 0) * 2 + 0) * 1024 + lane * 16) = h0;      // (the consumer never loads them)
+            *reinterpret_cast<half8*>(img + ((p * 2 + 0) * 2 + 1) * 1024 + lane * 16) = l0;
+        } else {                                    // rows of head 2p + 1: fragment t = 1
+            *reinterpret_cast<half8*>(img + ((p * 2 + 1) * 2 + 0) * 1024 + lane * 16) = h1;
+            *reinterpret_cast<half8*>(img + ((p * 2 + 1) * 2 + 1) * 1024 + lane * 16) = l1;
+        }
+        if (half == 0) reinterpret_cast<float*>(img + 16384)[32 * p + col] = ks;
+    }
+}
+
+dfsfm::SmemAttr attr_apply, attr_kv;
+
+}  // namespace
+
+extern "C" int dfsfm_encoder_kv_f32(const void* src_hi, const void* src_lo, int64_t ld_src, int N, int S,
+                                    const void* wstream_kv, const uint8_t* kv_mask, int kv_group, void* kv_image,
+                                    void* stream_) {
+    if (N == 0) return DFSFM_OK;
+    if (!src_hi || !src_lo || !wstream_kv || !kv_image) return DFSFM_E_BADARG;
+    if (N < 0 || S <= 0 || kv_group <= 0 || ld_src < EC) return DFSFM_E_BADARG;
+    const int64_t span = ((int64_t)N * S - 1) * ld_src * 2 + EC * 2;
+    if ((ld_src & 7) || span >= (int64_t)0xFFFFFFF0 || (reinterpret_cast<uintptr_t>(src_hi) & 15) ||
+        (reinterpret_cast<uintptr_t>(src_lo) & 15) || (reinterpret_cast<uintptr_t>(wstream_kv) & 15) ||
+        (reinterpret_cast<uintptr_t>(kv_image) & 15))
+        return DFSFM_E_UNSUPPORTED;
+    KvArgs g{};
+    g.xh = static_cast<const _Float16*>(src_hi);
+    g.xl = static_cast<const _Float16*>(src_lo);
+    g.ldx = ld_src;
+    g.xbytes = (unsigned)span;
+    g.wstream = static_cast<const char*>(wstream_kv);
+    g.kvmask = kv_mask;
+    g.kv_group = kv_group;
+    g.km_per_seq = (S + kv_group - 1) / kv_group;
+    g.kvimg = static_cast<char*>(kv_image);
+    g.S = S;
+    g.N = N;
+    attr_kv.ensure(reinterpret_cast<const void*>(&enc_kv_kernel), SMEM_BYTES);
+    hipLaunchKernelGGL(enc_kv_kernel, dim3((unsigned)N), dim3(256), SMEM_BYTES, static_cast<hipStream_t>(stream_), g);
+    return dfsfm::check_launch("dfsfm_encoder_kv_f32");
+}
+
+extern "C" int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int N, int L, int S,
+                                       const void* wstream, const void* kv_image, const uint8_t* q_mask, int q_group,
+                                       const float* gamma1, const float* beta1, float eps1, const float* gamma2,
+                                       const float* beta2, float eps2, float attn_eps, void* out_hi, void* out_lo,
+                                       int64_t ldo, float* out32, int64_t ldo32, float* debug, int debug_stage,
+                                       void* stream_) {
+    if (N == 0) return DFSFM_OK;
+    if (!x_hi || !x_lo || !wstream || !kv_image || !gamma1 || !beta1 || !gamma2 || !beta2) return DFSFM_E_BADARG;
+    if ((out_hi == nullptr) != (out_lo == nullptr) || (!out_hi && !out32)) return DFSFM_E_BADARG;
+    if (N < 0 || L <= 0 || S <= 0 || q_group <= 0 || ldx < EC || (out_hi && ldo < EC) || (out32 && ldo32 < EC))
+        return DFSFM_E_BADARG;
+    if (L < 32) return DFSFM_E_UNSUPPORTED;          // a 32-token tile may touch at most two sequences
+    const int64_t M = (int64_t)N * L;
+    const int64_t span = (M - 1) * ldx * 2 + EC * 2;
+    if ((ldx & 7) || (ldo & 7) || (ldo32 & 3) || span >= (int64_t)0xFFFFFFF0) return DFSFM_E_UNSUPPORTED;
+    for (const void* p : {x_hi, x_lo, wstream, kv_image, (const void*)out_hi, (const void*)out_lo, (const void*)out32,
+                          (const void*)gamma1, (const void*)beta1, (const void*)gamma2, (const void*)beta2})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return DFSFM_E_UNSUPPORTED;
+    ApplyArgs g{};
+    g.xh = static_cast<const _Float16*>(x_hi);
+    g.xl = static_cast<const _Float16*>(x_lo);
+    g.ldx = ldx;
+    g.xbytes = (unsigned)span;
+    g.wstream = static_cast<const char*>(wstream);
+    g.kvimg = static_cast<const char*>(kv_image);
+    g.qmask = q_mask;
+    g.q_group = q_group;
+    g.qm_per_seq = (L + q_group - 1) / q_group;
+    g.g1 = gamma1; g.b1 = beta1; g.g2 = gamma2; g.b2 = beta2;
+    g.eps1 = eps1; g.eps2 = eps2; g.attn_eps = attn_eps;
+    g.oh = static_cast<_Float16*>(out_hi);
+    g.ol = static_cast<_Float16*>(out_lo);
+    g.ldo = ldo;
+    g.o32 = out32;
+    g.ldo32 = ldo32;
+    g.M = M;
+    g.L = L; g.N = N; g.S = S;
+    g.ntiles = (int)((M + 127) / 128);
+    g.dbg = debug;
+    g.dbg_stage = debug_stage;
+    static const int stagger = [] { const char* e = getenv("DFSFM_ENC_STAGGER"); return e ? atoi(e) : 2; }();   // A/B knob
+    g.stagger = g.ntiles > 4 * 256 ? stagger : 0;       // only worth it when every workgroup walks several tiles
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = g.ntiles < cus ? g.ntiles : cus;   // persistent: one workgroup per CU walks the tiles
+    attr_apply.ensure(reinterpret_cast<const void*>(&enc_apply_kernel), SMEM_BYTES);
+    hipLaunchKernelGGL(enc_apply_kernel, dim3((unsigned)grid), dim3(256), SMEM_BYTES, static_cast<hipStream_t>(stream_), g);
+    return dfsfm::check_launch("dfsfm_encoder_apply_f32");
+}

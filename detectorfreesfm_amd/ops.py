@@ -860,6 +860,153 @@ def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=No
     return out
 
 
+# ---------------------------------------------------------------- fused encoder layer (csrc/encoder_fused.hip)
+ENC_C, ENC_SLAB, ENC_KV_IMAGE = 128, 16384, 16 * 1024 + 512
+
+
+def _split_planes(w):
+    """fp32 / fp64 matrix -> (hi, lo) fp16 planes, w = hi + lo / 2048 (the rule of PackedDense)."""
+    w = w.detach()
+    wd = w.dtype if w.dtype == torch.float64 else torch.float32
+    w = w.to(wd)
+    if not bool(torch.isfinite(w).all()) or float(w.abs().max()) >= FP16_MAX:
+        raise _lib.DfsfmError(f"EncoderFusedWeights: weights must be finite with |w| < {FP16_MAX:.0f} (split-plane range)")
+    hi = torch.where(w.abs() >= 2.0 ** -14, w, torch.zeros_like(w)).half()
+    return hi, ((w - hi.to(wd)) * 2048.0).half()
+
+
+def _kslots(kstep: int, d_order: bool) -> torch.Tensor:
+    """Column indices [2 (lane half), 8 (slot)] an MFMA 32x32x16 fragment holds for k-step ``kstep``.
+    natural: 16 kstep + 8 half + j.  D order (the k index the accumulator of a previous MFMA imposes when it is fed back as
+    an operand: register r of lane half h holds channel (r & 3) + 8 (r >> 2) + 4 h): 16 kstep + (j & 3) + 8 (j >> 2) + 4 half."""
+    j = torch.arange(8)
+    h = torch.arange(2)[:, None]
+    return 16 * kstep + ((j & 3) + 8 * (j >> 2) + 4 * h if d_order else 8 * h + j)
+
+
+def _fragment(plane: torch.Tensor, row0: int, kstep: int, d_order: bool) -> torch.Tensor:
+    """One 1-KB MFMA operand fragment [64 lanes, 8 halves] of rows row0..row0+31: lane l = (row l & 31, half l >> 5)."""
+    cols = _kslots(kstep, d_order).to(plane.device)                     # [2, 8]
+    rows = plane[row0:row0 + 32]                                        # [32, K]
+    return torch.stack([rows[:, cols[0]], rows[:, cols[1]]], 0).reshape(64, 8)
+
+
+class EncoderFusedWeights:
+    """Weights of one LoFTREncoderLayer (d_model 128, 8 heads) as the two fragment streams of csrc/encoder_fused.hip.
+
+    A stream is a sequence of 16-KB slabs; a slab is 16 fragments of 1 KB (64 lanes x 16 bytes, lane-linear), (hi, lo)
+    pairs in the order the kernel consumes them, so that the kernel's global -> LDS copy is linear and its LDS reads are
+    ``base + fragment * 1024 + lane * 16``.
+      kv stream (8 slabs, natural k order; enc_kv_kernel): slab 2 p + u = k-steps 4u..4u+3 of the rows
+          [W_k rows of head pair p (32) | W_v rows of head pair p (32)]; fragment order (ks, block, plane).
+      apply stream (32 slabs, D-order k; enc_apply_kernel): 4 slabs W_q (k-steps 2s, 2s+1 x 4 row blocks), 4 slabs merge,
+          then per 64-channel chunk hc of the MLP's hidden layer: 4 slabs of mlp.0 rows 64hc..64hc+63 (k-steps 4u..4u+3 of
+          the 256 input columns [x | norm1(message)] x 2 row blocks) and 2 slabs of mlp.2 (its columns 64hc + 16 (2v + ks),
+          4 row blocks)."""
+
+    def __init__(self, wq, wk, wv, wmerge, w1, w2, n1, n2, nhead=8):
+        C = ENC_C
+        if nhead != 8 or tuple(wq.shape) != (C, C) or tuple(w1.shape) != (2 * C, 2 * C) or tuple(w2.shape) != (C, 2 * C):
+            raise _lib.DfsfmError("EncoderFusedWeights: the fused encoder layer is built for d_model 128, 8 heads")
+        dev = wq.device
+        planes = {k: _split_planes(v) for k, v in (("q", wq), ("k", wk), ("v", wv), ("m", wmerge), ("1", w1), ("2", w2))}
+        # the values the kernels multiply with (hi + lo / 2048), under the reference's parameter names: what the CPU
+        # stand-ins of the tests evaluate the layer with
+        self.values = {n: (planes[k][0].float() + planes[k][1].float() / 2048.0) for n, k in
+                       (("q_proj.weight", "q"), ("k_proj.weight", "k"), ("v_proj.weight", "v"), ("merge.weight", "m"),
+                        ("mlp.0.weight", "1"), ("mlp.2.weight", "2"))}
+
+        def pair(name, row0, kstep, d_order):
+            return [_fragment(planes[name][0], row0, kstep, d_order), _fragment(planes[name][1], row0, kstep, d_order)]
+        frags = []
+        for p in range(4):                               # kv stream
+            for u in range(2):
+                for ks in range(4):
+                    frags += pair("k", 32 * p, 4 * u + ks, False) + pair("v", 32 * p, 4 * u + ks, False)
+        self.kv_stream = torch.stack(frags, 0).contiguous().to(dev)          # [128, 64, 8] fp16 = 8 slabs
+        frags = []
+        for name in ("q", "m"):
+            for s_ in range(4):
+                for ks in range(2):
+                    for b in range(4):
+                        frags += pair(name, 32 * b, 2 * s_ + ks, True)
+        for hc in range(4):
+            for u in range(4):
+                for ks in range(4):
+                    for b in range(2):
+                        frags += pair("1", 64 * hc + 32 * b, 4 * u + ks, True)
+            for v2 in range(2):
+                for ks in range(2):
+                    for b in range(4):
+                        frags += pair("2", 32 * b, 4 * hc + 2 * v2 + ks, True)
+        self.apply_stream = torch.stack(frags, 0).contiguous().to(dev)       # [512, 64, 8] fp16 = 32 slabs
+        assert self.kv_stream.numel() * 2 == 8 * ENC_SLAB and self.apply_stream.numel() * 2 == 32 * ENC_SLAB
+        self.n1 = tuple(t.detach().float().contiguous() for t in n1)
+        self.n2 = tuple(t.detach().float().contiguous() for t in n2)
+        self.values.update({"norm1.weight": self.n1[0], "norm1.bias": self.n1[1], "norm2.weight": self.n2[0],
+                            "norm2.bias": self.n2[1]})
+
+
+def _enc_rows(x: "SplitAct", what):
+    """(N, rows per sequence, row stride) of a SplitAct [N, L, 128] view whose rows are uniformly strided."""
+    if x.hi.dim() != 3 or x.hi.shape[-1] != ENC_C or x.hi.dtype != torch.float16 or x.lo.stride() != x.hi.stride():
+        raise _lib.DfsfmError(f"{what}: need split planes [N, L, 128]")
+    rows, ld = _rows_ld(x.hi, torch.float16)
+    return x.hi.shape[0], x.hi.shape[1], ld
+
+
+@_on_device
+def encoder_kv(src: "SplitAct", fw: EncoderFusedWeights, kv_mask=None, kv_group=1):
+    """First half of a fused encoder layer: source tokens [N, S, 128] (split planes) -> the per-sequence attention state
+    (KV^T fragments + Ksum) for ``encoder_apply``; k and v never reach memory."""
+    _require_cuda(src.hi)
+    N, S, ld = _enc_rows(src, "encoder_kv")
+    img = torch.empty((N, ENC_KV_IMAGE), dtype=torch.uint8, device=src.hi.device)
+    km = _as_u8(kv_mask)
+    if km is not None and km.shape != (N, (S + kv_group - 1) // kv_group):
+        raise _lib.DfsfmError("encoder_kv: kv_mask must be [N, ceil(S / kv_group)]")
+    rc = _lib.lib().dfsfm_encoder_kv_f32(_ptr(src.hi), _ptr(src.lo), ld, N, S, _ptr(fw.kv_stream), _ptr(km), int(kv_group),
+                                         _ptr(img), _stream())
+    _lib.check(rc, "dfsfm_encoder_kv_f32")
+    return img
+
+
+@_on_device
+def encoder_apply(x: "SplitAct", fw: EncoderFusedWeights, kv_image, S, q_mask=None, q_group=1, out_split=None, out=None,
+                  eps=1e-5, attn_eps=1e-6, debug_stage=0):
+    """Second half: x tokens [N, L, 128] (split planes) + attention state -> x + norm2(mlp([x | norm1(merge(attention))])) into
+    the SplitAct view ``out_split`` and / or the fp32 view ``out`` ([N, L, 128] each).  debug_stage != 0 additionally returns
+    an fp32 [N*L, 128] dump of that intermediate (tests)."""
+    _require_cuda(x.hi, kv_image)
+    N, L, ldx = _enc_rows(x, "encoder_apply")
+    if kv_image.shape != (N, ENC_KV_IMAGE) or kv_image.dtype != torch.uint8 or not kv_image.is_contiguous():
+        raise _lib.DfsfmError("encoder_apply: kv_image must come from encoder_kv for the same N")
+    oh = ol = None
+    ldo = ldo32 = 0
+    if out_split is not None:
+        n2, l2, ldo = _enc_rows(out_split, "encoder_apply(out_split)")
+        if (n2, l2) != (N, L):
+            raise _lib.DfsfmError("encoder_apply: out_split shape mismatch")
+        oh, ol = out_split.hi, out_split.lo
+    if out is not None:
+        rows_o, ldo32 = _rows_ld(out)
+        if rows_o != N * L or out.shape[-1] != ENC_C:
+            raise _lib.DfsfmError("encoder_apply: out shape mismatch")
+    qm = _as_u8(q_mask)
+    if qm is not None and qm.shape != (N, (L + q_group - 1) // q_group):
+        raise _lib.DfsfmError("encoder_apply: q_mask must be [N, ceil(L / q_group)]")
+    # debug_stage 100: stage time stamps of wave 0 of every tile (tools/bench_encoder_fused.py)
+    dbg = torch.zeros((max(N * L, (N * L + 127) // 128), ENC_C), dtype=torch.float32, device=x.hi.device) if debug_stage else None
+    rc = _lib.lib().dfsfm_encoder_apply_f32(_ptr(x.hi), _ptr(x.lo), ldx, N, L, int(S), _ptr(fw.apply_stream), _ptr(kv_image),
+                                            _ptr(qm), int(q_group), _ptr(fw.n1[0]), _ptr(fw.n1[1]), float(eps), _ptr(fw.n2[0]),
+                                            _ptr(fw.n2[1]), float(eps), float(attn_eps), _ptr(oh), _ptr(ol), ldo, _ptr(out),
+                                            ldo32, _ptr(dbg), int(debug_stage), _stream())
+    _lib.check(rc, "dfsfm_encoder_apply_f32")
+    if _debug_range and out_split is not None:
+        check_split_range(out_split, "encoder_apply")
+    return dbg
+
+
 @_on_device
 def merge_keypoints(rows, img0, img1, n_images):
     """Scene-wide keypoint merge + match re-indexing (coarse_match.py:203-237 on the device).

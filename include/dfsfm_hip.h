@@ -372,6 +372,35 @@ int dfsfm_merge_keypoints(const float* rows, const int32_t* img0, const int32_t*
                           float* kpts, float* scores, int64_t* offsets, int64_t* match_ids, int64_t* n_kpts,
                           int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K2 + K1 (+ K10) fused  one LoFTREncoderLayer application, d_model 128, 8 heads (csrc/encoder_fused.hip)
+ * Replaces LoFTREncoderLayer.forward + LinearAttention.forward of the refinement head
+ *   src/MultiviewMatcher/matcher_module/transformer.py:66-95, matcher_module/linear_attention.py:28-60
+ *   (the same layer as third_party/LoFTR/src/loftr/loftr_module/transformer.py:35-58, linear_attention.py:20-47)
+ * in two launches that read every token row once each and write it once:
+ *
+ * dfsfm_encoder_kv_f32     source rows [N*S, 128] (split fp16 planes src_hi/src_lo, row stride ld_src halves) ->
+ *                          k|v = W_k,v x (never stored) -> per sequence n the "apply image" kv_image[n]
+ *                          (DFSFM_ENCODER_KV_IMAGE_BYTES bytes: KV^T = (sum_s phi(k_s)^T v_s / S)^T per head as fp16 hi/lo
+ *                          MFMA fragments + Ksum = sum_s phi(k_s) as 128 floats).  kv_mask [N, ceil(S/kv_group)] uint8 or NULL.
+ * dfsfm_encoder_apply_f32  x rows [N*L, 128] (split planes) + kv_image -> out = x + norm2(mlp([x | norm1(merge(attn))]))
+ *                          as split planes (out_hi/out_lo, row stride ldo halves; may be NULL) and/or fp32 rows (out32, row
+ *                          stride ldo32 floats; may be NULL; = hi + lo/2048).  q_mask [N, ceil(L/q_group)] uint8 or NULL.
+ *                          S = tokens per sequence on the source side (the reference's v_length).  L >= 32.
+ *                          debug / debug_stage: fp32 [N*L,128] dump of one intermediate (1 q, 2 message, 3 norm1, 4 mlp
+ *                          output) for the tests; pass NULL / 0.
+ * The weights travel as ready-made fragment streams built once on the host (detectorfreesfm_amd/ops.py::
+ * EncoderFusedWeights: wstream_kv = 8 slabs, wstream = 32 slabs of 16 KB; layout documented there and in the kernel).
+ * ---------------------------------------------------------------------------------------- */
+#define DFSFM_ENCODER_KV_IMAGE_BYTES (16 * 1024 + 512)
+int dfsfm_encoder_kv_f32(const void* src_hi, const void* src_lo, int64_t ld_src, int N, int S, const void* wstream_kv,
+                         const uint8_t* kv_mask, int kv_group, void* kv_image, void* stream);
+int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int N, int L, int S, const void* wstream,
+                            const void* kv_image, const uint8_t* q_mask, int q_group, const float* gamma1,
+                            const float* beta1, float eps1, const float* gamma2, const float* beta2, float eps2,
+                            float attn_eps, void* out_hi, void* out_lo, int64_t ldo, float* out32, int64_t ldo32,
+                            float* debug, int debug_stage, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -336,6 +336,26 @@ def _merge(rows, img0, img1, n_images):
     return torch.from_numpy(kp), torch.from_numpy(sc), torch.from_numpy(off), torch.from_numpy(ids)
 
 
+def _enc_kv(src, fw, kv_mask=None, kv_group=1):
+    """Stand-in for ops.encoder_kv: the attention state is simply the source tokens and their mask (the layer is evaluated
+    in _enc_apply with the oracle's restatement on the values the split planes hold)."""
+    return {"src": src.float().clone(), "mask": kv_mask, "group": kv_group}
+
+
+def _enc_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=None, eps=1e-5, attn_eps=1e-6, debug_stage=0):
+    xv = x.float()
+    N, L, _ = xv.shape
+    xm = None if q_mask is None else q_mask.repeat_interleave(q_group, dim=1)[:, :L]
+    sm = None if state["mask"] is None else state["mask"].repeat_interleave(state["group"], dim=1)[:, :state["src"].shape[1]]
+    y = restate.encoder_layer(fw.values, "", xv, state["src"], 8, xm, sm)
+    if out_split is not None:
+        _put_split(out_split, y)
+    if out is not None:
+        hi, lo = _split(y)
+        out.copy_((hi + lo / 2048.0).reshape(out.shape))          # the kernel's fp32 form is the exact value of the planes
+    return None
+
+
 @contextlib.contextmanager
 def cpu_ops():
     from detectorfreesfm_amd import ops
@@ -343,7 +363,8 @@ def cpu_ops():
                                           "layernorm", "add_scatter_tokens", "conv2d_nhwc", "linear",
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
                                           "bilinear_up", "resample_u8", "avgpool", "full_attention",
-                                          "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear")}
+                                          "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear",
+                                          "encoder_kv", "encoder_apply")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
@@ -354,6 +375,7 @@ def cpu_ops():
     ops.avgpool, ops.full_attention, ops.span_attention = _avgpool, _full_attention, _span_attention
     ops.layernorm2d, ops.upsample, ops.flow_decode = _layernorm2d, _upsample, _flow_decode
     ops.resize_bilinear = _resize_bilinear
+    ops.encoder_kv, ops.encoder_apply = _enc_kv, _enc_apply
     try:
         yield
     finally:
