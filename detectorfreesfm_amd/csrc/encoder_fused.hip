@@ -223,23 +223,26 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
         g.dbg[((int64_t)tile * 16 + (k)) * 2] = (float)(t_ & 0xFFFFFF);                 \
         g.dbg[((int64_t)tile * 16 + (k)) * 2 + 1] = (float)((t_ >> 24) & 0xFFFFFF);     \
     }
+    // x rows of tile `t` -> this wave's staging (row-major rows of 256 B per plane, 16-byte chunks XOR-swizzled on the source side)
+    auto load_x = [&](int t) __attribute__((always_inline)) {
+        const int64_t r0 = ((int64_t)t * 4 + wave) * 32;
+        const int trow = lane >> 4, p = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tt = 4 * i + trow;
+            const int64_t rr = r0 + tt;
+            const unsigned off = rr < g.M ? (unsigned)((rr * g.ldx + ((p ^ (tt & 15)) << 3)) * 2) : g.xbytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + 8192 + i * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < g.ntiles) load_x(blockIdx.x);
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         ENC_STAMP(0)
         const int64_t row0 = ((int64_t)tile * 4 + wave) * 32;
         const int64_t row = row0 + tok;
         const bool valid = row < g.M;
-        // ---- S0: this wave's 32 token rows -> staging (row-major, swizzled) -> B fragments of x --------------------------
-        {
-            const int trow = lane >> 4, p = lane & 15;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t = 4 * i + trow;
-                const int64_t rr = row0 + t;
-                const unsigned off = rr < g.M ? (unsigned)((rr * g.ldx + ((p ^ (t & 15)) << 3)) * 2) : g.xbytes;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + 8192 + i * 1024), 16, off, 0, 0, 0);
-            }
-        }
+        // ---- S0: this wave's 32 token rows were requested before the previous tile's output stores (or above, first tile)
         // sequence of this lane's token; the tile touches at most two sequences (L >= 32)
         const int n_first = (int)(row0 / g.L);
         const int64_t bound = (int64_t)(n_first + 1) * g.L;
@@ -477,22 +480,31 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
             ENC_STAMP(8)
             {
                 // whole-row stores; the fp32 form (last layer: features for the fine matcher, which splits them the same
-                // way again) is the exact value of the planes, hi + lo / 2048
+                // way again) is the exact value of the planes, hi + lo / 2048.  The tile is read out of the staging first,
+                // then the NEXT tile's x rows are requested into it, then the stores are issued: the load's latency runs
+                // under the store issue instead of after it.
                 const int trow = lane >> 4, p = lane & 15;
+                uint4 dh[8], dl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 4 * i + trow;
+                    dh[i] = *reinterpret_cast<const uint4*>(stg + t * 256 + p * 16);
+                    dl[i] = *reinterpret_cast<const uint4*>(stg + 8192 + t * 256 + p * 16);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (tile + (int)gridDim.x < g.ntiles) load_x(tile + (int)gridDim.x);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int t = 4 * i + trow;
                     const int64_t rr = row0 + t;
-                    const uint4 dh = *reinterpret_cast<const uint4*>(stg + t * 256 + p * 16);
-                    const uint4 dl = *reinterpret_cast<const uint4*>(stg + 8192 + t * 256 + p * 16);
                     if (rr < g.M) {
                         const int cc = (p ^ (t & 15)) << 3;
                         if (g.oh) {
-                            *reinterpret_cast<uint4*>(g.oh + rr * g.ldo + cc) = dh;
-                            *reinterpret_cast<uint4*>(g.ol + rr * g.ldo + cc) = dl;
+                            *reinterpret_cast<uint4*>(g.oh + rr * g.ldo + cc) = dh[i];
+                            *reinterpret_cast<uint4*>(g.ol + rr * g.ldo + cc) = dl[i];
                         }
                         if (g.o32) {
-                            const half8 h8 = *reinterpret_cast<const half8*>(&dh), l8 = *reinterpret_cast<const half8*>(&dl);
+                            const half8 h8 = *reinterpret_cast<const half8*>(&dh[i]), l8 = *reinterpret_cast<const half8*>(&dl[i]);
                             float* o32 = g.o32 + rr * g.ldo32 + cc;
                             f32x4 f0, f1;
 #pragma unroll
@@ -506,9 +518,6 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                     }
                 }
             }
-            // staging reads done before the next tile's DMA lands; the stores themselves may stay in flight: a counted
-            // vmcnt wait only becomes more conservative with stores in the queue (SlabRing::acquire)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ENC_STAMP(9)
         }
 #undef ENC_ROWSTATS
