@@ -64,6 +64,22 @@ class BagPlanner:
             self.ref_kpt.append(kpt)
             # duplicated image ids collapse; the ORDER is CPython's set order, as in the reference (:37-39)
             self.queries.append(list(set(self.colmap_3ds[t].image_ids) - {img}))
+        # per (track, observing image): first keypoint index and the mean position of the track's observations in that image
+        # (a track may observe an image more than once; construct_matching_data.py:381-390) -- computed once here with the
+        # reference's own expressions instead of once per bag and view
+        self._obs = {}
+        for t in self.track_ids:
+            p3d = self.colmap_3ds[t]
+            ids = np.asarray(p3d.image_ids).tolist()
+            kps = np.asarray(p3d.point2D_idxs).tolist()
+            if len(set(ids)) == len(ids):                    # the common case: one observation per image (mean of one row = the row)
+                for img, kp in zip(ids, kps):
+                    self._obs[(t, img)] = (kp, np.asarray(self.colmap_images[img].xys[kp], dtype=np.float64))
+            else:
+                arr = np.asarray(ids)
+                for img in set(ids):
+                    idx = p3d.point2D_idxs[np.where(arr == img)]
+                    self._obs[(t, img)] = (int(idx[0]), np.mean(self.colmap_images[img].xys[idx], axis=0))
         # per image: K, R, t as arrays for the vectorised point-scale / view-point computation
         ids = sorted(self.intrin_extrin.keys())
         self._img_row = {i: k for k, i in enumerate(ids)}
@@ -75,6 +91,11 @@ class BagPlanner:
     def assign(self) -> List[dict]:
         n = len(self.track_ids)
         queries = [list(q) for q in self.queries]          # consumed while bags are formed
+        # tracks per image that still have query nodes to place: the reference rescans every track of an image for every
+        # bag (:103-110); finished tracks are skipped there, so dropping them from the scan lists (order kept) changes
+        # nothing but the cost -- 9 M skipped iterations for a 300-image / 190 K-track scene
+        active = {img: list(ts) for img, ts in self.frame_dict.items()}
+        stale = {img: 0 for img in active}
         length = np.array([len(q) + 1 for q in queries], dtype=np.int64)
         remaining = int(length.sum() - n)                   # query nodes not yet placed in a bag
         cap = self.max_track_length
@@ -93,12 +114,19 @@ class BagPlanner:
                 queries[k] = []
                 remaining -= int(length[k]) - 1
                 length[k] = 1
+                if ref in stale:
+                    stale[ref] += 1
             bag_imgs = [ref] + head
+            bag_set = set(bag_imgs)                         # == set(bag_imgs) at every point below: same insertion sequence
             tracks, corr = [self.track_ids[k]], [[ref, head]]
             # every other track whose reference node is one of the bag's images (:103-157); the bag may grow while
             # it is being scanned, exactly like the reference's loop over the list it appends to
             for img in bag_imgs:
-                for t in self.frame_dict[img]:
+                lst = active.get(img, ())
+                if stale.get(img, 0) * 2 > len(lst):        # compact the scan list once half of it is finished tracks
+                    lst = active[img] = [t for t in lst if t in self.track_pos and length[self.track_pos[t]] != 1]
+                    stale[img] = 0
+                for t in lst:
                     if t == self.track_ids[k] or t not in self.track_pos:
                         continue
                     j = self.track_pos[t]
@@ -106,12 +134,15 @@ class BagPlanner:
                         continue
                     assert self.ref_img[j] == img
                     q = queries[j]
-                    common = set(q) & set(bag_imgs)
-                    outside = set(q) - set(bag_imgs)
+                    qs = set(q)
+                    common = qs & bag_set
+                    outside = qs - bag_set
                     quota = max_bag - len(bag_imgs)
                     if quota > 0 and len(outside) != 0:
                         extra = list(outside)[:quota]
                         bag_imgs += extra
+                        for e in extra:
+                            bag_set.add(e)
                         outside -= set(extra)
                         common |= set(extra)
                     if len(common) != 0:                    # (:138-141 with exclude_value = 0: always true otherwise)
@@ -119,6 +150,8 @@ class BagPlanner:
                         queries[j] = list(set(q) - set(common))
                         remaining -= len(common)
                         length[j] -= len(common)
+                        if length[j] == 1:
+                            stale[img] += 1
                         tracks.append(t)
                         corr.append([img, list(common)])
             bags.append({"bag_image_ids": bag_imgs, "track_ids": tracks, "track_corresponding_imgs": corr})
@@ -194,11 +227,9 @@ class BagPlanner:
             tt, vv, ii = np.array(tt), np.array(vv), np.array(ii)
             kp = np.empty(len(tt), dtype=np.int64)
             xy = np.empty((len(tt), 2))
-            for n, (m, img) in enumerate(zip(tt, ii)):               # a track may observe one image more than once
-                p3d = self.colmap_3ds[tracks[m]]
-                idx = p3d.point2D_idxs[np.where(p3d.image_ids == img)]
-                kp[n] = idx[0]
-                xy[n] = np.mean(self.colmap_images[img].xys[idx], axis=0)
+            obs = self._obs
+            for n, (m, img) in enumerate(zip(tt.tolist(), ii.tolist())):
+                kp[n], xy[n] = obs[(tracks[m], img)]
             rows = np.array([self._img_row[i] for i in ii])
             q_xy[tt, vv], q_mask[tt, vv] = xy, True
             q_slot[tt, vv] = [img_slot[i] for i in ii]
