@@ -119,20 +119,35 @@ def kernel_rooflines(dev, batch):
     flops = 2.0 * nimg * 240 * 320 * 128 * 9 * 128
     out.append(_rl("conv_gemm_sf_same_kernel<128,3> (3x3, 128->128 @240x320)", "mfma", flops, ms, f"{nimg} images",
                    mfma_flops_executed_frac=3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
-                   step_share="45% of the coarse step and 22% of the refinement step; all conv / linear GEMM kernels together "
-                              "77% / 81% (profiles/r02_*_step_kernel_stats.csv)"))
+                   step_share="~46% of the coarse step and ~27% of the refinement step (profiles/r03_*_step_kernel_stats.csv)"))
     del x, xs, pw
-    # K10 linears of the refinement head (linear_gemm_sf_kernel, the largest share of the refinement step): mlp.0 of one
-    # encoder layer on the query tokens of a 2000-track x 4-view bag, [rows,256] -> relu -> [rows,256] split planes.
-    # HBM-bound: algorithmic bytes = rows * (K + Cout) * 4 (operands and result are fp32-class, 4 B per element).
-    rows = 2000 * 4 * 225
-    xs = ops.SplitAct.empty_rows((rows,), 256, dev)
-    ops.split_rows(torch.randn((rows, 256), generator=g).to(dev), None, out_split=xs)
-    pw = ops.PackedDense(torch.randn((256, 256), generator=g).to(dev) * 0.06)
-    ms = event_time_ms(lambda: ops.linear(xs, pw, relu=True, out_split=True))
-    out.append(_rl("linear_gemm_sf_kernel (refinement mlp.0: 256->256 on 1.8 M rows)", "hbm",
-                   rows * 512.0 * 4, ms, f"{rows} rows", tflops_algorithmic=2.0 * rows * 256 * 256 / ms / 1e9))
-    del xs, pw
+    # K10 + K1 of the refinement head: one fused encoder layer (csrc/encoder_fused.hip) on the query tokens of a 2000-track x
+    # 4-view bag: enc_kv_kernel (source tokens -> per-track attention state) + enc_apply_kernel (the rest of the layer).
+    # Algorithmic work per token row: apply 2 * (128*128 q + 128*16 attention + 128*128 merge + 256*256 mlp.0 + 256*128 mlp.2)
+    # = 266 240 flop and 1024 B (row read + row written as fp16x2 planes); kv 2 * 128 * 256 + 2 * 16 * 128 = 69 632 flop, 512 B.
+    # The kernel is bound by MFMA issue (3 MFMAs per product, one wave per SIMD) long before HBM: priced against the MFMA peak.
+    from detectorfreesfm_amd import coarse as _coarse
+    T, Vq, WW, C = 2000, 4, 225, 128
+    rows = T * Vq * WW
+    wsd = {n: torch.randn(sh, generator=g) * sc for n, sh, sc in (("q_proj.weight", (C, C), .12), ("k_proj.weight", (C, C), .12),
+           ("v_proj.weight", (C, C), .12), ("merge.weight", (C, C), .12), ("mlp.0.weight", (2 * C, 2 * C), .09),
+           ("mlp.2.weight", (C, 2 * C), .09))}
+    for nm in ("norm1", "norm2"):
+        wsd[nm + ".weight"], wsd[nm + ".bias"] = torch.ones(C), torch.zeros(C)
+    lw = _coarse.EncoderLayerWeights(lambda n: wsd[n].to(dev), "")
+    qs = ops.SplitAct.empty_rows((T, Vq * WW), C, dev)
+    ops.split_rows(torch.randn((T, Vq * WW, C), generator=g).to(dev), None, out_split=qs)
+    qo = ops.SplitAct.empty_rows((T, Vq * WW), C, dev)
+    st = ops.encoder_kv(qs, lw.fused)
+    ms = event_time_ms(lambda: ops.encoder_apply(qs, lw.fused, st, Vq * WW, out_split=qo))
+    out.append(_rl("enc_apply_kernel (fused encoder layer, d_model 128: q, attention, merge, LayerNorm, MLP, LayerNorm, residual)",
+                   "mfma", rows * 266240.0, ms, f"{rows} token rows", hbm_GBps_of_rows=rows * 1024.0 / ms / 1e6,
+                   mfma_flops_executed_frac=3.0 * rows * 266240.0 / ms / 1e9 / MFMA_F16_PEAK_TF,
+                   step_share="~30% of the refinement step together with enc_kv_kernel (was 48%: five GEMM + three attention launches)"))
+    ms = event_time_ms(lambda: ops.encoder_kv(qs, lw.fused))
+    out.append(_rl("enc_kv_kernel (fused k|v projection + phi(K)^T V per track)", "mfma", rows * 69632.0, ms, f"{rows} token rows",
+                   hbm_GBps_of_rows=rows * 512.0 / ms / 1e6))
+    del qs, qo, st, lw
     # K3+K4+K5 at batch x (4800 x 4800 x 256): algorithmic flops 2*L*S*C per pair
     L = S = 4800
     f0, f1 = synth.correlated_features(batch, L, S, 256, 7, 0.1)
@@ -272,7 +287,7 @@ def load_pmc(result):
     """Attach the HBM traffic measured by the committed rocprofv3 --pmc passes (tools/pmc_collect.py writes
     profiles/r02_pmc_traffic.json; traffic cannot be counted from inside this process).  Corrected as the MI355X
     guide prescribes: 2*FETCH_SIZE (16-byte/lane streaming reads) + WRITE_SIZE, per launch."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_kernels_only_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_kernels_only_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -281,7 +296,7 @@ def load_pmc(result):
     with open(path) as fh:
         rows = json.load(fh)["kernels"]
     groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
-              "linear_gemm_sf_kernel": ("linear_gemm_sf_kernel",),
+              "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",),
               "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_kernel",),
               "fine_match": ("fine_match_kernel",),
               "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact", "cm_top", "cm_eval"),
@@ -386,6 +401,12 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         result["roofline"]["algorithmic_bytes"] = 2 * args.batch * 240 * 320 * 128 * 4 * 2 + 9 * 128 * 128 * 4
         if "traffic_unit" in dom:
             result["roofline"]["traffic_unit"] = dom["traffic_unit"]
+        # the refinement step's own dominant hand-written kernels: the stride-1 3x3 convolutions of S2DNet run on the same
+        # kernel as the entry above; the transformer is the fused encoder layer
+        enc = next(r for r in rl if r["kernel"].startswith("enc_apply_kernel"))
+        result["secondary"]["roofline"] = {k: enc[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                 "mfma_flops_executed_frac", "hbm_GBps_of_rows")}
+        result["secondary"]["roofline"]["algorithmic_bytes_per_row"] = 1024
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -546,6 +546,120 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
     }
 }
 
+
+// Single-GEMM candidate pass on the 128 x 128 / two-workgroups-per-CU schedule (dfsfm_sf::sf2_mainloop): the statistics /
+// candidate epilogue of one workgroup runs under the correlation main loop of the co-resident one (with K = 256 the 512-thread
+// kernel above spends ~10 us in its main loop and ~7 us in this epilogue with nothing else on the CU), and the tiles are half
+// as tall.  Same arithmetic, same statistics, same candidates: rows and confidences are identical to cm_gemm_sf<MODE_CAND>.
+constexpr int SF2_BM = 128;
+__global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n = blockIdx.y;
+    const unsigned t_id = dfsfm_sf::xcd_band_tile(blockIdx.x, gridDim.x >> 3);
+    if (t_id >= g.ntiles) return;
+    const int tm = t_id / g.ntn, tn = t_id % g.ntn;
+    const int row0 = tm * SF2_BM, col0 = tn * SF_BN;
+
+    dfsfm_sf::ConvArgs a{};
+    a.xh = g.f0h + (int64_t)n * g.L * g.C;
+    a.xl = g.f0l + (int64_t)n * g.L * g.C;
+    a.wh = g.f1h + (int64_t)n * g.S * g.C;
+    a.wl = g.f1l + (int64_t)n * g.S * g.C;
+    a.M = g.L; a.H = 1; a.W = g.L; a.Cin = g.C; a.Kpad = g.C; a.ldx = g.C;
+    a.sxh = a.sxn = (int64_t)g.L * g.C;
+    a.xbytes = (unsigned)((int64_t)g.L * g.C * 2);           // rows past L / S are zero-filled by the DMA
+    a.wbytes = (unsigned)((int64_t)g.S * g.C * 2);
+    f32x16 accm[2][2], accx[2][2];
+    dfsfm_sf::sf2_mainloop<1>(a, smem, accm, accx, row0, col0);
+    __syncthreads();                                          // ring is dead
+
+    const int nrow = min(SF2_BM, g.L - row0), ncol = min(SF_BN, g.S - col0);
+    float2* s_rp = reinterpret_cast<float2*>(smem);                       // [2 wc][128]
+    float2* s_cp = s_rp + 2 * SF2_BM;                                     // [2 wr][128]
+    float* s_rg = reinterpret_cast<float*>(smem + 8192);                  // [128] tile-local row gate
+    float* s_cg = s_rg + SF2_BM;                                          // [128] tile-local column gate
+    int* s_cnt = reinterpret_cast<int*>(s_cg + SF_BN);                    // [128] slots taken per row
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
+                const int lc = wc * 64 + j * 32 + col;
+                const float sv = ((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
+                bool ok = lr < nrow && lc < ncol;
+                if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)] && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
+                accm[i][j][r] = ok ? sv : -INFINITY;
+            }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                                         // columns: 32 lane-local rows, then the other half
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, accm[i][j][r]);
+        float e = 0.f;
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e += fast_exp(accm[i][j][r] - m);
+        }
+        const float2 st = merge_stat(make_float2(m, e), make_float2(__shfl_xor(m, 32), __shfl_xor(e, 32)));
+        if (half == 0) s_cp[wr * SF_BN + wc * 64 + j * 32 + col] = st;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                                    // rows: 2 lane-local columns, then 32 lanes
+            const float v0 = accm[i][0][r], v1 = accm[i][1][r];
+            const float m = half_wave_max(fmaxf(v0, v1));
+            float e = (m != -INFINITY) ? fast_exp(v0 - m) + fast_exp(v1 - m) : 0.f;
+            e = half_wave_sum(e);
+            if (col == 0) s_rp[wc * SF2_BM + wr * 64 + i * 32 + mfma32_row(r, half)] = make_float2(m, e);
+        }
+    __syncthreads();
+    if (tid < SF2_BM) {
+        const float2 st = merge_stat(s_rp[tid], s_rp[SF2_BM + tid]);
+        if (tid < nrow) g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = st;
+        s_rg[tid] = (tid < nrow && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+        s_cnt[tid] = 0;
+    } else {
+        const int c = tid - SF2_BM;
+        const float2 st = merge_stat(s_cp[c], s_cp[SF_BN + c]);
+        if (c < ncol) g.col_part[((int64_t)n * g.nhalf + tm) * g.S + col0 + c] = st;    // one partial per 128-row tile
+        s_cg[c] = (c < ncol && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
+    }
+    __syncthreads();
+    float cg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cg[j] = s_cg[wc * 64 + j * 32 + col];
+    const int64_t slot0 = ((int64_t)n * g.ntn + tn) * g.L + row0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
+            const float rg = s_rg[lr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float sv = accm[i][j][r];                           // -inf outside the matrix
+                if (sv > rg && sv > cg[j]) {
+                    const int slot = atomicAdd(&s_cnt[lr], 1);
+                    if (slot < g.slots)
+                        g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + wc * 64 + j * 32 + col));
+                }
+            }
+        }
+    __syncthreads();
+    if (tid < nrow) g.cand_cnt[slot0 + tid] = (uint8_t)min(s_cnt[tid], g.slots);
+}
+
 // Merge per-tile (max, sumexp) partials; clear row_best / col_best.
 __global__ __launch_bounds__(256) void cm_reduce_stats(const float2* __restrict__ row_part,
                                                        const float2* __restrict__ col_part,
@@ -823,7 +937,18 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
         const int slots = thr > 0.f ? (int)floorf(1.f / (thr * 0.998f)) : CAND_SLOTS_MAX + 1;
         if (slots <= CAND_SLOTS_MAX && !force_two_pass) {
             g.cand = w.cand; g.cand_cnt = w.cand_cnt; g.slots = slots;
-            launch_gemm_sf<MODE_CAND>(g, N, stream);
+            // DFSFM_CM2=0: the 256 x 128 one-workgroup-per-CU candidate kernel (same-box A/B switch)
+            static const bool cm2 = [] { const char* e = getenv("DFSFM_CM2"); return !e || atoi(e) != 0; }();
+            if (cm2) {
+                const int ntm2 = (L + SF2_BM - 1) / SF2_BM;
+                g.ntiles = (unsigned)(ntm2 * g.ntn);
+                g.nhalf = nparts = ntm2;
+                static dfsfm::SmemAttr smem_attr2;
+                smem_attr2.ensure(reinterpret_cast<const void*>(&cm_gemm_sf2_cand), dfsfm_sf::V2S<1>::SMEM);
+                hipLaunchKernelGGL(cm_gemm_sf2_cand, dim3((g.ntiles + 7) / 8 * 8, N), dim3(256), dfsfm_sf::V2S<1>::SMEM, stream, g);
+            } else {
+                launch_gemm_sf<MODE_CAND>(g, N, stream);
+            }
             hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
                                w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, nparts, g.ntn);
             hipLaunchKernelGGL(cm_eval, dim3((L + 255) / 256, N), dim3(256), 0, stream, w.cand, w.cand_cnt, w.row_stat,

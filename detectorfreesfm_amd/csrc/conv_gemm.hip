@@ -1025,7 +1025,7 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             if (kh != kw || (kw != 3 && kw != 5) || stride != 1 || pad != kw / 2 || Kpad % (kw * kw * BK) != 0 ||
                 Kpad / (kw * kw) < Cin)
                 return DFSFM_E_UNSUPPORTED;
-            if (kw == 3) { if (Cout <= 64) launch_same<64, 3>(g, stream); else launch_same<128, 3>(g, stream); }
+            if (kw == 3) { if (Cout <= 64) launch_same<64, 3, 8>(g, stream); else launch_same<128, 3>(g, stream); }
             else         { if (Cout <= 64) launch_same<64, 5>(g, stream); else launch_same<128, 5>(g, stream); }
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(same)");
         }

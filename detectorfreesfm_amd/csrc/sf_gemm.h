@@ -66,14 +66,17 @@ __device__ __forceinline__ unsigned xcd_band_tile(unsigned b, unsigned per_xcd) 
 // Weights are packed tap-padded: K = (ky, kx, ceil32(Cin)).
 // =================================================================================================
 // WM = waves along M: 4 -> 256 x BN tile (BN 64 / 128, waves 4 x 2); 2 -> 128 x 256 tile (waves 2 x 4, 1x1 only):
-// a whole 256-channel row in one workgroup, for the LayerNorm-fused linear layers of the coarse transformer.
+// a whole 256-channel row in one workgroup, for the LayerNorm-fused linear layers of the coarse transformer;
+// 8 -> 512 x 64 tile (waves 8 x 1, 3x3 only): Cout <= 64 layers (S2DNet conv1_2: 12 M pixels) with the same 64 x 64 of
+// output per wave -- and therefore the same MFMAs per fragment read -- as the 256 x 128 tile (on the 256 x 64 tile a wave
+// owns 64 x 32 and the matrix pipe waits for LDS: 242 vs 357 TFLOP/s-effective).
 template <int BN_, int KW, int WM = 4>
 struct VS {
-    static_assert(WM == 4 || (WM == 2 && KW == 1), "the 128-row tile is for 1x1 / linear layers");
+    static_assert(WM == 4 || (WM == 2 && KW == 1) || (WM == 8 && KW == 3 && BN_ == 64), "tile shapes");
     static constexpr int PAD = KW / 2;
     static constexpr int BM = WM * 64, WN = 8 / WM;
-    static constexpr int AG = WM == 4 ? 17 : 8;              // 16-row groups per A stage (256 + KW - 1 <= 272)
-    static constexpr int APW = WM == 4 ? 5 : 2;              // A pieces per wave and super-slab
+    static constexpr int AG = WM == 8 ? 33 : WM == 4 ? 17 : 8;   // 16-row groups per A stage (BM + KW - 1 rows)
+    static constexpr int APW = WM == 8 ? 9 : WM == 4 ? 5 : 2;    // A pieces per wave and super-slab
     static constexpr int A_PLANE = AG * 1024;
     static constexpr int A_STAGE = 2 * A_PLANE;             // hi, lo
     static constexpr int B_PLANE = BN_ * 64;
@@ -88,15 +91,23 @@ struct VS {
     static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
     static_assert(RING <= 160 * 1024, "LDS ring");
     // DMA pieces a wave issues in the load segment of tap kx: B(t+NB-1), and A(S+NA-1) spread over taps 0 (3
-    // pieces) and 1 (2 pieces) -- all 5 at tap 0 for a 1x1 kernel
-    static constexpr int C(int kx) { return (KW == 1 ? APW : kx == 0 ? 3 : kx == 1 ? 2 : 0) + BN_I; }
+    // pieces) and 1 (2 pieces) -- all of them at tap 0 for a 1x1 kernel, three per tap for the 512-row tile
+    static constexpr int CA(int kx) { return KW == 1 ? APW : WM == 8 ? (kx < 3 ? 3 : 0) : kx == 0 ? 3 : kx == 1 ? 2 : 0; }
+    static constexpr int C(int kx) { return CA(kx) + BN_I; }
     // own pieces that may still be in flight when a wave publishes slab u = (S, kx) (the barrier that opens the
     // first load segment reading it): B(u) was the last piece of load segment u-NB+1, so everything issued in the
     // NB-2 segments since may be outstanding; with a 2-deep A ring A(S) was issued at taps 0/1 of S-1.
     static constexpr int NWAIT(int kx) {
         int n = 0;
         for (int d = 1; d <= NB - 2; ++d) n += C(((kx - d) % KW + KW) % KW);
-        if (KW > 1 && NA == 2 && kx == 0 && (KW - 1) * BN_I < n) n = (KW - 1) * BN_I;
+        // slab (S, 0) also needs A(S): only what was issued after its last piece may still fly -- the B pieces of that tap
+        // and every piece of the later taps
+        if (KW > 1 && NA == 2 && kx == 0) {
+            int last = 0, after = BN_I;
+            for (int k = 0; k < KW; ++k) if (CA(k) > 0) last = k;
+            for (int k = last + 1; k < KW; ++k) after += C(k);
+            if (after < n) n = after;
+        }
         return n;
     }
     static constexpr int NWAIT0 = APW * (NA - 2) + (NB - 2) * BN_I;    // prologue: A(0), B(0) landed
@@ -107,7 +118,8 @@ template <int BN_, int KW, int WM = 4>
 __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * WM / 256],
                                                  f32x16 (&accx)[2][BN_ * WM / 256], int64_t m0, int n0) {
     using S_ = VS<BN_, KW, WM>;
-    constexpr int WN = 8 / WM, NJ = BN_ / (32 * WN), PAD = KW / 2, BNI = S_::BN_I, NQ = WM == 4 ? 3 : 1;
+    constexpr int WN = 8 / WM, NJ = BN_ / (32 * WN), PAD = KW / 2, BNI = S_::BN_I, NQ = WM == 8 ? 5 : WM == 4 ? 3 : 1;
+    constexpr int NFULL = NQ == 1 ? 1 : NQ - 1;                 // full 16-row groups per wave (wave + 8 q); then the tail group
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,15 +135,15 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
 
     const int lrow = lane >> 2;
     const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
-    // A rows of this lane: groups wave, wave+8 and (waves 0/1 only: hi/lo plane of) group 16
-    int ay[3];                                                   // NQ used
-    int64_t abase[3];
-    bool aok[3];
+    // A rows of this lane: groups wave + 8 q and (waves 0/1 only: hi/lo plane of) the tail group 8 * NFULL
+    int ay[5];                                                   // NQ used
+    int64_t abase[5];
+    bool aok[5];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int grp = q < 2 ? wave + 8 * q : 16;
+        const int grp = q < NFULL ? wave + 8 * q : 8 * NFULL;
         const int64_t pix = m0 - PAD + grp * 16 + lrow;      // flattened pixel of LDS row grp*16 + lrow
-        aok[q] = pix >= 0 && pix < g.M && (q < 2 || wave < 2);
+        aok[q] = pix >= 0 && pix < g.M && (q < NFULL || wave < 2);
         const int64_t pp = aok[q] ? pix : 0;
         const int ox = (int)(pp % g.W);
         const int64_t t = pp / g.W;
@@ -140,7 +152,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     }
     const bool cok_lane = true;
     (void)cok_lane;
-    unsigned offA[3];                                            // NQ used
+    unsigned offA[5];                                            // NQ used
     auto addrA = [&](int Sn) __attribute__((always_inline)) {   // offsets of super-slab Sn = (ky, chunk)
         const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
         const bool in = Sn < nS && chunk * BK + lslot * 8 < g.Cin;
@@ -164,20 +176,20 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             offB[j] = Sn < nS ? bbase + koff + (unsigned)grp * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
         }
     };
-    // A piece p of a super-slab: 0,1 = group wave (hi, lo); 2,3 = group wave+8 (hi, lo); 4 = group 16 (wave 0: hi,
+    // A piece p of a super-slab: 2q, 2q+1 = group wave + 8q (hi, lo); the last = the tail group (wave 0: hi,
     // wave 1: lo, other waves: an out-of-range piece into the 1-KB sink so every wave issues the same count)
 #define SDMA_A(p, astage)                                                                                          \
     do {                                                                                                            \
-        if ((p) < 4) {                                                                                              \
+        if ((p) < 2 * NFULL) {                                                                                      \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(((p) & 1) ? rxl : rxh,                                         \
                                                      (lds_void*)(smem + (astage) * S_::A_STAGE + ((p) & 1) * S_::A_PLANE + \
                                                                  (wave + 8 * ((p) >> 1)) * 1024),                   \
                                                      16, offA[(p) >> 1], 0, 0, 0);                                  \
         } else {                                                                                                    \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 1 ? rxl : rxh,                                         \
-                                                     (lds_void*)(wave < 2 ? smem + (astage) * S_::A_STAGE + wave * S_::A_PLANE + 16 * 1024 \
+                                                     (lds_void*)(wave < 2 ? smem + (astage) * S_::A_STAGE + wave * S_::A_PLANE + 8 * NFULL * 1024 \
                                                                           : smem + S_::OFF_DUMMY),                  \
-                                                     16, offA[2], 0, 0, 0);                                         \
+                                                     16, offA[NFULL], 0, 0, 0);                                     \
         }                                                                                                           \
     } while (0)
 #define SDMA_B(j, bstage)                                                                                          \
@@ -275,7 +287,8 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
         if (t < S_::NA - 1) {
             addrA(t);
             SDMA_A(0, t); SDMA_A(1, t);
-            if constexpr (S_::APW == 5) { SDMA_A(2, t); SDMA_A(3, t); SDMA_A(4, t); }
+            if constexpr (S_::APW >= 5) { SDMA_A(2, t); SDMA_A(3, t); SDMA_A(4, t); }
+            if constexpr (S_::APW == 9) { SDMA_A(5, t); SDMA_A(6, t); SDMA_A(7, t); SDMA_A(8, t); }
         }
         if (t < S_::NB - 1) {
             addrB(t);
@@ -304,6 +317,11 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             if constexpr (S_::APW == 5) {
                 if (kx == 0) { SDMA_A(2, adm); }
                 if (KW == 1 || kx == 1) { SDMA_A(3, adm); SDMA_A(4, adm); }
+            }
+            if constexpr (S_::APW == 9) {                              // three pieces per tap
+                if (kx == 0) { SDMA_A(2, adm); }
+                if (kx == 1) { SDMA_A(3, adm); SDMA_A(4, adm); SDMA_A(5, adm); }
+                if (kx == 2) { SDMA_A(6, adm); SDMA_A(7, adm); SDMA_A(8, adm); }
             }
 #pragma unroll
             for (int j = 0; j < BNI; ++j) SDMA_B(j, bdm);
@@ -336,6 +354,214 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     wait_vmcnt<0>();
 #undef SDMA_A
 #undef SDMA_B
+}
+
+// =================================================================================================
+// Second schedule of the same product: 128 x 128 tile, 256 threads (4 waves as 2 x 2, 64 x 64 each), <= 80 KB of LDS, so
+// that TWO workgroups share a CU and one's epilogue (statistics / LayerNorm / split / stores) runs under the other's main
+// loop -- what linear_gemm_sf_kernel does for 1x1 layers (conv_gemm.hip), here with the activation reuse across the kx taps
+// for the stride-1 "same" 3x3 convolutions and as the main loop of the 128 x 128 coarse-correlation kernel.
+// One barrier per slab: [wait own pieces of slab t] [barrier] [DMA B(t+1); at kx == 0 also A(S+1)] [16 fragment reads]
+// [24 MFMAs].  B is issued before A, so the pieces that may stay in flight at the next wait are exactly the A pieces.
+// =================================================================================================
+template <int KW>
+struct V2S {
+    static constexpr int PAD = KW / 2;
+    static constexpr int BM = 128, BN = 128, NT = 256;
+    static constexpr int AG = KW == 1 ? 8 : 9;               // 16-row groups per A stage (128 + KW - 1 <= 144)
+    static constexpr int APW = KW == 1 ? 4 : 5;              // A pieces per wave and super-slab (group 8: waves 0 / 1, else a sink)
+    static constexpr int A_PLANE = AG * 1024;
+    static constexpr int A_STAGE = 2 * A_PLANE;
+    static constexpr int NA = KW == 1 ? 3 : 2;
+    static constexpr int B_PLANE = 128 * 64;
+    static constexpr int B_STAGE = 2 * B_PLANE;
+    static constexpr int NB = 2;
+    static constexpr int OFF_B = NA * A_STAGE;
+    static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;
+    static constexpr int RING = OFF_DUMMY + (KW == 1 ? 0 : 1024);   // 1 KB sink for the padding pieces of group 8
+    static constexpr int TILE_BYTES = BM * (BN + 4) * 4;
+    static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
+    static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int KW>
+__device__ __forceinline__ void sf2_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][2], f32x16 (&accx)[2][2],
+                                             int64_t m0, int n0) {
+    using T = V2S<KW>;
+    constexpr int PAD = T::PAD;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kgrp = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int Cin_p = g.Kpad / (KW * KW);
+    const int nchunk = Cin_p / BK, nS = KW * nchunk;          // super-slabs (ky, chunk); slabs t = S * KW + kx
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.wh, 0, g.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
+
+    const int lrow = lane >> 2;
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    // A rows of this lane: groups wave, wave + 4 and (KW > 1, waves 0 / 1 only: hi / lo plane of) group 8
+    constexpr int NQ = KW == 1 ? 2 : 3;
+    int ay[3];
+    int64_t abase[3];
+    bool aok[3];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int grp = q < 2 ? wave + 4 * q : 8;
+        const int64_t pix = m0 - PAD + grp * 16 + lrow;
+        aok[q] = pix >= 0 && pix < g.M && (q < 2 || wave < 2);
+        const int64_t pp = aok[q] ? pix : 0;
+        const int ox = (int)(pp % g.W);
+        const int64_t t = pp / g.W;
+        ay[q] = (int)(t % g.H);
+        abase[q] = (t / g.H) * g.sxn + (int64_t)ay[q] * g.sxh + (int64_t)ox * g.ldx + lslot * 8;
+    }
+    unsigned offA[3];
+    auto addrA = [&](int Sn) __attribute__((always_inline)) {
+        const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
+        const bool in = Sn < nS && chunk * BK + lslot * 8 < g.Cin;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int iy = ay[q] + ky - PAD;
+            const bool ok = aok[q] & in & (iy >= 0) & (iy < g.H);
+            const int64_t off = (abase[q] + (int64_t)(ky - PAD) * g.sxh + chunk * BK) * 2;
+            offA[q] = ok ? (unsigned)off : g.xbytes;
+        }
+    };
+    const unsigned bbase = (unsigned)(((int64_t)(n0 + lrow) * g.Kpad + lslot * 8) * 2);
+    unsigned offB[2];
+    auto addrB = [&](int t) __attribute__((always_inline)) {
+        const int Sn = t / KW, kx = t - Sn * KW;
+        const int ky = Sn / nchunk, chunk = Sn - ky * nchunk;
+        const unsigned koff = (unsigned)(((ky * KW + kx) * Cin_p + chunk * BK) * 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            offB[q] = Sn < nS ? bbase + koff + (unsigned)(wave + 4 * q) * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
+    };
+    auto dmaA = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            char* d = smem + stage * T::A_STAGE + (wave + 4 * q) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)d, 16, offA[q], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(d + T::A_PLANE), 16, offA[q], 0, 0, 0);
+        }
+        if constexpr (KW > 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 1 ? rxl : rxh,
+                                                     (lds_void*)(wave < 2 ? smem + stage * T::A_STAGE + wave * T::A_PLANE + 8 * 1024
+                                                                          : smem + T::OFF_DUMMY),
+                                                     16, offA[2], 0, 0, 0);
+    };
+    auto dmaB = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            char* d = smem + T::OFF_B + stage * T::B_STAGE + (wave + 4 * q) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_void*)d, 16, offB[q], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d + T::B_PLANE), 16, offB[q], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            accm[i][j] = f32x16{0};
+            accx[i][j] = f32x16{0};
+        }
+    int oxr[2];                                               // x coordinate of this lane's two output rows (kx borders)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) oxr[i] = (int)((m0 + wr * 64 + i * 32 + col) % g.W);
+
+    // prologue: B(0), then A(0) .. A(NA-2)
+    addrB(0);
+    dmaB(0);
+#pragma unroll
+    for (int Sn = 0; Sn < T::NA - 1; ++Sn) {
+        addrA(Sn);
+        dmaA(Sn);
+    }
+    int ast = 0, bst = 0;
+    for (int S = 0; S < nS; ++S) {
+        auto tap = [&](auto kxc) __attribute__((always_inline)) {
+            constexpr int kx = decltype(kxc)::value;
+            const int t = S * KW + kx;
+            // own pieces that may still fly: the A super-slab issued after this slab's B pieces (KW == 1: A(t+1), one slab
+            // ahead of its use; KW > 1: A(S+1), issued during tap 0, may still fly at tap 1)
+            if constexpr (KW == 1) wait_vmcnt<(T::NA - 2) * T::APW>();
+            else if constexpr (kx == 1) wait_vmcnt<T::APW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                     // slab t published; every wave is done with slab t - 1
+            __builtin_amdgcn_sched_barrier(0);
+            addrB(t + 1);
+            dmaB(bst ^ 1);
+            if constexpr (kx == 0) {
+                const int adm = ast == 0 ? T::NA - 1 : ast - 1;   // stage of A(S-1) = where A(S+NA-1) goes
+                addrA(S + T::NA - 1);
+                dmaA(adm);
+            }
+            const char* sa = smem + ast * T::A_STAGE;
+            const char* sb = smem + T::OFF_B + bst * T::B_STAGE;
+            half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int off = tile_off(wr * 64 + i * 32 + col + kx, ks * 2 + kgrp);
+                    ah[ks][i] = *reinterpret_cast<const half8*>(sa + off);
+                    al[ks][i] = *reinterpret_cast<const half8*>(sa + T::A_PLANE + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int off = tile_off(wc * 64 + j * 32 + col, ks * 2 + kgrp);
+                    bh[ks][j] = *reinterpret_cast<const half8*>(sb + off);
+                    bl[ks][j] = *reinterpret_cast<const half8*>(sb + T::B_PLANE + off);
+                }
+            }
+            if constexpr (KW > 1 && kx != PAD) {              // tap leaves the image row: contributes zero
+                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool out = (unsigned)(oxr[i] + kx - PAD) >= (unsigned)g.W;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        ah[ks][i] = out ? z : ah[ks][i];
+                        al[ks][i] = out ? z : al[ks][i];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], accm[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], accx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], accx[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            bst ^= 1;
+        };
+        tap(std::integral_constant<int, 0>{});
+        if constexpr (KW > 1) {
+            tap(std::integral_constant<int, 1>{});
+            tap(std::integral_constant<int, 2>{});
+        }
+        ast = ast == T::NA - 1 ? 0 : ast + 1;
+    }
+    wait_vmcnt<0>();                                          // the zero-fill tail pieces, before LDS is reused
 }
 
 }  // namespace dfsfm_sf
