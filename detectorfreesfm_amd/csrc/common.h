@@ -51,6 +51,18 @@ __device__ __forceinline__ float elu_plus_one(float x) {
     return (x > 0.f ? x : expm1f(x)) + 1.f;
 }
 
+// phi(x) = elu(x) + 1 = exp(x) for x <= 0, x + 1 otherwise.  The reference evaluates expm1(x) + 1 in fp32; here exp(x) comes
+// from the hardware exp2 with the argument's rounding error compensated (x * log2(e) carried as hi + lo), which stays within
+// ~2 ulp of it -- below the 2^-22 of the split operands this value is converted to next -- at a fifth of the instructions.
+__device__ __forceinline__ float phi_fast(float x) {
+    const float L2E = 1.4426950408889634f;
+    const float hi = x * L2E;
+    const float lo = __builtin_fmaf(x, L2E, -hi) + x * 1.925963033500853e-8f;      // rounding of x * L2E + (log2(e) - L2E)
+    const float e = __builtin_amdgcn_exp2f(hi);
+    const float r = __builtin_fmaf(e * 0.6931471805599453f, lo, e);                 // 2^(hi + lo) ~ 2^hi (1 + lo ln 2)
+    return x > 0.f ? x + 1.f : r;
+}
+
 // fp16x2 split of an fp32 value: v = hi + lo/2048 (22 significant bits).
 // The value saturates at the largest finite fp16 (65504) instead of overflowing to inf: an out-of-range activation
 // yields a finite, wrong value (hi = +-65504, lo = 0) that `hi == +-65504` flags (ops.check_split_range), never an

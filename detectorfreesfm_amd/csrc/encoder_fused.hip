@@ -59,18 +59,6 @@ __device__ __forceinline__ f32x16 mfma(const half8 a, const half8 b, const f32x1
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// phi(x) = elu(x) + 1 = exp(x) for x <= 0, x + 1 otherwise.  The reference evaluates expm1(x) + 1 in fp32; here exp(x) comes
-// from the hardware exp2 with the argument's rounding error compensated (x * log2(e) carried as hi + lo), which stays within
-// ~2 ulp of it -- below the 2^-22 of the split operands this value is converted to next -- at a fifth of the instructions.
-__device__ __forceinline__ float phi_fast(float x) {
-    const float L2E = 1.4426950408889634f;
-    const float hi = x * L2E;
-    const float lo = __builtin_fmaf(x, L2E, -hi) + x * 1.925963033500853e-8f;      // rounding of x * L2E + (log2(e) - L2E)
-    const float e = __builtin_amdgcn_exp2f(hi);
-    const float r = __builtin_fmaf(e * 0.6931471805599453f, lo, e);                 // 2^(hi + lo) ~ 2^hi (1 + lo ln 2)
-    return x > 0.f ? x + 1.f : r;
-}
-
 // channel (within a 32-channel block) that accumulator register r of lane half h holds
 __device__ __forceinline__ int dch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -22,6 +22,7 @@
 // keeps every lane's accesses contiguous.  Summation order is fixed -> results are run-to-run
 // deterministic.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void la_kv_partial_staged(
                 const float m = mask_at(kv_mask, kv_group, mbase, srow);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    a[e] = elu_plus_one(a[e]) * m;
+                    a[e] = phi_fast(a[e]) * m;
                     b[e] = (b[e] * m) / Sf;
                 }
             }
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void la_apply_staged_d32(
                 x = *reinterpret_cast<const f32x4*>(qn + (int64_t)(l0 + r) * ldq + c4 * 4);
                 const float m = mask_at(q_mask, q_group, mbase, l0 + r);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = elu_plus_one(x[e]) * m;
+                for (int e = 0; e < 4; ++e) x[e] = phi_fast(x[e]) * m;
             }
             rq[j] = x;
         }
@@ -588,7 +589,8 @@ __global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ 
 // Rows per kv_partial workgroup: aim for ~512 workgroups (one resident wave of 2 per CU), at least
 // 64 rows each.
 int chunk_rows(int N, int S) {
-    int64_t want = ((int64_t)S * N + 511) / 512;
+    static const int wgs = [] { const char* e = getenv("DFSFM_LA_WGS"); return e ? atoi(e) : 512; }();   // A/B knob
+    int64_t want = ((int64_t)S * N + wgs - 1) / wgs;
     int rows = (int)((want + 31) / 32 * 32);
     if (rows < 64) rows = 64;
     const int smax = (S + 31) / 32 * 32;
@@ -677,7 +679,10 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
     if (D == 32) {
         if (H == 8) {
             const int nblk = (L + 31) / 32;
-            const int bpw = (int64_t)nblk * N >= 4096 ? 4 : ((int64_t)nblk * N >= 1024 ? 2 : 1);
+            // blocks per workgroup: the whole grid in ONE round of 2 workgroups per CU when that takes <= 8 blocks each (a
+            // second, quarter-full round cost as much as the first: 16 x 150 blocks ran as 608 workgroups on 512 slots)
+            int bpw = (int)(((int64_t)nblk * N + 511) / 512);
+            bpw = bpw < 1 ? 1 : (bpw > 8 ? 4 : bpw);
             hipLaunchKernelGGL(la_apply_staged_d32, dim3((nblk + bpw - 1) / bpw, N), blk, 0, stream, q, q_mask,
                                q_group, kvf, out, L, S, ldq, ldo, eps, bpw, oh, ol, ldo_s);
         } else {
