@@ -70,14 +70,29 @@ def _require_cuda(*ts):
             raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
 
 
+_GUARD = 65536 if os.environ.get("DFSFM_GUARD", "0") == "1" else 0       # debugging aid: canary bands around the workspaces
+_GUARD_BYTE = 0xA5
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered."""
+    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered.  With DFSFM_GUARD=1 every workspace
+    sits between two 64-KB bands of a known byte that ``check_workspace_guards`` verifies (tools/gpu_harden.sh)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    if buf is None or buf.numel() - 2 * _GUARD < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20) + 2 * _GUARD, dtype=torch.uint8, device=device)
+        if _GUARD:
+            buf[:_GUARD].fill_(_GUARD_BYTE)
+            buf[buf.numel() - _GUARD:].fill_(_GUARD_BYTE)
         _workspaces[key] = buf
-    return buf
+    return buf[_GUARD:buf.numel() - _GUARD] if _GUARD else buf
+
+
+def check_workspace_guards():
+    """Raises if a kernel wrote outside a workspace (only meaningful with DFSFM_GUARD=1)."""
+    for key, buf in _workspaces.items():
+        if _GUARD and not (bool((buf[:_GUARD] == _GUARD_BYTE).all()) and bool((buf[buf.numel() - _GUARD:] == _GUARD_BYTE).all())):
+            raise _lib.DfsfmError(f"workspace {key}: guard band overwritten")
 
 
 def _as_u8(m: Optional[torch.Tensor]):

@@ -32,3 +32,15 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _workspace_guards():
+    """With DFSFM_GUARD=1 (tools/gpu_harden.sh) every test ends with a check of the canary bands around the kernels' workspaces."""
+    yield
+    if os.environ.get("DFSFM_GUARD", "0") == "1":
+        import torch
+        if torch.cuda.is_available():
+            from detectorfreesfm_amd import ops
+            torch.cuda.synchronize()
+            ops.check_workspace_guards()
