@@ -924,10 +924,12 @@ class EncoderFusedWeights:
         if nhead != 8 or tuple(wq.shape) != (C, C) or tuple(w1.shape) != (2 * C, 2 * C) or tuple(w2.shape) != (C, 2 * C):
             raise _lib.DfsfmError("EncoderFusedWeights: the fused encoder layer is built for d_model 128, 8 heads")
         dev = wq.device
-        planes = {k: _split_planes(v) for k, v in (("q", wq), ("k", wk), ("v", wv), ("m", wmerge), ("1", w1), ("2", w2))}
+        # the streams are assembled on the host (640 row gathers per layer: thousands of tiny launches on the device) and
+        # uploaded once
+        planes = {k: _split_planes(v.detach().cpu()) for k, v in (("q", wq), ("k", wk), ("v", wv), ("m", wmerge), ("1", w1), ("2", w2))}
         # the values the kernels multiply with (hi + lo / 2048), under the reference's parameter names: what the CPU
         # stand-ins of the tests evaluate the layer with
-        self.values = {n: (planes[k][0].float() + planes[k][1].float() / 2048.0) for n, k in
+        self.values = {n: (planes[k][0].float() + planes[k][1].float() / 2048.0).to(dev) for n, k in
                        (("q_proj.weight", "q"), ("k_proj.weight", "k"), ("v_proj.weight", "v"), ("merge.weight", "m"),
                         ("mlp.0.weight", "1"), ("mlp.2.weight", "2"))}
 
