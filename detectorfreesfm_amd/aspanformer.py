@@ -189,36 +189,69 @@ class HipASpanFormer(ParamModule):
         if "mask0" in data or "mask1" in data:
             raise NotImplementedError("padding masks: the reference's dataset path does not pad frames for aspanformer")
         P = self._packed or self._pack()
-        c = self.config["coarse"]
-        d, dfl, nhead, DS = c["d_model"], c["d_flow"], c["nhead"], self.DS
-        dev = img0.device
-        tr = c["train_res"]
-        tr_h, tr_w = (tr, tr) if len(tr) == 1 else (tr[0], tr[1])
-        # resize_input / resize_df (aspanformer.py:119-139): sides rounded down to multiples of 32 by torchvision 0.9.1's
-        # transforms.Resize on a float tensor = F.interpolate(size, 'bilinear', align_corners=False); identity when they already are
         orig = [(im.shape[2], im.shape[3]) for im in (img0, img1)]
-        imgs = []
-        for im in (img0, img1):
-            h, w = im.shape[2], im.shape[3]
-            h_new, w_new = h // 32 * 32, w // 32 * 32
-            imgs.append(ops.resize_bilinear(im, h_new, w_new) if (h_new, w_new) != (h, w) else im)
-        img0, img1 = imgs
+        img0, img1 = (self._online_resize(im) for im in (img0, img1))
         data["image0"], data["image1"] = img0, img1
-        pos_scale = [[tr_h / im.shape[2], tr_w / im.shape[3]] for im in imgs]
-        data["pos_scale0"], data["pos_scale1"] = pos_scale
-        rs = [torch.tensor([orig[i][1] / imgs[i].shape[3], orig[i][0] / imgs[i].shape[2]])[None].to(dev) for i in (0, 1)]
-        data["online_resize_scale0"], data["online_resize_scale1"] = rs
-        data.update({"bs": 1, "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
         tok = None
         if img0.shape[2:] == img1.shape[2:]:
             tok = backbone_tokens_hip(torch.cat([img0, img1], 0), P["bb"])
             toks = (tok[0:1], tok[1:2])
         else:
             toks = (backbone_tokens_hip(img0, P["bb"]), backbone_tokens_hip(img1, P["bb"]))
+        return self._forward_tokens(data, toks, tok, [tuple(img0.shape[2:]), tuple(img1.shape[2:])], orig)
+
+    @staticmethod
+    def _online_resize(im):
+        """resize_input / resize_df (aspanformer.py:119-139): sides rounded down to multiples of 32 by torchvision 0.9.1's
+        transforms.Resize on a float tensor = F.interpolate(size, 'bilinear', align_corners=False); identity when they already are."""
+        h, w = im.shape[2], im.shape[3]
+        h_new, w_new = h // 32 * 32, w // 32 * 32
+        return ops.resize_bilinear(im, h_new, w_new) if (h_new, w_new) != (h, w) else im
+
+    # -- "backbone once per image" for a scene (SURVEY 8(f) rank 1; VERDICT r02 missing #5): the ResNet is per image ---------
+    @torch.no_grad()
+    def image_tokens(self, images):
+        """[B,1,H,W] frames of one size -> (backbone tokens [B, h, w, C] of the online-resized frames, (h, w)); per-image results
+        do not depend on the batch, so they can be cached and paired freely (``match_tokens``)."""
+        P = self._packed or self._pack()
+        t = backbone_tokens_hip(self._online_resize(images), P["bb"])
+        return t, tuple(t.shape[1:3])
+
+    @torch.no_grad()
+    def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None):
+        """Transformer + matching on cached backbone tokens of N pairs (tok* [N, h, w, C]; ``hw0_i`` = ORIGINAL frame size, both
+        frames of one size); one pair per pass like the reference.  Returns the concatenated match dictionary (b_ids = pair)."""
+        outs = []
+        h_i, w_i = int(hw0_i[0]), int(hw0_i[1])
+        res = [(h_i // 32 * 32, w_i // 32 * 32)] * 2
+        for n in range(tok0.shape[0]):
+            d = {}
+            if scale0 is not None:
+                d["scale0"], d["scale1"] = scale0[n:n + 1], scale1[n:n + 1]
+            pair = torch.cat([tok0[n:n + 1], tok1[n:n + 1]], 0) if tuple(hw0_c) == tuple(hw1_c) else None
+            self._forward_tokens(d, (tok0[n:n + 1], tok1[n:n + 1]), pair, res, [(h_i, w_i)] * 2)
+            outs.append({"b_ids": torch.full_like(d["b_ids"], n), "i_ids": d["i_ids"], "j_ids": d["j_ids"], "mconf": d["mconf"],
+                         "mkpts0_c": d["mkpts0_c"], "mkpts1_c": d["mkpts1_c"]})
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+
+    def _forward_tokens(self, data, toks, tok, shapes, orig):
+        """Everything after the backbone: ``toks`` = the two token maps [1, h, w, C] (``tok`` = both stacked when the frames have
+        one size), ``shapes`` = (H, W) of the (resized) frames, ``orig`` = their sizes before the online resize."""
+        P = self._packed or self._pack()
+        c = self.config["coarse"]
+        d, dfl, nhead, DS = c["d_model"], c["d_flow"], c["nhead"], self.DS
+        dev = toks[0].device
+        tr = c["train_res"]
+        tr_h, tr_w = (tr, tr) if len(tr) == 1 else (tr[0], tr[1])
+        pos_scale = [[tr_h / sh[0], tr_w / sh[1]] for sh in shapes]
+        data["pos_scale0"], data["pos_scale1"] = pos_scale
+        rs = [torch.tensor([orig[i][1] / shapes[i][1], orig[i][0] / shapes[i][0]])[None].to(dev) for i in (0, 1)]
+        data["online_resize_scale0"], data["online_resize_scale1"] = rs
+        data.update({"bs": 1, "hw0_i": torch.Size(shapes[0]), "hw1_i": torch.Size(shapes[1])})
         hw = [tuple(t.shape[1:3]) for t in toks]
         data.update({"hw0_c": torch.Size(hw[0]), "hw1_c": torch.Size(hw[1]),
-                     "hw0_f": torch.Size((img0.shape[2] // 2, img0.shape[3] // 2)),
-                     "hw1_f": torch.Size((img1.shape[2] // 2, img1.shape[3] // 2))})
+                     "hw0_f": torch.Size((shapes[0][0] // 2, shapes[0][1] // 2)),
+                     "hw1_f": torch.Size((shapes[1][0] // 2, shapes[1][1] // 2))})
         L = [h * w for h, w in hw]
         pc = [self._positional(P, hw[i][0], hw[i][1], pos_scale[i], dev) for i in (0, 1)]
 
@@ -318,13 +351,13 @@ class HipASpanFormer(ParamModule):
         # ---- CoarseMatching (utils/coarse_matching.py:87-160, 226-262): sim = <f0, f1> / C * temperature
         mc = self.config["match_coarse"]
         m = ops.coarse_match(feats[0], feats[1], hw[0], hw[1], mc["thr"], mc["border_rm"], 1.0 / P["temperature"],
-                             data.get("scale0"), data.get("scale1"), img0.shape[2] / hw[0][0])
+                             data.get("scale0"), data.get("scale1"), shapes[0][0] / hw[0][0])
         data.update(m)
         data["m_bids"] = m["b_ids"]
         data["gt_mask"] = m["mconf"] == 0
         fl = [torch.stack(f, dim=0) for f in flows]                                       # [layer, 1, h, w, 4]
         data["predict_flow"] = torch.stack(fl, dim=0) if hw[0] == hw[1] else fl
-        scale = img0.shape[2] / hw[0][0]
+        scale = shapes[0][0] / hw[0][0]
         for side, f in (("left", fl[0]), ("right", fl[1])):                               # get_offset_match (:266-328)
             off = f.reshape(f.shape[0], 1, -1, 4)
             conf = off[..., 2:].mean(dim=-1)

@@ -207,13 +207,16 @@ def merge_match_tables(matches: dict, names: list, pair_name_split: str, device=
 
 
 @torch.no_grad()
-def match_scene_cached(matcher: HipLoFTR, images, pairs, batch=8, scales=None, to_host=True):
+def match_scene_cached(matcher, images, pairs, batch=8, scales=None, to_host=True):
     """Exhaustive / covisible pair matching of one scene with the backbone evaluated ONCE per image.
 
     The reference's match_worker (src/coarse_match/coarse_match_worker.py:102-145) feeds every pair through
     detector+matcher, so an image that appears in k pairs pays for k backbone passes -- 55 % of the coarse step
     here.  Backbone tokens are a per-image quantity: they are computed once, kept on the device, and paired by
     index; positional encoding, transformer and matching run per pair exactly as in ``HipLoFTR.forward``.
+    ``matcher``: HipLoFTR or HipASpanFormer (both expose ``image_tokens`` / ``match_tokens``; ASpanFormer's ResNet is per image
+    too -- 1.5 of its 5.1 ms per pair).  MatchFormer-LA's backbone interleaves cross attention between the two images of a pair,
+    so it has no per-image part to cache.
 
     images: tensor [n_images,1,H,W] (same size); pairs: list of (i, j); scales: optional [n_images,2] (h, w scale).
     Only the images that occur in ``pairs`` are run through the backbone (a rank's shard of a scene).

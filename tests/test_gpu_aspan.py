@@ -255,3 +255,21 @@ def test_aspanformer_plugin_surface(built_lib, tmp_path):
     with pytest.raises(NotImplementedError):
         matcher({"image0": torch.zeros(1, 1, 96, 128, device=DEV), "image1": torch.zeros(1, 1, 96, 128, device=DEV),
                  "mask0": torch.ones(1, 12, 16, device=DEV), "mask1": torch.ones(1, 12, 16, device=DEV)})
+
+
+def test_aspanformer_scene_cached_tokens(built_lib):
+    """plugin.match_scene_cached with the ASpanFormer matcher: backbone once per image, tables equal to the pairwise forward."""
+    cfg, sd, m = _aspan(0.2)
+    base = synth.coarse_pair_batch(2, 100, 140, seed=1000)                  # the online resize turns these into 96 x 128
+    images = torch.cat([base["image0"], base["image1"][:1]], 0)
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    tables = plugin.match_scene_cached(m, images, pairs, batch=2)
+    total = 0
+    for (i, j) in pairs:
+        d = synth.to_device({"image0": images[i:i + 1], "image1": images[j:j + 1]}, DEV)
+        m(d)
+        ref = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).cpu().numpy()
+        got = tables[(i, j)]
+        assert got.shape == ref.shape and np.array_equal(got[:, :4], ref[:, :4]) and np.abs(got[:, 4] - ref[:, 4]).max() <= 1e-6
+        total += len(ref)
+    assert total > 30

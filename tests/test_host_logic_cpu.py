@@ -257,3 +257,30 @@ def test_merge_match_tables_rejects_float64():
     """The device merge reproduces the reference's float32 arithmetic; float64 tables must not be cast silently."""
     with pytest.raises(TypeError):
         plugin.merge_match_tables({"a b": np.zeros((3, 5), dtype=np.float64)}, ["a", "b"], " ", device="cpu")
+
+
+def test_aspanformer_scene_cached_tokens_equal_pairwise():
+    """plugin.match_scene_cached with the ASpanFormer matcher (backbone once per image, VERDICT r02 missing #5): the same tables
+    as feeding every pair through HipASpanFormer.forward -- including frames that the online resize shrinks first."""
+    import numpy as np
+    from detectorfreesfm_amd import plugin
+    from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    cfg = aspanformer_coarse_only_config(0.2)
+    m = HipASpanFormer(cfg).eval()
+    m.load_state_dict(planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0), strict=True)
+    for H, W in ((96, 128), (100, 140)):                      # 100 x 140 -> 96 x 128 by the online resize
+        base = synth.coarse_pair_batch(2, H, W, seed=1000)
+        images = torch.cat([base["image0"], base["image1"][:1]], 0)            # 3 images -> 3 pairs
+        pairs = [(0, 1), (0, 2), (1, 2)]
+        scales = torch.tensor([[1.0, 1.0], [1.5, 2.0], [0.75, 1.25]])
+        with cpu_ops(), torch.no_grad():
+            tables = plugin.match_scene_cached(m, images, pairs, batch=2, scales=scales)
+            total = 0
+            for (i, j) in pairs:
+                d = {"image0": images[i:i + 1], "image1": images[j:j + 1], "scale0": scales[i:i + 1], "scale1": scales[j:j + 1]}
+                m(d)
+                ref = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).numpy()
+                assert np.array_equal(tables[(i, j)], ref), (H, W, i, j)
+                total += len(ref)
+        assert total > 30
