@@ -1,4 +1,5 @@
-"""One warm forward of each plugin (for rocprofv3 --kernel-trace --stats): python tools/profile_step.py [coarse|refine] [n]"""
+"""One warm forward of each plugin (for rocprofv3 --kernel-trace --stats):
+python tools/profile_step.py [coarse|refine|aspan|matchformer] [n]; prints the wall time per forward of the last n-1."""
 import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, synth
@@ -11,10 +12,29 @@ if which == 'coarse':
     cfg = loftr_coarse_only_config(0.2)
     m = HipLoFTR(cfg); m.load_state_dict(planted_loftr_state_dict(loftr_param_spec(cfg), 0)); m = m.eval().to(dev)
     data = synth.to_device(synth.coarse_pair_batch(8, 480, 640, seed=1000), dev)
+elif which == 'aspan':
+    from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    cfg = aspanformer_coarse_only_config(0.4)
+    m = HipASpanFormer(cfg); m.load_state_dict(planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0), strict=True)
+    m = m.eval().to(dev)
+    data = synth.to_device(synth.coarse_pair_batch(1, 480, 640, seed=1000), dev)
+elif which == 'matchformer':
+    from detectorfreesfm_amd.matchformer import HipMatchformer, matchformer_coarse_only_config
+    from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
+    cfg = matchformer_coarse_only_config(0.4)
+    m = HipMatchformer(cfg); m.load_state_dict(planted_matchformer_state_dict(matchformer_param_spec(), 0), strict=True)
+    m = m.eval().to(dev)
+    data = synth.to_device(synth.coarse_pair_batch(8, 480, 640, seed=1000), dev)
 else:
     cfg = multiview_refinement_config()
     m = HipMultiviewMatcher(cfg); m.load_state_dict(random_state_dict(multiview_param_spec(cfg), 1)); m = m.eval().to(dev)
     data = synth.to_device(synth.refine_bag(2000, 5, 480, 640, seed=2000), dev)
-for _ in range(n):
+import time
+m(dict(data))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n - 1):
     m(dict(data))
 torch.cuda.synchronize()
+if n > 1:
+    print(f"{which}: {1e3 * (time.perf_counter() - t0) / (n - 1):.3f} ms per forward (wall)")
