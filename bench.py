@@ -418,7 +418,17 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
     src/coarse_match/coarse_match.py:127-140): backbone once per image on every rank, the rank's contiguous shard of
     the pair list matched from the cached tokens, ONE gather-to-root of the tables, keypoint merge on rank 0."""
     n_img = args.scene_images
-    matcher = build_coarse(dev)
+    if args.scene_matcher == "aspanformer":       # backbone once per image + PAIRS_PER_PASS pairs per transformer pass
+        from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+        from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+        cfg = aspanformer_coarse_only_config(0.4)
+        matcher = HipASpanFormer(cfg)
+        matcher.load_state_dict(planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0), strict=True)
+        matcher = matcher.eval().to(dev)
+        mname = "ASpanFormer (thr 0.4), "
+    else:
+        matcher = build_coarse(dev)
+        mname = ""
     g = torch.Generator().manual_seed(4242)
     base = torch.rand((1, 1, 480, 640), generator=g)
     # a camera sweep: image k = the base texture rolled by k coarse cells (+ noise) -> every pair has a planted flow
@@ -460,7 +470,7 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
             "metric": "coarse_image_pairs_per_sec", "value": len(pairs) / dt, "unit": "image-pairs/s", "n_gpus": world,
             "steps": 1, "warmup": 0, "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"configs[3]: {n_img} images 640x480, {len(pairs)} exhaustive pairs, backbone once per image, "
+            "config": {"workload": f"configs[3]: {mname}{n_img} images 640x480, {len(pairs)} exhaustive pairs, backbone once per image, "
                                    "tables gathered to rank 0 once, keypoint merge on rank 0",
                        "parallelism": f"contiguous pair shards over {world} rank(s); one gather-to-root of match tables",
                        "rccl_ranks": world if distributed else 0},
@@ -558,6 +568,7 @@ def main():
     ap.add_argument("--workload", choices=("pairs", "scene300", "hires832", "matchformer", "aspanformer"), default="pairs")
     ap.add_argument("--scene-images", type=int, default=300)
     ap.add_argument("--scene-pairs", type=int, default=0, help="truncate the exhaustive pair list (0 = all)")
+    ap.add_argument("--scene-matcher", choices=("loftr", "aspanformer"), default="loftr", help="coarse matcher of --workload scene300")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
     ap.add_argument("--kernels-only", action="store_true",

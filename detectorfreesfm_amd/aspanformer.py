@@ -24,6 +24,7 @@ pinned against torch's ``F.interpolate``, not against torchvision.  Not implemen
 dataset path never pads for this matcher: src/coarse_match/coarse_match.py:88-90) and ``fine.enable``.
 """
 import math
+import os
 
 import torch
 
@@ -217,37 +218,47 @@ class HipASpanFormer(ParamModule):
         t = backbone_tokens_hip(self._online_resize(images), P["bb"])
         return t, tuple(t.shape[1:3])
 
+    # pairs per transformer pass of the scene path: the kernels pair image n with n ^ 1, so P pairs travel as one stream of 2P
+    # row-stacked images and every launch works on P times the rows (a single 640x480 pair fills a fraction of the 256 CUs)
+    PAIRS_PER_PASS = int(os.environ.get("DFSFM_ASPAN_PAIRS_PER_PASS", "8"))
+
     @torch.no_grad()
     def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None):
         """Transformer + matching on cached backbone tokens of N pairs (tok* [N, h, w, C]; ``hw0_i`` = ORIGINAL frame size, both
-        frames of one size); one pair per pass like the reference.  Returns the concatenated match dictionary (b_ids = pair)."""
+        frames of one size), ``PAIRS_PER_PASS`` pairs per pass: per-pair results do not depend on the other pairs of the pass
+        (every kernel works per row, per image or per image pair), so they equal the reference's one-pair-per-call results.
+        Returns the concatenated match dictionary (b_ids = pair)."""
         outs = []
         h_i, w_i = int(hw0_i[0]), int(hw0_i[1])
         res = [(h_i // 32 * 32, w_i // 32 * 32)] * 2
-        for n in range(tok0.shape[0]):
+        same = tuple(hw0_c) == tuple(hw1_c)
+        for c0 in range(0, tok0.shape[0], self.PAIRS_PER_PASS):
+            t0, t1 = tok0[c0:c0 + self.PAIRS_PER_PASS], tok1[c0:c0 + self.PAIRS_PER_PASS]
             d = {}
             if scale0 is not None:
-                d["scale0"], d["scale1"] = scale0[n:n + 1], scale1[n:n + 1]
-            pair = torch.cat([tok0[n:n + 1], tok1[n:n + 1]], 0) if tuple(hw0_c) == tuple(hw1_c) else None
-            self._forward_tokens(d, (tok0[n:n + 1], tok1[n:n + 1]), pair, res, [(h_i, w_i)] * 2)
-            outs.append({"b_ids": torch.full_like(d["b_ids"], n), "i_ids": d["i_ids"], "j_ids": d["j_ids"], "mconf": d["mconf"],
+                d["scale0"], d["scale1"] = scale0[c0:c0 + t0.shape[0]], scale1[c0:c0 + t0.shape[0]]
+            pair = torch.stack([t0, t1], 1).flatten(0, 1) if same else None            # images 2n, 2n + 1 = pair n
+            self._forward_tokens(d, (t0, t1), pair, res, [(h_i, w_i)] * 2)
+            outs.append({"b_ids": d["b_ids"] + c0, "i_ids": d["i_ids"], "j_ids": d["j_ids"], "mconf": d["mconf"],
                          "mkpts0_c": d["mkpts0_c"], "mkpts1_c": d["mkpts1_c"]})
         return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
     def _forward_tokens(self, data, toks, tok, shapes, orig):
-        """Everything after the backbone: ``toks`` = the two token maps [1, h, w, C] (``tok`` = both stacked when the frames have
-        one size), ``shapes`` = (H, W) of the (resized) frames, ``orig`` = their sizes before the online resize."""
+        """Everything after the backbone for N pairs: ``toks`` = the token maps [N, h, w, C] of the first and of the second frames
+        (``tok`` = both interleaved, [2N, h, w, C] with images 2n, 2n + 1 = pair n, when the frames have one size), ``shapes`` =
+        (H, W) of the (resized) frames, ``orig`` = their sizes before the online resize.  The reference runs N = 1 only."""
         P = self._packed or self._pack()
         c = self.config["coarse"]
         d, dfl, nhead, DS = c["d_model"], c["d_flow"], c["nhead"], self.DS
         dev = toks[0].device
+        N = toks[0].shape[0]
         tr = c["train_res"]
         tr_h, tr_w = (tr, tr) if len(tr) == 1 else (tr[0], tr[1])
         pos_scale = [[tr_h / sh[0], tr_w / sh[1]] for sh in shapes]
         data["pos_scale0"], data["pos_scale1"] = pos_scale
         rs = [torch.tensor([orig[i][1] / shapes[i][1], orig[i][0] / shapes[i][0]])[None].to(dev) for i in (0, 1)]
         data["online_resize_scale0"], data["online_resize_scale1"] = rs
-        data.update({"bs": 1, "hw0_i": torch.Size(shapes[0]), "hw1_i": torch.Size(shapes[1])})
+        data.update({"bs": N, "hw0_i": torch.Size(shapes[0]), "hw1_i": torch.Size(shapes[1])})
         hw = [tuple(t.shape[1:3]) for t in toks]
         data.update({"hw0_c": torch.Size(hw[0]), "hw1_c": torch.Size(hw[1]),
                      "hw0_f": torch.Size((shapes[0][0] // 2, shapes[0][1] // 2)),
@@ -257,12 +268,12 @@ class HipASpanFormer(ParamModule):
 
         # Every layer shares its weights between the two directions and updates both images from the pre-update pair
         # (transformer.py:34-41, 96-107), so two frames of one size travel as ONE stream of 2 row-stacked images (half the
-        # launches; attention pairs image n with n ^ 1); frames of different sizes are two streams of one image each.
+        # launches; attention pairs image n with n ^ 1); frames of different sizes are two streams of one image per pair each.
         stacked = hw[0] == hw[1] and pos_scale[0] == pos_scale[1]
         streams = [{"ids": (0, 1)}] if stacked else [{"ids": (0,)}, {"ids": (1,)}]
         for st in streams:
             i0 = st["ids"][0]
-            st.update(nb=len(st["ids"]), h=hw[i0][0], w=hw[i0][1], L=L[i0], pc=pc[i0])
+            st.update(nb=N * len(st["ids"]), h=hw[i0][0], w=hw[i0][1], L=L[i0], pc=pc[i0])
         other = (lambda st: st) if stacked else (lambda st: streams[1] if st is streams[0] else streams[0])
 
         def rep(t, nb):                      # a per-size constant for every image of the stream
@@ -337,14 +348,16 @@ class HipASpanFormer(ParamModule):
                     fe = ops.SplitAct.empty_rows((nb, st["L"]), d, dev)
                     ops.layernorm2d(y, *e["n2"], residual=st["U"].cols(0, d),
                                     out_split=ops.SplitAct(fe.hi.view(-1, d), fe.lo.view(-1, d), d), want_f32=False)
-                    for k, i in enumerate(st["ids"]):
-                        feats[i] = fe[k:k + 1]
+                    ns = len(st["ids"])
+                    for k, i in enumerate(st["ids"]):                                   # rows of side i: images k, k + ns, ...
+                        feats[i] = ops.SplitAct(fe.hi[k::ns].contiguous(), fe.lo[k::ns].contiguous(), d)
                 else:
                     st["Un"] = ops.SplitAct.empty_rows((nb * st["L"],), 2 * d + dfl, dev)
                     ops.layernorm2d(y, *e["n2"], residual=st["U"].cols(0, width), out_split=st["Un"].cols(0, width), want_f32=False)
             for st in streams:
+                ns = len(st["ids"])
                 for k, i in enumerate(st["ids"]):
-                    flows[i].append(st["flow"][k].view(1, st["h"], st["w"], 4))
+                    flows[i].append(st["flow"][k::ns].reshape(N, st["h"], st["w"], 4))
                 if "Un" in st:
                     st["U"] = st.pop("Un")
 
@@ -355,11 +368,11 @@ class HipASpanFormer(ParamModule):
         data.update(m)
         data["m_bids"] = m["b_ids"]
         data["gt_mask"] = m["mconf"] == 0
-        fl = [torch.stack(f, dim=0) for f in flows]                                       # [layer, 1, h, w, 4]
+        fl = [torch.stack(f, dim=0) for f in flows]                                       # [layer, N, h, w, 4]
         data["predict_flow"] = torch.stack(fl, dim=0) if hw[0] == hw[1] else fl
         scale = shapes[0][0] / hw[0][0]
         for side, f in (("left", fl[0]), ("right", fl[1])):                               # get_offset_match (:266-328)
-            off = f.reshape(f.shape[0], 1, -1, 4)
+            off = f.reshape(f.shape[0], N, -1, 4)
             conf = off[..., 2:].mean(dim=-1)
             keep = conf < 2
             keep[:, :, 0] = True

@@ -215,7 +215,7 @@ def match_scene_cached(matcher, images, pairs, batch=8, scales=None, to_host=Tru
     here.  Backbone tokens are a per-image quantity: they are computed once, kept on the device, and paired by
     index; positional encoding, transformer and matching run per pair exactly as in ``HipLoFTR.forward``.
     ``matcher``: HipLoFTR or HipASpanFormer (both expose ``image_tokens`` / ``match_tokens``; ASpanFormer's ResNet is per image
-    too -- 1.5 of its 5.1 ms per pair).  MatchFormer-LA's backbone interleaves cross attention between the two images of a pair,
+    too -- 1.5 of its 5.1 ms per pair -- and its ``match_tokens`` sends several pairs through the transformer per pass).  MatchFormer-LA's backbone interleaves cross attention between the two images of a pair,
     so it has no per-image part to cache.
 
     images: tensor [n_images,1,H,W] (same size); pairs: list of (i, j); scales: optional [n_images,2] (h, w scale).

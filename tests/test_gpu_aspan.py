@@ -258,11 +258,13 @@ def test_aspanformer_plugin_surface(built_lib, tmp_path):
 
 
 def test_aspanformer_scene_cached_tokens(built_lib):
-    """plugin.match_scene_cached with the ASpanFormer matcher: backbone once per image, tables equal to the pairwise forward."""
+    """plugin.match_scene_cached with the ASpanFormer matcher: backbone once per image and several pairs per transformer pass
+    (pairs (0,1), (0,2) travel as one stream of four images), tables equal to the one-pair-per-call forward."""
     cfg, sd, m = _aspan(0.2)
     base = synth.coarse_pair_batch(2, 100, 140, seed=1000)                  # the online resize turns these into 96 x 128
     images = torch.cat([base["image0"], base["image1"][:1]], 0)
     pairs = [(0, 1), (0, 2), (1, 2)]
+    assert m.PAIRS_PER_PASS >= 2
     tables = plugin.match_scene_cached(m, images, pairs, batch=2)
     total = 0
     for (i, j) in pairs:

@@ -275,12 +275,24 @@ def test_aspanformer_scene_cached_tokens_equal_pairwise():
         pairs = [(0, 1), (0, 2), (1, 2)]
         scales = torch.tensor([[1.0, 1.0], [1.5, 2.0], [0.75, 1.25]])
         with cpu_ops(), torch.no_grad():
-            tables = plugin.match_scene_cached(m, images, pairs, batch=2, scales=scales)
-            total = 0
+            refs = {}
             for (i, j) in pairs:
                 d = {"image0": images[i:i + 1], "image1": images[j:j + 1], "scale0": scales[i:i + 1], "scale1": scales[j:j + 1]}
                 m(d)
-                ref = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).numpy()
-                assert np.array_equal(tables[(i, j)], ref), (H, W, i, j)
-                total += len(ref)
+                refs[(i, j)] = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1).numpy()
+            total = sum(len(r) for r in refs.values())
+            # one pair per transformer pass: the host logic alone, bit for bit
+            m.PAIRS_PER_PASS = 1
+            tables = plugin.match_scene_cached(m, images, pairs, batch=2, scales=scales)
+            for pr in pairs:
+                assert np.array_equal(tables[pr], refs[pr]), (H, W, pr)
+            # several pairs per pass (the default): same rows; torch's CPU GEMMs behind the stand-ins choose their blocking by the
+            # row count, which this network amplifies to 1e-5 on a confidence (the HIP kernels are row-independent: the GPU test
+            # holds 1e-6)
+            del m.PAIRS_PER_PASS
+            assert m.PAIRS_PER_PASS >= 2
+            tables = plugin.match_scene_cached(m, images, pairs, batch=2, scales=scales)
+            for pr in pairs:
+                assert tables[pr].shape == refs[pr].shape and np.array_equal(tables[pr][:, :4], refs[pr][:, :4]), (H, W, pr)
+                assert np.abs(tables[pr][:, 4] - refs[pr][:, 4]).max() <= 1e-4
         assert total > 30
