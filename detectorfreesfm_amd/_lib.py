@@ -48,6 +48,10 @@ SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("dfsfm_fine_match_split", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("dfsfm_encoder_kv_f32", c_int,
      [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     ("dfsfm_encoder_apply_f32", c_int,

@@ -6,6 +6,8 @@
 //   :195-219 (_s2d_heatmap), :258-285 (argsoftmax), :129-179 (_obtain_left_normalized_offset),
 //   :221-252 (build_moved_query / build_mkpts)
 //
+// Two input forms: fp32 tensors (dfsfm_fine_match_f32) or the fp16x2-split planes the encoder kernels write
+// (dfsfm_fine_match_split: value = hi + lo/2048; same bytes, no conversion work in the stream).
 // One workgroup per feature track; 486 KB of features in (the query windows + the 49 candidate rows),
 // < 100 B out -> HBM-bound.  Wave w owns query views w, w+4, ...: it DMAs the view's W*W x C window
 // through a private two-stage LDS ring (whole 256-byte row segments), multiplies 32-row tiles against
@@ -15,7 +17,6 @@
 // The heat-map is never materialised.  Lane halves are merged with one shuffle; the masked mean over
 // views and the first-minimum argmin over candidates run in wave 0.
 #include "common.h"
-#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -29,6 +30,7 @@ constexpr int MAXWW = 256;     // window positions
 struct FineArgs {
     const float* ref;      // [T][WW][C]
     const float* qry;      // [T][Vq][WW][C]
+    const _Float16 *ref_h, *ref_l, *qry_h, *qry_l;     // the same tensors as split planes (SPLIT kernels)
     const uint8_t* track_mask;
     const uint8_t* movable;
     int T, Vq, W, left;
@@ -56,18 +58,36 @@ struct Moments {
 // reads the fragments back conflict-free, splits them into fp16 hi / lo planes in registers (v = hi + lo/2048, the
 // representation of every other GEMM of the path) and runs three fp16 MFMAs per product: fp32-class similarities at
 // 3/16 of the fp32-MFMA cost.  No workgroup barrier in the stream: ring, DMA queue and vmcnt are per wave.
-template <int C, bool FAST>
+// v3: (a) split-plane input: the windows are DMA'd as 128-byte segments of the hi and of the lo plane (a stage is still 32 rows
+// x 64 channels = 8 KB) and the fragments are read back ready for the MFMA -- the register split was 6 VALU operations per
+// value, as many cycles as the stage's 24 MFMAs; (b) the softmax exponentials on the compensated hardware exp2 (exp_neg):
+// with one wave per SIMD nothing hides VALU time, and expf was the larger half of it; (c) a wave requests the first two
+// stages of its first view before the workgroup stages the candidate rows, so that latency runs under the prologue.
+// (d) One workgroup per CU, always (the ring alone is 96 KB).  With one wave per SIMD the wave's DMA issue, LDS reads, MFMAs and
+// softmax VALU work add up (a 4-deep ring changed nothing: the stream is issue-bound, not latency-bound).  A 4-KB-stage build
+// (KC = 32: 78 KB per workgroup, two workgroups per CU, 0.25 ms instead of 0.30 ms per 2000 tracks) was measured and NOT kept:
+// with two workgroups resident on a CU 1-14 of 2000 tracks deviated by up to 1e-4 from run to run (one view of a track at a
+// time; never with one workgroup per CU, where every run is bit-identical).  The ring contents checked out against global memory
+// in an instrumented build and the cause was not found, so the shape that is reproducible ships.
+template <int C, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
+    constexpr int KC = 64;                   // channels per stage
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int NKH = C / 64;              // 64-channel (256-byte) segments of a row = DMA stages per 32-row tile
+    constexpr int NKH = C / KC;              // DMA stages per 32-row tile
     constexpr int SLOTS = C / 8;             // 16-byte slots of one fp16 reference row
-    constexpr int STAGE = 32 * 256;          // one A stage: 32 rows x 64 fp32
-    constexpr int NSTG = 3;                  // ring depth per wave: two stages (16 KB) in flight while one is multiplied
+    constexpr int STAGE = 32 * KC * 4;       // one A stage: 32 rows x KC channels (fp32, or fp16 hi plane + fp16 lo plane)
+    constexpr int PIECES = STAGE / 1024;     // DMA instructions per stage
+    constexpr int NSTG = 3;                  // ring depth per wave: two stages in flight while one is multiplied
+    constexpr int RB = SPLIT ? KC * 2 : KC * 4;          // bytes of a row inside a stage (per plane)
+    constexpr int NS = RB / 16;                          // its 16-byte slots: 16, 8 or 4
+    constexpr int PLANE = 32 * RB;                       // split input: bytes of one plane of a stage
+    // slot swizzle by row so that the fragment-shaped reads of 16 consecutive rows cover all 16 bank groups of 256 B
+    auto aswz = [](int r) __attribute__((always_inline)) { return NS == 16 ? (r & 15) : NS == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     // slot swizzle of a reference row: 16 slots (C = 128, 256-byte rows) -> row & 15; 8 slots (C = 64) -> (row >> 1) & 7
     auto rswz = [](int l) __attribute__((always_inline)) { return C == 128 ? (l & 15) : ((l >> 1) & 7); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* s_rh = reinterpret_cast<_Float16*>(smem);                       // [MAXL][C] hi plane, slot-swizzled
+    _Float16* s_rh = reinterpret_cast<_Float16*>(smem);                       // [MAXL][C] hi plane, slot-swizzled; rows >= L are zero
     _Float16* s_rl = s_rh + MAXL * C;                                         // lo plane
     float2* s_grid = reinterpret_cast<float2*>(s_rl + MAXL * C);              // [MAXWW]
     float* s_res = reinterpret_cast<float*>(s_grid + MAXWW);                  // [Vq][MAXL][3]
@@ -79,6 +99,41 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     const int t = blockIdx.x;
     const int W = g.W, WW = W * W, left = g.left, L = left * left, Vq = g.Vq;
     const int NT = (WW + 31) / 32;           // 32-row tiles of the window
+    const int nstage = NT * NKH;
+
+    char* ring = s_ring + wave * NSTG * STAGE;
+    // DMA lane geometry: one instruction = 1 KB = 64 / NS whole row segments of RB bytes (of one plane for split input, whose
+    // stage is [hi: 32 rows x RB][lo: the same]).  lane -> (row in piece, physical slot); the logical slot is on the source.
+    const int drow = lane / NS, dps = lane % NS;
+    __amdgpu_buffer_rsrc_t rq, rql;          // the current view's window (fp32, or hi plane) / its lo plane
+    auto open_view = [&](int n) __attribute__((always_inline)) {
+        const int64_t o = ((int64_t)t * Vq + n) * WW * C;
+        if constexpr (SPLIT) {
+            rq = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry_h + o), 0, WW * C * 2, 0x00020000);
+            rql = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry_l + o), 0, WW * C * 2, 0x00020000);
+        } else {
+            rq = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry + o), 0, WW * C * 4, 0x00020000);
+            rql = rq;
+        }
+    };
+    auto issue = [&](int s) __attribute__((always_inline)) {          // stage s = (tile s / NKH, segment s % NKH)
+        const int rt = s / NKH, kh = s - rt * NKH;
+        char* dst = ring + (s % NSTG) * STAGE;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            // rows past the window (and stages past the end) fall outside the descriptor: zero fill, no traffic
+            constexpr int PP = SPLIT ? PIECES / 2 : PIECES;           // pieces per plane
+            const int row = (p % PP) * (64 / NS) + drow;
+            const int elem = (rt * 32 + row) * C + kh * KC + (dps ^ aswz(row)) * (SPLIT ? 8 : 4);
+            const unsigned off = s < nstage ? (unsigned)(elem * (SPLIT ? 2 : 4)) : 0xFFFFFF00u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p < PP ? rq : rql, (lds_void*)(dst + p * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    if (wave < Vq) {                          // the first view's first two stages fly while the candidate rows are staged
+        open_view(wave);
+        issue(0);
+        issue(1);
+    }
 
     // candidate rows: centre left x left window of the reference patch (select_left_point), split once
     {
@@ -87,7 +142,11 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
         for (int e = tid; e < MAXL * SLOTS; e += 256) {
             const int l = e / SLOTS, q = e % SLOTS;
             half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = h;
-            if (l < L) {
+            if (l < L && SPLIT) {
+                const int64_t o = ((int64_t)t * WW + (c0 + l / left) * W + c0 + l % left) * C + q * 8;
+                h = *reinterpret_cast<const half8*>(g.ref_h + o);
+                lo = *reinterpret_cast<const half8*>(g.ref_l + o);
+            } else if (l < L) {
                 const int r = (c0 + l / left) * W + c0 + l % left;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(rbase + (int64_t)r * C + q * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(rbase + (int64_t)r * C + q * 8 + 4);
@@ -112,57 +171,48 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     __syncthreads();
 
     const float temp = (float)(1.0 / sqrt((double)C));   // softmax_temp = 1 / C**.5 (python double -> f32)
-    char* ring = s_ring + wave * NSTG * STAGE;
-    // DMA lane geometry: one instruction = 4 rows x 256 B; lane -> (row in piece, physical slot); logical slot on the source
-    const int drow = lane >> 4, dps = lane & 15;
     for (int n = wave; n < Vq; n += 4) {
-        const float* qbase = g.qry + ((int64_t)t * Vq + n) * WW * C;
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, WW * C * 4, 0x00020000);
         Moments st[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) st[b] = Moments{-INFINITY, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int nstage = NT * NKH;
-        auto issue = [&](int s) __attribute__((always_inline)) {      // stage s = (tile s / NKH, segment s % NKH); 8 pieces
-            const int rt = s / NKH, kh = s - rt * NKH;
-            char* dst = ring + (s % NSTG) * STAGE;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int row = p * 4 + drow;
-                // rows past the window (and stages past the end) fall outside the descriptor: zero fill, no traffic
-                const unsigned off = s < nstage ? (unsigned)(((rt * 32 + row) * C + kh * 64 + ((dps ^ (row & 15)) * 4)) * 4)
-                                                : 0xFFFFFF00u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(dst + p * 1024), 16, off, 0, 0, 0);
-            }
-        };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // previous view's fragment reads are done
-        issue(0);
-        issue(1);
+        if (n != wave) {
+            open_view(n);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // previous view's fragment reads are done
+            issue(0);
+            issue(1);
+        }
         f32x16 accm[2], accx[2];
         for (int s = 0; s < nstage; ++s) {
             const int rt = s / NKH, kh = s - rt * NKH;
             issue(s + 2);                                             // into the stage consumed in the previous iteration
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // stage s has landed (s+1, s+2 may still fly)
+asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");   // stage s has landed (s+1, s+2 may still fly)
             if (kh == 0) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) { accm[b] = f32x16{0}; accx[b] = f32x16{0}; }
             }
-            const char* sa = ring + (s % NSTG) * STAGE + col * 256;
+            const char* sa = ring + (s % NSTG) * STAGE + col * RB;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {                          // 16 channels per MFMA k-step, 8 per lane half
-                const int sl = (ks * 2 + half) * 2;                   // first of the two fp32 slots
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + ((sl ^ (col & 15)) * 16));
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + (((sl + 1) ^ (col & 15)) * 16));
-                const int q = (kh * 64 + ks * 16 + half * 8) / 8;     // fp16 slot of the reference rows
+            for (int ks = 0; ks < KC / 16; ++ks) {                    // 16 channels per MFMA k-step, 8 per lane half
+                const int q = (kh * KC + ks * 16 + half * 8) / 8;     // fp16 slot of the reference rows
                 const half8 bh0 = *reinterpret_cast<const half8*>(s_rh + col * C + ((q ^ rswz(col)) * 8));
                 const half8 bl0 = *reinterpret_cast<const half8*>(s_rl + col * C + ((q ^ rswz(col)) * 8));
-                const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
+const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
                 const half8 bl1 = *reinterpret_cast<const half8*>(s_rl + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
                 half8 ah, al;
+                if constexpr (SPLIT) {
+                    const int so = (((ks * 2 + half) ^ aswz(col)) * 16);
+                    ah = *reinterpret_cast<const half8*>(sa + so);
+                    al = *reinterpret_cast<const half8*>(sa + PLANE + so);
+                } else {
+                    const int sl = (ks * 2 + half) * 2;               // first of the two fp32 slots
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + ((sl ^ aswz(col)) * 16));
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + (((sl + 1) ^ aswz(col)) * 16));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    _Float16 x, y;
-                    split_f32(a0[k], x, y); ah[k] = x; al[k] = y;
-                    split_f32(a1[k], x, y); ah[4 + k] = x; al[4 + k] = y;
+                    for (int k = 0; k < 4; ++k) {
+                        _Float16 x, y;
+                        split_f32(a0[k], x, y); ah[k] = x; al[k] = y;
+                        split_f32(a1[k], x, y); ah[4 + k] = x; al[4 + k] = y;
+                    }
                 }
                 // A[i = window row][k], B[k][j = candidate]: sim^T keeps the softmax axis (rows) lane-local
                 accm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, accm[0], 0, 0, 0);
@@ -188,13 +238,13 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
                         tmax = fmaxf(tmax, x[r]);
                     }
                     const float m_new = fmaxf(st[b].m, tmax);
-                    const float sc = FAST ? __expf(st[b].m - m_new) : expf(st[b].m - m_new);     // exp(-inf) = 0 on the first tile
+                    const float sc = exp_neg(st[b].m - m_new);                    // exp(-inf) = 0 on the first tile
                     float s0 = st[b].s0 * sc, sx = st[b].sx * sc, sy = st[b].sy * sc;
                     float sxx = st[b].sxx * sc, syy = st[b].syy * sc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {          // rows past the window carry x = -inf -> e = 0: no branch
                         const int rr = rt * 32 + mfma32_row(r, half);
-                        const float e = FAST ? __expf(x[r] - m_new) : expf(x[r] - m_new);
+                        const float e = exp_neg(x[r] - m_new);
                         const float2 gxy = s_grid[rr];       // rr < MAXWW always
                         s0 += e;
                         sx += e * gxy.x;
@@ -283,17 +333,34 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     }
 }
 
-// dynamic LDS of one workgroup: reference planes (hi, lo) + grid + per-view results + 4 waves x 3 stages x 8 KB of DMA ring
+// dynamic LDS of one workgroup: candidate planes (hi, lo) + grid + per-view results + 4 waves x 3 stages x 8 KB of DMA ring
 inline size_t fine_smem_bytes(int C, int Vq) {
-    return (size_t)MAXL * C * 4 + MAXWW * 8 + (((size_t)Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + 4 * 3 * 32 * 256;
+    return (size_t)MAXL * C * 4 + MAXWW * 8 + (((size_t)Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + (size_t)4 * 3 * 32 * 256;
 }
 
-template <int C, bool FAST>
+template <int C, bool SPLIT>
 void launch(const FineArgs& g, hipStream_t stream) {
-    const size_t smem = fine_smem_bytes(C, g.Vq);
-    static dfsfm::SmemAttr smem_attr;
-    smem_attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C, FAST>), 160 * 1024);
-    hipLaunchKernelGGL((fine_match_kernel<C, FAST>), dim3(g.T), dim3(256), smem, stream, g);
+    static dfsfm::SmemAttr attr;
+    attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C, SPLIT>), 160 * 1024);
+    hipLaunchKernelGGL((fine_match_kernel<C, SPLIT>), dim3(g.T), dim3(256), fine_smem_bytes(C, g.Vq), stream, g);
+}
+
+int fine_match_any(FineArgs g, bool split, int C, hipStream_t stream, const char* what) {
+    if (g.T == 0) return DFSFM_OK;
+    if (!g.track_mask || (split ? (!g.ref_h || !g.ref_l || !g.qry_h || !g.qry_l) : (!g.ref || !g.qry))) return DFSFM_E_BADARG;
+    if (g.T < 0 || g.Vq <= 0 || g.W <= 1 || g.left <= 1) return DFSFM_E_BADARG;
+    if (g.query_refined && (!g.query_pts || !g.scale_q)) return DFSFM_E_BADARG;
+    if (g.ref_refined && (!g.ref_pts || !g.scale_r)) return DFSFM_E_BADARG;
+    if (g.left > g.W || g.left * g.left > MAXL || g.W * g.W > MAXWW || (g.left & 1) == 0 || (g.W & 1) == 0) return DFSFM_E_UNSUPPORTED;
+    if (C != 128 && C != 64) return DFSFM_E_UNSUPPORTED;
+    if (fine_smem_bytes(C, g.Vq) > 160 * 1024) return DFSFM_E_UNSUPPORTED;   // LDS budget: Vq <= 40 at C = 128, <= 61 at C = 64
+    const uintptr_t al = split ? (reinterpret_cast<uintptr_t>(g.ref_h) | reinterpret_cast<uintptr_t>(g.ref_l) |
+                                  reinterpret_cast<uintptr_t>(g.qry_h) | reinterpret_cast<uintptr_t>(g.qry_l))
+                               : (reinterpret_cast<uintptr_t>(g.ref) | reinterpret_cast<uintptr_t>(g.qry));
+    if (al & 15) return DFSFM_E_UNSUPPORTED;
+    if (C == 128) { if (split) launch<128, true>(g, stream); else launch<128, false>(g, stream); }
+    else { if (split) launch<64, true>(g, stream); else launch<64, false>(g, stream); }
+    return dfsfm::check_launch(what);
 }
 
 }  // namespace
@@ -304,21 +371,19 @@ extern "C" int dfsfm_fine_match_f32(const float* ref, const float* qry, const ui
                                     const float* scale_r, int64_t rs_t, int64_t rs_n, int32_t* best_index,
                                     float* left_norm, float* coords, float* std, float* query_refined,
                                     float* ref_refined, void* stream_) {
-    if (T == 0) return DFSFM_OK;
-    if (!ref || !qry || !track_mask) return DFSFM_E_BADARG;
-    if (T < 0 || Vq <= 0 || W <= 1 || left <= 1) return DFSFM_E_BADARG;
-    if (query_refined && (!query_pts || !scale_q)) return DFSFM_E_BADARG;
-    if (ref_refined && (!ref_pts || !scale_r)) return DFSFM_E_BADARG;
-    if (left > W || left * left > MAXL || W * W > MAXWW || (left & 1) == 0 || (W & 1) == 0) return DFSFM_E_UNSUPPORTED;
-    if (C != 128 && C != 64) return DFSFM_E_UNSUPPORTED;
-    if (fine_smem_bytes(C, Vq) > 160 * 1024) return DFSFM_E_UNSUPPORTED;   // LDS budget: Vq <= 39 at C = 128, <= 60 at C = 64
-    if ((reinterpret_cast<uintptr_t>(ref) & 15) || (reinterpret_cast<uintptr_t>(qry) & 15)) return DFSFM_E_UNSUPPORTED;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    FineArgs g{ref, qry, track_mask, movable, T, Vq, W, left, query_pts, scale_q, ref_pts, scale_r,
-               rs_t, rs_n, best_index, left_norm, coords, std, query_refined, ref_refined};
-    static const bool fast = [] { const char* e = getenv("DFSFM_FINE_FASTEXP"); return e && atoi(e) != 0; }();   // A/B switch
-    if (C == 128) { if (fast) launch<128, true>(g, stream); else launch<128, false>(g, stream); }
-    else if (C == 64) { if (fast) launch<64, true>(g, stream); else launch<64, false>(g, stream); }
-    else return DFSFM_E_UNSUPPORTED;
-    return dfsfm::check_launch("dfsfm_fine_match_f32");
+    FineArgs g{ref, qry, nullptr, nullptr, nullptr, nullptr, track_mask, movable, T, Vq, W, left, query_pts, scale_q, ref_pts,
+               scale_r, rs_t, rs_n, best_index, left_norm, coords, std, query_refined, ref_refined};
+    return fine_match_any(g, false, C, static_cast<hipStream_t>(stream_), "dfsfm_fine_match_f32");
+}
+
+extern "C" int dfsfm_fine_match_split(const void* ref_hi, const void* ref_lo, const void* qry_hi, const void* qry_lo,
+                                      const uint8_t* track_mask, const uint8_t* movable, int T, int Vq, int W, int left, int C,
+                                      const float* query_pts, const float* scale_q, const float* ref_pts,
+                                      const float* scale_r, int64_t rs_t, int64_t rs_n, int32_t* best_index,
+                                      float* left_norm, float* coords, float* std, float* query_refined,
+                                      float* ref_refined, void* stream_) {
+    FineArgs g{nullptr, nullptr, static_cast<const _Float16*>(ref_hi), static_cast<const _Float16*>(ref_lo),
+               static_cast<const _Float16*>(qry_hi), static_cast<const _Float16*>(qry_lo), track_mask, movable, T, Vq, W, left,
+               query_pts, scale_q, ref_pts, scale_r, rs_t, rs_n, best_index, left_norm, coords, std, query_refined, ref_refined};
+    return fine_match_any(g, true, C, static_cast<hipStream_t>(stream_), "dfsfm_fine_match_split");
 }

@@ -244,19 +244,35 @@ def roi_align(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapol
 @_on_device
 def fine_match(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, ref_pts=None,
                scale_r=None):
-    """K11+K12.  ref [T,WW,C], qry [T,Vq,WW,C] fp32; track_mask [T,Vq]; movable [T] or None.
+    """K11+K12.  ref [T,WW,C], qry [T,Vq,WW,C] fp32 -- or both as SplitAct planes of those shapes (the form the encoder kernels
+    write; streamed into the MFMA fragments without a conversion); track_mask [T,Vq]; movable [T] or None.
     query_pts / scale_q [T,2]; ref_pts / scale_r view-major [>=Vq, T, 2] (the reference's [V-1,T,2] layout; strided
     views such as ``x[0, :, i:]`` are taken as they are).  Any float dtype / device placement of the four point
     tensors is accepted like in the reference and converted to device fp32 here.
     Returns dict(best_index, left_norm, coords, std[, query_refined, ref_refined])."""
-    _require_cuda(ref, qry)
-    if ref.dtype != torch.float32 or qry.dtype != torch.float32 or ref.device != qry.device:
-        raise _lib.DfsfmError("fine_match: ref / qry must be fp32 tensors on one device")
-    ref, qry = ref.contiguous(), qry.contiguous()
-    T, Vq, WW, C = qry.shape
-    if ref.shape != (T, WW, C):
-        raise _lib.DfsfmError("fine_match: ref must be [T, W*W, C] matching qry [T, Vq, W*W, C]")
-    dev = ref.device
+    split = isinstance(ref, SplitAct)
+    if split != isinstance(qry, SplitAct):
+        raise _lib.DfsfmError("fine_match: ref and qry must both be fp32 or both be split planes")
+    if split:
+        _require_cuda(ref.hi, ref.lo, qry.hi, qry.lo)
+        for t in (ref.hi, ref.lo, qry.hi, qry.lo):
+            if t.dtype != torch.float16 or not t.is_contiguous():
+                raise _lib.DfsfmError("fine_match: split planes must be contiguous fp16")
+        if ref.hi.shape[-1] != ref.C or qry.hi.shape[-1] != qry.C or ref.lo.shape != ref.hi.shape or qry.lo.shape != qry.hi.shape:
+            raise _lib.DfsfmError("fine_match: split planes must not carry padded channels")
+        T, Vq, WW, C = qry.hi.shape
+        if tuple(ref.hi.shape) != (T, WW, C):
+            raise _lib.DfsfmError("fine_match: ref must be [T, W*W, C] matching qry [T, Vq, W*W, C]")
+        dev = ref.hi.device
+    else:
+        _require_cuda(ref, qry)
+        if ref.dtype != torch.float32 or qry.dtype != torch.float32 or ref.device != qry.device:
+            raise _lib.DfsfmError("fine_match: ref / qry must be fp32 tensors on one device")
+        ref, qry = ref.contiguous(), qry.contiguous()
+        T, Vq, WW, C = qry.shape
+        if ref.shape != (T, WW, C):
+            raise _lib.DfsfmError("fine_match: ref must be [T, W*W, C] matching qry [T, Vq, W*W, C]")
+        dev = ref.device
     tm = _as_u8(track_mask.to(dev))
     mv = None if movable is None else _as_u8(movable.to(dev))
     if tm.shape != (T, Vq) or (mv is not None and mv.shape != (T,)):
@@ -292,11 +308,14 @@ def fine_match(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=N
     std = torch.empty((T, Vq), dtype=torch.float32, device=dev)
     qref = torch.empty((T, 2), dtype=torch.float32, device=dev) if query_pts is not None else None
     rref = torch.empty((T, Vq, 2), dtype=torch.float32, device=dev) if ref_pts is not None else None
-    rc = _lib.lib().dfsfm_fine_match_f32(_ptr(ref), _ptr(qry), _ptr(tm), _ptr(mv), T, Vq, W, left, C,
-                                         _ptr(query_pts), _ptr(scale_q), _ptr(ref_pts), _ptr(scale_r),
-                                         rs_t, rs_n, _ptr(best), _ptr(left_norm), _ptr(coords), _ptr(std),
-                                         _ptr(qref), _ptr(rref), _stream())
-    _lib.check(rc, "dfsfm_fine_match_f32")
+    tail = (_ptr(tm), _ptr(mv), T, Vq, W, left, C, _ptr(query_pts), _ptr(scale_q), _ptr(ref_pts), _ptr(scale_r),
+            rs_t, rs_n, _ptr(best), _ptr(left_norm), _ptr(coords), _ptr(std), _ptr(qref), _ptr(rref), _stream())
+    if split:
+        rc = _lib.lib().dfsfm_fine_match_split(_ptr(ref.hi), _ptr(ref.lo), _ptr(qry.hi), _ptr(qry.lo), *tail)
+        _lib.check(rc, "dfsfm_fine_match_split")
+    else:
+        rc = _lib.lib().dfsfm_fine_match_f32(_ptr(ref), _ptr(qry), *tail)
+        _lib.check(rc, "dfsfm_fine_match_f32")
     out = {"best_index": best, "left_norm": left_norm, "coords": coords, "std": std}
     if qref is not None:
         out["query_refined"] = qref

@@ -245,33 +245,33 @@ class HipMultiviewMatcher(ParamModule):
                 i += nt
                 continue
             qm = tmask[sl, :Vq].contiguous()
-            if mt["enable"]:
-                # split planes [., ., 2C] = [x | norm1(message)], ping-pong; fp32 only for the last layer's output
+            if mt["enable"] and names:
+                # split planes [., ., 2C] = [x | norm1(message)], ping-pong; the last layer writes dense [., ., C] planes
                 rs = [ops.SplitAct.empty_rows((nt, WW), 2 * C, dev) for _ in range(2)]
                 qs = [ops.SplitAct.empty_rows((nt, Vq * WW), 2 * C, dev) for _ in range(2)]
                 ops.split_rows(feats[sl, 0], None, out_split=rs[0].cols(0, C))            # strided [nt, WW, C] blocks: no copy
                 ops.split_rows(feats[sl, 1:cv].reshape(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
-                ref = qry = None
                 for li, (w, name) in enumerate(zip(P["layers"], names)):   # matcher_module/transformer.py:158-172
                     last = li == len(names) - 1
-                    ors = None if last else rs[1].cols(0, C)
-                    oqs = None if last else qs[1].cols(0, C)
-                    if last:
-                        ref = torch.empty((nt, WW, C), dtype=torch.float32, device=dev)
-                        qry = torch.empty((nt, Vq * WW, C), dtype=torch.float32, device=dev)
+                    if last:     # the final features stay split planes (dense [., ., C]): the fine-matching kernel streams them
+                        ref = ors = ops.SplitAct.empty_rows((nt, WW), C, dev)
+                        qry = oqs = ops.SplitAct.empty_rows((nt, Vq * WW), C, dev)
+                    else:
+                        ors, oqs = rs[1].cols(0, C), qs[1].cols(0, C)
                     if name == "self":
-                        encoder_layer_split(w, rs[0], rs[0].cols(0, C), ref, ors, nhead, is_self=True)
-                        encoder_layer_split(w, qs[0], qs[0].cols(0, C), qry, oqs, nhead, qm, qm, WW, WW, is_self=True)
+                        encoder_layer_split(w, rs[0], rs[0].cols(0, C), None, ors, nhead, is_self=True)
+                        encoder_layer_split(w, qs[0], qs[0].cols(0, C), None, oqs, nhead, qm, qm, WW, WW, is_self=True)
                     elif name == "cross":                 # both sides from the PRE-update tensors (:163)
-                        encoder_layer_split(w, qs[0], rs[0].cols(0, C), qry, oqs, nhead, qm, None, WW, 1)
-                        encoder_layer_split(w, rs[0], qs[0].cols(0, C), ref, ors, nhead, None, qm, 1, WW)
+                        encoder_layer_split(w, qs[0], rs[0].cols(0, C), None, oqs, nhead, qm, None, WW, 1)
+                        encoder_layer_split(w, rs[0], qs[0].cols(0, C), None, ors, nhead, None, qm, 1, WW)
                     else:
                         raise NotImplementedError(name)
                     rs.reverse(); qs.reverse()
+                qry = ops.SplitAct(qry.hi.view(nt, Vq, WW, C), qry.lo.view(nt, Vq, WW, C), C)
             else:
                 ref = feats[sl, 0].contiguous()
-                qry = feats[sl, 1:cv].reshape(nt, Vq * WW, C)
-            m = ops.fine_match(ref, qry.view(nt, Vq, WW, C), qm, None if movable is None else movable[sl],
+                qry = feats[sl, 1:cv].reshape(nt, Vq, WW, C)
+            m = ops.fine_match(ref, qry, qm, None if movable is None else movable[sl],
                                W, left, qpts[sl], pt_scales[0, 0, sl], ref_coarse[0, :, sl],
                                pt_scales[0, 1:, sl])
             q_out[sl] = m["query_refined"]

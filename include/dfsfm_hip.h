@@ -160,6 +160,15 @@ int dfsfm_fine_match_f32(const float* ref, const float* qry, const uint8_t* trac
                          const float* ref_pts, const float* scale_r, int64_t rs_t, int64_t rs_n,
                          int32_t* best_index, float* left_norm, float* coords, float* std,
                          float* query_refined, float* ref_refined, void* stream);
+/* The same operation on features that arrive as fp16x2-split planes (value = hi + lo/2048, the form the encoder kernels write:
+ * dfsfm_encoder_apply_f32 out_hi / out_lo): ref_hi / ref_lo [T,W*W,C], qry_hi / qry_lo [T,Vq,W*W,C] fp16, dense.  The planes
+ * are streamed straight into the MFMA fragments; every other argument as above.  C = 64 or 128. */
+int dfsfm_fine_match_split(const void* ref_hi, const void* ref_lo, const void* qry_hi, const void* qry_lo,
+                           const uint8_t* track_mask, const uint8_t* movable, int T, int Vq, int W, int left, int C,
+                           const float* query_pts, const float* scale_q,
+                           const float* ref_pts, const float* scale_r, int64_t rs_t, int64_t rs_n,
+                           int32_t* best_index, float* left_norm, float* coords, float* std,
+                           float* query_refined, float* ref_refined, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2/K10 epilogues  LayerNorm (+ residual) with row strides

@@ -67,6 +67,9 @@ def _roi(feat, boxes, crop_h, crop_w, box_ind=None, out_slot=None, extrapolation
 
 def _fm(ref, qry, track_mask, movable, W, left, query_pts=None, scale_q=None, ref_pts=None, scale_r=None,
         rs_t=0, rs_n=0):
+    from detectorfreesfm_amd.ops import SplitAct
+    if isinstance(ref, SplitAct):            # the split-plane entry point: the planes' exact values
+        ref, qry = ref.float(), qry.float()
     T, Vq = qry.shape[:2]
     mv = torch.ones(T, dtype=torch.bool) if movable is None else movable.bool()
     left_norm, coords, std, best = restate.fine_matching(ref, qry, W, left, track_mask.bool(), mv)

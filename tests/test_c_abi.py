@@ -35,6 +35,10 @@ def test_argument_checks_do_not_launch(built_lib):
     assert L.dfsfm_roi_align_f32(None, 1, 3, 8, 8, None, None, None, 4, 35, 35, 0.0, None, None, None, 0, None) == -1
     assert L.dfsfm_fine_match_f32(None, None, None, None, 4, 2, 15, 7, 128, None, None, None, None, 0, 0, None,
                                   None, None, None, None, None, None) == -1
+    assert L.dfsfm_fine_match_split(None, None, None, None, None, None, 4, 2, 15, 7, 128, None, None, None, None, 0, 0, None,
+                                    None, None, None, None, None, None) == -1
+    assert L.dfsfm_fine_match_split(None, None, None, None, None, None, 0, 2, 15, 7, 128, None, None, None, None, 0, 0, None,
+                                    None, None, None, None, None, None) == 0
     # empty work lists are a no-op success
     assert L.dfsfm_roi_align_f32(None, 1, 3, 8, 8, None, None, None, 0, 35, 35, 0.0, None, None, None, 0, None) == 0
 
