@@ -185,8 +185,14 @@ def kernel_rooflines(dev, batch):
     ref = torch.randn((T, WW, C), generator=g).to(dev)
     qry = torch.randn((T, Vq, WW, C), generator=g).to(dev)
     mask = torch.ones((T, Vq), dtype=torch.bool, device=dev)
+    # the product feeds it the fp16x2-split planes the last transformer layer writes (same bytes per value as fp32)
+    rs, qs = ops.SplitAct.empty_rows((T, WW), C, dev), ops.SplitAct.empty_rows((T, Vq, WW), C, dev)
+    ops.split_rows(ref.view(-1, C), out_split=ops.SplitAct(rs.hi.view(-1, C), rs.lo.view(-1, C), C))
+    ops.split_rows(qry.view(-1, C), out_split=ops.SplitAct(qs.hi.view(-1, C), qs.lo.view(-1, C), C))
+    ms = event_time_ms(lambda: ops.fine_match(rs, qs, mask, None, 15, 7))
+    out.append(_rl("fine_match W=15", "hbm", T * (Vq * WW + 49) * C * 4.0, ms, f"{T} tracks, split-plane input"))
     ms = event_time_ms(lambda: ops.fine_match(ref, qry, mask, None, 15, 7))
-    out.append(_rl("fine_match W=15", "hbm", T * (Vq * WW + 49) * C * 4.0, ms, f"{T} tracks"))
+    out.append(_rl("fine_match W=15 (fp32 input)", "hbm", T * (Vq * WW + 49) * C * 4.0, ms, f"{T} tracks"))
     return out
 
 
@@ -297,7 +303,7 @@ def load_pmc(result):
         rows = json.load(fh)["kernels"]
     groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
               "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",),
-              "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_kernel",),
+              "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_rgb_kernel", "roi_align_kernel"),
               "fine_match": ("fine_match_kernel",),
               "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact", "cm_top", "cm_eval"),
               "coarse_match_f32": ("cm_gemm<",)}
