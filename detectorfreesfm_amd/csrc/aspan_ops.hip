@@ -15,6 +15,7 @@
 // The model runs one pair at a time (aspanformer.py:43), maps are 60x80 tokens and smaller: these are latency-sized
 // kernels, written for exact operation order first (ATen's CPU kernels are the oracle) and coalesced NHWC access.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -138,6 +139,10 @@ struct SpanArgs {
     int kv_swap;
 };
 
+// WIDE: the gathers as 16-byte loads (a lane owns four channels, a wave a sample row) with the 16 taps of four samples in
+// flight per lane -- for launches of many groups (several pairs per pass), where the bytes in flight per CU set the rate; the
+// narrow form (thread = channel, four 4-byte taps per trip) stays for unaligned operands.  Same products and sums per element.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
     extern __shared__ float smem[];
     float* rows = smem;                          // [64][257]
@@ -215,7 +220,31 @@ __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
             rows[m * SP_LD + tid] = r;
         }
     };
-    gather(a.k, a.ldk);
+    auto gather_wide = [&](const float* src, int64_t ld) {
+        constexpr int U = 4;                     // samples per trip: 16 loads of 16 B in flight per lane (8 measured slower)
+        const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll 1
+        for (int m0 = wv * 16; m0 < wv * 16 + 16; m0 += U) {
+            f32x4 t[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[u][c] = *reinterpret_cast<const f32x4*>(src + (int64_t)si[(m0 + u) * 4 + c] * ld + ln * 4);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float r = t[u][0][e] * sw[m * 4 + 0];
+                    r += t[u][1][e] * sw[m * 4 + 1];
+                    r += t[u][2][e] * sw[m * 4 + 2];
+                    r += t[u][3][e] * sw[m * 4 + 3];
+                    rows[m * SP_LD + ln * 4 + e] = r;
+                }
+            }
+        }
+    };
+    if constexpr (WIDE) gather_wide(a.k, a.ldk); else gather(a.k, a.ldk);
     __syncthreads();
     {   // QK[n][h][m]: thread = (n, m), the eight heads in sequence
         const int n = tid >> 6, m = tid & 63;
@@ -245,7 +274,7 @@ __global__ __launch_bounds__(256) void span_attention_kernel(SpanArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) p[i] = e[i] / sum;
     }
-    gather(a.v, a.ldv);      // rows <- sampled values (the keys are no longer needed; att is a different region)
+    if constexpr (WIDE) gather_wide(a.v, a.ldv); else gather(a.v, a.ldv);      // rows <- sampled values (keys no longer needed)
     __syncthreads();
     const int hd = tid >> 5;
     for (int n = 0; n < 4; ++n) {
@@ -432,10 +461,18 @@ extern "C" int dfsfm_span_attention_f32(const float* q, int64_t ldq, int64_t sq,
     a.scale = temp / sqrtf((float)(C / nhead));
     a.sq = sq; a.sk = sk; a.sv = sv; a.sflow = (int64_t)H0 * W0 * 4; a.so = (int64_t)h * w * ldo; a.kv_swap = kv_swap;
     const int smem = (SP_M * SP_LD + 4 * SP_C + 4 * 8 * SP_M + SP_M * 4 + SP_M * 4) * 4;
-    static dfsfm::SmemAttr attr;
-    attr.ensure(reinterpret_cast<const void*>(span_attention_kernel), smem);
-    hipLaunchKernelGGL(span_attention_kernel, dim3((unsigned)((h / 2) * (w / 2)), (unsigned)N), dim3(256), smem,
-                       static_cast<hipStream_t>(stream_), a);
+    static dfsfm::SmemAttr attr, attr_w;
+    static const int force = [] { const char* e = getenv("DFSFM_SPAN_WIDE"); return e ? atoi(e) : -1; }();   // A/B switch
+    const bool aligned = ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
+                         sk % 4 == 0 && sv % 4 == 0;
+    const dim3 grid((unsigned)((h / 2) * (w / 2)), (unsigned)N);
+    if (aligned && force != 0) {
+        attr_w.ensure(reinterpret_cast<const void*>(span_attention_kernel<true>), smem);
+        hipLaunchKernelGGL(span_attention_kernel<true>, grid, dim3(256), smem, static_cast<hipStream_t>(stream_), a);
+    } else {
+        attr.ensure(reinterpret_cast<const void*>(span_attention_kernel<false>), smem);
+        hipLaunchKernelGGL(span_attention_kernel<false>, grid, dim3(256), smem, static_cast<hipStream_t>(stream_), a);
+    }
     return dfsfm::check_launch("dfsfm_span_attention_f32");
 }
 

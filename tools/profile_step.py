@@ -19,6 +19,18 @@ elif which == 'aspan':
     m = HipASpanFormer(cfg); m.load_state_dict(planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0), strict=True)
     m = m.eval().to(dev)
     data = synth.to_device(synth.coarse_pair_batch(1, 480, 640, seed=1000), dev)
+elif which == 'aspan_scene':      # the scene path: cached backbone tokens, PAIRS_PER_PASS pairs per transformer pass
+    from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
+    from detectorfreesfm_amd.params import aspanformer_param_spec, planted_aspanformer_state_dict
+    cfg = aspanformer_coarse_only_config(0.4)
+    mm = HipASpanFormer(cfg); mm.load_state_dict(planted_aspanformer_state_dict(aspanformer_param_spec(cfg), 0), strict=True)
+    mm = mm.eval().to(dev)
+    b = synth.to_device(synth.coarse_pair_batch(8, 480, 640, seed=1000), dev)
+    with torch.no_grad():
+        tk0, hw = mm.image_tokens(b["image0"])
+        tk1, _ = mm.image_tokens(b["image1"])
+    m = lambda d: mm.match_tokens(tk0, tk1, hw, hw, (480, 640))
+    data = {}
 elif which == 'matchformer':
     from detectorfreesfm_amd.matchformer import HipMatchformer, matchformer_coarse_only_config
     from detectorfreesfm_amd.params import matchformer_param_spec, planted_matchformer_state_dict
