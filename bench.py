@@ -541,7 +541,8 @@ def run_alt_matcher(args, dev, rank, world, distributed, out_fd):
         per_call, name = 1, "ASpanFormer, coarse_only, online_resize, thr 0.4, one pair per call"
     m = m.eval().to(dev)
     calls = args.batch // per_call
-    batches = [[synth.to_device(synth.coarse_pair_batch(per_call, 480, 640, seed=1000 + 1000 * rank + 100 * k + c), dev)
+    fh, fw = (int(v) for v in args.alt_frame.lower().split("x"))
+    batches = [[synth.to_device(synth.coarse_pair_batch(per_call, fh, fw, seed=1000 + 1000 * rank + 100 * k + c), dev)
                 for c in range(calls)] for k in range(N_RESIDENT)]
     n_matches = [0]
 
@@ -559,7 +560,7 @@ def run_alt_matcher(args, dev, rank, world, distributed, out_fd):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{name}; 640x480, {args.batch} pairs per GPU per step, {N_RESIDENT} distinct resident batches "
+            "config": {"workload": f"{name}; {fw}x{fh}, {args.batch} pairs per GPU per step, {N_RESIDENT} distinct resident batches "
                                    "rotating, seeded weights on a planted backbone", "parallelism": f"{world} rank(s), weak"},
             "matches_last_step": n_matches[0]})
 
@@ -575,6 +576,7 @@ def main():
     ap.add_argument("--scene-images", type=int, default=300)
     ap.add_argument("--scene-pairs", type=int, default=0, help="truncate the exhaustive pair list (0 = all)")
     ap.add_argument("--scene-matcher", choices=("loftr", "aspanformer"), default="loftr", help="coarse matcher of --workload scene300")
+    ap.add_argument("--alt-frame", default="480x640", help="HxW of the frames of --workload matchformer / aspanformer (832x832: configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
     ap.add_argument("--kernels-only", action="store_true",

@@ -11,6 +11,8 @@ DFSFM_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload scene300 --scene
 timeout 400 python bench.py --workload hires832 --steps 6 --warmup 2 > $out/hires832.json 2> $out/hires832.err; echo "hires rc=$?"
 timeout 300 python bench.py --workload matchformer --steps 6 --warmup 2 > $out/matchformer.json 2> $out/mf.err; echo "mf rc=$?"
 timeout 300 python bench.py --workload aspanformer --steps 6 --warmup 2 > $out/aspanformer.json 2> $out/as.err; echo "as rc=$?"
+timeout 300 python bench.py --workload aspanformer --alt-frame 832x832 --batch 4 --steps 4 --warmup 1 > $out/aspanformer832.json 2> $out/as832.err; echo "as832 rc=$?"
+timeout 300 python bench.py --workload scene300 --scene-matcher aspanformer --scene-images 40 > $out/scene40_aspanformer.json 2> $out/scene40_as.err; echo "scene40 aspan rc=$?"
 cd /tmp
 for w in coarse refine; do
   timeout 600 env PYTHONPATH=$root rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$w -o $w -- python $root/tools/profile_step.py $w 4 > $root/$out/prof_$w.log 2>&1
