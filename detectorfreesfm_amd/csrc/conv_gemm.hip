@@ -271,24 +271,11 @@ struct V2 {
 // consecutive channels of one output row: bias (folded BN), fp32 / split residual, ReLU, then 32-byte fp32
 // stores and/or 16+16-byte split stores.  Must be entered with no LDS-DMA in flight.
 // NT = threads of the workgroup (512: 8 waves; 256: the 4-wave linear kernel); every wave owns 64 rows.
-template <int BN_, int BM_ = BM2, int NT = 512>
-__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * BM_ / (32 * NT)],
-                                            f32x16 (&accx)[2][BN_ * BM_ / (32 * NT)], int64_t m0, int n0, int tid,
-                                            int wr, int wc, int col, int kgrp) {
+// Second half of the epilogue: ROWS rows of a staged fp32 tile (row pitch BN_ + 4 floats), global rows m0 .. m0 + ROWS - 1.
+template <int BN_, int ROWS, int NT>
+__device__ __forceinline__ void sf_epilogue_rows(const ConvArgs& g, const float* tile, int64_t m0, int n0, int tid) {
     constexpr int TILE_LD_ = BN_ + 4;                        // fp32 staging-tile row (floats)
-    constexpr int NJ = BN_ * BM_ / (32 * NT);                // 32-wide column blocks per wave (waves: BM_/64 x NT/BM_)
-    constexpr int WCOLS = NJ * 32;                            // columns per wave
-    __syncthreads();
-    float* tile = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * TILE_LD_ + wc * WCOLS + j * 32 + col] =
-                    accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
-    __syncthreads();
+    constexpr int BM_ = ROWS;
     // Every thread owns one 8-channel chunk (fixed: NT % CH == 0) of IT rows.  All memory operations of the IT
     // rows are issued before anything waits on them: tile reads, then the residual loads, then arithmetic and
     // stores -- the epilogue is latency-bound otherwise (one dependent global load per row).
@@ -417,6 +404,27 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
             *reinterpret_cast<half8*>(g.outl + m * g.ldo_s + n) = l;
         }
     }
+}
+
+template <int BN_, int BM_ = BM2, int NT = 512>
+__device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * BM_ / (32 * NT)],
+                                            f32x16 (&accx)[2][BN_ * BM_ / (32 * NT)], int64_t m0, int n0, int tid,
+                                            int wr, int wc, int col, int kgrp) {
+    constexpr int TILE_LD_ = BN_ + 4;                        // fp32 staging-tile row (floats)
+    constexpr int NJ = BN_ * BM_ / (32 * NT);                // 32-wide column blocks per wave (waves: BM_/64 x NT/BM_)
+    constexpr int WCOLS = NJ * 32;                            // columns per wave
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(wr * 64 + i * 32 + mfma32_row(r, kgrp)) * TILE_LD_ + wc * WCOLS + j * 32 + col] =
+                    accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
+    __syncthreads();
+    sf_epilogue_rows<BN_, BM_, NT>(g, tile, m0, n0, tid);
 }
 
 template <int BN_>
@@ -647,6 +655,43 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
     f32x16 accm[2][NJ], accx[2][NJ];
     sf_same_mainloop<BN_, KW, WM>(g, smem, accm, accx, m0, n0);
     sf_epilogue<BN_, S_::BM>(g, smem, accm, accx, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane & 31, lane >> 5);
+}
+
+// LayerNorm-fused 256-channel linear on 160-row tiles (ln160_mainloop, sf_gemm.h).  Epilogue: the 160 x 256 fp32 tile does not
+// fit the LDS at once, so it is staged and finished in three passes of 64, 64 and 32 rows with the same per-row code as every
+// other kernel (sf_epilogue_rows): a row's arithmetic does not depend on the pass it is in.
+__global__ __launch_bounds__(512, 1) void linear_ln160_kernel(ConvArgs g) {
+    using T = V160;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kgrp = lane >> 5;
+    const unsigned tile_id = xcd_band_tile(blockIdx.x, gridDim.x >> 3);
+    if (tile_id >= g.ntiles) return;
+    const int64_t m0 = (int64_t)tile_id * T::BM;
+    f32x16 accm[5], accx[5];
+    ln160_mainloop(g, smem, accm, accx, m0);
+    constexpr int LD = T::BN + 4;
+    float* tile = reinterpret_cast<float*>(smem);
+    auto stage = [&](int i, int r0) __attribute__((always_inline)) {        // accumulator block i -> tile rows r0 ..
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tile[(r0 + mfma32_row(r, kgrp)) * LD + wave * 32 + col] = accm[i][r] + accx[i][r] * (1.f / 2048.f);
+    };
+    __syncthreads();
+    stage(0, 0);
+    stage(1, 32);
+    __syncthreads();
+    sf_epilogue_rows<T::BN, 64, T::NT>(g, tile, m0, 0, tid);
+    __syncthreads();
+    stage(2, 0);
+    stage(3, 32);
+    __syncthreads();
+    sf_epilogue_rows<T::BN, 64, T::NT>(g, tile, m0 + 64, 0, tid);
+    __syncthreads();
+    stage(4, 0);
+    __syncthreads();
+    sf_epilogue_rows<T::BN, 32, T::NT>(g, tile, m0 + 128, 0, tid);
 }
 
 // =================================================================================================
@@ -940,6 +985,31 @@ void launch_same(const ConvArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL((conv_gemm_sf_same_kernel<BN_, KW, WM>), grid, dim3(512), S_::SMEM, stream, a);
 }
 
+void launch_ln160(const ConvArgs& g, hipStream_t stream) {
+    using T = V160;
+    static dfsfm::SmemAttr smem_attr;
+    smem_attr.ensure(reinterpret_cast<const void*>(&linear_ln160_kernel), T::SMEM);
+    ConvArgs a = g;
+    a.ntiles = (unsigned)((g.M + T::BM - 1) / T::BM);
+    const dim3 grid((a.ntiles + 7) / 8 * 8);                 // 8 XCD bands (xcd_band_tile); surplus WGs exit
+    hipLaunchKernelGGL(linear_ln160_kernel, grid, dim3(T::NT), T::SMEM, stream, a);
+}
+
+// Tile height of the LayerNorm-fused 256-channel linear: 160 rows when that saves rounds on this device's CUs (a 160-row tile
+// costs 1.25 x a 128-row one); DFSFM_LN160 = 0 / 1 forces one of the two (A/B switch).
+bool use_ln160(int64_t M) {
+    const char* e = getenv("DFSFM_LN160");                    // read per call: the tests compare the two schedules in one process
+    if (e) return atoi(e) != 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    const int64_t r128 = ((M + 127) / 128 + cus - 1) / cus, r160 = ((M + 159) / 160 + cus - 1) / cus;
+    return 5 * r160 < 4 * r128;
+}
+
 template <int NA_>
 void launch_lin(const ConvArgs& g, hipStream_t stream) {
     using T = LIN<NA_>;
@@ -1029,7 +1099,11 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             else         { if (Cout <= 64) launch_same<64, 5>(g, stream); else launch_same<128, 5>(g, stream); }
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(same)");
         }
-        if (ln_gamma && Cout == 256) {     // a 256-channel row in ONE workgroup: the 128 x 256 tile (waves 2 x 4)
+        if (ln_gamma && Cout == 256) {     // a 256-channel row in ONE workgroup: the 128 x 256 tile (waves 2 x 4), or 160 x 256
+            if (use_ln160(g.M)) {
+                launch_ln160(g, stream);
+                return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1, 160x256 tile)");
+            }
             launch_same<256, 1, 2>(g, stream);
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1, 128x256 tile)");
         }

@@ -564,4 +564,143 @@ __device__ __forceinline__ void sf2_mainloop(const ConvArgs& g, char* smem, f32x
     wait_vmcnt<0>();                                          // the zero-fill tail pieces, before LDS is reused
 }
 
+// =================================================================================================
+// Third schedule, for the LayerNorm-fused 256-channel linears of the coarse transformer: a 160 x 256 tile, 512 threads,
+// wave w owns the 32 output columns [32w, 32w + 32) of all 160 rows (5 x 1 MFMA blocks, 160 accumulator registers).
+// Why 160 rows: a cross-attention layer works on 8 x 4800 = 38 400 rows -- 300 tiles of 128 rows on 256 CUs are two rounds for
+// 1.17 rounds of work, 240 tiles of 160 rows are ONE round (a self layer: 480 tiles = two rounds instead of three).  Same slab
+// order and the same per-accumulator MFMA order as the other schedules: identical results.
+// One barrier per slab like sf2_mainloop: [wait own pieces of slab t] [barrier] [DMA B(t+1), A(t+2)] [2 x (12 reads, 15 MFMAs)].
+// Per slab a wave issues 4 B pieces (weight row groups w, w + 8; hi, lo) and 3 A pieces (row group w hi, lo; waves 0-3 one
+// plane of row groups 8, 9; waves 4-7 an out-of-range piece into a 1 KB sink, so that the counted wait is uniform).
+// =================================================================================================
+struct V160 {
+    static constexpr int BM = 160, BN = 256, NT = 512;
+    static constexpr int AG = 10;                            // 16-row groups per A stage
+    static constexpr int APW = 3, BPW = 4;
+    static constexpr int A_PLANE = AG * 1024;
+    static constexpr int A_STAGE = 2 * A_PLANE;
+    static constexpr int NA = 3;
+    static constexpr int B_PLANE = BN * 64;
+    static constexpr int B_STAGE = 2 * B_PLANE;
+    static constexpr int NB = 2;
+    static constexpr int OFF_B = NA * A_STAGE;
+    static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;
+    static constexpr int RING = OFF_DUMMY + 1024;
+    static constexpr int EPI_ROWS = 64;                      // rows per epilogue pass (64, 64, 32)
+    static constexpr int TILE_BYTES = EPI_ROWS * (BN + 4) * 4;
+    static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
+__device__ __forceinline__ void ln160_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[5], f32x16 (&accx)[5], int64_t m0) {
+    using T = V160;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kgrp = lane >> 5;
+    const int nS = g.Kpad / BK;                               // slabs (1x1: one 32-channel chunk each)
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.wh, 0, g.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
+
+    const int lrow = lane >> 2;
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    int64_t abase[2];
+    bool aok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int grp = q == 0 ? wave : 8 + (wave >> 1);
+        const int64_t pix = m0 + grp * 16 + lrow;
+        aok[q] = pix < g.M && (q == 0 || wave < 4);
+        const int64_t pp = aok[q] ? pix : 0;
+        const int ox = (int)(pp % g.W);
+        const int64_t t = pp / g.W;
+        abase[q] = (t / g.H) * g.sxn + (t % g.H) * g.sxh + (int64_t)ox * g.ldx + lslot * 8;
+    }
+    unsigned offA[2];
+    auto addrA = [&](int Sn) __attribute__((always_inline)) {
+        const bool in = Sn < nS && Sn * BK + lslot * 8 < g.Cin;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) offA[q] = (aok[q] & in) ? (unsigned)((abase[q] + Sn * BK) * 2) : g.xbytes;
+    };
+    const unsigned bbase = (unsigned)(((int64_t)lrow * g.Kpad + lslot * 8) * 2);
+    unsigned offB[2];
+    auto addrB = [&](int Sn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            offB[q] = Sn < nS ? bbase + (unsigned)(Sn * BK * 2) + (unsigned)(wave + 8 * q) * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
+    };
+    auto dmaA = [&](int stage) __attribute__((always_inline)) {
+        char* d = smem + stage * T::A_STAGE + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)d, 16, offA[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(d + T::A_PLANE), 16, offA[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((wave & 1) ? rxl : rxh,
+                                                 (lds_void*)(wave < 4 ? smem + stage * T::A_STAGE + (wave & 1) * T::A_PLANE +
+                                                                            (8 + (wave >> 1)) * 1024
+                                                                      : smem + T::OFF_DUMMY),
+                                                 16, offA[1], 0, 0, 0);
+    };
+    auto dmaB = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            char* d = smem + T::OFF_B + stage * T::B_STAGE + (wave + 8 * q) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_void*)d, 16, offB[q], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d + T::B_PLANE), 16, offB[q], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        accm[i] = f32x16{0};
+        accx[i] = f32x16{0};
+    }
+    // prologue: B(0), then A(0) .. A(NA-2)
+    addrB(0);
+    dmaB(0);
+#pragma unroll
+    for (int Sn = 0; Sn < T::NA - 1; ++Sn) {
+        addrA(Sn);
+        dmaA(Sn);
+    }
+    int ast = 0, bst = 0;
+    for (int S = 0; S < nS; ++S) {
+        wait_vmcnt<(T::NA - 2) * T::APW>();                   // B(S), A(S) landed; A(S+1) may still fly
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                         // slab S published; every wave is done with slab S - 1
+        __builtin_amdgcn_sched_barrier(0);
+        addrB(S + 1);
+        dmaB(bst ^ 1);
+        addrA(S + T::NA - 1);
+        dmaA(ast == 0 ? T::NA - 1 : ast - 1);                 // the stage of A(S-1)
+        const char* sa = smem + ast * T::A_STAGE;
+        const char* sb = smem + T::OFF_B + bst * T::B_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 ah[5], al[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int off = tile_off(i * 32 + col, ks * 2 + kgrp);
+                ah[i] = *reinterpret_cast<const half8*>(sa + off);
+                al[i] = *reinterpret_cast<const half8*>(sa + T::A_PLANE + off);
+            }
+            const int offb = tile_off(wave * 32 + col, ks * 2 + kgrp);
+            const half8 bh = *reinterpret_cast<const half8*>(sb + offb);
+            const half8 bl = *reinterpret_cast<const half8*>(sb + T::B_PLANE + offb);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, accm[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, accx[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, accx[i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        bst ^= 1;
+        ast = ast == T::NA - 1 ? 0 : ast + 1;
+    }
+    wait_vmcnt<0>();                                          // the zero-fill tail pieces, before LDS is reused
+}
+
 }  // namespace dfsfm_sf
