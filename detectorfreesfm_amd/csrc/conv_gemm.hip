@@ -658,7 +658,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
 }
 
 // LayerNorm-fused 256-channel linear on 160-row tiles (ln160_mainloop, sf_gemm.h).  Epilogue: the 160 x 256 fp32 tile does not
-// fit the LDS at once, so it is staged and finished in three passes of 64, 64 and 32 rows with the same per-row code as every
+// fit the LDS at once, so it is staged and finished in two passes of 96 and 64 rows with the same per-row code as every
 // other kernel (sf_epilogue_rows): a row's arithmetic does not depend on the pass it is in.
 __global__ __launch_bounds__(512, 1) void linear_ln160_kernel(ConvArgs g) {
     using T = V160;
@@ -681,17 +681,14 @@ __global__ __launch_bounds__(512, 1) void linear_ln160_kernel(ConvArgs g) {
     __syncthreads();
     stage(0, 0);
     stage(1, 32);
+    stage(2, 64);
     __syncthreads();
-    sf_epilogue_rows<T::BN, 64, T::NT>(g, tile, m0, 0, tid);
+    sf_epilogue_rows<T::BN, 96, T::NT>(g, tile, m0, 0, tid);
     __syncthreads();
-    stage(2, 0);
-    stage(3, 32);
+    stage(3, 0);
+    stage(4, 32);
     __syncthreads();
-    sf_epilogue_rows<T::BN, 64, T::NT>(g, tile, m0 + 64, 0, tid);
-    __syncthreads();
-    stage(4, 0);
-    __syncthreads();
-    sf_epilogue_rows<T::BN, 32, T::NT>(g, tile, m0 + 128, 0, tid);
+    sf_epilogue_rows<T::BN, 64, T::NT>(g, tile, m0 + 96, 0, tid);
 }
 
 // =================================================================================================

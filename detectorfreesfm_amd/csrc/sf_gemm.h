@@ -587,7 +587,7 @@ struct V160 {
     static constexpr int OFF_B = NA * A_STAGE;
     static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;
     static constexpr int RING = OFF_DUMMY + 1024;
-    static constexpr int EPI_ROWS = 64;                      // rows per epilogue pass (64, 64, 32)
+    static constexpr int EPI_ROWS = 96;                      // rows per epilogue pass (96, 64)
     static constexpr int TILE_BYTES = EPI_ROWS * (BN + 4) * 4;
     static constexpr int SMEM = RING > TILE_BYTES ? RING : TILE_BYTES;
     static_assert(SMEM <= 160 * 1024, "LDS");
