@@ -48,6 +48,7 @@ constexpr int NSTG = 4;                  // ring depth (slabs)
 constexpr int RING = NSTG * SLAB;
 constexpr int STG = 16384;               // per-wave staging tile: 32 tokens x 128 channels, hi + lo planes
 constexpr int SMEM_BYTES = RING + 4 * STG;
+constexpr int SMEM_APPLY = SMEM_BYTES + 4 * EC * 4 + 4 * 1024;   // + the LayerNorms' gamma / beta (2 KB) + Ksum of a tile's two sequences per wave
 constexpr int NSLAB_APPLY = 32;          // q 4, merge 4, 4 x (mlp.0 chunk 4 + mlp.2 chunk 2)
 constexpr int NSLAB_KV = 8;              // 4 head pairs x 2
 constexpr int KVIMG = 16 * 1024 + 512;   // bytes per sequence: 16 KV^T fragments + Ksum[128]
@@ -184,6 +185,16 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, half = lane >> 5;
     char* stg = smem + RING + wave * STG;
+    // LayerNorm parameters in LDS: as global loads inside the tile loop every use drained the VM counter -- slab DMA included
+    // (the compiler waits vmcnt(0) for an ordinary load while LDS-DMA is in flight) -- and exposed an L2 round trip twice per tile
+    float* s_ln = reinterpret_cast<float*>(smem + SMEM_BYTES);               // [g1 | b1 | g2 | b2][EC]
+    if (tid < EC) {
+        s_ln[tid] = g.g1[tid];
+        s_ln[EC + tid] = g.b1[tid];
+        s_ln[2 * EC + tid] = g.g2[tid];
+        s_ln[3 * EC + tid] = g.b2[tid];
+    }
+    __syncthreads();
 
     SlabRing ring;
     ring.ring = smem;
@@ -212,9 +223,26 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
         g.dbg[((int64_t)tile * 16 + (k)) * 2 + 1] = (float)((t_ >> 24) & 0xFFFFFF);     \
     }
     // x rows of tile `t` -> this wave's staging (row-major rows of 256 B per plane, 16-byte chunks XOR-swizzled on the source side)
+    // The lane's row / chunk split for the staging traffic, recomputed from a lane id the compiler cannot hoist: as loop
+    // invariants these 14 values were spilled, and every reload (scratch_load + s_waitcnt vmcnt(0)) sat between two DMA
+    // requests of load_x -- each request waited for the previous one's data, 8 HBM latencies per tile (20 % of the tile time).
+    auto fresh_lane = []() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    // Ksum[128] of the (at most two) sequences of a wave's 32 rows travels with the x rows: one DMA piece, lanes 0-31 the first
+    // sequence, lanes 32-63 the next one -- read from the sequence image inside the tile loop it was an exposed L2 round trip
+    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void*)g.kvimg, 0, (unsigned)((int64_t)g.N * KVIMG), 0x00020000);
+    char* s_ks = smem + SMEM_BYTES + 4 * EC * 4 + wave * 1024;
     auto load_x = [&](int t) __attribute__((always_inline)) {
         const int64_t r0 = ((int64_t)t * 4 + wave) * 32;
-        const int trow = lane >> 4, p = lane & 15;
+        const int fl = fresh_lane();
+        const int trow = fl >> 4, p = fl & 15;
+        {
+            const int seq = min((int)(r0 / g.L) + (fl >> 5), g.N - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rkv, (lds_void*)s_ks, 16, (unsigned)((int64_t)seq * KVIMG + 16384 + (fl & 31) * 16), 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int tt = 4 * i + trow;
@@ -300,7 +328,7 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                 slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, th + 2, tl + 2);
             }
             ENC_STAMP(2)
-            const float* ks = reinterpret_cast<const float*>(g.kvimg + (int64_t)n_tok * KVIMG + 16384);
+            const float* ks = reinterpret_cast<const float*>(s_ks + (row >= bound ? 512 : 0));
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) {
                 float v[16];
@@ -381,8 +409,8 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                 float v[16];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.g1 + 32 * b + 8 * q4 + 4 * half);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(g.b1 + 32 * b + 8 * q4 + 4 * half);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ln + 32 * b + 8 * q4 + 4 * half);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ln + EC + 32 * b + 8 * q4 + 4 * half);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * q4 + e] = (ENC_V3(b, 4 * q4 + e) - mean) * rstd * gm[e] + bt[e];
                 }
@@ -435,8 +463,8 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                 }
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.g2 + 32 * b + 8 * q4 + 4 * half);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(g.b2 + 32 * b + 8 * q4 + 4 * half);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ln + 2 * EC + 32 * b + 8 * q4 + 4 * half);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ln + 3 * EC + 32 * b + 8 * q4 + 4 * half);
                     // residual x: this lane's 4 channels of chunk 4b + q4 sit where its output goes (read, then overwritten below)
                     const half4 xrh = *reinterpret_cast<const half4*>(stg + stg_off(tok, 4 * b + q4) + 8 * half);
                     const half4 xrl = *reinterpret_cast<const half4*>(stg + 8192 + stg_off(tok, 4 * b + q4) + 8 * half);
@@ -471,13 +499,14 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                 // way again) is the exact value of the planes, hi + lo / 2048.  The tile is read out of the staging first,
                 // then the NEXT tile's x rows are requested into it, then the stores are issued: the load's latency runs
                 // under the store issue instead of after it.
-                const int trow = lane >> 4, p = lane & 15;
+                const int fl = fresh_lane();
+                const int trow = fl >> 4, p = fl & 15;
                 uint4 dh[8], dl[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 8; ++i) {       // lane p takes LOGICAL chunk p (physical p ^ (t & 15)): its store is then lane-linear
                     const int t = 4 * i + trow;
-                    dh[i] = *reinterpret_cast<const uint4*>(stg + t * 256 + p * 16);
-                    dl[i] = *reinterpret_cast<const uint4*>(stg + 8192 + t * 256 + p * 16);
+                    dh[i] = *reinterpret_cast<const uint4*>(stg + t * 256 + ((p ^ (t & 15)) << 4));
+                    dl[i] = *reinterpret_cast<const uint4*>(stg + 8192 + t * 256 + ((p ^ (t & 15)) << 4));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (tile + (int)gridDim.x < g.ntiles) load_x(tile + (int)gridDim.x);
@@ -486,7 +515,7 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                     const int t = 4 * i + trow;
                     const int64_t rr = row0 + t;
                     if (rr < g.M) {
-                        const int cc = (p ^ (t & 15)) << 3;
+                        const int cc = p << 3;
                         if (g.oh) {
                             *reinterpret_cast<uint4*>(g.oh + rr * g.ldo + cc) = dh[i];
                             *reinterpret_cast<uint4*>(g.ol + rr * g.ldo + cc) = dl[i];
@@ -757,7 +786,8 @@ extern "C" int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = g.ntiles < cus ? g.ntiles : cus;   // persistent: one workgroup per CU walks the tiles
-    attr_apply.ensure(reinterpret_cast<const void*>(&enc_apply_kernel), SMEM_BYTES);
-    hipLaunchKernelGGL(enc_apply_kernel, dim3((unsigned)grid), dim3(256), SMEM_BYTES, static_cast<hipStream_t>(stream_), g);
+    if ((int64_t)N * KVIMG >= (int64_t)0xFFFFFFF0) return DFSFM_E_UNSUPPORTED;      // 32-bit buffer offsets into the sequence images
+    attr_apply.ensure(reinterpret_cast<const void*>(&enc_apply_kernel), SMEM_APPLY);
+    hipLaunchKernelGGL(enc_apply_kernel, dim3((unsigned)grid), dim3(256), SMEM_APPLY, static_cast<hipStream_t>(stream_), g);
     return dfsfm::check_launch("dfsfm_encoder_apply_f32");
 }
