@@ -48,6 +48,8 @@ constexpr int NSTG = 4;                  // ring depth (slabs)
 constexpr int RING = NSTG * SLAB;
 constexpr int STG = 16384;               // per-wave staging tile: 32 tokens x 128 channels, hi + lo planes
 constexpr int SMEM_BYTES = RING + 4 * STG;
+constexpr int KV_MASK_MAX = 4096;         // mask entries of a sequence kept in LDS by enc_kv_kernel
+constexpr int SMEM_KV = SMEM_BYTES + KV_MASK_MAX;
 constexpr int SMEM_APPLY = SMEM_BYTES + 4 * EC * 4 + 4 * 1024;   // + the LayerNorms' gamma / beta (2 KB) + Ksum of a tile's two sequences per wave
 constexpr int NSLAB_APPLY = 32;          // q 4, merge 4, 4 x (mlp.0 chunk 4 + mlp.2 chunk 2)
 constexpr int NSLAB_KV = 8;              // 4 head pairs x 2
@@ -581,6 +583,14 @@ __global__ __launch_bounds__(256) void enc_kv_kernel(KvArgs g) {
     const float Sf = (float)g.S;
     const int nblocks = (g.S + 31) / 32;
     const int niter = (nblocks + 3) / 4;            // every wave runs the same number of rounds (shared weight stream)
+    // the sequence's mask entries once into LDS: as byte loads inside the block loop each of a lane's 16 entries was its own
+    // global load + s_waitcnt vmcnt(0) -- sixteen serial L2 round trips per block, each also draining the x block's DMA
+    uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + SMEM_BYTES);
+    const bool lds_mask = g.kvmask && g.km_per_seq <= KV_MASK_MAX;
+    if (lds_mask) {
+        for (int i = tid; i < g.km_per_seq; i += 256) s_mask[i] = g.kvmask[(int64_t)n * g.km_per_seq + i];
+        __syncthreads();
+    }
 
     f32x16 kvm[NBLK], kvx[NBLK];                    // KV of head pair p: rows = k channel, cols = v channel (lane)
     float ksum[NBLK];
@@ -610,7 +620,8 @@ __global__ __launch_bounds__(256) void enc_kv_kernel(KvArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int s = s0 + dch(r, half);
             float m = s < g.S ? 1.f : 0.f;
-            if (g.kvmask && s < g.S) m = (float)g.kvmask[(int64_t)n * g.km_per_seq + s / g.kv_group];
+            if (lds_mask) { if (s < g.S) m = (float)s_mask[s / g.kv_group]; }
+            else if (g.kvmask && s < g.S) m = (float)g.kvmask[(int64_t)n * g.km_per_seq + s / g.kv_group];
             tm[r] = m;
         }
         wait_vmcnt<0>();
@@ -735,8 +746,8 @@ extern "C" int dfsfm_encoder_kv_f32(const void* src_hi, const void* src_lo, int6
     g.kvimg = static_cast<char*>(kv_image);
     g.S = S;
     g.N = N;
-    attr_kv.ensure(reinterpret_cast<const void*>(&enc_kv_kernel), SMEM_BYTES);
-    hipLaunchKernelGGL(enc_kv_kernel, dim3((unsigned)N), dim3(256), SMEM_BYTES, static_cast<hipStream_t>(stream_), g);
+    attr_kv.ensure(reinterpret_cast<const void*>(&enc_kv_kernel), SMEM_KV);
+    hipLaunchKernelGGL(enc_kv_kernel, dim3((unsigned)N), dim3(256), SMEM_KV, static_cast<hipStream_t>(stream_), g);
     return dfsfm::check_launch("dfsfm_encoder_kv_f32");
 }
 

@@ -56,6 +56,8 @@ for name, fused in (("fused", w.fused), ("five-GEMM", None)):
     print(f"{name:10s} self layer {ts:.3f} ms, cross layer {tc:.3f} ms  ({rows} rows; 4 layers: {2 * (ts + tc):.2f} ms)")
 f = w.fused
 tk = ev(lambda: ops.encoder_kv(qs.cols(0, C), f))
+tkm = ev(lambda: ops.encoder_kv(qs.cols(0, C), f, qm, WW))
+print(f"enc_kv with the per-view source mask: {tkm:.3f} ms")
 st = ops.encoder_kv(qs.cols(0, C), f)
 ta = ev(lambda: ops.encoder_apply(qs.cols(0, C), f, st, Vq * WW, out_split=qo))
 n = T * Vq * WW
