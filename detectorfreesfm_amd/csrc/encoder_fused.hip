@@ -105,6 +105,21 @@ struct SlabRing {
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + i * 1024), 16, src + i * 1024, 0, 0, 0);
     }
+    __device__ __forceinline__ void issue_piece(unsigned g, int i) const {
+        const unsigned src = (g % (unsigned)nslab) * SLAB + lane_off;
+        char* dst = ring + (g % NSTG) * SLAB + wave * 4096;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + i * 1024), 16, src + i * 1024, 0, 0, 0);
+    }
+    // acquire without the refill: the caller spreads the four pieces of slab next + NSTG - 1 between its MFMA groups
+    // (issue_piece) and then calls advance()
+    __device__ __forceinline__ const char* acquire_wait() {
+        wait_vmcnt<(NSTG - 2) * 4>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        return ring + (next % NSTG) * SLAB;
+    }
+    __device__ __forceinline__ void advance() { ++next; }
     __device__ __forceinline__ void prologue() {
 #pragma unroll
         for (int g = 0; g < NSTG - 1; ++g) issue(g);
@@ -148,6 +163,44 @@ __device__ __forceinline__ void slab_mma(const char* slab, int lane, f32x16 (&am
 #pragma unroll
         for (int b = 0; b < NB; ++b) ay[b] = mfma(wh[b], bl[ks], ay[b]);
     }
+}
+
+// The same with the ring refill inside: right after the barrier the four DMA requests of the refill (address arithmetic, M0,
+// ~100 issue cycles each with one wave per SIMD) stood in front of the slab's first MFMA; here each one follows a group of MFMAs
+// that is already executing.  sched_barriers pin the places (the compiler hoists the requests to the top otherwise).
+template <int NB, int KPS>
+__device__ __forceinline__ void slab_mma(SlabRing& ring, int lane, f32x16 (&am)[NB], f32x16 (&ax)[NB], f32x16 (&ay)[NB],
+                                         const half8* bh, const half8* bl) {
+    static_assert(NB * KPS == 8, "a slab holds 16 fragments");
+    const char* slab = ring.acquire_wait();
+    const unsigned gn = ring.next + NSTG - 1;
+    int piece = 0;
+#pragma unroll
+    for (int ks = 0; ks < KPS; ++ks) {
+        half8 wh[NB], wl[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 0) * 1024 + lane * 16);
+            wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 1) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) am[b] = mfma(wh[b], bh[ks], am[b]);
+        if (KPS == 2 || (ks & 1) == 0) {           // KPS = 2: after both first groups of a k-step; KPS = 4: once per k-step
+            __builtin_amdgcn_sched_barrier(0);
+            ring.issue_piece(gn, piece++);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ax[b] = mfma(wl[b], bh[ks], ax[b]);
+        if (KPS == 2 || (ks & 1) == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            ring.issue_piece(gn, piece++);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ay[b] = mfma(wh[b], bl[ks], ay[b]);
+    }
+    ring.advance();
 }
 
 struct ApplyArgs {
@@ -326,8 +379,8 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 half8 th[4], tl[4];
                 xfrags(4 * s2, th, tl);
-                slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, th, tl);
-                slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, th + 2, tl + 2);
+                slab_mma<NBLK, 2>(ring, lane, am, ax, ax, th, tl);
+                slab_mma<NBLK, 2>(ring, lane, am, ax, ax, th + 2, tl + 2);
             }
             ENC_STAMP(2)
             const float* ks = reinterpret_cast<const float*>(s_ks + (row >= bound ? 512 : 0));
@@ -402,7 +455,7 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) am[b] = ax[b] = f32x16{0};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) slab_mma<NBLK, 2>(ring.acquire(), lane, am, ax, ax, ah + 2 * s, al + 2 * s);
+            for (int s = 0; s < 4; ++s) slab_mma<NBLK, 2>(ring, lane, am, ax, ax, ah + 2 * s, al + 2 * s);
             ENC_STAMP(5)
 #define ENC_V3(b, r) (am[b][r] + ax[b][r] * (1.f / 2048.f))
             ENC_ROWSTATS(ENC_V3, g.eps1, mean, rstd)
@@ -435,12 +488,12 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                 {
                     half8 th[4], tl[4];
                     xfrags(0, th, tl);
-                    slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, th, tl);          // k-steps 0-3: x channels 0-63
+                    slab_mma<2, 4>(ring, lane, hm, hx, hy, th, tl);          // k-steps 0-3: x channels 0-63
                     xfrags(4, th, tl);
-                    slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, th, tl);          // 4-7
+                    slab_mma<2, 4>(ring, lane, hm, hx, hy, th, tl);          // 4-7
                 }
-                slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, ah, al);              // 8-11: norm1(merge) channels 0-63
-                slab_mma<2, 4>(ring.acquire(), lane, hm, hx, hy, ah + 4, al + 4);      // 12-15
+                slab_mma<2, 4>(ring, lane, hm, hx, hy, ah, al);              // 8-11: norm1(merge) channels 0-63
+                slab_mma<2, 4>(ring, lane, hm, hx, hy, ah + 4, al + 4);      // 12-15
                 half8 hh[4], hl[4];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
@@ -449,8 +502,8 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                     for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hm[b][r] + (hx[b][r] + hy[b][r]) * (1.f / 2048.f), 0.f);
                     to_frags(hv, hh[2 * b], hl[2 * b], hh[2 * b + 1], hl[2 * b + 1]);
                 }
-                slab_mma<NBLK, 2>(ring.acquire(), lane, om, ox, ox, hh, hl);
-                slab_mma<NBLK, 2>(ring.acquire(), lane, om, ox, ox, hh + 2, hl + 2);
+                slab_mma<NBLK, 2>(ring, lane, om, ox, ox, hh, hl);
+                slab_mma<NBLK, 2>(ring, lane, om, ox, ox, hh + 2, hl + 2);
             }
             ENC_STAMP(7)
 #define ENC_V5(b, r) (om[b][r] + ox[b][r] * (1.f / 2048.f))
