@@ -633,23 +633,30 @@ __device__ __forceinline__ void ln160_mainloop(const ConvArgs& g, char* smem, f3
         for (int q = 0; q < 2; ++q)
             offB[q] = Sn < nS ? bbase + (unsigned)(Sn * BK * 2) + (unsigned)(wave + 8 * q) * 16u * (unsigned)g.Kpad * 2u : g.wbytes;
     };
-    auto dmaA = [&](int stage) __attribute__((always_inline)) {
+    auto dmaA_own = [&](int stage) __attribute__((always_inline)) {         // row group `wave`, both planes
         char* d = smem + stage * T::A_STAGE + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)d, 16, offA[0], 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(d + T::A_PLANE), 16, offA[0], 0, 0, 0);
+    };
+    auto dmaA_extra = [&](int stage) __attribute__((always_inline)) {       // waves 0-3: one plane of row groups 8, 9; else the sink
         __builtin_amdgcn_raw_ptr_buffer_load_lds((wave & 1) ? rxl : rxh,
                                                  (lds_void*)(wave < 4 ? smem + stage * T::A_STAGE + (wave & 1) * T::A_PLANE +
                                                                             (8 + (wave >> 1)) * 1024
                                                                       : smem + T::OFF_DUMMY),
                                                  16, offA[1], 0, 0, 0);
     };
+    auto dmaA = [&](int stage) __attribute__((always_inline)) {
+        dmaA_own(stage);
+        dmaA_extra(stage);
+    };
+    auto dmaB_q = [&](int stage, int q) __attribute__((always_inline)) {
+        char* d = smem + T::OFF_B + stage * T::B_STAGE + (wave + 8 * q) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_void*)d, 16, offB[q], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d + T::B_PLANE), 16, offB[q], 0, 0, 0);
+    };
     auto dmaB = [&](int stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            char* d = smem + T::OFF_B + stage * T::B_STAGE + (wave + 8 * q) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_void*)d, 16, offB[q], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d + T::B_PLANE), 16, offB[q], 0, 0, 0);
-        }
+        dmaB_q(stage, 0);
+        dmaB_q(stage, 1);
     };
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -670,10 +677,11 @@ __device__ __forceinline__ void ln160_mainloop(const ConvArgs& g, char* smem, f3
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                         // slab S published; every wave is done with slab S - 1
         __builtin_amdgcn_sched_barrier(0);
+        // the refill -- B(S+1) then A(S+2): 4 + 3 requests, in this order for the counted wait -- is spread between the slab's
+        // MFMA groups instead of standing in front of its first MFMA (positions pinned by sched_barrier)
         addrB(S + 1);
-        dmaB(bst ^ 1);
         addrA(S + T::NA - 1);
-        dmaA(ast == 0 ? T::NA - 1 : ast - 1);                 // the stage of A(S-1)
+        const int adm = ast == 0 ? T::NA - 1 : ast - 1;       // the stage of A(S-1)
         const char* sa = smem + ast * T::A_STAGE;
         const char* sb = smem + T::OFF_B + bst * T::B_STAGE;
 #pragma unroll
@@ -691,8 +699,14 @@ __device__ __forceinline__ void ln160_mainloop(const ConvArgs& g, char* smem, f3
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 5; ++i) accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, accm[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) dmaB_q(bst ^ 1, 0); else dmaA_own(adm);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 5; ++i) accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, accx[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) dmaB_q(bst ^ 1, 1); else dmaA_extra(adm);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 5; ++i) accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, accx[i], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
