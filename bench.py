@@ -328,8 +328,8 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         matcher(d)
         table = torch.cat([d["mkpts0_f"], d["mkpts1_f"], d["mconf"][:, None]], -1)
         if distributed:       # the path's one exchange: the tables go to the merging rank (gather-to-root)
-            gathered = ddist.collect_tables([table], root=0)
-            n_matches[0] = sum(t.shape[0] for t in gathered) if gathered is not None else table.shape[0]
+            gathered = ddist.collect_tables([table], root=0, packed=True)      # (rows, counts): one host read per step
+            n_matches[0] = gathered[0].shape[0] if gathered is not None else table.shape[0]
         else:
             n_matches[0] = table.shape[0]
 
@@ -364,7 +364,7 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         refiner(d)
         if distributed:
             rows = torch.cat([d["query_points_refined"][0], d["reference_points_refined"][-1][0].reshape(-1, 2)], 0)
-            ddist.collect_tables([rows], root=0)
+            ddist.collect_tables([rows], root=0, packed=True)
 
     r_steps = max(2, args.steps // 2)
     rdt = timed_steps(refine_step, r_steps, min(args.warmup, 2), distributed)
@@ -421,8 +421,8 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
 
 def run_scene(args, dev, rank, world, distributed, out_fd):
     """configs[3]: ETH3D-shaped scene, exhaustive pairs sharded over the ranks (the analogue of
-    src/coarse_match/coarse_match.py:127-140): backbone once per image on every rank, the rank's contiguous shard of
-    the pair list matched from the cached tokens, ONE gather-to-root of the tables, keypoint merge on rank 0."""
+    src/coarse_match/coarse_match.py:127-140): backbone once per image on every rank, the rank's tile shard of
+    the pair list (dist.shard_pairs_tiled) matched from the cached tokens, ONE gather-to-root of the tables, keypoint merge on rank 0."""
     n_img = args.scene_images
     if args.scene_matcher == "aspanformer":       # backbone once per image + PAIRS_PER_PASS pairs per transformer pass
         from detectorfreesfm_amd.aspanformer import HipASpanFormer, aspanformer_coarse_only_config
@@ -443,24 +443,24 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
     pairs = ddist.exhaustive_pairs(n_img)
     if args.scene_pairs:
         pairs = pairs[:args.scene_pairs]
-    lo, hi = ddist.shard_range(len(pairs), rank, world)
+    order = ddist.shard_pairs_tiled(pairs, n_img, world)      # blocks of the (i, j) plane: ~ n/sqrt(world) images per rank
+    mine = [pairs[k] for k in order[rank]]
     torch.cuda.synchronize()
     if distributed:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    tables = plugin.match_scene_cached(matcher, images, pairs[lo:hi], batch=args.batch, to_host=False)
+    tables = plugin.match_scene_cached(matcher, images, mine, batch=args.batch, to_host=False)
     torch.cuda.synchronize()
     t_match = time.perf_counter() - t0
-    flat = [tables[p] for p in pairs[lo:hi]]
-    gathered = ddist.collect_tables(flat, root=0) if distributed else flat        # merge runs on rank 0 only
+    flat = [tables[p] for p in mine]
+    gathered = ddist.collect_tables(flat, root=0, packed=True) if distributed or rank == 0 else None   # merge on rank 0 only
     torch.cuda.synchronize()
     t_gather = time.perf_counter() - t0 - t_match
-    n_rows, n_kpts = (sum(int(t.shape[0]) for t in gathered) if gathered is not None else 0), 0
+    n_rows, n_kpts = (int(gathered[0].shape[0]) if gathered is not None else 0), 0
     if rank == 0:
-        rows = torch.cat(gathered, 0)
-        lens = torch.tensor([t.shape[0] for t in gathered])
-        pid = torch.tensor(pairs, dtype=torch.int32)
-        rep = torch.repeat_interleave(pid, lens, dim=0).to(dev)
+        rows, lens = gathered                                 # rows of all ranks in rank order, row counts per pair
+        pid = torch.tensor([pairs[k] for o in order for k in o], dtype=torch.int32, device=dev)
+        rep = torch.repeat_interleave(pid, lens.to(torch.int64), dim=0)
         kpts, scores, offsets, ids = ops.merge_keypoints(rows, rep[:, 0].contiguous(), rep[:, 1].contiguous(), n_img)
         n_kpts = int(kpts.shape[0])
     torch.cuda.synchronize()
@@ -478,7 +478,7 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
             "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"configs[3]: {mname}{n_img} images 640x480, {len(pairs)} exhaustive pairs, backbone once per image, "
                                    "tables gathered to rank 0 once, keypoint merge on rank 0",
-                       "parallelism": f"contiguous pair shards over {world} rank(s); one gather-to-root of match tables",
+                       "parallelism": f"tiled pair shards (blocks of the image x image plane) over {world} rank(s); one gather-to-root of match tables",
                        "rccl_ranks": world if distributed else 0},
             "phases_s": {"match_rank0": t_match, "gather_rank0": t_gather, "total_max_over_ranks": dt},
             "match_rows": n_rows, "keypoints": n_kpts})

@@ -252,33 +252,55 @@ def match_scene_cached(matcher, images, pairs, batch=8, scales=None, to_host=Tru
 
 @torch.no_grad()
 def match_scene_sharded(matcher: HipLoFTR, images, names, pair_name_split=" ", batch=8, scales=None, pairs=None, group=None,
-                        root=0):
+                        root=None, shard="tiles"):
     """One scene on all ranks of the process group -- the analogue of the reference's Ray fan-out + merge
-    (src/coarse_match/coarse_match.py:127-140, 203-237): every rank matches a contiguous shard of the pair list
+    (src/coarse_match/coarse_match.py:127-140, 203-237): every rank matches its shard of the pair list
     (``match_scene_cached``: backbone once per image), the match tables are collected with ONE payload collective
     (``dist.collect_tables``: RCCL over xGMI, gloo in the CPU tests), and the keypoint merge runs on the device.
 
-    root=r (default 0): gather-to-root -- like the reference, whose driver process alone merges and writes the h5 files
-    (coarse_match.py:203-254), only rank r receives the tables (an exact-size buffer) and runs the merge; the other ranks
-    return None.  root=None: every rank receives the tables and merges (the round-1/2 behaviour).
+    root=None (default): every rank receives the tables, merges and returns the dictionaries -- the contract of rounds 1-2.
+    root=r (opt-in, a rank of ``group``): gather-to-root -- like the reference, whose driver process alone merges and writes
+    the h5 files (coarse_match.py:203-254), only rank r receives the tables (an exact-size buffer) and runs the merge; the
+    other ranks return None.
+    shard="tiles" (default): ``dist.shard_pairs_tiled`` -- blocks of the (i, j) plane, so that a rank runs the backbone on
+    ~ n/sqrt(world) images instead of nearly all of them; "contiguous": ``dist.shard_range`` of the pair list.  The result
+    does not depend on the sharding (tables are put back in pair order).
 
     images [n_images,1,H,W]; names: image names in the same order; pairs: list of (i, j) (default: exhaustive, in the
     order of src/construct_pairs/pairs_exhaustive.py).  Returns the reference's dictionaries
     (matches {"name0<split>name1": [M,5]}, final_keypoints, final_scores, updated_matches)."""
     from . import dist as ddist
-    import torch.distributed as tdist
     pairs = ddist.exhaustive_pairs(len(names)) if pairs is None else [tuple(p) for p in pairs]
-    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
-    rank = tdist.get_rank(group) if world > 1 else 0
-    lo, hi = ddist.shard_range(len(pairs), rank, world)
-    mine = match_scene_cached(matcher, images, pairs[lo:hi], batch=batch, scales=scales, to_host=False)
-    tables = ddist.collect_tables([mine[p] for p in pairs[lo:hi]], group=group, root=root)   # rank order == pair order
+    world, rank = _world_rank(group)
+    order = _pair_shards(pairs, len(names), world, shard)
+    mine = match_scene_cached(matcher, images, [pairs[k] for k in order[rank]], batch=batch, scales=scales, to_host=False)
+    tables = ddist.collect_tables([mine[pairs[k]] for k in order[rank]], group=group, root=root)
     if tables is None:
         return None
     assert len(tables) == len(pairs)
-    matches = {f"{names[i]}{pair_name_split}{names[j]}": t.cpu().numpy() for (i, j), t in zip(pairs, tables)}
+    flat = [k for o in order for k in o]                                       # tables arrive in rank order
+    matches = {}
+    by_pair = dict(zip(flat, tables))
+    for k, (i, j) in enumerate(pairs):                                          # back to pair order
+        matches[f"{names[i]}{pair_name_split}{names[j]}"] = by_pair[k].cpu().numpy()
     kp, sc, upd = merge_match_tables(matches, names, pair_name_split, device=next(matcher.parameters()).device)
     return matches, kp, sc, upd
+
+
+def _world_rank(group):
+    import torch.distributed as tdist
+    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
+    return world, (tdist.get_rank(group) if world > 1 else 0)
+
+
+def _pair_shards(pairs, n_images, world, shard):
+    """Per-rank index lists into ``pairs`` (identical on every rank)."""
+    from . import dist as ddist
+    if shard == "tiles":
+        return ddist.shard_pairs_tiled(pairs, n_images, world)
+    if shard == "contiguous":
+        return [list(range(*ddist.shard_range(len(pairs), r, world))) for r in range(world)]
+    raise ValueError(f"shard must be 'tiles' or 'contiguous', got {shard!r}")
 
 
 # dataset rules of detector_free_coarse_matching per matcher (src/coarse_match/coarse_match.py:82-90)
@@ -336,29 +358,35 @@ def match_worker(subset_ids, image_lists, covis_pairs_out, cfgs, device="cuda", 
 
 
 @torch.no_grad()
-def match_worker_sharded(image_lists, covis_pairs_out, cfgs, device="cuda", frames=None, models=None, group=None, root=0):
+def match_worker_sharded(image_lists, covis_pairs_out, cfgs, device="cuda", frames=None, models=None, group=None, root=None,
+                         shard="tiles"):
     """The reference's Ray fan-out of ``match_worker`` over chunks of the pair list (coarse_match.py:127-140) as one process
-    per GPU: rank r matches its contiguous shard, ONE payload collective (``dist.collect_tables``) hands rank ``root`` (every
-    rank with root=None) the scene's table dictionary in pair order; the other ranks return None."""
+    per GPU: rank r matches its shard (``shard="tiles"``: blocks of the (image, image) plane, so a rank reads and resizes
+    few frames; "contiguous": a slice of the list), ONE payload collective (``dist.collect_tables``) hands every rank
+    (root=None, default) or only rank ``root`` of the group (the others then return None) the scene's table dictionary in
+    pair order."""
     from . import dist as ddist
-    import torch.distributed as tdist
     if isinstance(covis_pairs_out, (list, tuple)):
         pair_list = list(covis_pairs_out)
     else:
         with open(covis_pairs_out, "r") as f:
             pair_list = f.read().rstrip("\n").split("\n")
-    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
-    rank = tdist.get_rank(group) if world > 1 else 0
-    lo, hi = ddist.shard_range(len(pair_list), rank, world)
-    mine = match_worker(list(range(lo, hi)), image_lists, pair_list, cfgs, device=device, frames=frames, models=models)
+    world, rank = _world_rank(group)
+    paths = {}
+    for p in pair_list:
+        for q in p.split(" "):
+            paths.setdefault(q, len(paths))
+    order = _pair_shards([tuple(paths[q] for q in p.split(" ")) for p in pair_list], len(paths), world, shard)
+    mine = match_worker(order[rank], image_lists, pair_list, cfgs, device=device, frames=frames, models=models)
     split = cfgs["matcher"].get("pair_name_split", " ")
     keys = [split.join(p.split(" ")) for p in pair_list]
-    tables = ddist.collect_tables([torch.from_numpy(mine[k]).to(torch.float32).to(device) for k in keys[lo:hi]], group=group,
-                                  root=root)
+    tables = ddist.collect_tables([torch.from_numpy(mine[keys[k]]).to(torch.float32).to(device) for k in order[rank]],
+                                  group=group, root=root)
     if tables is None:
         return None
     assert len(tables) == len(keys)
-    return {k: t.cpu().numpy() for k, t in zip(keys, tables)}
+    by_pair = dict(zip([k for o in order for k in o], tables))
+    return {keys[k]: by_pair[k].cpu().numpy() for k in range(len(keys))}
 
 
 def _batched(bag: dict, device):
@@ -408,7 +436,7 @@ def match_tracks_worker(colmap_dataset, matcher, subset_track_idxs=None, dataset
 
 
 @torch.no_grad()
-def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, device="cuda", group=None, root=0):
+def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, device="cuda", group=None, root=None):
     """One scene's feature tracks on all ranks of the process group -- the analogue of ``multiview_matcher`` with Ray
     (src/post_optimization/matcher_model/multiview_match.py:39-62): tracks are dealt to the ranks by index
     (``dist.shard_tracks``: all bags of one track on one rank), every rank runs ``match_tracks_worker`` on its subset,
@@ -416,25 +444,33 @@ def refine_scene_sharded(matcher, colmap_dataset, dataset_cfgs, seed=None, devic
     as 16-byte rows: the two coordinates are fp32 values already (``.cpu().numpy()`` of fp32 tensors, widened to float64 only
     by the reference's ``np.concatenate`` with the integer columns, multiview_match_worker.py:136-139), so they travel as
     their fp32 bits, and the image id / keypoint index as int32.  Returns the concatenated list of per-bag float64 arrays
-    (rank order, then bag order) on rank ``root`` (default 0; None elsewhere) or on every rank with root=None."""
+    (rank order, then bag order) on every rank (root=None, the default) or only on rank ``root`` of the group (opt-in
+    gather-to-root; None elsewhere).  A rank whose rows do not fit the 16-byte form does not raise alone: it sends a
+    one-column table, which makes ``collect_tables`` raise on every rank."""
     from . import dist as ddist
-    import torch.distributed as tdist
-    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
-    rank = tdist.get_rank(group) if world > 1 else 0
+    world, rank = _world_rank(group)
     n = len(colmap_dataset.point_cloud_assigned_imgID_kptID)
     mine = match_tracks_worker(colmap_dataset, matcher, ddist.shard_tracks(n, rank, world, seed), dataset_cfgs, device)
     if world == 1:
         return mine
     dev = torch.device(device)
-    words = []
+    words, bad = [], False
     for a in mine:
         xy = a[:, :2].astype(np.float32)
         ids = a[:, 2:]
-        if not (np.array_equal(xy.astype(np.float64), a[:, :2]) and np.array_equal(np.rint(ids), ids) and
+        # NaN coordinates are legitimate fp32 values (equal_nan); the ids must be integers that fit int32
+        if not (np.array_equal(xy.astype(np.float64), a[:, :2], equal_nan=True) and np.array_equal(np.rint(ids), ids) and
                 (np.abs(ids) < 2 ** 31).all()):
-            raise ValueError("refine_scene_sharded: result rows are not (fp32 x, fp32 y, int32 image id, int32 keypoint index)")
+            bad = True
+            break
         words.append(torch.from_numpy(np.concatenate([xy.view(np.int32), ids.astype(np.int32)], 1)).to(dev))
-    tabs = ddist.collect_tables(words, group=group, root=root, dtype=torch.int32)
+    if bad:     # raise TOGETHER with the other ranks (a lone raise would leave them inside the collective)
+        words = [torch.zeros((1, 1), dtype=torch.float64, device=dev)]
+    try:
+        tabs = ddist.collect_tables(words, group=group, root=root, dtype=torch.int32)
+    except TypeError as e:
+        raise ValueError("refine_scene_sharded: result rows are not (fp32 x, fp32 y, int32 image id, int32 keypoint index) "
+                         f"on some rank ({e})") from e
     if tabs is None:
         return None
     out = []

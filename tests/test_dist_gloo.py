@@ -20,6 +20,22 @@ def test_shard_ranges_partition_the_list():
     assert ddist.exhaustive_pairs(3) == [(0, 1), (0, 2), (1, 2)]
 
 
+def test_tiled_pair_shards_cover_and_balance():
+    """shard_pairs_tiled: a partition of the pair list, balanced, and a rank touches ~ n/sqrt(world) images."""
+    pairs = ddist.exhaustive_pairs(300)
+    for ws in (1, 2, 3, 4, 8):
+        sh = ddist.shard_pairs_tiled(pairs, 300, ws)
+        assert len(sh) == ws and sorted(k for s in sh for k in s) == list(range(len(pairs)))
+        assert all(s == sorted(s) for s in sh)
+        assert max(len(s) for s in sh) <= 1.02 * (len(pairs) / ws) + 1
+    imgs8 = [len({x for k in s for x in pairs[k]}) for s in ddist.shard_pairs_tiled(pairs, 300, 8)]
+    assert max(imgs8) <= 150                                        # contiguous shards: 300, 263, ... images
+    sparse = [(0, 5), (5, 0), (2, 3), (7, 1)]                       # any list, either order, also fewer pairs than ranks
+    sh = ddist.shard_pairs_tiled(sparse, 8, 8)
+    assert sorted(k for s in sh for k in s) == [0, 1, 2, 3]
+    assert ddist.shard_pairs_tiled([], 4, 2) == [[], []]
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,6 +57,16 @@ def _worker(rank, world, port, q):
     ok = ok and len(gi) == 4 and gi[0].dtype == torch.int32 and torch.equal(gi[2], torch.arange(12, dtype=torch.int32).view(3, 4) * 2 - 7)
     none = ddist.collect_tables([], root=0)
     ok = ok and (none == [] if rank == 0 else none is None)
+    # packed form: one rows tensor + the counts, no list of views
+    rows, cnt = ddist.collect_tables(all_tables[lo:hi], root=None, packed=True)
+    ok = ok and torch.equal(rows, torch.cat(all_tables)) and cnt.tolist() == [t.shape[0] for t in all_tables]
+    # an argument error on ONE rank (float64 table / mixed widths) raises on EVERY rank, before the payload collective
+    for bad in ([torch.ones((2, 5), dtype=torch.float64)], [torch.ones(2, 5), torch.ones(2, 4)]):
+        try:
+            ddist.collect_tables(bad if rank == 1 else all_tables[lo:hi], root=None)
+            ok = False
+        except TypeError as e:
+            ok = ok and "rank 1" in str(e)
     q.put((rank, ok, len(pairs)))
     dist.barrier()
     dist.destroy_process_group()
@@ -77,9 +103,14 @@ def _scene_worker(rank, world, port, q):
     images = torch.cat([base["image0"], base["image1"]], 0)            # 4 images -> 6 exhaustive pairs, 3 per rank
     names = [f"scene/img{k}.jpg" for k in range(4)]
     with cpu_ops(), torch.no_grad():
-        on_root = plugin.match_scene_sharded(m, images, names, " ", batch=2)          # default: gather-to-root 0
+        on_root = plugin.match_scene_sharded(m, images, names, " ", batch=2, root=0)   # opt-in: gather-to-root 0
         ok = (on_root is None) == (rank != 0)
-        matches, kp, sc, upd = plugin.match_scene_sharded(m, images, names, " ", batch=2, root=None)
+        matches, kp, sc, upd = plugin.match_scene_sharded(m, images, names, " ", batch=2)   # default: on EVERY rank
+        contig = plugin.match_scene_sharded(m, images, names, " ", batch=2, shard="contiguous")
+        # the sharding changes which pairs share a transformer batch (summation order), never the table layout
+        ok = ok and list(contig[0]) == list(matches) and all(
+            np.array_equal(contig[0][k][:, :4], matches[k][:, :4]) and np.allclose(contig[0][k][:, 4], matches[k][:, 4], atol=1e-5)
+            for k in matches)
         ok = ok and len(matches) == 6 and list(matches) == [f"{names[i]} {names[j]}" for i, j in ddist.exhaustive_pairs(4)]
         if rank == 0:          # the same scene in one process
             ok = ok and all(np.array_equal(on_root[0][k], matches[k]) for k in matches)
@@ -131,9 +162,9 @@ def _refine_worker(rank, world, port, q):
         rows = np.concatenate(results, 0)
         return {(int(r[2]), int(r[3])): r[:2] for r in rows}, rows.shape[0]
     with cpu_ops(), torch.no_grad():
-        res_all = plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu", root=None)
+        res_all = plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu")               # default: on EVERY rank
         got, n_got = table(res_all)
-        res_root = plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu")              # default: gather-to-root 0
+        res_root = plugin.refine_scene_sharded(m, scene, dcfg, seed=2, device="cpu", root=0)      # opt-in: gather-to-root 0
         ok = (res_root is None) == (rank != 0)
         if rank == 0:
             ok = ok and len(res_root) == len(res_all) and all(a.dtype == np.float64 and np.array_equal(a, b)

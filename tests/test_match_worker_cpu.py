@@ -124,9 +124,9 @@ def _sharded(rank, world, port, q):
     frames = scene_frames()
     cfgs, models, _ = build("loftr_hip")
     with cpu_ops():
-        on_root = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)
-        assert (on_root is None) == (rank != 0)                    # default: gather-to-root 0
-        got = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models, root=None)
+        on_root = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models, root=0)
+        assert (on_root is None) == (rank != 0)                    # opt-in: gather-to-root 0
+        got = plugin.match_worker_sharded(list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)   # every rank
         if rank == 0:
             assert list(on_root) == PAIRS and all(np.array_equal(on_root[p], got[p]) for p in PAIRS)
             ref = plugin.match_worker([0, 1, 2], list(frames), PAIRS, cfgs, device="cpu", frames=frames, models=models)
