@@ -14,7 +14,8 @@ on 127.0.0.1; under the driver's own torchrun it just reads RANK / LOCAL_RANK / 
 
 Other workloads (explicit, not the headline): ``--workload scene300`` = configs[3] (300 images, 44 850 exhaustive
 pairs sharded over the ranks, backbone once per image, gather-to-root of the tables, keypoint merge on rank 0);
-``--workload hires832`` = configs[4] (832x832 pairs + one 16 000-track refinement chunk);
+``--workload hires832`` = configs[4] (832x832 pairs + one 16 000-track refinement chunk); ``--workload eth3d1600`` /
+``demo1200`` = the frame sizes the reference's shipped configs feed the matcher (1600x1064: L = 26 600; 1200x800: L = 15 000);
 ``--workload matchformer`` / ``aspanformer`` = the alternative coarse matchers of SURVEY 8(f) at the configs[1] frame size.
 
 Extra objects: ``roofline`` (dominant hand-written kernel, measured live with events on the launch stream),
@@ -484,11 +485,23 @@ def run_scene(args, dev, rank, world, distributed, out_fd):
             "match_rows": n_rows, "keypoints": n_kpts})
 
 
+# --workload name -> (H, W, pairs per step at --batch 8, refinement chunk, label)
+HIRES = {"hires832": (832, 832, 4, 16000, "configs[4]"),
+         # what the reference's shipped configs feed the matcher: img_resize 1600 (hydra_configs/eth3d_sfm/dfsfm.yaml:76;
+         # ETH3D frames are 3:2 -> 1600x1064 after the df=8 rounding), refinement chunks of 2000 tracks (:65)
+         "eth3d1600": (1064, 1600, 2, 2000, "production frame size of hydra_configs/eth3d_sfm/dfsfm.yaml"),
+         # img_resize 1200 (src/coarse_match/coarse_match.py:15, hydra_configs/demo/dfsfm.yaml:48)
+         "demo1200": (800, 1200, 4, 2000, "production frame size of hydra_configs/demo/dfsfm.yaml")}
+
+
 def run_hires(args, dev, rank, world, distributed, out_fd):
-    """configs[4]: 832x832 frames through the LoFTR coarse matcher + one 16 000-track refinement chunk."""
+    """configs[4] (832x832) and the reference's production frame sizes (1600x1064, 1200x800) through the LoFTR coarse
+    matcher + one refinement chunk on frames of that size."""
+    H, W, nb8, T, label = HIRES[args.workload]
+    L = (H // 8) * (W // 8)
     matcher = build_coarse(dev)
-    nb = max(1, args.batch // 2)
-    batches = [synth.to_device(synth.coarse_pair_batch(nb, 832, 832, seed=500 + 1000 * rank + 10 * k), dev) for k in range(2)]
+    nb = max(1, args.batch * nb8 // 8)
+    batches = [synth.to_device(synth.coarse_pair_batch(nb, H, W, seed=500 + 1000 * rank + 10 * k), dev) for k in range(2)]
     n_matches = [0]
 
     def coarse_step(i):
@@ -496,29 +509,44 @@ def run_hires(args, dev, rank, world, distributed, out_fd):
         matcher(d)
         n_matches[0] = int(d["mconf"].shape[0])
     dt = timed_steps(coarse_step, args.steps, args.warmup, distributed)
+    breakdown = {}
+    if rank == 0:
+        data = batches[0]
+        P = matcher._packed or matcher._pack()
+        imgs = torch.cat([data["image0"], data["image1"]], 0)
+        with torch.no_grad():
+            breakdown["backbone_ms"] = event_time_ms(lambda: matcher._backbone_hip(imgs, P), 3, 1)
+            c = matcher._backbone_hip(imgs, P).flatten(1, 2)
+            pe = matcher._pe_tokens((H // 8, W // 8))
+            f0, f1 = c[:nb], c[nb:]
+            breakdown["transformer_ms"] = event_time_ms(lambda: matcher._transformer(f0, f1, P, pe, pe), 3, 1)
+            matcher._transformer(f0, f1, P, pe, pe)
+            g0, g1 = matcher._feat_split
+            breakdown["coarse_match_ms"] = event_time_ms(
+                lambda: ops.coarse_match(g0, g1, (H // 8, W // 8), (H // 8, W // 8), 0.2, 2, 0.1), 3, 1)
+        del imgs, c, f0, f1, g0, g1
     refiner = build_refiner(dev)
-    T = 16000
-    bag = synth.to_device(synth.refine_bag(T, 5, 832, 832, seed=2500 + rank), dev)
+    bag = synth.to_device(synth.refine_bag(T, 5, H, W, seed=2500 + rank), dev)
 
     def refine_step(i):
         refiner(dict(bag))
     r_steps = max(2, args.steps // 4)
     rdt = timed_steps(refine_step, r_steps, 1, distributed)
     if rank == 0:
-        flops = nb * (2 * BACKBONE_FLOP_PER_IMAGE * (832 * 832) / (640 * 480) + 16 * 6.45e9 * 10816 / 4800 + 2.0 * 10816 * 10816 * 256)
+        flops = nb * (2 * BACKBONE_FLOP_PER_IMAGE * (H * W) / (640 * 480) + 16 * 6.45e9 * L / 4800 + 2.0 * L * L * 256)
         _emit(out_fd, {
             "metric": "coarse_image_pairs_per_sec", "value": nb * world * args.steps / dt, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"configs[4]: LoFTR coarse_only at 832x832 (L = S = 10816), batch {nb} pairs per GPU per step; "
-                                   "refinement chunk_size 16000 x 5 views", "parallelism": f"{world} rank(s), weak"},
-            "matches_last_step": n_matches[0],
+            "config": {"workload": f"{label}: LoFTR coarse_only at {W}x{H} (L = S = {L}), batch {nb} pairs per GPU per step; "
+                                   f"refinement chunk_size {T} x 5 views", "parallelism": f"{world} rank(s), weak"},
+            "matches_last_step": n_matches[0], "breakdown_ms": breakdown,
             "step_roofline": {"algorithmic_flops_per_step": flops, "achieved_tflops_per_gpu": flops * args.steps / dt / 1e12,
                               "frac_of_fp16_mfma_peak": flops * args.steps / dt / 1e12 / MFMA_F16_PEAK_TF},
             "secondary": {"metric": "refinement_tracks_per_sec", "value": T * world * r_steps / rdt, "unit": "tracks/s",
                           "steps": r_steps, "ms_per_step": 1000.0 * rdt / r_steps,
-                          "workload": "configs[4]: one 16 000-track x 5-view chunk, 832x832 RGB frames"}})
+                          "workload": f"{label}: one {T}-track x 5-view chunk, {W}x{H} RGB frames"}})
 
 
 def run_alt_matcher(args, dev, rank, world, distributed, out_fd):
@@ -572,7 +600,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--tracks", type=int, default=2000, help="tracks per refinement bag (configs[2]: 2000)")
-    ap.add_argument("--workload", choices=("pairs", "scene300", "hires832", "matchformer", "aspanformer"), default="pairs")
+    ap.add_argument("--workload", choices=("pairs", "scene300", "hires832", "eth3d1600", "demo1200", "matchformer", "aspanformer"), default="pairs")
     ap.add_argument("--scene-images", type=int, default=300)
     ap.add_argument("--scene-pairs", type=int, default=0, help="truncate the exhaustive pair list (0 = all)")
     ap.add_argument("--scene-matcher", choices=("loftr", "aspanformer"), default="loftr", help="coarse matcher of --workload scene300")

@@ -183,6 +183,7 @@ class HipASpanFormer(ParamModule):
 
     # -- forward ------------------------------------------------------------------------------------------------
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def forward(self, data: dict):
         """Updates ``data`` in place like ASpanFormer.forward (aspanformer.py:31-108, fine.enable=False)."""
         img0, img1 = data["image0"], data["image1"]
@@ -211,6 +212,7 @@ class HipASpanFormer(ParamModule):
 
     # -- "backbone once per image" for a scene (SURVEY 8(f) rank 1; VERDICT r02 missing #5): the ResNet is per image ---------
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def image_tokens(self, images):
         """[B,1,H,W] frames of one size -> (backbone tokens [B, h, w, C] of the online-resized frames, (h, w)); per-image results
         do not depend on the batch, so they can be cached and paired freely (``match_tokens``)."""
@@ -223,6 +225,7 @@ class HipASpanFormer(ParamModule):
     PAIRS_PER_PASS = int(os.environ.get("DFSFM_ASPAN_PAIRS_PER_PASS", "8"))
 
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None):
         """Transformer + matching on cached backbone tokens of N pairs (tok* [N, h, w, C]; ``hw0_i`` = ORIGINAL frame size, both
         frames of one size), ``PAIRS_PER_PASS`` pairs per pass: per-pair results do not depend on the other pairs of the pass

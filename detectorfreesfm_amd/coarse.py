@@ -222,11 +222,12 @@ class HipLoFTR(ParamModule):
         return backbone_tokens_hip(x, P["hip"])
 
     # -- K2/K1: LocalFeatureTransformer.forward (transformer.py:80-101) -------------------------
-    def _transformer(self, f0, f1, P, pe0=None, pe1=None):
+    def _transformer(self, f0, f1, P, pe0=None, pe1=None, mask0=None, mask1=None):
         """f0 [N,L,C], f1 [N,S,C] (+ optional positional-encoding tables added on the way in) -> updated
         features (contiguous fp32).  When both images have the same grid they share buffers so that
         self layers run as ONE batch of 2N sequences.  Split planes [.,.,2C] = [x | norm1(message)] ping-pong, fp32 only
-        for the result (encoder_layer_split)."""
+        for the result (encoder_layer_split).  mask0 [N,L] / mask1 [N,S] (uint8 / bool, 1 = valid): the padding masks of
+        transformer.py:80-97 -- query mask and source mask of every layer's linear attention (K1)."""
         nhead = self.config["coarse"]["nhead"]
         names = self.config["coarse"]["layer_names"]
         N, L, C = f0.shape
@@ -252,6 +253,7 @@ class HipLoFTR(ParamModule):
         ops.split_rows(f1, pe1, out_split=XS[2].cols(0, C))
         fin = new_split(C)      # the final features as contiguous split planes: operands of the correlation
         out = (None, None, None)
+        m01 = torch.cat([mask0, mask1], 0) if (mask0 is not None and same) else None
         for li, (w, name) in enumerate(zip(P["enc"], names)):
             last = li == len(names) - 1
             oxs = fin if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
@@ -259,20 +261,20 @@ class HipLoFTR(ParamModule):
                 out = new_f32(C)            # fp32 copy of the final features only
             if name == "self":
                 if same:   # both images through one batched call
-                    encoder_layer_split(w, XS[0], XS[0].cols(0, C), out[0], oxs[0], nhead, is_self=True)
+                    encoder_layer_split(w, XS[0], XS[0].cols(0, C), out[0], oxs[0], nhead, m01, m01, is_self=True)
                 else:
-                    for i in (1, 2):
-                        encoder_layer_split(w, XS[i], XS[i].cols(0, C), out[i], oxs[i], nhead, is_self=True)
+                    for i, mk in ((1, mask0), (2, mask1)):
+                        encoder_layer_split(w, XS[i], XS[i].cols(0, C), out[i], oxs[i], nhead, mk, mk, is_self=True)
             elif name == "cross":
-                encoder_layer_split(w, XS[1], XS[2].cols(0, C), out[1], oxs[1], nhead)
-                encoder_layer_split(w, XS[2], oxs[1], out[2], oxs[2], nhead)         # sees the updated feat0 (:96-97)
+                encoder_layer_split(w, XS[1], XS[2].cols(0, C), out[1], oxs[1], nhead, mask0, mask1)
+                encoder_layer_split(w, XS[2], oxs[1], out[2], oxs[2], nhead, mask1, mask0)   # sees the updated feat0 (:96-97)
             else:
                 raise KeyError(name)
             XS, XSn = XSn, XS
         self._feat_split = (fin[1], fin[2])
         return out[1], out[2]
 
-    def coarse_features(self, image0, image1):
+    def coarse_features(self, image0, image1, mask0=None, mask1=None):
         """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c)."""
         P = self._packed or self._pack()
         bs = image0.size(0)
@@ -284,11 +286,12 @@ class HipLoFTR(ParamModule):
             c0, c1 = self._backbone_hip(image0, P), self._backbone_hip(image1, P)
         hw0_c, hw1_c = tuple(c0.shape[1:3]), tuple(c1.shape[1:3])
         f0, f1 = self._transformer(c0.flatten(1, 2), c1.flatten(1, 2), P, self._pe_tokens(hw0_c),
-                                   self._pe_tokens(hw1_c))     # pos-enc added while splitting
+                                   self._pe_tokens(hw1_c), mask0, mask1)     # pos-enc added while splitting
         return f0, f1, hw0_c, hw1_c
 
     # -- "backbone once per image" (SURVEY 8(f) rank 1: the reference re-runs the CNN for every pair an image is in)
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def image_tokens(self, images):
         """[B,1,H,W] -> (coarse backbone tokens [B, h*w, C] fp32, (h, w)).  Per-image results do not depend on what
         else is in the batch, so they can be cached and paired freely (``match_tokens``)."""
@@ -297,17 +300,34 @@ class HipLoFTR(ParamModule):
         return c.flatten(1, 2), tuple(c.shape[1:3])
 
     @torch.no_grad()
-    def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None):
+    @ops.first_call_range_sweep
+    def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None, mask0=None, mask1=None):
         """Positional encoding + transformer + coarse matching on cached backbone tokens of N pairs
-        (tok0 [N,L,C], tok1 [N,S,C]); the same dict of matches ``forward`` leaves in ``data``."""
+        (tok0 [N,L,C], tok1 [N,S,C]; optional padding masks [N,h0c,w0c] / [N,h1c,w1c]); the same dict of matches
+        ``forward`` leaves in ``data``."""
         P = self._packed or self._pack()
         self._feat_split = None
-        f0, f1 = self._transformer(tok0, tok1, P, self._pe_tokens(tuple(hw0_c)), self._pe_tokens(tuple(hw1_c)))
+        m0, m1 = self._flat_masks(mask0, mask1, tok0.shape[0], tuple(hw0_c), tuple(hw1_c), tok0.device)
+        f0, f1 = self._transformer(tok0, tok1, P, self._pe_tokens(tuple(hw0_c)), self._pe_tokens(tuple(hw1_c)), m0, m1)
         f0, f1 = self._feat_split
         self._feat_split = None
         mc = self.config["match_coarse"]
         return ops.coarse_match(f0, f1, tuple(hw0_c), tuple(hw1_c), mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
-                                scale0, scale1, hw0_i[0] / hw0_c[0])
+                                scale0, scale1, hw0_i[0] / hw0_c[0], mask0=m0, mask1=m1)
+
+    @staticmethod
+    def _flat_masks(mask0, mask1, N, hw0_c, hw1_c, dev):
+        """data['mask0'] / data['mask1'] ([N,h,w] at the coarse resolution, '0' = padded position; loftr.py:35-36, 61-63)
+        as contiguous uint8 [N,L] / [N,S] on the device, or (None, None)."""
+        if (mask0 is None) != (mask1 is None):
+            raise ValueError("mask0 and mask1 come together (loftr.py:62-63 reads both)")
+        if mask0 is None:
+            return None, None
+        if tuple(mask0.shape) != (N, *hw0_c) or tuple(mask1.shape) != (N, *hw1_c):
+            raise ValueError(f"mask0 / mask1 must be [N,h,w] at the coarse resolution {hw0_c} / {hw1_c}, "
+                             f"got {tuple(mask0.shape)} / {tuple(mask1.shape)}")
+        return ((mask0.to(dev) != 0).to(torch.uint8).flatten(1).contiguous(),
+                (mask1.to(dev) != 0).to(torch.uint8).flatten(1).contiguous())
 
     def _pe_tokens(self, hw):
         """Positional encoding in token-major layout [h*w, C] (cached per grid size)."""
@@ -318,14 +338,17 @@ class HipLoFTR(ParamModule):
         return cache[key]
 
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def forward(self, data: dict):
         """Updates ``data`` in place like LoFTR.forward (loftr.py:29-73, fine.enable=False)."""
         img0, img1 = data["image0"], data["image1"]
-        if "mask0" in data:
-            raise NotImplementedError("padding masks (training-time feature) are not on the inference path")
         data.update({"bs": img0.size(0), "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
         self._feat_split = None
-        f0, f1, hw0_c, hw1_c = self.coarse_features(img0, img1)
+        m0 = m1 = None
+        if "mask0" in data:     # padded frames (loftr.py:61-65): masks through every attention, the dual-softmax, the border
+            hw0, hw1 = (img0.shape[2] // 8, img0.shape[3] // 8), (img1.shape[2] // 8, img1.shape[3] // 8)
+            m0, m1 = self._flat_masks(data["mask0"], data.get("mask1"), img0.size(0), hw0, hw1, img0.device)
+        f0, f1, hw0_c, hw1_c = self.coarse_features(img0, img1, m0, m1)
         f0, f1 = self._feat_split              # correlate the split planes the last LayerNorm wrote
         self._feat_split = None
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
@@ -334,7 +357,7 @@ class HipLoFTR(ParamModule):
         mc = self.config["match_coarse"]
         scale = data["hw0_i"][0] / hw0_c[0]
         m = ops.coarse_match(f0, f1, hw0_c, hw1_c, mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
-                             data.get("scale0"), data.get("scale1"), scale)
+                             data.get("scale0"), data.get("scale1"), scale, mask0=m0, mask1=m1)
         data.update({"b_ids": m["b_ids"], "i_ids": m["i_ids"], "j_ids": m["j_ids"],
                      "gt_mask": m["mconf"] == 0, "m_bids": m["b_ids"], "mkpts0_c": m["mkpts0_c"],
                      "mkpts1_c": m["mkpts1_c"], "mconf": m["mconf"],

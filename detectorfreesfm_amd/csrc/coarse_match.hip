@@ -26,6 +26,7 @@
 // conflict-free; next k-slab is prefetched into registers while the MFMAs run.
 #include "common.h"
 #include "sf_gemm.h"
+#include <climits>
 #include <cstdlib>
 
 namespace {
@@ -728,15 +729,61 @@ __global__ __launch_bounds__(256) void cm_eval(const float2* __restrict__ cand, 
     if (key != 0ull) row_best[(int64_t)n * L + i] = key;
 }
 
+// Valid extents of the padded frames of pair n, as mask_border_with_padding computes them (coarse_matching.py:35-36):
+// h = max over the columns of the column sums, w = max over the rows of the row sums.  One workgroup per (pair, frame);
+// ext[n] = {h0, w0, h1, w1}.
+__global__ __launch_bounds__(256) void cm_mask_extents(const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                                       int32_t* __restrict__ ext, int h0c, int w0c, int h1c, int w1c) {
+    const int n = blockIdx.x, which = blockIdx.y;
+    const int h = which ? h1c : h0c, w = which ? w1c : w0c;
+    const uint8_t* m = (which ? mask1 : mask0) + (int64_t)n * h * w;
+    __shared__ int s_h, s_w;
+    if (threadIdx.x == 0) { s_h = 0; s_w = 0; }
+    __syncthreads();
+    int best_h = 0, best_w = 0;
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+        int c = 0;
+        for (int y = 0; y < h; ++y) c += m[y * w + x] ? 1 : 0;
+        best_h = max(best_h, c);
+    }
+    for (int y = threadIdx.x; y < h; y += blockDim.x) {
+        int c = 0;
+        for (int x = 0; x < w; ++x) c += m[y * w + x] ? 1 : 0;
+        best_w = max(best_w, c);
+    }
+    atomicMax(&s_h, best_h);
+    atomicMax(&s_w, best_w);
+    __syncthreads();
+    if (threadIdx.x == 0) { ext[n * 4 + which * 2] = s_h; ext[n * 4 + which * 2 + 1] = s_w; }
+}
+
+// First index a Python slice ``m[start:]`` with start = extent - border removes on an axis of length len
+// (a negative start counts from the end, clamped at 0).
+__device__ __forceinline__ int py_slice_start(int extent, int border, int len) {
+    int s = extent - border;
+    if (s < 0) s = max(s + len, 0);
+    return s;
+}
+
 // Per-row decision; one workgroup per pair.  flags[n][i] = 1 iff row i yields a match.
 __global__ __launch_bounds__(1024) void cm_select(const unsigned long long* __restrict__ row_best,
                                                   const unsigned int* __restrict__ col_best,
                                                   uint8_t* __restrict__ flags, int32_t* __restrict__ counts,
-                                                  int L, int S, float thr, int border, int w0c, int w1c) {
+                                                  int L, int S, float thr, int border, int w0c, int w1c,
+                                                  const int32_t* __restrict__ ext) {
     const int n = blockIdx.x;
     __shared__ int s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
+    // mask_border: only the LOW side of each grid axis is removed (reference quirk, coarse_matching.py:8-22).  With
+    // padding masks (mask_border_with_padding, :25-41; ext != nullptr) also [extent - border, end) of every axis.
+    int hi_y0 = INT_MAX, hi_x0 = INT_MAX, hi_y1 = INT_MAX, hi_x1 = INT_MAX;
+    if (ext && border > 0) {
+        hi_y0 = py_slice_start(ext[n * 4 + 0], border, L / w0c);
+        hi_x0 = py_slice_start(ext[n * 4 + 1], border, w0c);
+        hi_y1 = py_slice_start(ext[n * 4 + 2], border, S / w1c);
+        hi_x1 = py_slice_start(ext[n * 4 + 3], border, w1c);
+    }
     int local = 0;
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
         const unsigned long long key = row_best[(int64_t)n * L + i];
@@ -746,8 +793,8 @@ __global__ __launch_bounds__(1024) void cm_select(const unsigned long long* __re
             const int j = (int)(~(unsigned)(key & 0xffffffffull));
             const float v = __uint_as_float(bits);
             ok = v > thr && col_best[(int64_t)n * S + j] == bits;
-            // mask_border: only the LOW side of each grid axis is removed (reference quirk).
             ok = ok && (i / w0c >= border) && (i % w0c >= border) && (j / w1c >= border) && (j % w1c >= border);
+            ok = ok && (i / w0c < hi_y0) && (i % w0c < hi_x0) && (j / w1c < hi_y1) && (j % w1c < hi_x1);
         }
         flags[(int64_t)n * L + i] = ok ? 1 : 0;
         local += ok ? 1 : 0;
@@ -815,6 +862,7 @@ struct Workspace {
     unsigned int* col_best;
     uint8_t* flags;
     int32_t* counts;
+    int32_t* extents;        // [N][4] valid (h0, w0, h1, w1) of padded frames (masked entry point)
     float2* cand;            // [N][ntn][L][CAND_SLOTS_MAX]
     uint8_t* cand_cnt;       // [N][ntn][L]
     size_t bytes;
@@ -838,6 +886,7 @@ Workspace carve(void* base, int N, int L, int S) {
     w.col_best = reinterpret_cast<unsigned int*>(take((size_t)N * S * 4));
     w.flags = reinterpret_cast<uint8_t*>(take((size_t)N * L));
     w.counts = reinterpret_cast<int32_t*>(take((size_t)N * 4));
+    w.extents = reinterpret_cast<int32_t*>(take((size_t)N * 16));
     w.cand_cnt = reinterpret_cast<uint8_t*>(take((size_t)N * ntn * L));
     w.cand = reinterpret_cast<float2*>(take((size_t)N * ntn * L * CAND_SLOTS_MAX * sizeof(float2)));
     w.bytes = off;
@@ -967,8 +1016,10 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
                            w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, g.ntm, g.ntn);
         launch_gemm<MODE_SELECT>(g, N, prescale, stream);
     }
+    if (mask0 && border > 0)
+        hipLaunchKernelGGL(cm_mask_extents, dim3(N, 2), dim3(256), 0, stream, mask0, mask1, w.extents, h0c, w0c, h1c, w1c);
     hipLaunchKernelGGL(cm_select, dim3(N), dim3(1024), 0, stream, w.row_best, w.col_best, w.flags, w.counts, L,
-                       S, thr, border, w0c, w1c);
+                       S, thr, border, w0c, w1c, mask0 && border > 0 ? w.extents : nullptr);
     hipLaunchKernelGGL(cm_compact, dim3(N), dim3(1024), 0, stream, w.row_best, w.flags, w.counts, N, L, w0c,
                        w1c, scale0, scale1, coarse_scale, b_ids, i_ids, j_ids, mconf, mkpts0, mkpts1, count);
     return check_launch(what);

@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     constexpr int STAGE = 32 * KC * 4;       // one A stage: 32 rows x KC channels (fp32, or fp16 hi plane + fp16 lo plane)
     constexpr int PIECES = STAGE / 1024;     // DMA instructions per stage
     constexpr int NSTG = 3;                  // ring depth per wave: two stages in flight while one is multiplied
+    // (d) below: the schedule is only known to be reproducible with ONE workgroup per CU.  __launch_bounds__ does not cap
+    // residency; the LDS footprint does -- the ring alone must exceed half of the CU's 160 KB, whatever C, Vq or MAXL are.
+    static_assert(2 * (4 * NSTG * STAGE) > 160 * 1024, "fine_match: the DMA ring must force one workgroup per CU");
     constexpr int RB = SPLIT ? KC * 2 : KC * 4;          // bytes of a row inside a stage (per plane)
     constexpr int NS = RB / 16;                          // its 16-byte slots: 16, 8 or 4
     constexpr int PLANE = 32 * RB;                       // split input: bytes of one plane of a stage
@@ -354,6 +357,7 @@ int fine_match_any(FineArgs g, bool split, int C, hipStream_t stream, const char
     if (g.left > g.W || g.left * g.left > MAXL || g.W * g.W > MAXWW || (g.left & 1) == 0 || (g.W & 1) == 0) return DFSFM_E_UNSUPPORTED;
     if (C != 128 && C != 64) return DFSFM_E_UNSUPPORTED;
     if (fine_smem_bytes(C, g.Vq) > 160 * 1024) return DFSFM_E_UNSUPPORTED;   // LDS budget: Vq <= 40 at C = 128, <= 61 at C = 64
+    if (2 * fine_smem_bytes(C, g.Vq) <= 160 * 1024) return DFSFM_E_UNSUPPORTED;  // single-residency invariant (see the kernel header, (d))
     const uintptr_t al = split ? (reinterpret_cast<uintptr_t>(g.ref_h) | reinterpret_cast<uintptr_t>(g.ref_l) |
                                   reinterpret_cast<uintptr_t>(g.qry_h) | reinterpret_cast<uintptr_t>(g.qry_l))
                                : (reinterpret_cast<uintptr_t>(g.ref) | reinterpret_cast<uintptr_t>(g.qry));

@@ -153,6 +153,7 @@ class HipMatchformer(ParamModule):
         return ops.conv2d_nhwc(t, P["l3o2_3"], 1, 1, out_split=True)                    # conv3x3 -> c3_out [B,h,w,256]
 
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def forward(self, data: dict):
         """Updates ``data`` in place like Matchformer.forward (matchformer.py:21-52, fine.enable=False)."""
         img0, img1 = data["image0"], data["image1"]

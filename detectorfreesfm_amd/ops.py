@@ -14,9 +14,15 @@ from . import _lib
 
 _workspaces = {}
 FP16_MAX = 65504.0
-# opt-in range guard of the split-plane representation (|v| < 65504): every producer of split
-# planes checks its output for saturation (one abs-max reduction + host sync per launch: a debugging aid, off by default)
+# Range guards of the split-plane representation (|v| < 65504).
+# * default: the FIRST call of every model entry point after ``load_state_dict`` runs inside ``range_sweep`` -- every
+#   producer of split planes queues the abs-max of what it wrote (device scalars, no host sync per launch) and the sweep
+#   reads them back ONCE at the end of the call; a saturated activation raises there instead of silently clamping.  Later
+#   calls pay nothing.  DFSFM_RANGE_SWEEP=0 switches it off.
+# * DFSFM_DEBUG_RANGE=1 / set_debug_range(True): every producer checks every launch at once (one host sync per launch).
 _debug_range = os.environ.get("DFSFM_DEBUG_RANGE", "0") == "1"
+RANGE_SWEEP = os.environ.get("DFSFM_RANGE_SWEEP", "1") != "0"
+_sweep = None            # list of (producer, abs-max device scalar) while a sweep is open
 
 
 def set_debug_range(on: bool):
@@ -30,6 +36,56 @@ def check_split_range(sa, what: str):
     if sa.hi.numel() and float(sa.hi.abs().max()) >= FP16_MAX:
         raise _lib.DfsfmError(f"{what}: activation outside the split-plane range |v| < {FP16_MAX:.0f} "
                               "(the fp16x2 representation would saturate; rescale the layer)")
+
+
+def _range(sa, what: str):
+    """Called by every producer of split planes on its output."""
+    if _debug_range:
+        check_split_range(sa, what)
+    elif _sweep is not None and sa.hi.numel():
+        _sweep.append((what, sa.hi.abs().max()))
+
+
+class range_sweep:
+    """Context manager: collect the abs-max of every split-plane tensor produced inside, check them with one host read."""
+
+    def __init__(self, label: str):
+        self.label, self.mine = label, False
+
+    def __enter__(self):
+        global _sweep
+        if _sweep is None and RANGE_SWEEP and not _debug_range:
+            _sweep, self.mine = [], True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _sweep
+        if not self.mine:
+            return False
+        items, _sweep = _sweep, None
+        if et is None and items:
+            mx = torch.stack([v.float() for _, v in items]).cpu()
+            bad = sorted({n for (n, _), m in zip(items, mx.tolist()) if m >= FP16_MAX})
+            if bad:
+                raise _lib.DfsfmError(f"{self.label}: activations outside the split-plane range |v| < {FP16_MAX:.0f} after "
+                                      f"{', '.join(bad)} (the fp16x2 representation saturates there; these weights need a "
+                                      "rescaled layer -- DFSFM_DEBUG_RANGE=1 names the first launch)")
+        return False
+
+
+def first_call_range_sweep(fn):
+    """Method decorator for the models' entry points: the first call after ``load_state_dict`` (``_range_done`` is cleared
+    there, params.ParamModule) runs under ``range_sweep``."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        done = self.__dict__.setdefault("_range_done", set())
+        if fn.__name__ in done or not RANGE_SWEEP:
+            return fn(self, *a, **kw)
+        with range_sweep(f"{type(self).__name__}.{fn.__name__}"):
+            out = fn(self, *a, **kw)
+        done.add(fn.__name__)
+        return out
+    return wrapper
 
 
 def _device_of(a):
@@ -135,8 +191,8 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, 
                                         _ptr(out), N, L, S, H, D, q.stride(1), k.stride(1), v.stride(1),
                                         ldo, eps, _ptr(oh), _ptr(ol), ldos, _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "dfsfm_linear_attention_f32")
-    if _debug_range and out_split:
-        check_split_range(res, "linear_attention")
+    if out_split:
+        _range(res, "linear_attention")
     return res
 
 
@@ -177,8 +233,8 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=No
     if (mask0 is None) != (mask1 is None):
         raise _lib.DfsfmError("coarse_match: mask0 and mask1 come together")
     if mask0 is not None:
-        if not split or int(border) != 0:
-            raise _lib.DfsfmError("coarse_match: padding masks need the split-plane entry point and border 0")
+        if not split:
+            raise _lib.DfsfmError("coarse_match: padding masks need the split-plane entry point")
         mk0 = _as_u8(mask0.to(dev).reshape(N, -1))
         mk1 = _as_u8(mask1.to(dev).reshape(N, -1))
         if mk0.shape != (N, L) or mk1.shape != (N, S):
@@ -376,8 +432,8 @@ def layernorm(x, gamma, beta, eps=1e-5, residual=None, out=None, out_split=None,
     rc = _lib.lib().dfsfm_layernorm_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(r32), _ptr(rh),
                                         _ptr(rl), ldr, _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
     _lib.check(rc, "dfsfm_layernorm_f32")
-    if _debug_range and out_split is not None:
-        check_split_range(out_split, "layernorm")
+    if out_split is not None:
+        _range(out_split, "layernorm")
     return out
 
 
@@ -395,8 +451,7 @@ def split_rows(x, add=None, out=None, out_split=None):
         rc = _lib.lib().dfsfm_split_rows_blocked_f32(_ptr(x), x.shape[1], x.stride(0), x.stride(1), _ptr(out_split.hi),
                                                      _ptr(out_split.lo), ldos, rows_s, C, _stream())
         _lib.check(rc, "dfsfm_split_rows_blocked_f32")
-        if _debug_range:
-            check_split_range(out_split, "split_rows")
+        _range(out_split, "split_rows")
         return
     rows, ldx = _rows_ld(x)
     ldo = ldos = 0
@@ -413,8 +468,8 @@ def split_rows(x, add=None, out=None, out_split=None):
     rc = _lib.lib().dfsfm_split_rows_f32(_ptr(x), ldx, _ptr(add), add_rows, _ptr(out), ldo, _ptr(oh), _ptr(ol), ldos,
                                          rows, C, _stream())
     _lib.check(rc, "dfsfm_split_rows_f32")
-    if _debug_range and out_split is not None:
-        check_split_range(out_split, "split_rows")
+    if out_split is not None:
+        _range(out_split, "split_rows")
 
 
 @_on_device
@@ -439,8 +494,8 @@ def dwconv3x3(x, w, bias, mode=0, out_split=False):
     rc = _lib.lib().dfsfm_dwconv3x3_nhwc_f32(_ptr(x), N, H, W, C, _ptr(w9c), _ptr(bias), int(mode), _ptr(out), _ptr(oh),
                                              _ptr(ol), _stream())
     _lib.check(rc, "dfsfm_dwconv3x3_nhwc_f32")
-    if _debug_range and out_split:
-        check_split_range(res, "dwconv3x3")
+    if out_split:
+        _range(res, "dwconv3x3")
     return res
 
 
@@ -557,8 +612,8 @@ def layernorm2d(x, affine, bias, residual=None, out=None, out_split=None, want_f
     rc = _lib.lib().dfsfm_layernorm2d_f32(_ptr(x), ldx, _ptr(affine), _ptr(bias), _ptr(rh), _ptr(rl), ldr, _ptr(out), ldo,
                                           _ptr(oh), _ptr(ol), ldos, rows, C, _stream())
     _lib.check(rc, "dfsfm_layernorm2d_f32")
-    if _debug_range and out_split is not None:
-        check_split_range(out_split, "layernorm2d")
+    if out_split is not None:
+        _range(out_split, "layernorm2d")
     return out
 
 
@@ -815,8 +870,8 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
             _ptr(x), sxn, xt.stride(1), xt.stride(2), N, H, W, Cin, _ptr(pw.w32), pw.Cout, pw.kh, pw.kw, stride, pad,
             _ptr(pw.bias), 1 if relu else 0, _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, _stream())
         _lib.check(rc, "dfsfm_conv2d_direct_f32")
-        if _debug_range and out_split:
-            check_split_range(result, "conv2d_nhwc(direct)")
+        if out_split:
+            _range(result, "conv2d_nhwc(direct)")
         return result
     rc = _lib.lib().dfsfm_conv2d_nhwc_f32(
         None if split_in else _ptr(x), _ptr(x.hi) if split_in else None, _ptr(x.lo) if split_in else None,
@@ -824,8 +879,8 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
         stride, pad, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, int(relu),
         _ptr(o32), ldo, _ptr(oh), _ptr(ol), ldo_s, cout_s, 1 if pw.tap_padded else 0, None, None, 0.0, _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32")
-    if _debug_range and out_split:
-        check_split_range(result, "conv2d_nhwc")
+    if out_split:
+        _range(result, f"conv2d_nhwc({pw.kh}x{pw.kw}, {Cin}->{pw.Cout})")
     return result
 
 
@@ -889,8 +944,8 @@ def linear_ln(x: "SplitAct", pw: PackedDense, gamma, beta, eps=1e-5, residual=No
         pw.Kpad, 1, 1, 1, 0, _ptr(pw.bias), _ptr(r32), _ptr(rh), _ptr(rl), ldr, 0, _ptr(out), ldo, _ptr(oh), _ptr(ol),
         ldo_s, pw.Cout if oh is not None else 0, 0, _ptr(gamma), _ptr(beta), float(eps), _stream())
     _lib.check(rc, "dfsfm_conv2d_nhwc_f32(ln)")
-    if _debug_range and out_split is not None:
-        check_split_range(out_split, "linear_ln")
+    if out_split is not None:
+        _range(out_split, "linear_ln")
     return out
 
 
@@ -1038,8 +1093,8 @@ def encoder_apply(x: "SplitAct", fw: EncoderFusedWeights, kv_image, S, q_mask=No
                                             _ptr(fw.n2[1]), float(eps), float(attn_eps), _ptr(oh), _ptr(ol), ldo, _ptr(out),
                                             ldo32, _ptr(dbg), int(debug_stage), _stream())
     _lib.check(rc, "dfsfm_encoder_apply_f32")
-    if _debug_range and out_split is not None:
-        check_split_range(out_split, "encoder_apply")
+    if out_split is not None:
+        _range(out_split, "encoder_apply")
     return dbg
 
 

@@ -327,6 +327,11 @@ class ParamModule(nn.Module):
                 mod.register_parameter(parts[-1], nn.Parameter(init, requires_grad=False))
             self._names.append(name)
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """New weights: the next call of every entry point runs the split-plane range sweep again (ops.range_sweep)."""
+        self.__dict__["_range_done"] = set()
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
     def p(self, name: str) -> torch.Tensor:
         obj = self
         for part in name.split("."):

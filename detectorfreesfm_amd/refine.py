@@ -140,6 +140,7 @@ class HipMultiviewMatcher(ParamModule):
         return dst
 
     @torch.no_grad()
+    @ops.first_call_range_sweep
     def forward(self, data: dict, chunk_track: int = 1000, chunk_backbone_img: bool = True):
         """Updates ``data`` in place like MultiviewMatcher.forward(test) (MultiviewMatcher.py:59-405)."""
         P = self._packed or self._pack()

@@ -21,6 +21,28 @@ def coarse_pair_batch(n_pairs: int, H: int = 480, W: int = 640, seed: int = 1000
             "scale0": torch.ones(n_pairs, 2), "scale1": torch.ones(n_pairs, 2)}
 
 
+def coarse_pair_padded(n_pairs: int, H: int = 96, W: int = 128, seed: int = 1000, shift=(1, 2), valid=None):
+    """``coarse_pair_batch`` frames as a ``pad_to`` dataset hands them over (src/dataset/utils.py:104-121: the frame sits in
+    the top-left corner of a zero canvas; the mask marks it) plus ``mask0`` / ``mask1`` [N, H/8, W/8] bool at the coarse
+    resolution -- the optional inputs of LoFTR.forward (loftr.py:35-36, 61-63).  ``valid``: per pair ((h0, w0), (h1, w1)) in
+    coarse cells; default: a different rectangle for each of the first pairs, the rest full frames."""
+    data = coarse_pair_batch(n_pairs, H, W, seed, shift)
+    hc, wc = H // 8, W // 8
+    default = [((hc - 3, wc - 2), (hc - 1, wc)), ((hc, wc - 4), (hc - 2, wc - 1))]
+    m0 = torch.zeros((n_pairs, hc, wc), dtype=torch.bool)
+    m1 = torch.zeros((n_pairs, hc, wc), dtype=torch.bool)
+    for p in range(n_pairs):
+        (h0, w0), (h1, w1) = (valid[p] if valid is not None else default[p] if p < len(default) else ((hc, wc), (hc, wc)))
+        m0[p, :h0, :w0] = True
+        m1[p, :h1, :w1] = True
+        data["image0"][p, :, 8 * h0:] = 0
+        data["image0"][p, :, :, 8 * w0:] = 0
+        data["image1"][p, :, 8 * h1:] = 0
+        data["image1"][p, :, :, 8 * w1:] = 0
+    data["mask0"], data["mask1"] = m0, m1
+    return data
+
+
 def coarse_pair_two_sizes(H0: int = 96, W0: int = 128, H1: int = 80, W1: int = 112, seed: int = 1000, shift=(1, 2)):
     """A pair whose two frames differ in size (LoFTR.forward's two-backbone-call branch, loftr.py:45-49):
     image1 = the (H1, W1) window of image0 that starts ``shift`` coarse cells in, + 0.02 N(0,1)."""

@@ -100,8 +100,10 @@ int dfsfm_coarse_match_split(const void* feat0_hi, const void* feat0_lo, const v
 /* The same with padding masks (mask0 [N,L], mask1 [N,S] uint8, 1 = valid): rows / columns of padded coarse cells take
  * no part in the softmaxes and produce no match, as `sim_matrix.masked_fill_(~(mask_c0[..., None] * mask_c1[:, None]), -INF)`
  * does in the reference (third_party/LoFTR/src/loftr/utils/coarse_matching.py:110-113; the MatchFormer copy
- * third_party/MatchFormer/model/backbone/coarse_matching.py:104-107).  `border` must be 0 with masks
- * (mask_border_with_padding is not implemented; MatchFormer's config has BORDER_RM = 0). */
+ * third_party/MatchFormer/model/backbone/coarse_matching.py:104-107).  With `border` > 0 the border rule is
+ * `mask_border_with_padding` (coarse_matching.py:25-41): the low `border` rows / columns of both grids as without masks,
+ * and per pair the last `border` rows / columns of each frame's valid extent (h = max column sum, w = max row sum of
+ * the mask) plus everything beyond them. */
 int dfsfm_coarse_match_split_masked(const void* feat0_hi, const void* feat0_lo, const void* feat1_hi,
                                     const void* feat1_lo, const uint8_t* mask0, const uint8_t* mask1, int N, int L, int S,
                                     int C, float temperature, float thr, int border, int h0c, int w0c, int h1c, int w1c,

@@ -38,6 +38,9 @@ CASES = {
     "loftr_e2e_planted": dict(weight_seed=0, alpha=3.0, data_seed=1000, n_pairs=2, H=96, W=128, thr=0.2),
     # two frames of different size: LoFTR.forward's two-backbone-call branch (loftr.py:45-49), L != S
     "loftr_e2e_two_sizes": dict(weight_seed=0, alpha=3.0, data_seed=1000, H0=96, W0=128, H1=80, W1=112, thr=0.2),
+    # padded frames with mask0 / mask1 (loftr.py:61-65): masks through the transformer, the dual-softmax and
+    # mask_border_with_padding (coarse_matching.py:25-41)
+    "loftr_e2e_masked": dict(weight_seed=0, alpha=3.0, data_seed=1000, n_pairs=2, H=96, W=128, thr=0.2),
 }
 
 
@@ -164,6 +167,8 @@ def main():
                  j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_f=data["mkpts0_f"].numpy(),
                  mkpts1_f=data["mkpts1_f"].numpy(), scale0=data["scale0"].numpy(), scale1=data["scale1"].numpy(), **c)
 
+        loftr_masked_golden(LoFTR)
+
         # refinement end-to-end: the real MultiviewMatcher with seeded weights (RoIAlign = stand-in)
         c = CASES["multiview_e2e"]
         rcfg = multiview_refinement_config()
@@ -178,6 +183,27 @@ def main():
                  scales=rdata["scales"].numpy(), **c)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def loftr_masked_golden(LoFTR=None):
+    """The real LoFTR module on padded frames with ``mask0`` / ``mask1`` -> tests/golden/loftr_e2e_masked.npz."""
+    if LoFTR is None:
+        LoFTR, _ = ref_import.import_loftr()
+    with torch.no_grad():
+        c = CASES["loftr_e2e_masked"]
+        cfg = loftr_coarse_only_config(c["thr"])
+        sd = planted_loftr_state_dict(loftr_param_spec(cfg), c["weight_seed"], c["alpha"])
+        m = LoFTR(cfg).eval()
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        data = synth.coarse_pair_padded(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+        data["scale0"] = torch.tensor([[1.5, 2.0], [1.0, 1.0]])
+        data["scale1"] = torch.tensor([[1.0, 1.25], [0.5, 2.0]])
+        m(data)
+        assert data["i_ids"].numel() > 60
+        np.savez(os.path.join(OUT, "loftr_e2e_masked.npz"), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(),
+                 j_ids=data["j_ids"].numpy(), mconf=data["mconf"].numpy(), mkpts0_f=data["mkpts0_f"].numpy(),
+                 mkpts1_f=data["mkpts1_f"].numpy(), scale0=data["scale0"].numpy(), scale1=data["scale1"].numpy(), **c)
+        print("loftr_e2e_masked.npz", data["i_ids"].numel(), "rows; per pair", torch.bincount(data["b_ids"]).tolist())
 
 
 def merge_golden():
@@ -348,6 +374,8 @@ def read_image_golden():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "merge":
         merge_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "loftr_masked":
+        loftr_masked_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "bags":
         bags_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "matchformer":

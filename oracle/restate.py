@@ -189,18 +189,24 @@ def resnet_fpn_8_2(sd, p, x, with_fine=True):
 # ----------------------------------------------------------------------------------------------
 
 
-def dual_softmax_conf(feat0, feat1, temperature):
-    """CoarseMatching.forward -- LoFTR utils/coarse_matching.py:103-116 (dual_softmax, no masks)."""
+def dual_softmax_conf(feat0, feat1, temperature, mask0=None, mask1=None):
+    """CoarseMatching.forward -- LoFTR utils/coarse_matching.py:103-116 (dual_softmax; padding masks [N,L] / [N,S]:
+    ``sim_matrix.masked_fill_(~(mask_c0[..., None] * mask_c1[:, None]).bool(), -INF)`` with INF = 1e9, :108-112)."""
     C = feat0.shape[-1]
     f0, f1 = feat0 / C ** 0.5, feat1 / C ** 0.5
     sim = torch.einsum("nlc,nsc->nls", f0, f1) / temperature
+    if mask0 is not None:
+        sim.masked_fill_(~(mask0[..., None] * mask1[:, None]).bool(), -1e9)
     return F.softmax(sim, 1) * F.softmax(sim, 2)
 
 
-def coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border_rm, scale0=None, scale1=None):
+def coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border_rm, scale0=None, scale1=None, mask0=None, mask1=None):
     """CoarseMatching.get_coarse_match (eval) -- coarse_matching.py:148-258, mask_border :8-22.
     The high-side border slices ``m[:, -b:0]`` are EMPTY, so only the first ``b`` rows/cols of
-    each grid are removed; reproduced here for index parity."""
+    each grid are removed; reproduced here for index parity.  With padding masks (``'mask0' in data``, [N,h,w]) the
+    border is ``mask_border_with_padding`` (:25-41) instead: the low side as above, and per pair the last ``b`` rows /
+    columns of each frame's VALID extent (h = max over columns of the column sums, w = max over rows of the row sums) and
+    everything beyond -- Python slices ``m[b_idx, h0 - bd:]``, so a negative start counts from the end."""
     N = conf.shape[0]
     h0, w0 = hw0_c
     h1, w1 = hw1_c
@@ -211,6 +217,14 @@ def coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border_rm, scale0=Non
         mask[:, :, :b] = False
         mask[:, :, :, :b] = False
         mask[:, :, :, :, :b] = False
+        if mask0 is not None:
+            h0s, w0s = mask0.sum(1).max(-1)[0].int(), mask0.sum(-1).max(-1)[0].int()
+            h1s, w1s = mask1.sum(1).max(-1)[0].int(), mask1.sum(-1).max(-1)[0].int()
+            for n, (a0, b0, a1, b1) in enumerate(zip(h0s, w0s, h1s, w1s)):
+                mask[n, a0 - b:] = False
+                mask[n, :, b0 - b:] = False
+                mask[n, :, :, a1 - b:] = False
+                mask[n, :, :, :, b1 - b:] = False
     mask = mask.view(N, h0 * w0, h1 * w1)
     mask = mask * (conf == conf.max(dim=2, keepdim=True)[0]) * (conf == conf.max(dim=1, keepdim=True)[0])
     mask_v, all_j = mask.max(dim=2)
@@ -228,9 +242,13 @@ def coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border_rm, scale0=Non
 
 
 def coarse_matching(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1,
-                    scale0=None, scale1=None, return_conf=False):
-    conf = dual_softmax_conf(feat0, feat1, temperature)
-    out = coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border_rm, scale0, scale1)
+                    scale0=None, scale1=None, return_conf=False, mask0=None, mask1=None):
+    """mask0 / mask1: padding masks [N,h0c,w0c] / [N,h1c,w1c] (1 = valid), as ``data['mask0']`` (loftr.py:61-65)."""
+    N = feat0.shape[0]
+    m0 = None if mask0 is None else mask0.reshape(N, -1)
+    m1 = None if mask1 is None else mask1.reshape(N, -1)
+    conf = dual_softmax_conf(feat0, feat1, temperature, m0, m1)
+    out = coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border_rm, scale0, scale1, mask0, mask1)
     if return_conf:
         out["conf_matrix"] = conf
     return out
@@ -254,11 +272,15 @@ def loftr_coarse_forward(sd, cfg, data, with_fine_backbone=True):
     pe = position_encoding_sine(cfg["coarse"]["d_model"], temp_bug_fix=cfg["coarse"]["temp_bug_fix"])
     f0 = (c0 + pe[:, :, :hw0_c[0], :hw0_c[1]]).flatten(2).transpose(1, 2)
     f1 = (c1 + pe[:, :, :hw1_c[0], :hw1_c[1]]).flatten(2).transpose(1, 2)
+    m0 = m1 = None                      # loftr.py:61-63: padding masks at the coarse resolution, flattened
+    if "mask0" in data:
+        m0, m1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
     f0, f1 = coarse_transformer(sd, "loftr_coarse.", f0, f1, cfg["coarse"]["layer_names"],
-                                cfg["coarse"]["nhead"])
+                                cfg["coarse"]["nhead"], m0, m1)
     mc = cfg["match_coarse"]
     out = coarse_matching(f0, f1, hw0_c, hw1_c, hw0_i, mc["thr"], mc["border_rm"],
-                          mc["dsmax_temperature"], data.get("scale0"), data.get("scale1"))
+                          mc["dsmax_temperature"], data.get("scale0"), data.get("scale1"),
+                          mask0=data.get("mask0"), mask1=data.get("mask1"))
     out.update({"feat_c0": f0, "feat_c1": f1, "hw0_c": hw0_c, "hw1_c": hw1_c,
                 "mkpts0_f": out["mkpts0_c"], "mkpts1_f": out["mkpts1_c"]})
     return out

@@ -41,10 +41,9 @@ def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale
         feat0, feat1 = feat0.float(), feat1.float()
     hw0_i = (hw0_c[0] * coarse_scale, hw0_c[1] * coarse_scale)
     if mask0 is not None:
-        from oracle import restate_matchformer as rmf
         N = feat0.shape[0]
-        conf = rmf.dual_softmax_conf_masked(feat0, feat1, temperature, mask0.reshape(N, -1).bool(), mask1.reshape(N, -1).bool())
-        return restate.coarse_match_from_conf(conf, hw0_c, hw1_c, hw0_i, thr, border, scale0, scale1)
+        return restate.coarse_matching(feat0, feat1, hw0_c, hw1_c, hw0_i, thr, border, temperature, scale0, scale1,
+                                       mask0=mask0.reshape(N, *hw0_c).bool(), mask1=mask1.reshape(N, *hw1_c).bool())
     return restate.coarse_matching(feat0, feat1, hw0_c, hw1_c, hw0_i, thr, border, temperature, scale0, scale1)
 
 

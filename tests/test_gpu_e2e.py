@@ -46,7 +46,9 @@ def _oracle_coarse(sd, cfg, data):
     """Oracle tables + its dense confidence matrix (for the per-entry exemption analysis)."""
     with torch.no_grad():
         o = restate.loftr_coarse_forward(sd, cfg, data, with_fine_backbone=False)
-        conf = restate.dual_softmax_conf(o["feat_c0"], o["feat_c1"], cfg["match_coarse"]["dsmax_temperature"])
+        m0 = data["mask0"].flatten(-2) if "mask0" in data else None
+        m1 = data["mask1"].flatten(-2) if "mask1" in data else None
+        conf = restate.dual_softmax_conf(o["feat_c0"], o["feat_c1"], cfg["match_coarse"]["dsmax_temperature"], m0, m1)
     return o, conf
 
 
@@ -111,6 +113,68 @@ def test_loftr_e2e_two_sizes_golden(built_lib, golden):
     _, conf = _oracle_coarse(sd, cfg, data)
     ex = _strict_coarse(d, {k: gz[k] for k in MATCH_KEYS}, conf, c["thr"], "loftr_e2e_two_sizes")
     assert len(ex) == 0 and len(gz["i_ids"]) > 30
+
+
+def test_loftr_e2e_masked_golden(built_lib, golden):
+    """Padded frames with mask0 / mask1 (loftr.py:61-65): fixture from the real LoFTR module -- masks in every linear
+    attention, the dual-softmax and mask_border_with_padding; both pairs of the batch share the 2N-sequence self layers."""
+    gz = golden("loftr_e2e_masked")
+    c = _case(gz)
+    cfg, sd, m = _loftr(c["thr"], seed=c["weight_seed"])
+    data = synth.coarse_pair_padded(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    d = synth.to_device(data, DEV)
+    m(d)
+    _, conf = _oracle_coarse(sd, cfg, data)
+    ex = _strict_coarse(d, {k: gz[k] for k in MATCH_KEYS}, conf, c["thr"], "loftr_e2e_masked")
+    assert len(ex) == 0 and len(d["i_ids"]) == len(gz["i_ids"]) > 60
+    assert np.array_equal(d["i_ids"].cpu().numpy(), gz["i_ids"]) and np.array_equal(d["j_ids"].cpu().numpy(), gz["j_ids"])
+    # the cached-token scene entry point takes the same masks
+    t0, hw = m.image_tokens(d["image0"])
+    t1, _ = m.image_tokens(d["image1"])
+    mt = m.match_tokens(t0, t1, hw, hw, (c["H"], c["W"]), d["scale0"], d["scale1"], mask0=d["mask0"], mask1=d["mask1"])
+    assert torch.equal(mt["i_ids"], d["i_ids"]) and torch.equal(mt["j_ids"], d["j_ids"])
+
+
+def test_loftr_masked_640x480_and_two_sizes_vs_oracle(built_lib):
+    """Masks at BASELINE configs[1]'s frame size (a 640x480 canvas holding a 600x440 and a 560x480 frame) and on frames of
+    two sizes (per-image self layers, L != S): rows identical to the oracle's."""
+    cfg, sd, m = _loftr(0.2)
+    data = synth.coarse_pair_padded(1, 480, 640, seed=1100, valid=[((55, 75), (60, 70))])
+    d = synth.to_device(data, DEV)
+    m(d)
+    o, conf = _oracle_coarse(sd, cfg, data)
+    assert o["i_ids"].numel() > 2000
+    ex = _strict_coarse(d, o, conf, 0.2, "640x480 masked")
+    assert len(ex) <= 3
+    two = synth.coarse_pair_two_sizes(96, 128, 80, 112, 1000)
+    two["mask0"] = torch.ones((1, 12, 16), dtype=torch.bool)
+    two["mask1"] = torch.ones((1, 10, 14), dtype=torch.bool)
+    two["mask0"][0, 10:] = False
+    two["mask1"][0, :, 11:] = False
+    d2 = synth.to_device(two, DEV)
+    m(d2)
+    o2, conf2 = _oracle_coarse(sd, cfg, two)
+    assert o2["i_ids"].numel() > 20
+    assert len(_strict_coarse(d2, o2, conf2, 0.2, "two sizes masked")) == 0
+
+
+@pytest.mark.parametrize("H,W", [(800, 1200), (1064, 1600)])
+def test_loftr_production_frame_sizes_vs_oracle(built_lib, H, W):
+    """The frame sizes the reference actually feeds the matcher: every shipped config resizes to 1200 or 1600 px
+    (src/coarse_match/coarse_match.py:15, hydra_configs/eth3d_sfm/dfsfm.yaml:76, hydra_configs/demo/dfsfm.yaml:48) ->
+    coarse grids 150x100 / 200x133, L = 15 000 / 26 600 (the positional-encoding buffer allows 256x256,
+    position_encoding.py:11-22).  One planted pair end to end against the oracle under the north_star rules: K1 with
+    S = 26 600 per image, K3 with 208 column tiles and its full candidate workspace, cm_compact over 26 600 rows."""
+    cfg, sd, m = _loftr(0.2)
+    data = synth.coarse_pair_batch(1, H, W, seed=1300)
+    d = synth.to_device(data, DEV)
+    m(d)
+    assert tuple(d["hw0_c"]) == (H // 8, W // 8)
+    o, conf = _oracle_coarse(sd, cfg, data)
+    assert o["i_ids"].numel() > 0.5 * (H // 8) * (W // 8)
+    ex = _strict_coarse(d, o, conf, 0.2, f"{W}x{H} planted")
+    assert len(ex) <= 3
 
 
 def test_loftr_640x480_planted_vs_oracle(built_lib):

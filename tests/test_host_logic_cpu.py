@@ -48,6 +48,74 @@ def test_coarse_different_image_sizes():
     assert torch.allclose(d["mkpts1_f"], o["mkpts1_f"])
 
 
+def test_range_sweep_bookkeeping_cpu():
+    """ops.range_sweep / first_call_range_sweep without a GPU: producers queue abs-max scalars only while a sweep is open,
+    one read at the end, a saturated plane raises, load_state_dict re-arms the sweep."""
+    from detectorfreesfm_amd import _lib, ops
+    ok = ops.SplitAct(torch.full((4, 8), 3.0).half(), torch.zeros((4, 8)).half(), 8)
+    sat = ops.SplitAct(torch.full((4, 8), 65504.0).half(), torch.zeros((4, 8)).half(), 8)
+    ops._range(sat, "outside")                       # no sweep open: ignored
+    with ops.range_sweep("t"):
+        ops._range(ok, "a")
+        assert len(ops._sweep) == 1
+    assert ops._sweep is None
+    with pytest.raises(_lib.DfsfmError, match="after b"):
+        with ops.range_sweep("t"):
+            ops._range(ok, "a")
+            ops._range(sat, "b")
+    assert ops._sweep is None
+    cfg = loftr_coarse_only_config(1e-3)
+    m = HipLoFTR(cfg).eval()
+    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    m.load_state_dict(sd, strict=True)
+    with cpu_ops():
+        m(dict(synth.coarse_pair_batch(1, 32, 32, seed=1)))
+    assert m._range_done == {"forward"}
+    m.load_state_dict(sd, strict=True)
+    assert m._range_done == set()
+
+
+def test_coarse_host_logic_with_padding_masks():
+    """mask0 / mask1 (loftr.py:61-65) through HipLoFTR's host logic: one batched 2N-sequence self layer with the
+    concatenated masks, cross layers with (query, source) masks swapped per direction, masked matching with
+    mask_border_with_padding -- equal frames, frames of two sizes, and the cached-token scene entry point."""
+    from detectorfreesfm_amd.params import planted_loftr_state_dict
+    cfg = loftr_coarse_only_config(0.2)
+    sd = planted_loftr_state_dict(loftr_param_spec(cfg), 0)
+    m = HipLoFTR(cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    data = synth.coarse_pair_padded(2, 96, 128, seed=1000)
+    with cpu_ops(), torch.no_grad():
+        d = dict(data)
+        m(d)
+        t0, hw = m.image_tokens(data["image0"])
+        t1, _ = m.image_tokens(data["image1"])
+        mt = m.match_tokens(t0, t1, hw, hw, (96, 128), mask0=data["mask0"], mask1=data["mask1"])
+    with torch.no_grad():
+        o = restate.loftr_coarse_forward(sd, cfg, data, with_fine_backbone=False)
+        plain = restate.loftr_coarse_forward(sd, cfg, {k: v for k, v in data.items() if not k.startswith("mask")},
+                                             with_fine_backbone=False)
+    assert o["i_ids"].numel() > 60 and not torch.equal(o["i_ids"], plain["i_ids"][:o["i_ids"].numel()])
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert torch.equal(d[k], o[k]) and torch.equal(mt[k], o[k]), k
+    assert torch.allclose(d["mconf"], o["mconf"], atol=1e-4) and torch.equal(d["mkpts1_f"], o["mkpts1_f"])
+    # two sizes: per-image self layers, L != S
+    two = synth.coarse_pair_two_sizes(96, 128, 80, 112, 1000)
+    two["mask0"] = torch.ones((1, 12, 16), dtype=torch.bool)
+    two["mask1"] = torch.ones((1, 10, 14), dtype=torch.bool)
+    two["mask0"][0, 10:] = False
+    two["mask1"][0, :, 11:] = False
+    with cpu_ops(), torch.no_grad():
+        d2 = dict(two)
+        m(d2)
+    with torch.no_grad():
+        o2 = restate.loftr_coarse_forward(sd, cfg, two, with_fine_backbone=False)
+    assert o2["i_ids"].numel() > 20
+    assert torch.equal(d2["i_ids"], o2["i_ids"]) and torch.equal(d2["j_ids"], o2["j_ids"])
+    with pytest.raises(ValueError):
+        m({"image0": data["image0"], "image1": data["image1"], "mask0": data["mask0"]})
+
+
 @pytest.mark.parametrize("factor,varlen", [(None, True), (2, False), (2, True)])
 def test_refine_host_logic(factor, varlen):
     cfg = multiview_refinement_config(factor)

@@ -99,6 +99,28 @@ def test_loftr_e2e_two_sizes(golden):
         assert np.array_equal(o[k].numpy(), gz[k]), k
 
 
+def test_loftr_e2e_masked(golden):
+    """Padded frames with mask0 / mask1 (loftr.py:61-65; mask_border_with_padding, coarse_matching.py:25-41): oracle ==
+    real reference, and no match lies in the padding or in the last two valid rows / columns."""
+    gz = golden("loftr_e2e_masked")
+    c = _case(gz)
+    cfg = loftr_coarse_only_config(c["thr"])
+    sd = planted_loftr_state_dict(loftr_param_spec(cfg), c["weight_seed"], c["alpha"])
+    data = synth.coarse_pair_padded(c["n_pairs"], c["H"], c["W"], c["data_seed"])
+    data["scale0"], data["scale1"] = torch.from_numpy(gz["scale0"]), torch.from_numpy(gz["scale1"])
+    with torch.no_grad():
+        o = restate.loftr_coarse_forward(sd, cfg, data)
+    assert len(gz["i_ids"]) > 60
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+        assert np.array_equal(o[k].numpy(), gz[k]), k
+    wc = c["W"] // 8
+    for n in range(c["n_pairs"]):
+        sel = gz["b_ids"] == n
+        h0, w0 = int(data["mask0"][n].sum(0).max()), int(data["mask0"][n].sum(1).max())
+        assert (gz["i_ids"][sel] // wc < h0 - 2).all() and (gz["i_ids"][sel] % wc < w0 - 2).all()
+        assert (gz["i_ids"][sel] // wc >= 2).all() and (gz["i_ids"][sel] % wc >= 2).all()
+
+
 def test_multiview_e2e(golden):
     gz = golden("multiview_e2e")
     c = _case(gz)
