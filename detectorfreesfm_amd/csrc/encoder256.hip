@@ -1,0 +1,533 @@
+// K2 + K1 (apply half) fused for d_model 256, 8 heads of 32 -- the COARSE transformer's LoFTREncoderLayer on gfx950 (MI355X).
+//
+// Replaces, per layer application of
+//   LoFTREncoderLayer.forward   third_party/LoFTR/src/loftr/loftr_module/transformer.py:35-58
+//   LinearAttention.forward     third_party/LoFTR/src/loftr/loftr_module/linear_attention.py:31-47 (the query side)
+// the launches  q GEMM -> attention apply -> merge + LayerNorm1 -> mlp.0 + ReLU -> mlp.2 + LayerNorm2 + residual  (five
+// kernels that round-trip q, the message, [x | norm1(message)] and the 512-wide hidden layer through HBM) by ONE kernel
+// that reads a token row once (1 KB as fp16x2 split planes) and writes it once.  The source side (k | v projection,
+// phi(K)^T V) stays on the split-plane GEMM + K1's partial-sum kernel; `enc256_image_kernel` (linear_attention.hip) turns
+// the per-head KV / Ksum sums into the "apply image" this kernel consumes.
+//
+// Same construction as encoder_fused.hip (d_model 128), re-tiled so that a 256-channel layer fits one wave's registers:
+//  * TOKEN-STATIONARY, TRANSPOSED: out^T[channel][token] = W[channel][k] x^T[k][token] on v_mfma_f32_16x16x32_f16: a wave owns
+//    16 tokens (lane = token n = lane & 15, lane group g = lane >> 4); an accumulator block is 16 channels x 16 tokens in
+//    4 registers (row 4 g + r), and two consecutive blocks ARE the B operand of the next GEMM's 32-wide k-step after an
+//    fp32 -> fp16x2 split in registers: slot (g, j) of k-step s  <->  channel 32 s + 16 (j >> 2) + 4 g + (j & 3).  The host
+//    permutes the weight columns accordingly (ops.Encoder256Weights); x fragments are read from the staging tile in the
+//    same order.  No activation touches LDS between the input tile and the output tile, no cross-lane traffic except the
+//    lane-group reductions (xor 16, xor 32) of Z and the LayerNorm statistics.
+//  * fp16x2 split arithmetic (value = hi + lo / 2048): three MFMAs per product, fp32 accumulation, lo * lo dropped.
+//  * The four waves of a workgroup (64 tokens) share only the weight stream: 128 slabs of 16 KB per tile (q 16, merge 16,
+//    8 x [mlp.0 chunk 8 + mlp.2 chunk 4]) through the 4-deep LDS ring of enc_common.h; one wave per SIMD.
+//  * With D = 32 a head is exactly one k-step: KV^T of a head is two 16 x 32 A fragments, the message of a head 6 MFMAs.
+#include "common.h"
+#include "enc_common.h"
+#include <cstdlib>
+
+namespace {
+
+using namespace dfsfm;
+using namespace dfsfm_enc;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int EC = 256;                  // d_model
+constexpr int NB16 = EC / 16;            // 16-channel accumulator blocks
+constexpr int NKS = EC / 32;             // 32-wide k-steps over d_model (= heads)
+constexpr int STG = 16384;               // per-wave staging tile: 16 tokens x 256 channels, hi + lo planes (8 KB each)
+constexpr int PLANE = 8192;
+constexpr int NSLAB = 128;               // q 16, merge 16, 8 x (mlp.0 chunk 8 + mlp.2 chunk 4)
+constexpr int KVIMG = 32 * 1024 + 1024;  // bytes per sequence: 16 KV^T fragment pairs (hi, lo) + Ksum[256]
+constexpr int SMEM_APPLY = RING + 4 * STG + 4 * EC * 4 + 4 * 2048;   // + LayerNorm gamma / beta + Ksum of a wave's two sequences
+
+__device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// Two consecutive accumulator blocks (lane (n, g): a[r] = channel 16 (2 s) + 4 g + r, b[r] = channel 16 (2 s + 1) + 4 g + r of
+// token n) -> the operand fragment pair of k-step s.  Same saturating split as encoder_fused.hip's to_frags.
+__device__ __forceinline__ void to_frag16(const float (&a)[4], const float (&b)[4], half8& h, half8& l) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const half2_t big = {(_Float16)65504.f, (_Float16)65504.f};
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        half2_t ha = {(_Float16)a[r], (_Float16)a[r + 1]};
+        ha = __builtin_elementwise_max(__builtin_elementwise_min(ha, big), -big);
+        const half2_t la = {(_Float16)((a[r] - (float)ha[0]) * 2048.f), (_Float16)((a[r + 1] - (float)ha[1]) * 2048.f)};
+        half2_t hb = {(_Float16)b[r], (_Float16)b[r + 1]};
+        hb = __builtin_elementwise_max(__builtin_elementwise_min(hb, big), -big);
+        const half2_t lb = {(_Float16)((b[r] - (float)hb[0]) * 2048.f), (_Float16)((b[r + 1] - (float)hb[1]) * 2048.f)};
+        h[r] = ha[0]; h[r + 1] = ha[1]; l[r] = la[0]; l[r + 1] = la[1];
+        h[4 + r] = hb[0]; h[5 + r] = hb[1]; l[4 + r] = lb[0]; l[5 + r] = lb[1];
+    }
+}
+
+// byte offset of 16-byte chunk c (0..31) of token row t inside a staging plane (16 rows x 512 B): XOR swizzle of the low four
+// chunk bits by the row, so that the 8-byte fragment reads of 16 different rows (same logical chunk) spread over all banks
+__device__ __forceinline__ int stg_off(int t, int c) { return t * 512 + ((c ^ (t & 15)) << 4); }
+
+// One slab = KPS k-steps x NB blocks of (hi, lo) A fragments:  acc[B0 + b] += W(b, ks) * B[ks]  with the 3-MFMA split product
+// am += W_hi B_hi, ax += W_lo B_hi + W_hi B_lo (an accumulator is reused after NB >= 4 other MFMAs).  The four DMA requests of the
+// ring refill follow groups of MFMAs that are already executing (encoder_fused.hip: in front of the first MFMA they cost
+// ~100 issue cycles each); sched_barriers pin the places.
+template <int NB, int KPS, int B0>
+__device__ __forceinline__ void slab_mma16(SlabRing& ring, int lane, f32x4 (&am)[NB16], f32x4 (&ax)[NB16], const half8* bh,
+                                           const half8* bl) {
+    static_assert(NB * KPS == 8, "a slab holds 16 fragments");
+    const char* slab = ring.acquire_wait();
+    const unsigned gn = ring.next + NSTG - 1;
+    int piece = 0;
+#pragma unroll
+    for (int ks = 0; ks < KPS; ++ks) {
+        half8 wh[NB], wl[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 0) * 1024 + lane * 16);
+            wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 1) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            am[B0 + b] = mfma16(wh[b], bh[ks], am[B0 + b]);
+            if (KPS == 1 && b == NB / 2 - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                ring.issue_piece(gn, piece++);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ring.issue_piece(gn, piece++);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ax[B0 + b] = mfma16(wl[b], bh[ks], ax[B0 + b]);
+        __builtin_amdgcn_sched_barrier(0);
+        ring.issue_piece(gn, piece++);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            ax[B0 + b] = mfma16(wh[b], bl[ks], ax[B0 + b]);
+            if (KPS == 1 && b == NB / 2 - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                ring.issue_piece(gn, piece++);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    ring.advance();
+}
+
+struct Apply256Args {
+    const _Float16 *xh, *xl;     // x rows as split planes, row stride ldx (elements)
+    int64_t ldx;
+    unsigned xbytes;
+    const char* wstream;         // NSLAB slabs
+    const char* kvimg;           // [N][KVIMG]
+    const uint8_t* qmask;        // [N][qm_per_seq] or null
+    int q_group, qm_per_seq;
+    const float *g1, *b1, *g2, *b2;
+    float eps1, eps2, attn_eps;
+    _Float16 *oh, *ol;           // out rows as split planes (or null)
+    int64_t ldo;
+    float* o32;                  // out rows fp32 (or null)
+    int64_t ldo32;
+    int64_t M;                   // rows = N * L
+    int L, N, S;
+    int ntiles;                  // ceil(M / 64)
+    float* dbg;                  // [M][256] fp32 dump of one intermediate (tests), or null
+    int dbg_stage;               // 1 q, 2 message, 3 norm1(merge), 4 mlp output (before norm2)
+};
+
+// accumulator-layout values of block B (lane (n, g): v[r] = channel 16 B + 4 g + r) -> dbg rows.  Force-inlined like everything
+// in the fused encoder kernels (a real call from a 512-register kernel corrupted caller state, encoder_fused.hip).
+__device__ __forceinline__ void dump16(const Apply256Args& g, const float (&v)[4], int B, int64_t row, bool valid, int grp) {
+    if (!valid) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g.dbg[row * EC + 16 * B + 4 * grp + r] = v[r];
+}
+
+__global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 15, grp = lane >> 4;
+    char* stg = smem + RING + wave * STG;
+    float* s_ln = reinterpret_cast<float*>(smem + RING + 4 * STG);               // [g1 | b1 | g2 | b2][EC]
+    if (tid < EC) {
+        s_ln[tid] = g.g1[tid];
+        s_ln[EC + tid] = g.b1[tid];
+        s_ln[2 * EC + tid] = g.g2[tid];
+        s_ln[3 * EC + tid] = g.b2[tid];
+    }
+    __syncthreads();
+
+    SlabRing ring;
+    ring.ring = smem;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.wstream, 0, NSLAB * SLAB, 0x00020000);
+    ring.lane_off = (unsigned)(wave * 4096 + lane * 16);
+    ring.wave = wave;
+    ring.nslab = NSLAB;
+    ring.prologue();
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void*)g.kvimg, 0, (unsigned)((int64_t)g.N * KVIMG), 0x00020000);
+    const float Sf = (float)g.S;
+    char* s_ks = smem + RING + 4 * STG + 4 * EC * 4 + wave * 2048;             // Ksum[256] of the wave's (at most) two sequences
+
+    // a lane id the compiler cannot hoist out of the tile loop (as loop invariants the staging addresses were spilled, and
+    // every scratch reload drained the DMA queue: encoder_fused.hip)
+    auto fresh_lane = []() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    // x rows of tile t -> this wave's staging (rows of 512 B per plane, 16-byte chunks XOR-swizzled on the SOURCE side: LDS-DMA
+    // destinations are lane-linear) + Ksum of the two sequences the 16 rows may belong to
+    auto load_x = [&](int t) __attribute__((always_inline)) {
+        const int64_t r0 = ((int64_t)t * 4 + wave) * 16;
+        const int fl = fresh_lane();
+        const int trow = fl >> 5, p = fl & 31;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int seq = min((int)(r0 / g.L) + u, g.N - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rkv, (lds_void*)(s_ks + u * 1024), 16,
+                                                     (unsigned)((int64_t)seq * KVIMG + 32768 + fl * 16), 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tt = 2 * i + trow;
+            const int64_t rr = r0 + tt;
+            const unsigned off = rr < g.M ? (unsigned)((rr * g.ldx + ((p ^ (tt & 15)) << 3)) * 2) : g.xbytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + PLANE + i * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < g.ntiles) load_x(blockIdx.x);
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        const int64_t row0 = ((int64_t)tile * 4 + wave) * 16;
+        const int64_t row = row0 + tok;
+        const bool valid = row < g.M;
+        // sequence of this lane's token; the wave's 16 rows touch at most two sequences (L >= 16)
+        const int n_first = (int)(row0 / g.L);
+        const int64_t bound = (int64_t)(n_first + 1) * g.L;
+        const int n_tok = min(row >= bound ? n_first + 1 : n_first, g.N - 1);
+        const int l_tok = (int)(row - (int64_t)n_tok * g.L);
+        float qm = valid ? 1.f : 0.f;
+        if (g.qmask && valid) qm = (float)g.qmask[(int64_t)n_tok * g.qm_per_seq + l_tok / g.q_group];
+        const bool two = __builtin_amdgcn_readfirstlane((int)(row0 + 15 >= bound && n_first + 1 < g.N)) != 0;
+
+        wait_vmcnt<0>();        // the x tile has landed (this also waits for the slabs in flight: once per tile)
+        // B fragment pair of x for k-step s, from the staging tile (it stays intact until the output overwrites it in place):
+        // slots j < 4: channels 32 s + 4 g + j, slots j >= 4: channels 32 s + 16 + 4 g + (j - 4)
+        auto xfrag = [&](int s, half8& fh, half8& fl) __attribute__((always_inline)) {
+            const int c0 = 4 * s + (grp >> 1), o8 = 8 * (grp & 1);
+            const half4 a0 = *reinterpret_cast<const half4*>(stg + stg_off(tok, c0) + o8);
+            const half4 a1 = *reinterpret_cast<const half4*>(stg + stg_off(tok, c0 + 2) + o8);
+            const half4 b0 = *reinterpret_cast<const half4*>(stg + PLANE + stg_off(tok, c0) + o8);
+            const half4 b1 = *reinterpret_cast<const half4*>(stg + PLANE + stg_off(tok, c0 + 2) + o8);
+            fh = half8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            fl = half8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        };
+
+        // KV^T fragments of the wave's first sequence: requested now, consumed after the q GEMM
+        half8 kvh[2 * NKS], kvl[2 * NKS];
+        {
+            const char* img = g.kvimg + (int64_t)min(n_first, g.N - 1) * KVIMG + lane * 16;
+#pragma unroll
+            for (int f = 0; f < 2 * NKS; ++f) {
+                kvh[f] = *reinterpret_cast<const half8*>(img + (f * 2 + 0) * 1024);
+                kvl[f] = *reinterpret_cast<const half8*>(img + (f * 2 + 1) * 1024);
+            }
+        }
+        // LayerNorm statistics of this lane's token: its 64 channels (16 blocks x 4) + the other three lane groups' (xor 16, 32)
+#define ENC_ROWSTATS(VAL, EPS, MEAN, RSTD)                                                                            \
+        float MEAN, RSTD;                                                                                             \
+        {                                                                                                             \
+            float sum_ = 0.f;                                                                                         \
+            _Pragma("unroll") for (int b = 0; b < NB16; ++b) _Pragma("unroll") for (int r = 0; r < 4; ++r) sum_ += VAL(b, r); \
+            sum_ += __shfl_xor(sum_, 16);                                                                             \
+            sum_ += __shfl_xor(sum_, 32);                                                                             \
+            MEAN = sum_ / (float)EC;                                                                                  \
+            float sq_ = 0.f;                                                                                          \
+            _Pragma("unroll") for (int b = 0; b < NB16; ++b) _Pragma("unroll") for (int r = 0; r < 4; ++r)            \
+                sq_ += (VAL(b, r) - MEAN) * (VAL(b, r) - MEAN);                                                       \
+            sq_ += __shfl_xor(sq_, 16);                                                                               \
+            sq_ += __shfl_xor(sq_, 32);                                                                               \
+            RSTD = 1.f / sqrtf(sq_ / (float)EC + (EPS));                                                              \
+        }
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        half8 ah[NKS], al[NKS];          // operand of the next GEMM: phi(q), then the message, then norm1(merge)
+        float Z[NKS];
+        // ---- S1: q = W_q x, phi(q), Z ------------------------------------------------------------------------------------
+        {
+            f32x4 am[NB16], ax[NB16];
+#pragma unroll
+            for (int b = 0; b < NB16; ++b) am[b] = ax[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                half8 th, tl;
+                xfrag(ks, th, tl);
+                slab_mma16<8, 1, 0>(ring, lane, am, ax, &th, &tl);
+                slab_mma16<8, 1, 8>(ring, lane, am, ax, &th, &tl);
+            }
+            const float* ks = reinterpret_cast<const float*>(s_ks + (row >= bound ? 1024 : 0));
+#pragma unroll
+            for (int h = 0; h < NKS; ++h) {                      // head h = blocks 2 h, 2 h + 1
+                float v[2][4];
+                float z = 0.f;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[b][r] = am[2 * h + b][r] + ax[2 * h + b][r] * (1.f / 2048.f);
+                    if (g.dbg && g.dbg_stage == 1) dump16(g, v[b], 2 * h + b, row, valid, grp);
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(ks + 16 * (2 * h + b) + 4 * grp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[b][r] = phi_fast(v[b][r]) * qm;
+                        z += v[b][r] * k4[r];
+                    }
+                }
+                z += __shfl_xor(z, 16);
+                z += __shfl_xor(z, 32);
+                Z[h] = 1.f / (z + g.attn_eps);
+                to_frag16(v[0], v[1], ah[h], al[h]);
+            }
+        }
+        // ---- S2: message^T of head h = KV_h^T phi(q_h)^T: two 16-row blocks, K = 32 = one k-step ------------------------------
+        {
+            f32x4 mm[NB16], mx[NB16];
+#pragma unroll
+            for (int b = 0; b < NB16; ++b) mm[b] = mx[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                const bool mine = n_tok == min(n_first, g.N - 1);    // tokens of the other sequence contribute zero columns
+#pragma unroll
+                for (int f = 0; f < NB16; ++f) {
+                    const half8 qh = mine ? ah[f >> 1] : zero8, ql = mine ? al[f >> 1] : zero8;
+                    mm[f] = mfma16(kvh[f], qh, mm[f]);
+                    mx[f] = mfma16(kvl[f], qh, mx[f]);
+                }
+#pragma unroll
+                for (int f = 0; f < NB16; ++f) {
+                    const half8 ql = mine ? al[f >> 1] : zero8;
+                    mx[f] = mfma16(kvh[f], ql, mx[f]);
+                }
+            }
+            if (two) {                                               // the wave's second sequence (uniform branch)
+                const bool mine = n_tok == n_first + 1;
+                const char* img = g.kvimg + (int64_t)(n_first + 1) * KVIMG + lane * 16;
+#pragma unroll
+                for (int f = 0; f < NB16; ++f) {
+                    const half8 kh = *reinterpret_cast<const half8*>(img + (f * 2 + 0) * 1024);
+                    const half8 kl = *reinterpret_cast<const half8*>(img + (f * 2 + 1) * 1024);
+                    const half8 qh = mine ? ah[f >> 1] : zero8, ql = mine ? al[f >> 1] : zero8;
+                    mm[f] = mfma16(kh, qh, mm[f]);
+                    mx[f] = mfma16(kl, qh, mx[f]);
+                    mx[f] = mfma16(kh, ql, mx[f]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < NKS; ++h) {
+                float v[2][4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[b][r] = ((mm[2 * h + b][r] + mx[2 * h + b][r] * (1.f / 2048.f)) * Z[h]) * Sf;
+                    if (g.dbg && g.dbg_stage == 2) dump16(g, v[b], 2 * h + b, row, valid, grp);
+                }
+                to_frag16(v[0], v[1], ah[h], al[h]);
+            }
+        }
+        // ---- S3: merge, LayerNorm1 ------------------------------------------------------------------------------------------
+        {
+            f32x4 am[NB16], ax[NB16];
+#pragma unroll
+            for (int b = 0; b < NB16; ++b) am[b] = ax[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                slab_mma16<8, 1, 0>(ring, lane, am, ax, &ah[ks], &al[ks]);
+                slab_mma16<8, 1, 8>(ring, lane, am, ax, &ah[ks], &al[ks]);
+            }
+#define ENC_V3(b, r) (am[b][r] + ax[b][r] * (1.f / 2048.f))
+            ENC_ROWSTATS(ENC_V3, g.eps1, mean, rstd)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                float v[2][4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ln + 16 * (2 * s + b) + 4 * grp);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ln + EC + 16 * (2 * s + b) + 4 * grp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[b][r] = (ENC_V3(2 * s + b, r) - mean) * rstd * gm[r] + bt[r];
+                    if (g.dbg && g.dbg_stage == 3) dump16(g, v[b], 2 * s + b, row, valid, grp);
+                }
+                to_frag16(v[0], v[1], ah[s], al[s]);
+            }
+#undef ENC_V3
+        }
+        // ---- S4: mlp.2(relu(mlp.0([x | m]))) in eight 64-channel chunks of the hidden layer; S5: x + LayerNorm2(.) ----------
+        {
+            f32x4 om[NB16], ox[NB16];
+#pragma unroll
+            for (int b = 0; b < NB16; ++b) om[b] = ox[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int hc = 0; hc < 8; ++hc) {
+                f32x4 hm[NB16], hx[NB16];                         // only blocks 0..3 are used (the arrays are register-allocated per element)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) hm[b] = hx[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                     // k-steps 2 u, 2 u + 1: x channels
+                    half8 th[2], tl[2];
+                    xfrag(2 * u, th[0], tl[0]);
+                    xfrag(2 * u + 1, th[1], tl[1]);
+                    slab_mma16<4, 2, 0>(ring, lane, hm, hx, th, tl);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)                       // k-steps 8 + 2 u, 9 + 2 u: norm1(merge) channels
+                    slab_mma16<4, 2, 0>(ring, lane, hm, hx, ah + 2 * u, al + 2 * u);
+                half8 hh[2], hl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float hv[2][4];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            hv[b][r] = fmaxf(hm[2 * t + b][r] + hx[2 * t + b][r] * (1.f / 2048.f), 0.f);
+                    to_frag16(hv[0], hv[1], hh[t], hl[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    slab_mma16<8, 1, 0>(ring, lane, om, ox, &hh[t], &hl[t]);
+                    slab_mma16<8, 1, 8>(ring, lane, om, ox, &hh[t], &hl[t]);
+                }
+            }
+#define ENC_V5(b, r) (om[b][r] + ox[b][r] * (1.f / 2048.f))
+            ENC_ROWSTATS(ENC_V5, g.eps2, mean, rstd)
+#pragma unroll
+            for (int b = 0; b < NB16; ++b) {
+                float v[4];
+                if (g.dbg && g.dbg_stage == 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ENC_V5(b, r);
+                    dump16(g, v, b, row, valid, grp);
+                }
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ln + 2 * EC + 16 * b + 4 * grp);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ln + 3 * EC + 16 * b + 4 * grp);
+                // residual x: this lane's 4 channels of block b sit where its output goes (read, then overwritten below)
+                const int o = stg_off(tok, 2 * b + (grp >> 1)) + 8 * (grp & 1);
+                const half4 xrh = *reinterpret_cast<const half4*>(stg + o);
+                const half4 xrl = *reinterpret_cast<const half4*>(stg + PLANE + o);
+                half4 h4, l4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xr = (float)xrh[r] + (float)xrl[r] * (1.f / 2048.f);
+                    const float y = xr + ((ENC_V5(b, r) - mean) * rstd * gm[r] + bt[r]);
+                    _Float16 a, c;
+                    split_f32(y, a, c);
+                    h4[r] = a;
+                    l4[r] = c;
+                }
+                *reinterpret_cast<half4*>(stg + o) = h4;
+                *reinterpret_cast<half4*>(stg + PLANE + o) = l4;
+            }
+#undef ENC_V5
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                // whole-row stores (lane-linear: the swizzle is undone on the LDS read).  The tile is read out of the staging first,
+                // then the NEXT tile's x rows are requested into it, then the stores are issued.
+                const int fl = fresh_lane();
+                const int trow = fl >> 5, p = fl & 31;
+                uint4 dh[8], dl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 2 * i + trow;
+                    dh[i] = *reinterpret_cast<const uint4*>(stg + t * 512 + ((p ^ (t & 15)) << 4));
+                    dl[i] = *reinterpret_cast<const uint4*>(stg + PLANE + t * 512 + ((p ^ (t & 15)) << 4));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (tile + (int)gridDim.x < g.ntiles) load_x(tile + (int)gridDim.x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 2 * i + trow;
+                    const int64_t rr = row0 + t;
+                    if (rr < g.M) {
+                        const int cc = p << 3;
+                        if (g.oh) {
+                            *reinterpret_cast<uint4*>(g.oh + rr * g.ldo + cc) = dh[i];
+                            *reinterpret_cast<uint4*>(g.ol + rr * g.ldo + cc) = dl[i];
+                        }
+                        if (g.o32) {
+                            const half8 h8 = *reinterpret_cast<const half8*>(&dh[i]), l8 = *reinterpret_cast<const half8*>(&dl[i]);
+                            float* o32 = g.o32 + rr * g.ldo32 + cc;
+                            f32x4 f0, f1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                f0[e] = (float)h8[e] + (float)l8[e] * (1.f / 2048.f);
+                                f1[e] = (float)h8[4 + e] + (float)l8[4 + e] * (1.f / 2048.f);
+                            }
+                            *reinterpret_cast<f32x4*>(o32) = f0;
+                            *reinterpret_cast<f32x4*>(o32 + 4) = f1;
+                        }
+                    }
+                }
+            }
+        }
+#undef ENC_ROWSTATS
+    }
+    wait_vmcnt<0>();        // prefetched slabs still in flight must land before the LDS allocation is released
+}
+
+dfsfm::SmemAttr attr_apply256;
+
+}  // namespace
+
+extern "C" int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int N, int L, int S,
+                                          const void* wstream, const void* kv_image, const uint8_t* q_mask, int q_group,
+                                          const float* gamma1, const float* beta1, float eps1, const float* gamma2,
+                                          const float* beta2, float eps2, float attn_eps, void* out_hi, void* out_lo,
+                                          int64_t ldo, float* out32, int64_t ldo32, float* debug, int debug_stage,
+                                          void* stream_) {
+    if (N == 0) return DFSFM_OK;
+    if (!x_hi || !x_lo || !wstream || !kv_image || !gamma1 || !beta1 || !gamma2 || !beta2) return DFSFM_E_BADARG;
+    if ((out_hi == nullptr) != (out_lo == nullptr) || (!out_hi && !out32)) return DFSFM_E_BADARG;
+    if (N < 0 || L <= 0 || S <= 0 || q_group <= 0 || ldx < EC || (out_hi && ldo < EC) || (out32 && ldo32 < EC))
+        return DFSFM_E_BADARG;
+    if (L < 16) return DFSFM_E_UNSUPPORTED;          // a wave's 16 tokens may touch at most two sequences
+    const int64_t M = (int64_t)N * L;
+    const int64_t span = (M - 1) * ldx * 2 + EC * 2;
+    if ((ldx & 7) || (ldo & 7) || (ldo32 & 3) || span >= (int64_t)0xFFFFFFF0) return DFSFM_E_UNSUPPORTED;
+    if ((int64_t)N * KVIMG >= (int64_t)0xFFFFFFF0) return DFSFM_E_UNSUPPORTED;      // 32-bit buffer offsets into the sequence images
+    for (const void* p : {x_hi, x_lo, wstream, kv_image, (const void*)out_hi, (const void*)out_lo, (const void*)out32,
+                          (const void*)gamma1, (const void*)beta1, (const void*)gamma2, (const void*)beta2})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return DFSFM_E_UNSUPPORTED;
+    Apply256Args g{};
+    g.xh = static_cast<const _Float16*>(x_hi);
+    g.xl = static_cast<const _Float16*>(x_lo);
+    g.ldx = ldx;
+    g.xbytes = (unsigned)span;
+    g.wstream = static_cast<const char*>(wstream);
+    g.kvimg = static_cast<const char*>(kv_image);
+    g.qmask = q_mask;
+    g.q_group = q_group;
+    g.qm_per_seq = (L + q_group - 1) / q_group;
+    g.g1 = gamma1; g.b1 = beta1; g.g2 = gamma2; g.b2 = beta2;
+    g.eps1 = eps1; g.eps2 = eps2; g.attn_eps = attn_eps;
+    g.oh = static_cast<_Float16*>(out_hi);
+    g.ol = static_cast<_Float16*>(out_lo);
+    g.ldo = ldo;
+    g.o32 = out32;
+    g.ldo32 = ldo32;
+    g.M = M;
+    g.L = L; g.N = N; g.S = S;
+    g.ntiles = (int)((M + 63) / 64);
+    g.dbg = debug;
+    g.dbg_stage = debug_stage;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = g.ntiles < cus ? g.ntiles : cus;   // persistent: one workgroup per CU walks the tiles
+    attr_apply256.ensure(reinterpret_cast<const void*>(&enc256_apply_kernel), SMEM_APPLY);
+    hipLaunchKernelGGL(enc256_apply_kernel, dim3((unsigned)grid), dim3(256), SMEM_APPLY, static_cast<hipStream_t>(stream_), g);
+    return dfsfm::check_launch("dfsfm_encoder256_apply_f32");
+}

@@ -30,22 +30,20 @@
 // phi(k)^T v is again an MFMA fed from accumulator registers; a workgroup owns one sequence, its 4 waves take every fourth
 // 32-token block, partial sums are combined in a fixed order (run-to-run deterministic, independent of the batch).
 #include "common.h"
+#include "enc_common.h"
 #include <cstdlib>
 
 namespace {
 
 using namespace dfsfm;
+using namespace dfsfm_enc;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int EC = 128;                  // d_model
 constexpr int NBLK = EC / 32;            // 32-channel blocks
 constexpr int NKS = EC / 16;             // k-steps over d_model
-constexpr int SLAB = 16384;              // bytes of one weight slab: 16 A fragments of 1 KB
-constexpr int NSTG = 4;                  // ring depth (slabs)
-constexpr int RING = NSTG * SLAB;
 constexpr int STG = 16384;               // per-wave staging tile: 32 tokens x 128 channels, hi + lo planes
 constexpr int SMEM_BYTES = RING + 4 * STG;
 constexpr int KV_MASK_MAX = 4096;         // mask entries of a sequence kept in LDS by enc_kv_kernel
@@ -54,9 +52,6 @@ constexpr int SMEM_APPLY = SMEM_BYTES + 4 * EC * 4 + 4 * 1024;   // + the LayerN
 constexpr int NSLAB_APPLY = 32;          // q 4, merge 4, 4 x (mlp.0 chunk 4 + mlp.2 chunk 2)
 constexpr int NSLAB_KV = 8;              // 4 head pairs x 2
 constexpr int KVIMG = 16 * 1024 + 512;   // bytes per sequence: 16 KV^T fragments + Ksum[128]
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ f32x16 mfma(const half8 a, const half8 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -87,59 +82,6 @@ __device__ __forceinline__ void to_frags(const float (&v)[16], half8& h0, half8&
 // byte offset of 16-byte chunk c of token row t inside a staging plane (32 rows x 256 B): XOR swizzle so that the
 // fragment-shaped 8/16-byte reads of 32 different rows spread over all banks
 __device__ __forceinline__ int stg_off(int t, int c) { return t * 256 + ((c ^ (t & 15)) << 4); }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// weight-slab ring shared by both kernels: slab g of the cyclic stream lives in stage g % NSTG
-// ---------------------------------------------------------------------------------------------------------------------
-struct SlabRing {
-    char* ring;
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned lane_off;       // wave * 4096 + lane * 16
-    int wave, nslab;
-    unsigned next;           // next slab index to consume (monotonic)
-
-    __device__ __forceinline__ void issue(unsigned g) const {
-        const unsigned src = (g % (unsigned)nslab) * SLAB + lane_off;
-        char* dst = ring + (g % NSTG) * SLAB + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + i * 1024), 16, src + i * 1024, 0, 0, 0);
-    }
-    __device__ __forceinline__ void issue_piece(unsigned g, int i) const {
-        const unsigned src = (g % (unsigned)nslab) * SLAB + lane_off;
-        char* dst = ring + (g % NSTG) * SLAB + wave * 4096;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + i * 1024), 16, src + i * 1024, 0, 0, 0);
-    }
-    // acquire without the refill: the caller spreads the four pieces of slab next + NSTG - 1 between its MFMA groups
-    // (issue_piece) and then calls advance()
-    __device__ __forceinline__ const char* acquire_wait() {
-        wait_vmcnt<(NSTG - 2) * 4>();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        return ring + (next % NSTG) * SLAB;
-    }
-    __device__ __forceinline__ void advance() { ++next; }
-    __device__ __forceinline__ void prologue() {
-#pragma unroll
-        for (int g = 0; g < NSTG - 1; ++g) issue(g);
-        next = 0;
-    }
-    // make slab `next` readable by every wave and refill the stage the previous slab occupied; returns its LDS address.
-    // Loads complete in issue order, so "at most (NSTG-2)*4 outstanding" means this wave's pieces of the slab have landed
-    // (anything issued in between -- other loads, or stores, which may complete out of order with respect to loads but
-    // only ever add to the count -- makes the wait more conservative, never less).
-    __device__ __forceinline__ const char* acquire() {
-        wait_vmcnt<(NSTG - 2) * 4>();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        issue(next + NSTG - 1);
-        const char* p = ring + (next % NSTG) * SLAB;
-        ++next;
-        return p;
-    }
-};
 
 // one slab = KPS k-steps x NB blocks of (hi, lo) fragments; acc[b] += W(b, ks) * B[ks] with the 3-MFMA split product:
 // am += W_hi B_hi, ax += W_lo B_hi, ay += W_hi B_lo (callers with NB = 4 pass ax for ay: an accumulator is then reused
