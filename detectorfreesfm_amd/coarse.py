@@ -52,6 +52,8 @@ def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
 
 # DFSFM_FUSED_ENCODER=0 keeps d_model-128 layers on the five-GEMM path as well (same-box A/B switch, read once at import)
 FUSED_ENCODER = os.environ.get("DFSFM_FUSED_ENCODER", "1") != "0"
+# DFSFM_FUSED_ENCODER256=0: the same switch for the d_model-256 layers of the coarse transformer (csrc/encoder256.hip)
+FUSED_ENCODER256 = os.environ.get("DFSFM_FUSED_ENCODER256", "1") != "0"
 
 
 class EncoderLayerWeights:
@@ -70,6 +72,12 @@ class EncoderLayerWeights:
         if wq.shape == (ops.ENC_C, ops.ENC_C) and FUSED_ENCODER:
             self.fused = ops.EncoderFusedWeights(wq, wk, wv, get(prefix + "merge.weight"), get(prefix + "mlp.0.weight"),
                                                  get(prefix + "mlp.2.weight"), self.n1, self.n2)
+        # d_model 256 (the coarse transformer): the query side of the layer is ONE fused kernel (csrc/encoder256.hip); the
+        # k | v projection stays a split-plane GEMM (pkv)
+        self.fused256 = None
+        if wq.shape == (ops.ENC256_C, ops.ENC256_C) and FUSED_ENCODER256:
+            self.fused256 = ops.Encoder256Weights(wq, get(prefix + "merge.weight"), get(prefix + "mlp.0.weight"),
+                                                  get(prefix + "mlp.2.weight"), self.n1, self.n2)
 
 
 def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
@@ -95,6 +103,14 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
         # merged message and the MLP's hidden layer never reach memory (the second half of ``xs`` stays unused)
         state = ops.encoder_kv(src, w.fused, source_mask, kv_group)
         ops.encoder_apply(xs_x, w.fused, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
+        return out_x
+    if w.fused256 is not None and nhead == 8 and L >= 16 and (out_x is not None or out_xs is not None):
+        # three launches + one: k | v projection, K1's partial sums + the apply image, then q, attention, merge, LayerNorm,
+        # MLP, LayerNorm and the residual in one kernel (q, the message, [x | norm1] and the hidden layer never reach memory;
+        # the second half of ``xs`` stays unused)
+        kv = ops.linear(src, w.pkv).view(N, S, 2 * C)
+        state = ops.encoder256_state(kv[..., :C], kv[..., C:], source_mask, kv_group)
+        ops.encoder256_apply(xs_x, w.fused256, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
         return out_x
     if is_self:
         qkv = ops.linear(xs_x, w.pqkv).view(N, L, 3 * C)

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
                 const bool mine = n_tok == min(n_first, g.N - 1);    // tokens of the other sequence contribute zero columns
 #pragma unroll
                 for (int f = 0; f < NB16; ++f) {
-                    const half8 qh = mine ? ah[f >> 1] : zero8, ql = mine ? al[f >> 1] : zero8;
+                    const half8 qh = mine ? ah[f >> 1] : zero8;
                     mm[f] = mfma16(kvh[f], qh, mm[f]);
                     mx[f] = mfma16(kvl[f], qh, mx[f]);
                 }

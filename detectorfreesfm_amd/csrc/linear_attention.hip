@@ -586,6 +586,47 @@ __global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ 
     kvf[(int64_t)nh * kvsz + e] = (s0 + s1) + (s2 + s3);
 }
 
+// Chunk partials -> the "apply image" of the d_model-256 fused encoder layer (encoder256.hip): per sequence, for head h and
+// row block rb the A fragment pair (hi, lo planes of 1 KB, lane-linear) of KV_h^T rows 16 rb .. 16 rb + 15 -- lane (i, g) slot j
+// = KV_h[d][16 rb + i] with d = 16 (j >> 2) + 4 g + (j & 3), the k order in which that kernel's accumulators hold phi(q_h) --
+// then Ksum[256] as fp32.  Same four-way interleaved chunk sum as la_kv_finalize (fixed order: deterministic).
+constexpr int ENC256_KVIMG = 32 * 1024 + 1024;
+
+__global__ __launch_bounds__(256) void enc256_image_kernel(const float* __restrict__ part, char* __restrict__ img, int nchunks) {
+    const int nh = blockIdx.x, n = nh >> 3, h = nh & 7;
+    const float* p0 = part + ((int64_t)n * nchunks * 8 + h) * KV32;
+    const int64_t stride = (int64_t)8 * KV32;
+    char* out = img + (int64_t)n * ENC256_KVIMG;
+    for (int e = threadIdx.x; e < KV32; e += 256) {
+        int src = e, rb = 0, lane = 0, j = 0;
+        if (e < 1024) {
+            rb = e >> 9; lane = (e >> 3) & 63; j = e & 7;
+            const int i = lane & 15, g = lane >> 4;
+            src = (16 * (j >> 2) + 4 * g + (j & 3)) * 32 + 16 * rb + i;
+        }
+        const float* p = p0 + src;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = 0;
+        for (; c + 4 <= nchunks; c += 4) {
+            s0 += p[(c + 0) * stride];
+            s1 += p[(c + 1) * stride];
+            s2 += p[(c + 2) * stride];
+            s3 += p[(c + 3) * stride];
+        }
+        for (; c < nchunks; ++c) s0 += p[c * stride];
+        const float val = (s0 + s1) + (s2 + s3);
+        if (e < 1024) {
+            _Float16 hi, lo;
+            dfsfm::split_f32(val, hi, lo);
+            char* q = out + ((h * 2 + rb) * 2) * 1024 + lane * 16 + j * 2;
+            *reinterpret_cast<_Float16*>(q) = hi;
+            *reinterpret_cast<_Float16*>(q + 1024) = lo;
+        } else {
+            reinterpret_cast<float*>(out + 32768)[32 * h + (e - 1024)] = val;
+        }
+    }
+}
+
 // Rows per kv_partial workgroup: aim for ~512 workgroups (one resident wave of 2 per CU), at least
 // 64 rows each.
 int chunk_rows(int N, int S) {
@@ -694,4 +735,30 @@ extern "C" int dfsfm_linear_attention_f32(const float* q, const float* k, const 
                            H, ldq, ldo, eps, oh, ol, ldo_s);
     }
     return dfsfm::check_launch("dfsfm_linear_attention_f32");
+}
+
+extern "C" size_t dfsfm_encoder256_state_workspace(int N, int S) {
+    if (N <= 0 || S <= 0) return 0;
+    const int rows = chunk_rows(N, S);
+    const int nchunks = (S + rows - 1) / rows;
+    return dfsfm::align_up((size_t)N * nchunks * 8 * KV32 * sizeof(float), 256);
+}
+
+extern "C" int dfsfm_encoder256_state_f32(const float* k, const float* v, int ldk, int ldv, const uint8_t* kv_mask,
+                                          int kv_group, int N, int S, void* kv_image, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    if (!k || !v || !kv_image || !workspace) return DFSFM_E_BADARG;
+    if (N <= 0 || S <= 0 || ldk < 256 || ldv < 256 || (kv_mask && kv_group <= 0)) return DFSFM_E_BADARG;
+    if (N > 65535 || (ldk & 3) || (ldv & 3) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(v) & 15) ||
+        (reinterpret_cast<uintptr_t>(kv_image) & 15))
+        return DFSFM_E_UNSUPPORTED;
+    if (workspace_bytes < dfsfm_encoder256_state_workspace(N, S)) return DFSFM_E_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int rows = chunk_rows(N, S);
+    const int nchunks = (S + rows - 1) / rows;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(la_kv_partial_staged<32>, dim3(nchunks, N), dim3(256), 0, stream, k, v, kv_mask, kv_group, part, S, ldk,
+                       ldv, rows, nchunks);
+    hipLaunchKernelGGL(enc256_image_kernel, dim3(N * 8), dim3(256), 0, stream, part, static_cast<char*>(kv_image), nchunks);
+    return dfsfm::check_launch("dfsfm_encoder256_state_f32");
 }

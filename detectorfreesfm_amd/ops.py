@@ -1098,6 +1098,136 @@ def encoder_apply(x: "SplitAct", fw: EncoderFusedWeights, kv_image, S, q_mask=No
     return dbg
 
 
+# ---------------------------------------------------------------- fused encoder layer, d_model 256 (csrc/encoder256.hip)
+ENC256_C, ENC256_KV_IMAGE, ENC256_NSLAB = 256, 32 * 1024 + 1024, 128
+
+
+def _kslots16(kstep: int) -> torch.Tensor:
+    """Column indices [4 (lane group g), 8 (slot j)] of a v_mfma_f32_16x16x32_f16 operand fragment for 32-wide k-step
+    ``kstep`` in the order encoder256.hip chains accumulators into operands: two consecutive 16-channel accumulator blocks
+    (lane group g holds rows 4 g + r) become one k-step, slot (g, j) = channel 32 kstep + 16 (j >> 2) + 4 g + (j & 3)."""
+    j = torch.arange(8)
+    g = torch.arange(4)[:, None]
+    return 32 * kstep + 16 * (j >> 2) + 4 * g + (j & 3)
+
+
+def _fragment16(plane: torch.Tensor, row0: int, kstep: int) -> torch.Tensor:
+    """One 1-KB A fragment [64 lanes, 8 halves] of rows row0..row0+15: lane l = (row l & 15, group l >> 4)."""
+    cols = _kslots16(kstep).to(plane.device)                            # [4, 8]
+    rows = plane[row0:row0 + 16]                                        # [16, K]
+    return torch.stack([rows[:, cols[g]] for g in range(4)], 0).reshape(64, 8)
+
+
+class Encoder256Weights:
+    """Weights of one LoFTREncoderLayer with d_model 256, 8 heads (the coarse transformer) as the fragment stream of
+    csrc/encoder256.hip: 128 slabs of 16 KB = 16 fragments of 1 KB (64 lanes x 16 bytes, lane-linear), (hi, lo) pairs in
+    the order the kernel consumes them:
+      q      16 slabs: k-step ks (0..7) x row half nb2 (0..1): rows 16 (8 nb2 + b), b = 0..7
+      merge  16 slabs: the same
+      per 64-channel chunk hc (0..7) of the MLP's hidden layer:
+        mlp.0   8 slabs: slab u = k-steps 2u, 2u+1 of the 512 input columns [x | norm1(message)] x rows 64 hc + 16 b, b = 0..3
+        mlp.2   4 slabs: k-step 2 hc + t (t = 0..1) of its 512 columns x row half nb2: rows 16 (8 nb2 + b), b = 0..7
+    k columns inside a k-step are in ``_kslots16`` order.  k_proj / v_proj stay ordinary split-plane GEMM weights (pkv)."""
+
+    def __init__(self, wq, wmerge, w1, w2, n1, n2, nhead=8):
+        C = ENC256_C
+        if nhead != 8 or tuple(wq.shape) != (C, C) or tuple(wmerge.shape) != (C, C) or tuple(w1.shape) != (2 * C, 2 * C) or \
+                tuple(w2.shape) != (C, 2 * C):
+            raise _lib.DfsfmError("Encoder256Weights: the fused layer is built for d_model 256, 8 heads")
+        dev = wq.device
+        planes = {k: _split_planes(v.detach().cpu()) for k, v in (("q", wq), ("m", wmerge), ("1", w1), ("2", w2))}
+        self.values = {n: (planes[k][0].float() + planes[k][1].float() / 2048.0).to(dev) for n, k in
+                       (("q_proj.weight", "q"), ("merge.weight", "m"), ("mlp.0.weight", "1"), ("mlp.2.weight", "2"))}
+
+        def pair(name, row0, kstep):
+            return [_fragment16(planes[name][0], row0, kstep), _fragment16(planes[name][1], row0, kstep)]
+        frags = []
+        for name in ("q", "m"):
+            for ks in range(8):
+                for nb2 in range(2):
+                    for b in range(8):
+                        frags += pair(name, 16 * (8 * nb2 + b), ks)
+        for hc in range(8):
+            for u in range(8):
+                for ks in range(2):
+                    for b in range(4):
+                        frags += pair("1", 64 * hc + 16 * b, 2 * u + ks)
+            for t in range(2):
+                for nb2 in range(2):
+                    for b in range(8):
+                        frags += pair("2", 16 * (8 * nb2 + b), 2 * hc + t)
+        self.stream = torch.stack(frags, 0).contiguous().to(dev)            # [2048, 64, 8] fp16 = 128 slabs
+        assert self.stream.numel() * 2 == ENC256_NSLAB * ENC_SLAB
+        self.n1 = tuple(t.detach().float().contiguous() for t in n1)
+        self.n2 = tuple(t.detach().float().contiguous() for t in n2)
+        self.values.update({"norm1.weight": self.n1[0], "norm1.bias": self.n1[1], "norm2.weight": self.n2[0],
+                            "norm2.bias": self.n2[1]})
+
+
+@_on_device
+def encoder256_state(k, v, kv_mask=None, kv_group=1):
+    """Source side of a d_model-256 fused layer application: k, v [N, S, 256] fp32 (column slices of the k|v projection:
+    stride(-1) = 1, uniform row stride) -> the per-sequence attention state for ``encoder256_apply`` [N, ENC256_KV_IMAGE]
+    bytes (KV^T per head as MFMA fragments + Ksum)."""
+    _require_cuda(k, v)
+    if k.dim() != 3 or k.shape != v.shape or k.shape[-1] != ENC256_C or k.dtype != torch.float32 or v.dtype != torch.float32:
+        raise _lib.DfsfmError("encoder256_state: need fp32 k, v [N, S, 256]")
+    N, S, _ = k.shape
+    _, ldk = _rows_ld(k)
+    _, ldv = _rows_ld(v)
+    km = _as_u8(kv_mask)
+    if km is not None and km.shape != (N, (S + kv_group - 1) // kv_group):
+        raise _lib.DfsfmError("encoder256_state: kv_mask must be [N, ceil(S / kv_group)]")
+    lib = _lib.lib()
+    ws = _workspace(lib.dfsfm_encoder256_state_workspace(N, S), k.device)
+    img = torch.empty((N, ENC256_KV_IMAGE), dtype=torch.uint8, device=k.device)
+    rc = lib.dfsfm_encoder256_state_f32(_ptr(k), _ptr(v), ldk, ldv, _ptr(km), int(kv_group), N, S, _ptr(img), _ptr(ws),
+                                        ws.numel(), _stream())
+    _lib.check(rc, "dfsfm_encoder256_state_f32")
+    return img
+
+
+@_on_device
+def encoder256_apply(x: "SplitAct", fw: Encoder256Weights, kv_image, S, q_mask=None, q_group=1, out_split=None, out=None,
+                     eps=1e-5, attn_eps=1e-6, debug_stage=0):
+    """Query side: x tokens [N, L, 256] (split planes) + attention state -> x + norm2(mlp([x | norm1(merge(attention))])) into
+    the SplitAct view ``out_split`` and / or the fp32 view ``out`` ([N, L, 256] each) in ONE launch.  debug_stage != 0
+    additionally returns an fp32 [N*L, 256] dump of that intermediate (tests)."""
+    _require_cuda(x.hi, kv_image)
+
+    def rows_of(t, what):
+        if t.hi.dim() != 3 or t.hi.shape[-1] != ENC256_C or t.hi.dtype != torch.float16 or t.lo.stride() != t.hi.stride():
+            raise _lib.DfsfmError(f"{what}: need split planes [N, L, 256]")
+        _, ld = _rows_ld(t.hi, torch.float16)
+        return t.hi.shape[0], t.hi.shape[1], ld
+    N, L, ldx = rows_of(x, "encoder256_apply")
+    if kv_image.shape != (N, ENC256_KV_IMAGE) or kv_image.dtype != torch.uint8 or not kv_image.is_contiguous():
+        raise _lib.DfsfmError("encoder256_apply: kv_image must come from encoder256_state for the same N")
+    oh = ol = None
+    ldo = ldo32 = 0
+    if out_split is not None:
+        n2, l2, ldo = rows_of(out_split, "encoder256_apply(out_split)")
+        if (n2, l2) != (N, L):
+            raise _lib.DfsfmError("encoder256_apply: out_split shape mismatch")
+        oh, ol = out_split.hi, out_split.lo
+    if out is not None:
+        rows_o, ldo32 = _rows_ld(out)
+        if rows_o != N * L or out.shape[-1] != ENC256_C:
+            raise _lib.DfsfmError("encoder256_apply: out shape mismatch")
+    qm = _as_u8(q_mask)
+    if qm is not None and qm.shape != (N, (L + q_group - 1) // q_group):
+        raise _lib.DfsfmError("encoder256_apply: q_mask must be [N, ceil(L / q_group)]")
+    dbg = torch.zeros((N * L, ENC256_C), dtype=torch.float32, device=x.hi.device) if debug_stage else None
+    rc = _lib.lib().dfsfm_encoder256_apply_f32(_ptr(x.hi), _ptr(x.lo), ldx, N, L, int(S), _ptr(fw.stream), _ptr(kv_image),
+                                               _ptr(qm), int(q_group), _ptr(fw.n1[0]), _ptr(fw.n1[1]), float(eps),
+                                               _ptr(fw.n2[0]), _ptr(fw.n2[1]), float(eps), float(attn_eps), _ptr(oh), _ptr(ol),
+                                               ldo, _ptr(out), ldo32, _ptr(dbg), int(debug_stage), _stream())
+    _lib.check(rc, "dfsfm_encoder256_apply_f32")
+    if out_split is not None:
+        _range(out_split, "encoder256_apply")
+    return dbg
+
+
 @_on_device
 def merge_keypoints(rows, img0, img1, n_images):
     """Scene-wide keypoint merge + match re-indexing (coarse_match.py:203-237 on the device).

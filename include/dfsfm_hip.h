@@ -412,6 +412,31 @@ int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int
                             float attn_eps, void* out_hi, void* out_lo, int64_t ldo, float* out32, int64_t ldo32,
                             float* debug, int debug_stage, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K2 + K1 fused for d_model 256, 8 heads of 32: the COARSE transformer's LoFTREncoderLayer (csrc/encoder256.hip)
+ *   third_party/LoFTR/src/loftr/loftr_module/transformer.py:35-58, 80-101; linear_attention.py:20-47
+ *
+ * dfsfm_encoder256_state_f32  source side of a layer application: k, v [N*S, 256] fp32 rows (row strides ldk / ldv floats;
+ *                             the two halves of the k|v projection) -> per sequence n the apply image kv_image[n]
+ *                             (DFSFM_ENCODER256_KV_IMAGE_BYTES: per head and 16-row block the fp16 hi/lo MFMA A fragment
+ *                             of KV_h^T = (sum_s phi(k_s)^T v_s / S)^T, then Ksum = sum_s phi(k_s) as 256 floats).
+ *                             kv_mask [N, ceil(S/kv_group)] uint8 or NULL.  Two launches (chunked partial sums, a
+ *                             fixed-order reduction: deterministic); workspace dfsfm_encoder256_state_workspace(N, S).
+ * dfsfm_encoder256_apply_f32  query side in ONE launch: x rows [N*L, 256] (split planes) + kv_image ->
+ *                             out = x + norm2(mlp.2(relu(mlp.0([x | norm1(merge(attention(W_q x)))]))))
+ *                             as split planes and / or fp32 rows; arguments as dfsfm_encoder_apply_f32 (L >= 16;
+ *                             debug dump [N*L, 256]).  wstream: 128 slabs of 16 KB (ops.Encoder256Weights).
+ * ---------------------------------------------------------------------------------------- */
+#define DFSFM_ENCODER256_KV_IMAGE_BYTES (32 * 1024 + 1024)
+size_t dfsfm_encoder256_state_workspace(int N, int S);
+int dfsfm_encoder256_state_f32(const float* k, const float* v, int ldk, int ldv, const uint8_t* kv_mask, int kv_group,
+                               int N, int S, void* kv_image, void* workspace, size_t workspace_bytes, void* stream);
+int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int N, int L, int S, const void* wstream,
+                               const void* kv_image, const uint8_t* q_mask, int q_group, const float* gamma1,
+                               const float* beta1, float eps1, const float* gamma2, const float* beta2, float eps2,
+                               float attn_eps, void* out_hi, void* out_lo, int64_t ldo, float* out32, int64_t ldo32,
+                               float* debug, int debug_stage, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

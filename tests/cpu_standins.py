@@ -4,6 +4,7 @@ skipping) can be exercised by ``-m "not gpu"`` tests.  The product never uses th
 import contextlib
 
 import torch
+import torch.nn.functional as F
 
 from oracle import restate
 
@@ -358,6 +359,34 @@ def _enc_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=None
     return None
 
 
+def _enc256_state(k, v, kv_mask=None, kv_group=1):
+    """Stand-in for ops.encoder256_state: the attention state is the projected k, v and their mask."""
+    return {"k": k.float().clone(), "v": v.float().clone(), "mask": kv_mask, "group": kv_group}
+
+
+def _enc256_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=None, eps=1e-5, attn_eps=1e-6, debug_stage=0):
+    """Stand-in for ops.encoder256_apply: the query side of LoFTREncoderLayer.forward (transformer.py:35-58) on the values the
+    fragment stream holds (fw.values), attention through the oracle's linear_attention."""
+    xv = x.float()
+    N, L, C = xv.shape
+    W = fw.values
+    Sk = state["k"].shape[1]
+    xm = None if q_mask is None else q_mask.repeat_interleave(q_group, dim=1)[:, :L]
+    sm = None if state["mask"] is None else state["mask"].repeat_interleave(state["group"], dim=1)[:, :Sk]
+    q = F.linear(xv, W["q_proj.weight"]).view(N, L, 8, C // 8)
+    msg = restate.linear_attention(q, state["k"].reshape(N, Sk, 8, C // 8), state["v"].reshape(N, Sk, 8, C // 8), xm, sm)
+    msg = F.linear(msg.reshape(N, L, C), W["merge.weight"])
+    msg = F.layer_norm(msg, (C,), W["norm1.weight"], W["norm1.bias"], eps)
+    msg = F.linear(F.relu(F.linear(torch.cat([xv, msg], 2), W["mlp.0.weight"])), W["mlp.2.weight"])
+    y = xv + F.layer_norm(msg, (C,), W["norm2.weight"], W["norm2.bias"], eps)
+    if out_split is not None:
+        _put_split(out_split, y)
+    if out is not None:
+        hi, lo = _split(y)
+        out.copy_((hi + lo / 2048.0).reshape(out.shape))
+    return None
+
+
 @contextlib.contextmanager
 def cpu_ops():
     from detectorfreesfm_amd import ops
@@ -366,7 +395,7 @@ def cpu_ops():
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
                                           "bilinear_up", "resample_u8", "avgpool", "full_attention",
                                           "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear",
-                                          "encoder_kv", "encoder_apply")}
+                                          "encoder_kv", "encoder_apply", "encoder256_state", "encoder256_apply")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
@@ -378,6 +407,7 @@ def cpu_ops():
     ops.layernorm2d, ops.upsample, ops.flow_decode = _layernorm2d, _upsample, _flow_decode
     ops.resize_bilinear = _resize_bilinear
     ops.encoder_kv, ops.encoder_apply = _enc_kv, _enc_apply
+    ops.encoder256_state, ops.encoder256_apply = _enc256_state, _enc256_apply
     try:
         yield
     finally:
