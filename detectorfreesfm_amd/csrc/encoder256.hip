@@ -19,7 +19,8 @@
 //    lane-group reductions (xor 16, xor 32) of Z and the LayerNorm statistics.
 //  * fp16x2 split arithmetic (value = hi + lo / 2048): three MFMAs per product, fp32 accumulation, lo * lo dropped.
 //  * The four waves of a workgroup (64 tokens) share only the weight stream: 128 slabs of 16 KB per tile (q 16, merge 16,
-//    8 x [mlp.0 chunk 8 + mlp.2 chunk 4]) through the 4-deep LDS ring of enc_common.h; one wave per SIMD.
+//    8 x [mlp.0 chunk 8 + mlp.2 chunk 4]) through the 4-deep LDS ring of enc_common.h; one wave per SIMD; the fragment reads of
+//    slab s + 1 run under the MFMAs of slab s (register double buffering, slab_step).
 //  * With D = 32 a head is exactly one k-step: KV^T of a head is two 16 x 32 A fragments, the message of a head 6 MFMAs.
 #include "common.h"
 #include "enc_common.h"
@@ -42,8 +43,20 @@ constexpr int NSLAB = 128;               // q 16, merge 16, 8 x (mlp.0 chunk 8 +
 constexpr int KVIMG = 32 * 1024 + 1024;  // bytes per sequence: 16 KV^T fragment pairs (hi, lo) + Ksum[256]
 constexpr int SMEM_APPLY = RING + 4 * STG + 4 * EC * 4 + 4 * 2048;   // + LayerNorm gamma / beta + Ksum of a wave's two sequences
 
+// Timing-only ablation switches (tools/build_enc256_abl.sh builds them into csrc/abl/; results are WRONG with any of them set):
+// ENC256_NOMFMA the matrix instructions of the slab stream become register moves, ENC256_NODMA no ring refill, ENC256_NOBAR no
+// per-slab barrier, ENC256_NOREAD the weight fragments are not re-read from LDS.
 __device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16s(const half8 a, const half8 b, const f32x4 c) {
+#ifdef ENC256_NOMFMA
+    f32x4 r = c;
+    r[0] += (float)a[0] + (float)b[0];
+    return r;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // Two consecutive accumulator blocks (lane (n, g): a[r] = channel 16 (2 s) + 4 g + r, b[r] = channel 16 (2 s + 1) + 4 g + r of
@@ -69,49 +82,64 @@ __device__ __forceinline__ void to_frag16(const float (&a)[4], const float (&b)[
 __device__ __forceinline__ int stg_off(int t, int c) { return t * 512 + ((c ^ (t & 15)) << 4); }
 
 // One slab = KPS k-steps x NB blocks of (hi, lo) A fragments:  acc[B0 + b] += W(b, ks) * B[ks]  with the 3-MFMA split product
-// am += W_hi B_hi, ax += W_lo B_hi + W_hi B_lo (an accumulator is reused after NB >= 4 other MFMAs).  The four DMA requests of the
-// ring refill follow groups of MFMAs that are already executing (encoder_fused.hip: in front of the first MFMA they cost
-// ~100 issue cycles each); sched_barriers pin the places.
+// am += W_hi B_hi, ax += W_lo B_hi + W_hi B_lo (an accumulator is reused after NB >= 4 other MFMAs).
+//
+// SOFTWARE-PIPELINED over the slab stream: the 16 fragments of the slab being multiplied sit in registers (`cur`); between its 24
+// MFMAs the NEXT slab's fragments are read from LDS into `nxt`, one read per MFMA, and the ring slot the current slab came from is
+// refilled (slab next + NSTG).  A slab is 64 KB of LDS reads per CU (four waves x 16 KB) = 256 LDS cycles for 384 cycles of MFMA
+// issue: read-then-multiply per slab serialised the two (first version: 65 us per 64-token tile for 20 us of MFMA issue).  One s_barrier per slab as before; it now means "every wave's pieces of slab next + 1 have landed AND every wave
+// has the fragments of slab next in registers" (lgkmcnt(0) before it), so the refill cannot overtake a reader.  Callers alternate
+// the two register sets (the slab sequence of a tile is static and even).
+#ifdef ENC256_NODMA
+#define ENC256_REFILL(ring, gn, piece) do { (void)(gn); ++piece; } while (0)
+#else
+#define ENC256_REFILL(ring, gn, piece) (ring).issue_piece((gn), (piece)++)
+#endif
 template <int NB, int KPS, int B0>
-__device__ __forceinline__ void slab_mma16(SlabRing& ring, int lane, f32x4 (&am)[NB16], f32x4 (&ax)[NB16], const half8* bh,
-                                           const half8* bl) {
+__device__ __forceinline__ void slab_step(SlabRing& ring, int lane, f32x4 (&am)[NB16], f32x4 (&ax)[NB16], const half8* bh,
+                                          const half8* bl, const half8 (&cur)[16], half8 (&nxt)[16]) {
     static_assert(NB * KPS == 8, "a slab holds 16 fragments");
-    const char* slab = ring.acquire_wait();
-    const unsigned gn = ring.next + NSTG - 1;
-    int piece = 0;
+    wait_vmcnt<(NSTG - 2) * 4>();                   // this wave's pieces of slab next + 1 (next + 2, next + 3 may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its fragment reads of slab next are complete
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef ENC256_NOBAR
+    __builtin_amdgcn_s_barrier();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    const char* nslab = ring.ring + ((ring.next + 1) % NSTG) * SLAB + lane * 16;
+    const unsigned gn = ring.next + NSTG;           // into the slot slab `next` was read from
+    // 24 MFMAs; behind each of the first 16 ONE fragment read of the next slab, behind MFMAs 3, 9, 15, 21 one DMA request of the
+    // refill.  Issued as a burst after the barrier, the four waves' 64 KB of ds_read_b128 saturate the LDS for ~256 cycles during
+    // which none of them issues an MFMA (stage profile: 760 cycles per slab for 384 of MFMA); one read per MFMA is the rate the
+    // LDS sustains (4 waves x 4 cycles per 16-cycle MFMA).  sched_barriers pin the order.
+    int m = 0, piece = 0;
+    auto after = [&]() __attribute__((always_inline)) {
+#ifndef ENC256_NOREAD
+        if (m < 16) nxt[m] = *reinterpret_cast<const half8*>(nslab + m * 1024);
+#else
+        if (m < 16) nxt[m] = cur[m];
+#endif
+        if (m % 6 == 3) ENC256_REFILL(ring, gn, piece);
+        ++m;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    (void)nslab;
 #pragma unroll
     for (int ks = 0; ks < KPS; ++ks) {
-        half8 wh[NB], wl[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 0) * 1024 + lane * 16);
-            wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 1) * 1024 + lane * 16);
+            am[B0 + b] = mfma16s(cur[(ks * NB + b) * 2], bh[ks], am[B0 + b]);
+            after();
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            am[B0 + b] = mfma16(wh[b], bh[ks], am[B0 + b]);
-            if (KPS == 1 && b == NB / 2 - 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                ring.issue_piece(gn, piece++);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            ax[B0 + b] = mfma16s(cur[(ks * NB + b) * 2 + 1], bh[ks], ax[B0 + b]);
+            after();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        ring.issue_piece(gn, piece++);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) ax[B0 + b] = mfma16(wl[b], bh[ks], ax[B0 + b]);
-        __builtin_amdgcn_sched_barrier(0);
-        ring.issue_piece(gn, piece++);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            ax[B0 + b] = mfma16(wh[b], bl[ks], ax[B0 + b]);
-            if (KPS == 1 && b == NB / 2 - 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                ring.issue_piece(gn, piece++);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            ax[B0 + b] = mfma16s(cur[(ks * NB + b) * 2], bl[ks], ax[B0 + b]);
+            after();
         }
     }
     ring.advance();
@@ -167,7 +195,15 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
     ring.lane_off = (unsigned)(wave * 4096 + lane * 16);
     ring.wave = wave;
     ring.nslab = NSLAB;
-    ring.prologue();
+    // pipeline prologue: all four ring slots requested; slab 0 goes to the register set wa
+#pragma unroll
+    for (int gq = 0; gq < NSTG; ++gq) ring.issue(gq);
+    ring.next = 0;
+    half8 wa[16], wb[16];                    // fragment registers of the slab being multiplied / being fetched (ping-pong)
+    wait_vmcnt<(NSTG - 1) * 4>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) wa[f] = *reinterpret_cast<const half8*>(smem + f * 1024 + lane * 16);
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
@@ -203,8 +239,18 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + PLANE + i * 1024), 16, off, 0, 0, 0);
         }
     };
+    // dbg_stage 100: wave 0 of every workgroup records s_memtime at the stage boundaries of each of its tiles
+    // (dbg[(tile * 16 + k) * 2 ..] = low 24 bits, next 24 bits): the stage profile of DESIGN.md (tools/bench_enc256.py profile)
+    const bool stamp = g.dbg && g.dbg_stage == 100 && tid == 0;
+#define ENC_STAMP(k)                                                                    \
+    if (stamp) {                                                                        \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();                               \
+        g.dbg[((int64_t)tile * 16 + (k)) * 2] = (float)(t_ & 0xFFFFFF);                 \
+        g.dbg[((int64_t)tile * 16 + (k)) * 2 + 1] = (float)((t_ >> 24) & 0xFFFFFF);     \
+    }
     if ((int)blockIdx.x < g.ntiles) load_x(blockIdx.x);
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        ENC_STAMP(0)
         const int64_t row0 = ((int64_t)tile * 4 + wave) * 16;
         const int64_t row = row0 + tok;
         const bool valid = row < g.M;
@@ -218,6 +264,7 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
         const bool two = __builtin_amdgcn_readfirstlane((int)(row0 + 15 >= bound && n_first + 1 < g.N)) != 0;
 
         wait_vmcnt<0>();        // the x tile has landed (this also waits for the slabs in flight: once per tile)
+        ENC_STAMP(1)
         // B fragment pair of x for k-step s, from the staging tile (it stays intact until the output overwrites it in place):
         // slots j < 4: channels 32 s + 4 g + j, slots j >= 4: channels 32 s + 16 + 4 g + (j - 4)
         auto xfrag = [&](int s, half8& fh, half8& fl) __attribute__((always_inline)) {
@@ -230,16 +277,6 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             fl = half8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         };
 
-        // KV^T fragments of the wave's first sequence: requested now, consumed after the q GEMM
-        half8 kvh[2 * NKS], kvl[2 * NKS];
-        {
-            const char* img = g.kvimg + (int64_t)min(n_first, g.N - 1) * KVIMG + lane * 16;
-#pragma unroll
-            for (int f = 0; f < 2 * NKS; ++f) {
-                kvh[f] = *reinterpret_cast<const half8*>(img + (f * 2 + 0) * 1024);
-                kvl[f] = *reinterpret_cast<const half8*>(img + (f * 2 + 1) * 1024);
-            }
-        }
         // LayerNorm statistics of this lane's token: its 64 channels (16 blocks x 4) + the other three lane groups' (xor 16, 32)
 #define ENC_ROWSTATS(VAL, EPS, MEAN, RSTD)                                                                            \
         float MEAN, RSTD;                                                                                             \
@@ -258,6 +295,7 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
         }
         const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
         half8 ah[NKS], al[NKS];          // operand of the next GEMM: phi(q), then the message, then norm1(merge)
+        half8 kb[32];                    // KV^T fragments (hi, lo) of the wave's first sequence, between the q GEMM and S2
         float Z[NKS];
         // ---- S1: q = W_q x, phi(q), Z ------------------------------------------------------------------------------------
         {
@@ -268,10 +306,20 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             for (int ks = 0; ks < NKS; ++ks) {
                 half8 th, tl;
                 xfrag(ks, th, tl);
-                slab_mma16<8, 1, 0>(ring, lane, am, ax, &th, &tl);
-                slab_mma16<8, 1, 8>(ring, lane, am, ax, &th, &tl);
+                slab_step<8, 1, 0>(ring, lane, am, ax, &th, &tl, wa, wb);
+                slab_step<8, 1, 8>(ring, lane, am, ax, &th, &tl, wb, wa);
+            }
+            ENC_STAMP(2)
+            // KV^T fragments of the wave's first sequence: ordinary 16-byte loads, the first half requested now, consumed in S2 (the L2
+            // round trip runs under phi / Z; left to itself the compiler waited for every pair: sixteen serial round trips)
+            {
+                const char* img = g.kvimg + (int64_t)min(n_first, g.N - 1) * KVIMG + lane * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kb[i] = *reinterpret_cast<const half8*>(img + i * 1024);     // heads 0-3 now,
+                __builtin_amdgcn_sched_barrier(0);                                                       // 4-7 at the top of S2
             }
             const float* ks = reinterpret_cast<const float*>(s_ks + (row >= bound ? 1024 : 0));
+            float zp[NKS];
 #pragma unroll
             for (int h = 0; h < NKS; ++h) {                      // head h = blocks 2 h, 2 h + 1
                 float v[2][4];
@@ -288,42 +336,54 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
                         z += v[b][r] * k4[r];
                     }
                 }
-                z += __shfl_xor(z, 16);
-                z += __shfl_xor(z, 32);
-                Z[h] = 1.f / (z + g.attn_eps);
+                zp[h] = z;
                 to_frag16(v[0], v[1], ah[h], al[h]);
             }
+            // the four lane groups' partial sums: eight independent exchanges per round instead of eight serial pairs
+#pragma unroll
+            for (int h = 0; h < NKS; ++h) zp[h] += __shfl_xor(zp[h], 16);
+#pragma unroll
+            for (int h = 0; h < NKS; ++h) zp[h] += __shfl_xor(zp[h], 32);
+#pragma unroll
+            for (int h = 0; h < NKS; ++h) Z[h] = 1.f / (zp[h] + g.attn_eps);
         }
+        ENC_STAMP(3)
         // ---- S2: message^T of head h = KV_h^T phi(q_h)^T: two 16-row blocks, K = 32 = one k-step ------------------------------
         {
             f32x4 mm[NB16], mx[NB16];
 #pragma unroll
             for (int b = 0; b < NB16; ++b) mm[b] = mx[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // tokens of the other sequence contribute zero columns
             {
-                const bool mine = n_tok == min(n_first, g.N - 1);    // tokens of the other sequence contribute zero columns
+                const bool mine = n_tok == min(n_first, g.N - 1);
+                const char* img = g.kvimg + (int64_t)min(n_first, g.N - 1) * KVIMG + lane * 16;
+#pragma unroll
+                for (int i = 16; i < 32; ++i) kb[i] = *reinterpret_cast<const half8*>(img + i * 1024);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int f = 0; f < NB16; ++f) {
                     const half8 qh = mine ? ah[f >> 1] : zero8;
-                    mm[f] = mfma16(kvh[f], qh, mm[f]);
-                    mx[f] = mfma16(kvl[f], qh, mx[f]);
+                    mm[f] = mfma16(kb[2 * f], qh, mm[f]);
+                    mx[f] = mfma16(kb[2 * f + 1], qh, mx[f]);
                 }
 #pragma unroll
                 for (int f = 0; f < NB16; ++f) {
                     const half8 ql = mine ? al[f >> 1] : zero8;
-                    mx[f] = mfma16(kvh[f], ql, mx[f]);
+                    mx[f] = mfma16(kb[2 * f], ql, mx[f]);
                 }
             }
-            if (two) {                                               // the wave's second sequence (uniform branch)
+            if (two) {                                               // the wave's second sequence (uniform branch, rare)
                 const bool mine = n_tok == n_first + 1;
                 const char* img = g.kvimg + (int64_t)(n_first + 1) * KVIMG + lane * 16;
 #pragma unroll
+                for (int i = 0; i < 32; ++i) kb[i] = *reinterpret_cast<const half8*>(img + i * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
                 for (int f = 0; f < NB16; ++f) {
-                    const half8 kh = *reinterpret_cast<const half8*>(img + (f * 2 + 0) * 1024);
-                    const half8 kl = *reinterpret_cast<const half8*>(img + (f * 2 + 1) * 1024);
                     const half8 qh = mine ? ah[f >> 1] : zero8, ql = mine ? al[f >> 1] : zero8;
-                    mm[f] = mfma16(kh, qh, mm[f]);
-                    mx[f] = mfma16(kl, qh, mx[f]);
-                    mx[f] = mfma16(kh, ql, mx[f]);
+                    mm[f] = mfma16(kb[2 * f], qh, mm[f]);
+                    mx[f] = mfma16(kb[2 * f + 1], qh, mx[f]);
+                    mx[f] = mfma16(kb[2 * f], ql, mx[f]);
                 }
             }
 #pragma unroll
@@ -338,6 +398,7 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
                 to_frag16(v[0], v[1], ah[h], al[h]);
             }
         }
+        ENC_STAMP(4)
         // ---- S3: merge, LayerNorm1 ------------------------------------------------------------------------------------------
         {
             f32x4 am[NB16], ax[NB16];
@@ -345,9 +406,10 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             for (int b = 0; b < NB16; ++b) am[b] = ax[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                slab_mma16<8, 1, 0>(ring, lane, am, ax, &ah[ks], &al[ks]);
-                slab_mma16<8, 1, 8>(ring, lane, am, ax, &ah[ks], &al[ks]);
+                slab_step<8, 1, 0>(ring, lane, am, ax, &ah[ks], &al[ks], wa, wb);
+                slab_step<8, 1, 8>(ring, lane, am, ax, &ah[ks], &al[ks], wb, wa);
             }
+            ENC_STAMP(5)
 #define ENC_V3(b, r) (am[b][r] + ax[b][r] * (1.f / 2048.f))
             ENC_ROWSTATS(ENC_V3, g.eps1, mean, rstd)
 #pragma unroll
@@ -365,6 +427,7 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             }
 #undef ENC_V3
         }
+        ENC_STAMP(6)
         // ---- S4: mlp.2(relu(mlp.0([x | m]))) in eight 64-channel chunks of the hidden layer; S5: x + LayerNorm2(.) ----------
         {
             f32x4 om[NB16], ox[NB16];
@@ -376,15 +439,20 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) hm[b] = hx[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                     // k-steps 2 u, 2 u + 1: x channels
+                for (int u = 0; u < 4; u += 2) {                  // k-steps 2 u, 2 u + 1: x channels
                     half8 th[2], tl[2];
                     xfrag(2 * u, th[0], tl[0]);
                     xfrag(2 * u + 1, th[1], tl[1]);
-                    slab_mma16<4, 2, 0>(ring, lane, hm, hx, th, tl);
+                    slab_step<4, 2, 0>(ring, lane, hm, hx, th, tl, wa, wb);
+                    xfrag(2 * u + 2, th[0], tl[0]);
+                    xfrag(2 * u + 3, th[1], tl[1]);
+                    slab_step<4, 2, 0>(ring, lane, hm, hx, th, tl, wb, wa);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)                       // k-steps 8 + 2 u, 9 + 2 u: norm1(merge) channels
-                    slab_mma16<4, 2, 0>(ring, lane, hm, hx, ah + 2 * u, al + 2 * u);
+                for (int u = 0; u < 4; u += 2) {                  // k-steps 8 + 2 u, 9 + 2 u: norm1(merge) channels
+                    slab_step<4, 2, 0>(ring, lane, hm, hx, ah + 2 * u, al + 2 * u, wa, wb);
+                    slab_step<4, 2, 0>(ring, lane, hm, hx, ah + 2 * u + 2, al + 2 * u + 2, wb, wa);
+                }
                 half8 hh[2], hl[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -398,10 +466,11 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    slab_mma16<8, 1, 0>(ring, lane, om, ox, &hh[t], &hl[t]);
-                    slab_mma16<8, 1, 8>(ring, lane, om, ox, &hh[t], &hl[t]);
+                    slab_step<8, 1, 0>(ring, lane, om, ox, &hh[t], &hl[t], wa, wb);
+                    slab_step<8, 1, 8>(ring, lane, om, ox, &hh[t], &hl[t], wb, wa);
                 }
             }
+            ENC_STAMP(7)
 #define ENC_V5(b, r) (om[b][r] + ox[b][r] * (1.f / 2048.f))
             ENC_ROWSTATS(ENC_V5, g.eps2, mean, rstd)
 #pragma unroll
@@ -433,6 +502,7 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             }
 #undef ENC_V5
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ENC_STAMP(8)
             {
                 // whole-row stores (lane-linear: the swizzle is undone on the LDS read).  The tile is read out of the staging first,
                 // then the NEXT tile's x rows are requested into it, then the stores are issued.
@@ -472,9 +542,11 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
                     }
                 }
             }
+            ENC_STAMP(9)
         }
 #undef ENC_ROWSTATS
     }
+#undef ENC_STAMP
     wait_vmcnt<0>();        // prefetched slabs still in flight must land before the LDS allocation is released
 }
 

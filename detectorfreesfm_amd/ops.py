@@ -1217,6 +1217,7 @@ def encoder256_apply(x: "SplitAct", fw: Encoder256Weights, kv_image, S, q_mask=N
     qm = _as_u8(q_mask)
     if qm is not None and qm.shape != (N, (L + q_group - 1) // q_group):
         raise _lib.DfsfmError("encoder256_apply: q_mask must be [N, ceil(L / q_group)]")
+    # debug_stage 100: stage time stamps of wave 0 of every tile (tools/bench_enc256.py profile)
     dbg = torch.zeros((N * L, ENC256_C), dtype=torch.float32, device=x.hi.device) if debug_stage else None
     rc = _lib.lib().dfsfm_encoder256_apply_f32(_ptr(x.hi), _ptr(x.lo), ldx, N, L, int(S), _ptr(fw.stream), _ptr(kv_image),
                                                _ptr(qm), int(q_group), _ptr(fw.n1[0]), _ptr(fw.n1[1]), float(eps),
