@@ -183,8 +183,13 @@ def kernel_rooflines(dev, batch):
                        f"{rows} source rows (k, v fp32 read once)"))
         ms = event_time_ms(lambda: ops.linear(src, lw.pkv))
         out.append(_rl("linear_gemm_sf_kernel (k|v projection, K = 256, N = 512)", "mfma", rows * 262144.0, ms, f"{rows} rows"))
+        if lw.fused256.kv_stream is not None:
+            ms = event_time_ms(lambda: ops.encoder256_kv(src, lw.fused256))
+            out.append(_rl("enc256_kv_kernel + enc256_image_kernel (k|v projection fused with phi(K)^T V partial sums)", "mfma",
+                           rows * (262144.0 + 16384.0), ms, f"{rows} source rows", hbm_GBps_of_rows=rows * 1024.0 / ms / 1e6))
         ms = event_time_ms(lambda: _coarse.encoder_layer_split(lw, xs2, src, None, xo, 8))
-        out.append(_rl("coarse encoder layer application, fused (4 launches)", "mfma", layer_flop, ms, f"{rows} rows, cross layer"))
+        out.append(_rl("coarse encoder layer application, fused (enc256_kv + image + enc256_apply: 3 launches)", "mfma", layer_flop, ms,
+                       f"{rows} rows, cross layer"))
         del kv, st
     f256, lw.fused256 = lw.fused256, None
     ms = event_time_ms(lambda: _coarse.encoder_layer_split(lw, xs2, src, None, xo, 8))

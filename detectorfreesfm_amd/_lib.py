@@ -60,6 +60,9 @@ SIGNATURES = [
     ("dfsfm_encoder256_state_workspace", c_size_t, [c_int, c_int]),
     ("dfsfm_encoder256_state_f32", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("dfsfm_encoder256_kv_workspace", c_size_t, [c_int, c_int]),
+    ("dfsfm_encoder256_kv_f32", c_int,
+     [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("dfsfm_encoder256_apply_f32", c_int,
      [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
       c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p]),

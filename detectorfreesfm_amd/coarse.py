@@ -52,8 +52,10 @@ def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
 
 # DFSFM_FUSED_ENCODER=0 keeps d_model-128 layers on the five-GEMM path as well (same-box A/B switch, read once at import)
 FUSED_ENCODER = os.environ.get("DFSFM_FUSED_ENCODER", "1") != "0"
-# DFSFM_FUSED_ENCODER256=0: the same switch for the d_model-256 layers of the coarse transformer (csrc/encoder256.hip)
+# DFSFM_FUSED_ENCODER256=0: the same switch for the d_model-256 layers of the coarse transformer (csrc/encoder256.hip);
+# DFSFM_FUSED_KV256=0 keeps their source side on the k | v projection GEMM + K1's partial sums (encoder256_state)
 FUSED_ENCODER256 = os.environ.get("DFSFM_FUSED_ENCODER256", "1") != "0"
+FUSED_KV256 = os.environ.get("DFSFM_FUSED_KV256", "1") != "0"
 
 
 class EncoderLayerWeights:
@@ -77,7 +79,7 @@ class EncoderLayerWeights:
         self.fused256 = None
         if wq.shape == (ops.ENC256_C, ops.ENC256_C) and FUSED_ENCODER256:
             self.fused256 = ops.Encoder256Weights(wq, get(prefix + "merge.weight"), get(prefix + "mlp.0.weight"),
-                                                  get(prefix + "mlp.2.weight"), self.n1, self.n2)
+                                                  get(prefix + "mlp.2.weight"), self.n1, self.n2, wk=wk, wv=wv)
 
 
 def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x_mask=None, source_mask=None,
@@ -105,11 +107,14 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
         ops.encoder_apply(xs_x, w.fused, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
         return out_x
     if w.fused256 is not None and nhead == 8 and L >= 16 and (out_x is not None or out_xs is not None):
-        # three launches + one: k | v projection, K1's partial sums + the apply image, then q, attention, merge, LayerNorm,
-        # MLP, LayerNorm and the residual in one kernel (q, the message, [x | norm1] and the hidden layer never reach memory;
-        # the second half of ``xs`` stays unused)
-        kv = ops.linear(src, w.pkv).view(N, S, 2 * C)
-        state = ops.encoder256_state(kv[..., :C], kv[..., C:], source_mask, kv_group)
+        # source side: k | v projection fused with K1's partial sums (+ the small image kernel); query side: q, attention,
+        # merge, LayerNorm, MLP, LayerNorm and the residual in one kernel.  q, k, v, the message, [x | norm1] and the hidden
+        # layer never reach memory; the second half of ``xs`` stays unused
+        if FUSED_KV256 and w.fused256.kv_stream is not None:
+            state = ops.encoder256_kv(src, w.fused256, source_mask, kv_group)        # k, v never reach memory either
+        else:
+            kv = ops.linear(src, w.pkv).view(N, S, 2 * C)
+            state = ops.encoder256_state(kv[..., :C], kv[..., C:], source_mask, kv_group)
         ops.encoder256_apply(xs_x, w.fused256, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
         return out_x
     if is_self:

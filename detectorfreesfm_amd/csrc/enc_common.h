@@ -68,4 +68,8 @@ struct SlabRing {
     }
 };
 
+// chunk partials [N][nchunks][8][32*32 + 32] (K1's layout: KV[d][v], then Ksum[d]) -> the apply image of encoder256.hip
+// (defined there; also used by dfsfm_encoder256_state_f32 in linear_attention.hip)
+void enc256_launch_image(const float* part, char* img, int N, int nchunks, hipStream_t stream);
+
 }  // namespace dfsfm_enc

@@ -41,6 +41,7 @@ constexpr int STG = 16384;               // per-wave staging tile: 16 tokens x 2
 constexpr int PLANE = 8192;
 constexpr int NSLAB = 128;               // q 16, merge 16, 8 x (mlp.0 chunk 8 + mlp.2 chunk 4)
 constexpr int KVIMG = 32 * 1024 + 1024;  // bytes per sequence: 16 KV^T fragment pairs (hi, lo) + Ksum[256]
+constexpr int KVSZ = 32 * 32 + 32;       // floats per (n, chunk, head) of the chunk partials: KV[d][v] then Ksum[d] (K1's layout)
 constexpr int SMEM_APPLY = RING + 4 * STG + 4 * EC * 4 + 4 * 2048;   // + LayerNorm gamma / beta + Ksum of a wave's two sequences
 
 // Timing-only ablation switches (tools/build_enc256_abl.sh builds them into csrc/abl/; results are WRONG with any of them set):
@@ -550,9 +551,347 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
     wait_vmcnt<0>();        // prefetched slabs still in flight must land before the LDS allocation is released
 }
 
+
+// One slab of the k | v projection (classic orientation: A = x fragments, B = weight fragments): 2 k-steps x 4 blocks, walked as
+// four (k-step, block pair) groups of 4 consecutive fragments [wh(b0), wl(b0), wh(b1), wl(b1)] and 6 MFMAs.  The KV accumulators of
+// the eight heads take 256 registers, so the apply kernel's whole-slab double buffer (128 registers) does not fit here: the
+// fragments travel through a WINDOW of two groups (32 registers) -- while group q is multiplied, group q + 1 is read; the last
+// group of a slab reads the first group of the NEXT slab.  That needs the next slab visible one step early: s_barrier(s) publishes
+// slab s + 1 (so two slabs are resident and being read, one is landing, one slot is refilled: the prefetch distance is two steps
+// instead of three).  On entry `wa` holds group 0 of slab `next`.
+__device__ __forceinline__ void kv_slab_step(SlabRing& ring, int lane, f32x4 (&dm)[NB16], f32x4 (&dx)[NB16], const half8* xh,
+                                             const half8* xl, half8 (&wa)[4], half8 (&wb)[4]) {
+    wait_vmcnt<4>();                                 // this wave's pieces of slab next + 1 (next + 2 may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                    // slab next + 1 is visible; every wave is done with slab next - 1
+    __builtin_amdgcn_sched_barrier(0);
+    const char* cslab = ring.ring + (ring.next % NSTG) * SLAB + lane * 16;
+    const char* nslab = ring.ring + ((ring.next + 1) % NSTG) * SLAB + lane * 16;
+    const unsigned gn = ring.next + NSTG - 1;       // into the slot of slab next - 1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ks = q >> 1, b0 = 2 * (q & 1), b1 = b0 + 1;
+        half8(&c)[4] = (q & 1) ? wb : wa;
+        half8(&nx)[4] = (q & 1) ? wa : wb;
+        const char* src = q < 3 ? cslab + (q + 1) * 4096 : nslab;
+        dm[b0] = mfma16(xh[ks], c[0], dm[b0]);
+        nx[0] = *reinterpret_cast<const half8*>(src);
+        __builtin_amdgcn_sched_barrier(0);
+        dx[b0] = mfma16(xh[ks], c[1], dx[b0]);
+        nx[1] = *reinterpret_cast<const half8*>(src + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        dm[b1] = mfma16(xh[ks], c[2], dm[b1]);
+        ring.issue_piece(gn, q);
+        __builtin_amdgcn_sched_barrier(0);
+        dx[b1] = mfma16(xh[ks], c[3], dx[b1]);
+        nx[2] = *reinterpret_cast<const half8*>(src + 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        dx[b0] = mfma16(xl[ks], c[0], dx[b0]);
+        nx[3] = *reinterpret_cast<const half8*>(src + 3072);
+        __builtin_amdgcn_sched_barrier(0);
+        dx[b1] = mfma16(xl[ks], c[2], dx[b1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ring.advance();
+}
+
+// Chunk partials -> the "apply image" of the d_model-256 fused encoder layer (encoder256.hip): per sequence, for head h and
+// row block rb the A fragment pair (hi, lo planes of 1 KB, lane-linear) of KV_h^T rows 16 rb .. 16 rb + 15 -- lane (i, g) slot j
+// = KV_h[d][16 rb + i] with d = 16 (j >> 2) + 4 g + (j & 3), the k order in which that kernel's accumulators hold phi(q_h) --
+// then Ksum[256] as fp32.  Same four-way interleaved chunk sum as la_kv_finalize (fixed order: deterministic).
+
+__global__ __launch_bounds__(256) void enc256_image_kernel(const float* __restrict__ part, char* __restrict__ img, int nchunks) {
+    const int nh = blockIdx.x, n = nh >> 3, h = nh & 7;
+    const float* p0 = part + ((int64_t)n * nchunks * 8 + h) * KVSZ;
+    const int64_t stride = (int64_t)8 * KVSZ;
+    char* out = img + (int64_t)n * KVIMG;
+    for (int e = threadIdx.x; e < KVSZ; e += 256) {
+        int src = e, rb = 0, lane = 0, j = 0;
+        if (e < 1024) {
+            rb = e >> 9; lane = (e >> 3) & 63; j = e & 7;
+            const int i = lane & 15, g = lane >> 4;
+            src = (16 * (j >> 2) + 4 * g + (j & 3)) * 32 + 16 * rb + i;
+        }
+        const float* p = p0 + src;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = 0;
+        for (; c + 4 <= nchunks; c += 4) {
+            s0 += p[(c + 0) * stride];
+            s1 += p[(c + 1) * stride];
+            s2 += p[(c + 2) * stride];
+            s3 += p[(c + 3) * stride];
+        }
+        for (; c < nchunks; ++c) s0 += p[c * stride];
+        const float val = (s0 + s1) + (s2 + s3);
+        if (e < 1024) {
+            _Float16 hi, lo;
+            split_f32(val, hi, lo);
+            char* q = out + ((h * 2 + rb) * 2) * 1024 + lane * 16 + j * 2;
+            *reinterpret_cast<_Float16*>(q) = hi;
+            *reinterpret_cast<_Float16*>(q + 1024) = lo;
+        } else {
+            reinterpret_cast<float*>(out + 32768)[32 * h + (e - 1024)] = val;
+        }
+    }
+}
+
+
+// =====================================================================================================================
+// enc256_kv_kernel: the SOURCE side of a layer application -- k | v projection fused with K1's partial sums.
+//   k | v = W_kv x (never stored), phi(k), v / S and the padding mask applied in registers, then per head
+//   KV_h += phi(k_h)^T v_h and Ksum_h += sum_t phi(k_h) for the workgroup's chunk of the sequence; the chunk partials go to memory in
+//   K1's layout ([n][chunk][head][KV[d][v] | Ksum[d]]) and enc256_image_kernel reduces them (fixed order) into the apply image.
+// Replaces ops.linear(src, W_kv) (a 2 KB / row fp32 round trip through HBM) + la_kv_partial_staged.
+// Classic orientation D[token][channel] = x[token][k] W[channel][k] on v_mfma_f32_16x16x32_f16: lane = channel (lane & 15),
+// registers = tokens 4 g + r of a 16-token block -- so that the contraction over tokens of phi(k)^T v is again an MFMA whose A and
+// B fragments ARE the k and v accumulators: slots j < 4 of lane group g = tokens 4 g + j, slots j >= 4 zero (16 of the MFMA's 32
+// k positions; the 12 KV MFMAs of a head are 1/9 of its MFMAs).  A wave owns a 16-token block per pass; its x fragments (natural k
+// order, 64 registers) feed all eight heads; KV of the eight heads stays in 256 accumulator registers for the whole chunk.
+// Weight stream: 32 slabs, head h = slabs 4 h .. 4 h + 3, slab u = k-steps 2 u, 2 u + 1 x rows [k_h (2 blocks) | v_h (2 blocks)],
+// through the same ring; the fragments pass through a two-group register window (kv_slab_step).
+// =====================================================================================================================
+constexpr int NSLAB_KV = 32;
+constexpr int KV_MASK_MAX = 8192;         // mask entries of a chunk kept in LDS
+constexpr int SMEM_KV = RING + 4 * STG + 16384;      // the mask entries (8 KB) during the passes; 128 KB of KV partials + 16 KB of Ksum
+                                                      // partials for the cross-wave sums at the end
+static_assert(KV_MASK_MAX <= 16384 && 4 * NKS * 16 * 64 * 4 == RING + 4 * STG, "enc256_kv_kernel: LDS layout of the final reduction");
+
+struct Kv256Args {
+    const _Float16 *xh, *xl;     // source rows as split planes, row stride ldx (elements)
+    int64_t ldx;
+    unsigned xbytes;
+    const char* wstream;         // NSLAB_KV slabs
+    const uint8_t* kvmask;       // [N][km_per_seq] or null
+    int kv_group, km_per_seq;
+    float* part;                 // [N][nchunks][8][KVSZ] out
+    int S, N, rows_per_chunk, nchunks;
+};
+
+__global__ __launch_bounds__(256) void enc256_kv_kernel(Kv256Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, grp = lane >> 4;
+    char* stg = smem + RING + wave * STG;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int s_begin = chunk * g.rows_per_chunk;
+    const int s_end = min(g.S, s_begin + g.rows_per_chunk);
+    const int nblocks = (s_end - s_begin + 15) / 16;
+    const int niter = (nblocks + 3) / 4;            // every wave runs the same number of passes (shared weight stream)
+
+    SlabRing ring;
+    ring.ring = smem;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.wstream, 0, NSLAB_KV * SLAB, 0x00020000);
+    ring.lane_off = (unsigned)(wave * 4096 + lane * 16);
+    ring.wave = wave;
+    ring.nslab = NSLAB_KV;
+#pragma unroll
+    for (int gq = 0; gq < NSTG - 1; ++gq) ring.issue(gq);        // slabs 0, 1, 2; step s refills the slot of slab s - 1 with s + 3
+    ring.next = 0;
+
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
+    const float Sf = (float)g.S;
+    // the chunk's mask entries once into LDS (as byte loads inside the block loop every entry was its own drain of the DMA queue)
+    uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + RING + 4 * STG);
+    const int m_lo = s_begin / g.kv_group;
+    const int m_cnt = g.kvmask ? (s_end - 1) / g.kv_group - m_lo + 1 : 0;
+    const bool lds_mask = g.kvmask && m_cnt <= KV_MASK_MAX;
+    if (lds_mask)
+        for (int i = tid; i < m_cnt; i += 256) s_mask[i] = g.kvmask[(int64_t)n * g.km_per_seq + m_lo + i];
+    // x rows of the wave's block `it` -> staging (rows of 512 B per plane, 16-byte chunks XOR-swizzled on the source side)
+    auto load_x = [&](int it) __attribute__((always_inline)) {
+        const int s0 = s_begin + (it * 4 + wave) * 16;
+        const int trow = lane >> 5, p = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tt = 2 * i + trow;
+            const int srow = s0 + tt;
+            const unsigned off = srow < s_end ? (unsigned)((((int64_t)n * g.S + srow) * g.ldx + ((p ^ (tt & 15)) << 3)) * 2) : g.xbytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + PLANE + i * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    load_x(0);
+    half8 wa[4], wb[4];                      // the fragment window: group being multiplied / group being fetched (ping-pong)
+    wait_vmcnt<0>();                         // slabs 0-2 and the first x block
+    __syncthreads();                         // ... of every wave; and the mask entries
+#pragma unroll
+    for (int f = 0; f < 4; ++f) wa[f] = *reinterpret_cast<const half8*>(smem + f * 1024 + lane * 16);
+
+    f32x4 kvm[NKS][4], kvx[NKS][4];          // KV of head h, block (kb, vb) = [2 kb + vb]: rows d = 16 kb + 4 g + r, column v = 16 vb + lane & 15
+    float ksum[NKS][2];                      // sum over this lane's tokens of phi(k) of channel 32 h + 16 kb + (lane & 15)
+#pragma unroll
+    for (int h = 0; h < NKS; ++h) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) kvm[h][b] = kvx[h][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ksum[h][0] = ksum[h][1] = 0.f;
+    }
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int it = 0; it < niter; ++it) {
+        const int s0 = s_begin + (it * 4 + wave) * 16;    // first token of this wave's block (may be past the chunk: all masked)
+        // masks of the 4 tokens this lane's accumulator registers hold: token s0 + 4 g + r
+        float tm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sidx = s0 + 4 * grp + r;
+            float mk = sidx < s_end ? 1.f : 0.f;
+            if (lds_mask) { if (sidx < s_end) mk = (float)s_mask[sidx / g.kv_group - m_lo]; }
+            else if (g.kvmask && sidx < s_end) mk = (float)g.kvmask[(int64_t)n * g.km_per_seq + sidx / g.kv_group];
+            tm[r] = mk;
+        }
+        wait_vmcnt<0>();                                  // the x block has landed (and the slabs in flight: once per pass)
+        // A fragments of x for all eight k-steps: lane (token, g) slots = channels 32 s + 8 g + j (natural order: one 16-byte read)
+        half8 xh[NKS], xl[NKS];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            xh[s] = *reinterpret_cast<const half8*>(stg + stg_off(col, 4 * s + grp));
+            xl[s] = *reinterpret_cast<const half8*>(stg + PLANE + stg_off(col, 4 * s + grp));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (it + 1 < niter) load_x(it + 1);               // the staging tile is free again: the next block flies under this pass
+#pragma unroll
+        for (int h = 0; h < NKS; ++h) {
+            f32x4 dm[NB16], dx[NB16];                     // blocks 0, 1 = k channels of head h, 2, 3 = v channels (only 0..3 used)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dm[b] = dx[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kv_slab_step(ring, lane, dm, dx, xh + 0, xl + 0, wa, wb);
+            kv_slab_step(ring, lane, dm, dx, xh + 2, xl + 2, wa, wb);
+            kv_slab_step(ring, lane, dm, dx, xh + 4, xl + 4, wa, wb);
+            kv_slab_step(ring, lane, dm, dx, xh + 6, xl + 6, wa, wb);
+            half8 kfh[2], kfl[2], vfh[2], vfl[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float kf[4], vf[4];
+                const float zz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    kf[r] = phi_fast(dm[b][r] + dx[b][r] * (1.f / 2048.f)) * tm[r];
+                    vf[r] = ((dm[2 + b][r] + dx[2 + b][r] * (1.f / 2048.f)) * tm[r]) / Sf;
+                    ksum[h][b] += kf[r];
+                }
+                to_frag16(kf, zz, kfh[b], kfl[b]);        // slots 4..7 (the other 16 k positions of the MFMA) stay zero
+                to_frag16(vf, zz, vfh[b], vfl[b]);
+            }
+            // KV_h[d][v] += sum over the block's tokens: A = phi(k)^T (lane = d), B = v (lane = v channel), same token slots
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int vb = 0; vb < 2; ++vb) {
+                    kvm[h][2 * kb + vb] = mfma16(kfh[kb], vfh[vb], kvm[h][2 * kb + vb]);
+                    kvx[h][2 * kb + vb] = mfma16(kfl[kb], vfh[vb], kvx[h][2 * kb + vb]);
+                }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int vb = 0; vb < 2; ++vb)
+                    kvx[h][2 * kb + vb] = mfma16(kfh[kb], vfl[vb], kvx[h][2 * kb + vb]);
+        }
+    }
+    (void)zero8;
+    wait_vmcnt<0>();
+    __syncthreads();                                // ring and staging are free: reuse them for the cross-wave sums
+    // every wave parks its partial KV (fp32) at [wave][h][b][r][lane] and its Ksum at [wave][h][kb][lane]: 4 x 32 KB + 4 x 4 KB
+    float* park = reinterpret_cast<float*>(smem);
+    float* ksp = park + 4 * NKS * 16 * 64;
+#pragma unroll
+    for (int h = 0; h < NKS; ++h) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                park[((wave * NKS + h) * 16 + b * 4 + r) * 64 + lane] = kvm[h][b][r] + kvx[h][b][r] * (1.f / 2048.f);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) ksp[((wave * NKS + h) * 2 + kb) * 64 + lane] = ksum[h][kb];
+    }
+    __syncthreads();
+    // wave w finishes heads 2 w, 2 w + 1: fixed summation order over the waves (deterministic)
+    float* out = g.part + ((int64_t)n * g.nchunks + chunk) * NKS * KVSZ;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * wave + hh;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) a += park[((w * NKS + h) * 16 + b * 4 + r) * 64 + lane];
+                out[h * KVSZ + (16 * (b >> 1) + 4 * grp + r) * 32 + 16 * (b & 1) + col] = a;
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += ksp[((w * NKS + h) * 2 + kb) * 64 + lane];
+            a += __shfl_xor(a, 16);                 // the four lane groups hold different tokens of the same channel
+            a += __shfl_xor(a, 32);
+            if (grp == 0) out[h * KVSZ + 1024 + 16 * kb + col] = a;
+        }
+    }
+}
+
 dfsfm::SmemAttr attr_apply256;
 
+dfsfm::SmemAttr attr_kv256;
+
 }  // namespace
+
+void dfsfm_enc::enc256_launch_image(const float* part, char* img, int N, int nchunks, hipStream_t stream) {
+    hipLaunchKernelGGL(enc256_image_kernel, dim3(N * 8), dim3(256), 0, stream, part, img, nchunks);
+}
+
+// rows of a sequence per workgroup of enc256_kv_kernel: a multiple of 64 (4 waves x 16 tokens), about one workgroup per CU
+static int kv256_chunk_rows(int N, int S) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t steps = ((int64_t)N * ((S + 63) / 64) + cus - 1) / cus;       // 64-token passes per workgroup
+    int rows = (int)(steps < 1 ? 1 : steps) * 64;
+    const int smax = (S + 63) / 64 * 64;
+    return rows > smax ? smax : rows;
+}
+
+extern "C" size_t dfsfm_encoder256_kv_workspace(int N, int S) {
+    if (N <= 0 || S <= 0) return 0;
+    const int rows = kv256_chunk_rows(N, S);
+    const int nchunks = (S + rows - 1) / rows;
+    return dfsfm::align_up((size_t)N * nchunks * 8 * KVSZ * sizeof(float), 256);
+}
+
+extern "C" int dfsfm_encoder256_kv_f32(const void* src_hi, const void* src_lo, int64_t ld_src, int N, int S,
+                                       const void* wstream_kv, const uint8_t* kv_mask, int kv_group, void* kv_image,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    if (N == 0) return DFSFM_OK;
+    if (!src_hi || !src_lo || !wstream_kv || !kv_image || !workspace) return DFSFM_E_BADARG;
+    if (N < 0 || S <= 0 || kv_group <= 0 || ld_src < EC) return DFSFM_E_BADARG;
+    const int64_t span = ((int64_t)N * S - 1) * ld_src * 2 + EC * 2;
+    if (N > 65535 || (ld_src & 7) || span >= (int64_t)0xFFFFFFF0) return DFSFM_E_UNSUPPORTED;
+    for (const void* p : {src_hi, src_lo, wstream_kv, (const void*)kv_image, (const void*)workspace})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return DFSFM_E_UNSUPPORTED;
+    if (workspace_bytes < dfsfm_encoder256_kv_workspace(N, S)) return DFSFM_E_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Kv256Args g{};
+    g.xh = static_cast<const _Float16*>(src_hi);
+    g.xl = static_cast<const _Float16*>(src_lo);
+    g.ldx = ld_src;
+    g.xbytes = (unsigned)span;
+    g.wstream = static_cast<const char*>(wstream_kv);
+    g.kvmask = kv_mask;
+    g.kv_group = kv_group;
+    g.km_per_seq = (S + kv_group - 1) / kv_group;
+    g.part = static_cast<float*>(workspace);
+    g.S = S;
+    g.N = N;
+    g.rows_per_chunk = kv256_chunk_rows(N, S);
+    g.nchunks = (S + g.rows_per_chunk - 1) / g.rows_per_chunk;
+    attr_kv256.ensure(reinterpret_cast<const void*>(&enc256_kv_kernel), SMEM_KV);
+    hipLaunchKernelGGL(enc256_kv_kernel, dim3((unsigned)g.nchunks, (unsigned)N), dim3(256), SMEM_KV, stream, g);
+    dfsfm_enc::enc256_launch_image(g.part, static_cast<char*>(kv_image), N, g.nchunks, stream);
+    return dfsfm::check_launch("dfsfm_encoder256_kv_f32");
+}
 
 extern "C" int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int N, int L, int S,
                                           const void* wstream, const void* kv_image, const uint8_t* q_mask, int q_group,

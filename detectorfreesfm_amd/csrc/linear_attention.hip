@@ -22,6 +22,7 @@
 // keeps every lane's accesses contiguous.  Summation order is fixed -> results are run-to-run
 // deterministic.
 #include "common.h"
+#include "enc_common.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -586,47 +587,6 @@ __global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ 
     kvf[(int64_t)nh * kvsz + e] = (s0 + s1) + (s2 + s3);
 }
 
-// Chunk partials -> the "apply image" of the d_model-256 fused encoder layer (encoder256.hip): per sequence, for head h and
-// row block rb the A fragment pair (hi, lo planes of 1 KB, lane-linear) of KV_h^T rows 16 rb .. 16 rb + 15 -- lane (i, g) slot j
-// = KV_h[d][16 rb + i] with d = 16 (j >> 2) + 4 g + (j & 3), the k order in which that kernel's accumulators hold phi(q_h) --
-// then Ksum[256] as fp32.  Same four-way interleaved chunk sum as la_kv_finalize (fixed order: deterministic).
-constexpr int ENC256_KVIMG = 32 * 1024 + 1024;
-
-__global__ __launch_bounds__(256) void enc256_image_kernel(const float* __restrict__ part, char* __restrict__ img, int nchunks) {
-    const int nh = blockIdx.x, n = nh >> 3, h = nh & 7;
-    const float* p0 = part + ((int64_t)n * nchunks * 8 + h) * KV32;
-    const int64_t stride = (int64_t)8 * KV32;
-    char* out = img + (int64_t)n * ENC256_KVIMG;
-    for (int e = threadIdx.x; e < KV32; e += 256) {
-        int src = e, rb = 0, lane = 0, j = 0;
-        if (e < 1024) {
-            rb = e >> 9; lane = (e >> 3) & 63; j = e & 7;
-            const int i = lane & 15, g = lane >> 4;
-            src = (16 * (j >> 2) + 4 * g + (j & 3)) * 32 + 16 * rb + i;
-        }
-        const float* p = p0 + src;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int c = 0;
-        for (; c + 4 <= nchunks; c += 4) {
-            s0 += p[(c + 0) * stride];
-            s1 += p[(c + 1) * stride];
-            s2 += p[(c + 2) * stride];
-            s3 += p[(c + 3) * stride];
-        }
-        for (; c < nchunks; ++c) s0 += p[c * stride];
-        const float val = (s0 + s1) + (s2 + s3);
-        if (e < 1024) {
-            _Float16 hi, lo;
-            dfsfm::split_f32(val, hi, lo);
-            char* q = out + ((h * 2 + rb) * 2) * 1024 + lane * 16 + j * 2;
-            *reinterpret_cast<_Float16*>(q) = hi;
-            *reinterpret_cast<_Float16*>(q + 1024) = lo;
-        } else {
-            reinterpret_cast<float*>(out + 32768)[32 * h + (e - 1024)] = val;
-        }
-    }
-}
-
 // Rows per kv_partial workgroup: aim for ~512 workgroups (one resident wave of 2 per CU), at least
 // 64 rows each.
 int chunk_rows(int N, int S) {
@@ -759,6 +719,6 @@ extern "C" int dfsfm_encoder256_state_f32(const float* k, const float* v, int ld
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(la_kv_partial_staged<32>, dim3(nchunks, N), dim3(256), 0, stream, k, v, kv_mask, kv_group, part, S, ldk,
                        ldv, rows, nchunks);
-    hipLaunchKernelGGL(enc256_image_kernel, dim3(N * 8), dim3(256), 0, stream, part, static_cast<char*>(kv_image), nchunks);
+    dfsfm_enc::enc256_launch_image(part, static_cast<char*>(kv_image), N, nchunks, stream);
     return dfsfm::check_launch("dfsfm_encoder256_state_f32");
 }

@@ -1118,6 +1118,13 @@ def _fragment16(plane: torch.Tensor, row0: int, kstep: int) -> torch.Tensor:
     return torch.stack([rows[:, cols[g]] for g in range(4)], 0).reshape(64, 8)
 
 
+def _fragment16_nat(plane: torch.Tensor, row0: int, kstep: int) -> torch.Tensor:
+    """The same with the k columns in natural order (lane (i, g) slot j = column 32 kstep + 8 g + j): the B fragments of
+    enc256_kv_kernel, whose A operand (the x tile) is read from memory in natural order as well."""
+    rows = plane[row0:row0 + 16, 32 * kstep:32 * kstep + 32]          # [16, 32]
+    return rows.reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8)
+
+
 class Encoder256Weights:
     """Weights of one LoFTREncoderLayer with d_model 256, 8 heads (the coarse transformer) as the fragment stream of
     csrc/encoder256.hip: 128 slabs of 16 KB = 16 fragments of 1 KB (64 lanes x 16 bytes, lane-linear), (hi, lo) pairs in
@@ -1127,9 +1134,11 @@ class Encoder256Weights:
       per 64-channel chunk hc (0..7) of the MLP's hidden layer:
         mlp.0   8 slabs: slab u = k-steps 2u, 2u+1 of the 512 input columns [x | norm1(message)] x rows 64 hc + 16 b, b = 0..3
         mlp.2   4 slabs: k-step 2 hc + t (t = 0..1) of its 512 columns x row half nb2: rows 16 (8 nb2 + b), b = 0..7
-    k columns inside a k-step are in ``_kslots16`` order.  k_proj / v_proj stay ordinary split-plane GEMM weights (pkv)."""
+    k columns inside a k-step are in ``_kslots16`` order.
+    ``kv_stream`` (when wk / wv are given; enc256_kv_kernel): 32 slabs, head h = slabs 4 h .. 4 h + 3, slab u = k-steps 2 u,
+    2 u + 1 x rows [W_k rows 32 h + 16 b (b = 0, 1) | W_v rows 32 h + 16 b], natural k order; fragment order (ks, block, plane)."""
 
-    def __init__(self, wq, wmerge, w1, w2, n1, n2, nhead=8):
+    def __init__(self, wq, wmerge, w1, w2, n1, n2, nhead=8, wk=None, wv=None):
         C = ENC256_C
         if nhead != 8 or tuple(wq.shape) != (C, C) or tuple(wmerge.shape) != (C, C) or tuple(w1.shape) != (2 * C, 2 * C) or \
                 tuple(w2.shape) != (C, 2 * C):
@@ -1158,6 +1167,22 @@ class Encoder256Weights:
                         frags += pair("2", 16 * (8 * nb2 + b), 2 * hc + t)
         self.stream = torch.stack(frags, 0).contiguous().to(dev)            # [2048, 64, 8] fp16 = 128 slabs
         assert self.stream.numel() * 2 == ENC256_NSLAB * ENC_SLAB
+        self.kv_stream = None
+        if wk is not None:
+            if tuple(wk.shape) != (C, C) or tuple(wv.shape) != (C, C):
+                raise _lib.DfsfmError("Encoder256Weights: k_proj / v_proj must be [256, 256]")
+            pk, pv = _split_planes(wk.detach().cpu()), _split_planes(wv.detach().cpu())
+            self.values["k_proj.weight"] = (pk[0].float() + pk[1].float() / 2048.0).to(dev)
+            self.values["v_proj.weight"] = (pv[0].float() + pv[1].float() / 2048.0).to(dev)
+            frags = []
+            for h in range(8):
+                for u in range(4):
+                    for ks in range(2):
+                        for b in range(4):
+                            pl, r0 = (pk, 32 * h + 16 * b) if b < 2 else (pv, 32 * h + 16 * (b - 2))
+                            frags += [_fragment16_nat(pl[0], r0, 2 * u + ks), _fragment16_nat(pl[1], r0, 2 * u + ks)]
+            self.kv_stream = torch.stack(frags, 0).contiguous().to(dev)      # [512, 64, 8] fp16 = 32 slabs
+            assert self.kv_stream.numel() * 2 == 32 * ENC_SLAB
         self.n1 = tuple(t.detach().float().contiguous() for t in n1)
         self.n2 = tuple(t.detach().float().contiguous() for t in n2)
         self.values.update({"norm1.weight": self.n1[0], "norm1.bias": self.n1[1], "norm2.weight": self.n2[0],
@@ -1184,6 +1209,30 @@ def encoder256_state(k, v, kv_mask=None, kv_group=1):
     rc = lib.dfsfm_encoder256_state_f32(_ptr(k), _ptr(v), ldk, ldv, _ptr(km), int(kv_group), N, S, _ptr(img), _ptr(ws),
                                         ws.numel(), _stream())
     _lib.check(rc, "dfsfm_encoder256_state_f32")
+    return img
+
+
+@_on_device
+def encoder256_kv(src: "SplitAct", fw: Encoder256Weights, kv_mask=None, kv_group=1):
+    """Source side of a d_model-256 fused layer application in ONE projection launch: source tokens [N, S, 256] (split planes)
+    -> k | v = W_kv x (never stored) -> phi(K)^T V / S and sum phi(K) per head -> the attention state for ``encoder256_apply``
+    (the same image ``encoder256_state`` builds from a materialised k | v)."""
+    _require_cuda(src.hi)
+    if fw.kv_stream is None:
+        raise _lib.DfsfmError("encoder256_kv: these weights were packed without k_proj / v_proj")
+    if src.hi.dim() != 3 or src.hi.shape[-1] != ENC256_C or src.hi.dtype != torch.float16 or src.lo.stride() != src.hi.stride():
+        raise _lib.DfsfmError("encoder256_kv: need split planes [N, S, 256]")
+    N, S = src.hi.shape[0], src.hi.shape[1]
+    _, ld = _rows_ld(src.hi, torch.float16)
+    km = _as_u8(kv_mask)
+    if km is not None and km.shape != (N, (S + kv_group - 1) // kv_group):
+        raise _lib.DfsfmError("encoder256_kv: kv_mask must be [N, ceil(S / kv_group)]")
+    lib = _lib.lib()
+    ws = _workspace(lib.dfsfm_encoder256_kv_workspace(N, S), src.hi.device)
+    img = torch.empty((N, ENC256_KV_IMAGE), dtype=torch.uint8, device=src.hi.device)
+    rc = lib.dfsfm_encoder256_kv_f32(_ptr(src.hi), _ptr(src.lo), ld, N, S, _ptr(fw.kv_stream), _ptr(km), int(kv_group), _ptr(img),
+                                     _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "dfsfm_encoder256_kv_f32")
     return img
 
 

@@ -422,6 +422,10 @@ int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int
  *                             of KV_h^T = (sum_s phi(k_s)^T v_s / S)^T, then Ksum = sum_s phi(k_s) as 256 floats).
  *                             kv_mask [N, ceil(S/kv_group)] uint8 or NULL.  Two launches (chunked partial sums, a
  *                             fixed-order reduction: deterministic); workspace dfsfm_encoder256_state_workspace(N, S).
+ * dfsfm_encoder256_kv_f32     the same state straight from the source TOKENS: source rows [N*S, 256] (split planes, row stride
+ *                             ld_src halves) -> k | v = W_kv x (never stored; wstream_kv: 32 slabs of 16 KB, ops.Encoder256Weights)
+ *                             -> chunk partials of phi(K)^T V / S and sum phi(K) -> the same image.  Replaces the k | v projection
+ *                             GEMM + dfsfm_encoder256_state_f32; workspace dfsfm_encoder256_kv_workspace(N, S).
  * dfsfm_encoder256_apply_f32  query side in ONE launch: x rows [N*L, 256] (split planes) + kv_image ->
  *                             out = x + norm2(mlp.2(relu(mlp.0([x | norm1(merge(attention(W_q x)))]))))
  *                             as split planes and / or fp32 rows; arguments as dfsfm_encoder_apply_f32 (L >= 16;
@@ -431,6 +435,10 @@ int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int
 size_t dfsfm_encoder256_state_workspace(int N, int S);
 int dfsfm_encoder256_state_f32(const float* k, const float* v, int ldk, int ldv, const uint8_t* kv_mask, int kv_group,
                                int N, int S, void* kv_image, void* workspace, size_t workspace_bytes, void* stream);
+size_t dfsfm_encoder256_kv_workspace(int N, int S);
+int dfsfm_encoder256_kv_f32(const void* src_hi, const void* src_lo, int64_t ld_src, int N, int S, const void* wstream_kv,
+                            const uint8_t* kv_mask, int kv_group, void* kv_image, void* workspace, size_t workspace_bytes,
+                            void* stream);
 int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, int N, int L, int S, const void* wstream,
                                const void* kv_image, const uint8_t* q_mask, int q_group, const float* gamma1,
                                const float* beta1, float eps1, const float* gamma2, const float* beta2, float eps2,

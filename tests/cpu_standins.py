@@ -364,6 +364,13 @@ def _enc256_state(k, v, kv_mask=None, kv_group=1):
     return {"k": k.float().clone(), "v": v.float().clone(), "mask": kv_mask, "group": kv_group}
 
 
+def _enc256_kv(src, fw, kv_mask=None, kv_group=1):
+    """Stand-in for ops.encoder256_kv: k | v projection of the source tokens on the values the kv stream holds."""
+    sv = src.float()
+    return {"k": F.linear(sv, fw.values["k_proj.weight"]), "v": F.linear(sv, fw.values["v_proj.weight"]), "mask": kv_mask,
+            "group": kv_group}
+
+
 def _enc256_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=None, eps=1e-5, attn_eps=1e-6, debug_stage=0):
     """Stand-in for ops.encoder256_apply: the query side of LoFTREncoderLayer.forward (transformer.py:35-58) on the values the
     fragment stream holds (fw.values), attention through the oracle's linear_attention."""
@@ -395,7 +402,7 @@ def cpu_ops():
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
                                           "bilinear_up", "resample_u8", "avgpool", "full_attention",
                                           "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear",
-                                          "encoder_kv", "encoder_apply", "encoder256_state", "encoder256_apply")}
+                                          "encoder_kv", "encoder_apply", "encoder256_state", "encoder256_apply", "encoder256_kv")}
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool
@@ -407,7 +414,7 @@ def cpu_ops():
     ops.layernorm2d, ops.upsample, ops.flow_decode = _layernorm2d, _upsample, _flow_decode
     ops.resize_bilinear = _resize_bilinear
     ops.encoder_kv, ops.encoder_apply = _enc_kv, _enc_apply
-    ops.encoder256_state, ops.encoder256_apply = _enc256_state, _enc256_apply
+    ops.encoder256_state, ops.encoder256_apply, ops.encoder256_kv = _enc256_state, _enc256_apply, _enc256_kv
     try:
         yield
     finally:

@@ -143,6 +143,47 @@ def model_apply(fw, x, frags_kv, ksum, S, n1, n2):
     return q_rows, msg_rows, m1, o_rows, out
 
 
+def model_kv(fw, src):
+    """enc256_kv_kernel for one chunk [S, 256]: classic orientation (lane = channel, registers = tokens 4 g + r of a 16-token
+    block), the kv stream's slabs in order (head h: slabs 4 h .. 4 h + 3 = k-steps 2 u, 2 u + 1 x blocks [k0, k1, v0, v1]), then the
+    KV MFMAs whose A / B fragments are the accumulators with slots 4-7 zero.  Returns K1's partial layout (KV[h][d][v], Ksum[h][d])."""
+    S = src.shape[0]
+    KV = np.zeros((H, D, D))
+    ksum = np.zeros((H, D))
+
+    def x_frag_nat(tile, s):                       # lane (token, g) slots = channels 32 s + 8 g + j
+        f = np.empty((64, 8))
+        for g in range(4):
+            f[16 * g:16 * g + 16] = tile[:, 32 * s + 8 * g:32 * s + 8 * g + 8]
+        return f
+    for s0 in range(0, S, 16):
+        tile = np.zeros((16, C))
+        n = min(16, S - s0)
+        tile[:n] = src[s0:s0 + n]
+        tm = np.zeros(16)
+        tm[:n] = 1.0
+        tm_l = np.stack([np.repeat(tm[4 * g + r], 16) for g in range(4) for r in range(4)]).reshape(4, 4, 16)   # [g, r, lane&15]
+        tm_l = np.concatenate([tm_l[g].T for g in range(4)], 0)                                                  # [64 lanes, 4]
+        for h in range(H):
+            d = [np.zeros((16, 16)) for _ in range(4)]
+            for u in range(4):
+                for ks in range(2):
+                    for b in range(4):
+                        # D[token][channel] += A(x)[token][k] B(W)[k][channel]
+                        d[b] += a_matrix(x_frag_nat(tile, 2 * u + ks)) @ b_matrix(stream_frag(fw.kv_stream, 4 * h + u, ks * 4 + b))
+            acc = [d_lanes(m) for m in d]           # lane (n = channel, g), reg r = D[token 4 g + r][channel n]
+            kf = [(np.where(acc[b] > 0, acc[b], np.expm1(acc[b])) + 1.0) * tm_l for b in range(2)]
+            vf = [acc[2 + b] * tm_l / S for b in range(2)]
+            z = np.zeros((64, 4))
+            for kb in range(2):
+                ks_l = kf[kb].sum(1)                # per lane: its channel, its 4 tokens
+                ksum[h, 16 * kb:16 * kb + 16] += ks_l.reshape(4, 16).sum(0)
+                for vb in range(2):
+                    blk = a_matrix(to_frag16(kf[kb], z)) @ b_matrix(to_frag16(vf[vb], z))     # [16 d, 16 v]
+                    KV[h, 16 * kb:16 * kb + 16, 16 * vb:16 * vb + 16] += blk
+    return KV, ksum
+
+
 def _layer(seed):
     g = torch.Generator().manual_seed(seed)
     sd = {}
@@ -159,8 +200,9 @@ def test_fragment_stream_and_chaining_reproduce_the_layer():
     sd, g = _layer(5)
     n1 = (sd["l.norm1.weight"], sd["l.norm1.bias"])
     n2 = (sd["l.norm2.weight"], sd["l.norm2.bias"])
-    fw = ops.Encoder256Weights(sd["l.q_proj.weight"], sd["l.merge.weight"], sd["l.mlp.0.weight"], sd["l.mlp.2.weight"], n1, n2)
-    assert fw.stream.shape == (2048, 64, 8)
+    fw = ops.Encoder256Weights(sd["l.q_proj.weight"], sd["l.merge.weight"], sd["l.mlp.0.weight"], sd["l.mlp.2.weight"], n1, n2,
+                               wk=sd["l.k_proj.weight"], wv=sd["l.v_proj.weight"])
+    assert fw.stream.shape == (2048, 64, 8) and fw.kv_stream.shape == (512, 64, 8)
     S, L = 45, 16
     src = torch.randn((1, S, C), generator=g).half().double()
     x = torch.randn((1, L, C), generator=g).half().double()
@@ -170,7 +212,10 @@ def test_fragment_stream_and_chaining_reproduce_the_layer():
     v = (src[0] @ sd64["l.v_proj.weight"].T).view(S, H, D)
     KV = torch.einsum("shd,shv->hdv", k, v / S).numpy()
     ksum = k.sum(0).reshape(-1).numpy()
-    q, msg, m1, o, out = model_apply(fw, x[0].numpy(), image_frags(KV), ksum, S, n1, n2)
+    # the fused source-side kernel reproduces both from the tokens and the kv stream (ragged: 45 = 2 blocks of 16 + 13 tokens)
+    KV_m, ksum_m = model_kv(fw, src[0].numpy())
+    assert np.abs(KV_m - KV).max() < 1e-12 and np.abs(ksum_m.reshape(-1) - ksum).max() < 1e-10
+    q, msg, m1, o, out = model_apply(fw, x[0].numpy(), image_frags(KV_m), ksum_m.reshape(-1), S, n1, n2)
     ref = restate.encoder_layer(sd64, "l.", x, src, H)[0].numpy()
     qr = (x[0] @ sd64["l.q_proj.weight"].T).numpy()
     assert np.abs(q - qr).max() < 1e-10

@@ -30,7 +30,8 @@ def _weights(seed):
 def _fused(sd):
     d = {k: v.to(DEV) for k, v in sd.items()}
     return ops.Encoder256Weights(d["l.q_proj.weight"], d["l.merge.weight"], d["l.mlp.0.weight"], d["l.mlp.2.weight"],
-                                 (d["l.norm1.weight"], d["l.norm1.bias"]), (d["l.norm2.weight"], d["l.norm2.bias"]))
+                                 (d["l.norm1.weight"], d["l.norm1.bias"]), (d["l.norm2.weight"], d["l.norm2.bias"]),
+                                 wk=d["l.k_proj.weight"], wv=d["l.v_proj.weight"])
 
 
 def _to_split(t, pad_cols=0):
@@ -113,6 +114,54 @@ def test_fused256_layer_vs_fp64(built_lib, case):
     assert torch.equal(out_b.hi, out_s.hi) and torch.equal(out_b.lo, out_s.lo)
 
 
+def _decode_image(img, N):
+    """apply image [N, 33 KB] -> (KV [N, H, d, v], Ksum [N, 256]) as float64"""
+    fr = img[:, :32768].contiguous().view(torch.float16).view(N, H, 2, 2, 64, 8).double()      # [n, h, rb, plane, lane, slot]
+    val = fr[:, :, :, 0] + fr[:, :, :, 1] / 2048.0
+    dec = torch.empty((N, H, D, D), dtype=torch.float64)
+    for lane in range(64):
+        i, grp = lane & 15, lane >> 4
+        for j in range(8):
+            d = 16 * (j >> 2) + 4 * grp + (j & 3)
+            for rb in range(2):
+                dec[:, :, d, 16 * rb + i] = val[:, :, rb, lane, j]
+    return dec, img[:, 32768:].contiguous().view(torch.float32).view(N, C).double()
+
+
+@pytest.mark.parametrize("N,S,masked", [(2, 4800, False), (3, 333, True), (1, 26600, True), (5, 40, False), (16, 4800, False)])
+def test_fused_kv_vs_fp64_and_vs_state(built_lib, N, S, masked):
+    """dfsfm_encoder256_kv_f32 (k | v projection fused with the partial KV sums) against float64, and against the unfused
+    source side (projection GEMM + dfsfm_encoder256_state_f32) it replaces; ragged lengths, masks, many chunks, determinism."""
+    sd = _weights(40 + N)
+    fw = _fused(sd)
+    g = torch.Generator().manual_seed(300 + S)
+    src = torch.randn((N, S, C), generator=g)
+    smask = None
+    if masked:
+        smask = torch.rand((N, S), generator=g) > 0.3
+        smask[:, 0] = True
+    ss = _to_split(src)
+    s64 = ss.float().double().cpu()
+    img = ops.encoder256_kv(ss, fw, smask.to(DEV) if masked else None, 1)
+    KVd, ksd = _decode_image(img.cpu(), N)
+    w64 = {n: w.double() for n, w in sd.items()}
+    K = restate.elu1(s64 @ w64["l.k_proj.weight"].T).view(N, S, H, D)
+    V = (s64 @ w64["l.v_proj.weight"].T).view(N, S, H, D)
+    if masked:
+        K = K * smask.double()[:, :, None, None]
+        V = V * smask.double()[:, :, None, None]
+    KV = torch.einsum("nshd,nshv->nhdv", K, V / S)
+    e_kv = ((KVd - KV).abs().max() / KV.abs().max()).item()
+    e_ks = ((ksd - K.sum(1).reshape(N, C)).abs().max() / K.sum(1).abs().max()).item()
+    print(f"[fused kv N={N} S={S}] relative errors KV {e_kv:.1e}, Ksum {e_ks:.1e}")
+    assert e_kv < 2e-6 and e_ks < 2e-6
+    pkv = ops.PackedDense(torch.cat([sd["l.k_proj.weight"], sd["l.v_proj.weight"]], 0).to(DEV))
+    kv = ops.linear(ss, pkv).view(N, S, 2 * C)
+    KVu, ksu = _decode_image(ops.encoder256_state(kv[..., :C], kv[..., C:], smask.to(DEV) if masked else None, 1).cpu(), N)
+    assert ((KVd - KVu).abs().max() / KV.abs().max()).item() < 2e-6 and ((ksd - ksu).abs().max() / ksu.abs().max()).item() < 2e-6
+    assert torch.equal(img, ops.encoder256_kv(ss, fw, smask.to(DEV) if masked else None, 1))      # fixed summation order
+
+
 def test_state_image_vs_fp64(built_lib):
     """dfsfm_encoder256_state_f32 alone: the image's fragments hold KV_h^T = (sum phi(k)^T v / S)^T in the kernel's k order, the
     tail Ksum -- decoded on the host and compared with float64 sums (chunked partial sums: S = 4800 runs as 34 chunks)."""
@@ -155,17 +204,19 @@ def test_fused256_equals_unfused_path_and_batch_independence(built_lib):
     full = ops.SplitAct(xs.hi.as_strided((N, L, 2 * C), xs.hi.stride()), xs.lo.as_strided((N, L, 2 * C), xs.lo.stride()), 2 * C)
     ys = _to_split(y)
 
-    def run(fused, src, is_self, masks):
+    def run(fused, src, is_self, masks, fused_kv=True):
         keep, w.fused256 = w.fused256, (w.fused256 if fused else None)
+        keep_kv, coarse.FUSED_KV256 = coarse.FUSED_KV256, fused_kv
         out = torch.empty((N, L, C), device=DEV)
         m = (xm, xm if is_self else ym) if masks else (None, None)
         coarse.encoder_layer_split(w, full, src, out, None, H, m[0], m[1], is_self=is_self)
-        w.fused256 = keep
+        w.fused256, coarse.FUSED_KV256 = keep, keep_kv
         return out
     for is_self, masks in ((True, False), (False, False), (False, True), (True, True)):
         src = full.cols(0, C) if is_self else ys
-        a, b = run(True, src, is_self, masks), run(False, src, is_self, masks)
+        a, b, c = run(True, src, is_self, masks), run(False, src, is_self, masks), run(True, src, is_self, masks, fused_kv=False)
         assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5, (is_self, masks)
+        assert ((a - c).abs().max() / b.abs().max()).item() < 2e-5, (is_self, masks)
     out_f = run(True, full.cols(0, C), True, False)
     sub = ops.SplitAct(full.hi[1:3], full.lo[1:3], 2 * C)
     out_s = torch.empty((2, L, C), device=DEV)
