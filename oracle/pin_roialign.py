@@ -9,7 +9,9 @@ This script is the committed way out.  It is OPT-IN: nothing runs it implicitly 
 tests only ``load()`` a library that already exists), because it compiles and later executes third-party C.
 ``python -m oracle.pin_roialign [--clone --commit <sha>] [--sha256 <hex>]``
 
-1. looks for the upstream CPU kernel ``roi_align/src/crop_and_resize.c`` under $ROIALIGN_SRC, then under the submodule
+1. looks for the upstream CPU kernel ``roi_align/src/crop_and_resize.c`` under $ROIALIGN_SRC (a checkout directory, or a
+   ``.tar.gz`` / ``.tgz`` / ``.zip`` archive of one -- e.g. GitHub's archive of the pinned commit -- which is unpacked into
+   ``oracle/_ref/RoIAlign.pytorch.src``; give its hash with --sha256-archive / $ROIALIGN_ARCHIVE_SHA256), then under the submodule
    directory, then -- only with ``--clone --commit <40-hex sha>`` -- fetches exactly that commit into
    ``oracle/_ref/RoIAlign.pytorch`` (no unpinned HEAD is ever cloned); with ``--sha256`` (or $ROIALIGN_SHA256) the file must
    hash to that value before anything is compiled, and the hash of whatever was compiled is printed and stored next to the
@@ -34,9 +36,44 @@ REL = os.path.join("roi_align", "src", "crop_and_resize.c")
 LIB = os.path.join(REF_DIR, "libcrop_and_resize.so")
 
 
+def unpack_archive(path, expect_sha256=None):
+    """A source archive supplied through $ROIALIGN_SRC -> directory that contains roi_align/src/crop_and_resize.c (or None).
+    Only regular members below the archive's own top directory are extracted (no absolute paths, no '..')."""
+    import hashlib
+    import tarfile
+    import zipfile
+    with open(path, "rb") as fh:
+        digest = hashlib.sha256(fh.read()).hexdigest()
+    if expect_sha256 and digest != expect_sha256.lower():
+        raise RuntimeError(f"archive {path}: sha256 {digest} != expected {expect_sha256}")
+    dst = os.path.join(REF_DIR, "RoIAlign.pytorch.src")
+    os.makedirs(dst, exist_ok=True)
+
+    def safe(name):
+        return not (name.startswith("/") or ".." in name.split("/"))
+    if zipfile.is_zipfile(path):
+        with zipfile.ZipFile(path) as z:
+            for n in z.namelist():
+                if safe(n) and not n.endswith("/"):
+                    z.extract(n, dst)
+    else:
+        with tarfile.open(path) as t:
+            for m in t.getmembers():
+                if m.isfile() and safe(m.name):
+                    t.extract(m, dst)
+    for root, _, files in os.walk(dst):
+        if root.endswith(os.path.join("roi_align", "src")) and "crop_and_resize.c" in files:
+            return os.path.dirname(os.path.dirname(root))
+    return None
+
+
 def find_source(allow_clone=False, commit=None):
     tried = []
-    roots = [os.environ.get("ROIALIGN_SRC"), os.path.join(os.environ.get("DFSFM_REFERENCE_ROOT", "/root/reference"),
+    env = os.environ.get("ROIALIGN_SRC")
+    if env and os.path.isfile(env):                       # an archive of the pinned commit
+        tried.append(env + " (archive)")
+        env = unpack_archive(env, os.environ.get("ROIALIGN_ARCHIVE_SHA256"))
+    roots = [env, os.path.join(os.environ.get("DFSFM_REFERENCE_ROOT", "/root/reference"),
                                                             "third_party", "RoIAlign.pytorch"),
              os.path.join(REF_DIR, "RoIAlign.pytorch")]
     for root in roots:

@@ -10,13 +10,18 @@ and ONLY those are exempted -- one entry at a time, never as a percentage:
 * refinement: a track whose two best candidate scores (mean std over valid views, fine_matching.py:129-179)
   differ by less than ``TOL_SCORE`` in the oracle (the first-minimum argmin may pick the other candidate).
 
-* coarse, LARGE GRIDS ONLY (rule "oracle-sum", opt-in through ``feats=``): a confidence that differs from the fp32
-  oracle's by more than 1e-4 is accepted iff it lies within 1e-4 of the EXACT value -- the float64 dual-softmax of the oracle's
-  own fp32 features (``exact_conf_at``) -- and the oracle itself is within ``TOL_ORACLE_SUM`` of that value.  Reason, measured
-  by tools/studies/loftr_hires_noise_study.py (profiles/r04_loftr_hires_noise_study.txt): a confidence is a ratio of sums over
-  L competitors; ATen's fp32 CPU softmax over 26 600 entries (1600x1064 frames, the reference's production size) is up to
-  1.15e-4 (mean +2.9e-5, biased high) from the exact value of its own inputs, 3.3e-5 at 640x480; the features contribute
-  1.7e-5.  The rule never accepts a value that is not within north_star's 1e-4 of the exact confidence.
+* coarse, rule "oracle-noise" (opt-in through ``exact=``, used by exactly two tests whose studies are committed): a confidence
+  that differs from the fp32 oracle's by more than 1e-4 is accepted iff it lies within 1e-4 of the EXACT value of that entry
+  and the fp32 oracle itself is within ``TOL_ORACLE_NOISE`` of that value -- i.e. where the oracle's own fp32 rounding, not the
+  product, is what breaks the 1e-4.  The rule never accepts a value that is not within north_star's 1e-4 of the exact confidence.
+    - LoFTR at the reference's production frame sizes (``exact=(feat_c0, feat_c1, temperature)``: the float64 dual-softmax of
+      the oracle's own fp32 features, ``exact_conf_at``).  tools/studies/loftr_hires_noise_study.py
+      (profiles/r04_loftr_hires_noise_study.txt): a confidence is a ratio of sums over L competitors; ATen's fp32 CPU softmax
+      over 26 600 entries (1600x1064 frames) is up to 1.15e-4 (mean +2.9e-5, biased high) from the exact value of its own
+      inputs, 3.3e-5 at 640x480; the features contribute 1.7e-5.
+    - ASpanFormer at 640x480 (``exact=callable`` returning the float64 evaluation of the whole oracle).
+      tools/studies/aspan_noise_study.py (profiles/r03_aspan_noise_study.txt): the network amplifies rounding noise ~500x, the
+      fp32 oracle sits 8.8e-5 from its own float64 evaluation, another fp32 summation order 2.1e-4 from the oracle.
 
 Every exemption is returned so the caller can print / bound the list.
 """
@@ -28,7 +33,7 @@ TOL_THR = 1e-5      # |conf - thr| below which the threshold test is undecidable
 TOL_TIE = 1e-6      # |conf - competing max| below which the mutual-max test is undecidable
 TOL_PX = 1e-4       # north_star tolerance on refined coordinates / std
 TOL_SCORE = 1e-5    # candidate-score gap below which the argmin is undecidable
-TOL_ORACLE_SUM = 2e-4   # bound on the fp32 oracle's own softmax-summation error under the "oracle-sum" rule (measured 1.15e-4)
+TOL_ORACLE_NOISE = 2e-4   # bound on the fp32 oracle's own distance from the exact value under the "oracle-noise" rule (measured <= 1.15e-4)
 
 
 def exact_conf_at(feat0, feat1, temperature, b, i, j, chunk=2048):
@@ -62,13 +67,12 @@ def _np(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
-def check_coarse(hip, ref, conf, thr, border=None, tol_conf=TOL_CONF, feats=None):
+def check_coarse(hip, ref, conf, thr, border=None, exact=None):
     """hip / ref: dicts with b_ids, i_ids, j_ids, mconf (+ optional mkpts*); conf: the ORACLE's dense
     confidence matrix [N,L,S].  Asserts the per-entry rules above; returns the list of exempted entries.
-    ``tol_conf`` is north_star's 1e-4 everywhere except in ONE test, where a committed study shows that no fp32-class
-    evaluation of the network (the reference's included) is reproducible to that level
-    (tests/test_gpu_aspan.py::test_aspanformer_480x640_vs_oracle; tools/studies/aspan_noise_study.py).
-    ``feats`` = (oracle feat_c0, feat_c1, temperature) switches the "oracle-sum" rule on (module docstring)."""
+    ``exact`` switches the "oracle-noise" rule on (module docstring): (oracle feat_c0, feat_c1, temperature), or a callable
+    (b, i, j arrays) -> exact confidences."""
+    tol_conf = TOL_CONF
     conf = _np(conf).astype(np.float64)
     hb, hi_, hj, hc = (_np(hip[k]) for k in ("b_ids", "i_ids", "j_ids", "mconf"))
     rb, ri, rj, rc = (_np(ref[k]) for k in ("b_ids", "i_ids", "j_ids", "mconf"))
@@ -98,7 +102,7 @@ def check_coarse(hip, ref, conf, thr, border=None, tol_conf=TOL_CONF, feats=None
             (j, c), (jr, cr) = H[key], R[key]
             if j == jr:
                 if abs(c - cr) > tol_conf:
-                    (sums if feats is not None else bad).append(("conf", key, j, c, cr))
+                    (sums if exact is not None else bad).append(("conf", key, j, c, cr))
             elif selectable(b, i, j) and fragile(b, i, jr):
                 exempt.append(("tie", key, j, jr))
             else:
@@ -118,11 +122,13 @@ def check_coarse(hip, ref, conf, thr, border=None, tol_conf=TOL_CONF, feats=None
                 exempt.append(("missing", key, j, c))
             else:
                 bad.append(("missing entry", key, j, c))
-    if sums:     # rule "oracle-sum": judge these entries against the exact confidence of the oracle's own features
-        ex = exact_conf_at(feats[0], feats[1], feats[2], [e[1][0] for e in sums], [e[1][1] for e in sums], [e[2] for e in sums])
+    if sums:     # rule "oracle-noise": judge these entries against their exact confidence
+        bb, ii, jj = [e[1][0] for e in sums], [e[1][1] for e in sums], [e[2] for e in sums]
+        ex = exact(np.asarray(bb), np.asarray(ii), np.asarray(jj)) if callable(exact) else \
+            exact_conf_at(exact[0], exact[1], exact[2], bb, ii, jj)
         for (_, key, j, c, cr), ce in zip(sums, ex):
-            if abs(c - ce) <= TOL_CONF and abs(cr - ce) <= TOL_ORACLE_SUM:
-                exempt.append(("oracle-sum", key, j, c, cr, float(ce)))
+            if abs(c - ce) <= TOL_CONF and abs(cr - ce) <= TOL_ORACLE_NOISE:
+                exempt.append(("oracle-noise", key, j, c, cr, float(ce)))
             else:
                 bad.append(("conf (also off the exact value)", key, j, c, cr, float(ce)))
     assert not bad, (len(bad), bad[:8])

@@ -199,13 +199,12 @@ def test_aspanformer_480x640_vs_oracle(built_lib):
     be kept exact (tools/studies/aspan_noise_study.py, log in profiles/r03_aspan_noise_study.txt: with the backbone alone
     evaluated in float64 the result is within 9.3e-5 of the fp32 oracle, with anything less it is not -- a plain fp32
     evaluation of the same network in another summation order already deviates 2.1e-4 from the oracle, 8-9 rows beyond
-    1e-4, and the oracle itself sits 8.8e-5 from its own float64 evaluation).  north_star's 1e-4 against the fp32 oracle is
-    therefore not attainable by fp32-class arithmetic at this size; what IS asserted:
-      * against the float64 evaluation of the oracle (the reference algorithm's exact output) the GPU is as accurate as the
-        reference's own fp32 evaluation: max deviation <= 1.25 x the oracle's fp32-vs-fp64 deviation (measured r03: 9.4e-5
-        vs 8.8e-5, after folding BatchNorm in float64 -- 1.4e-4 before);
-      * against the fp32 oracle every confidence is within 2e-4 (measured 1.45e-4) and at most 0.3 % of the rows are beyond
-        1e-4 (measured 4 of 3545).
+    1e-4, and the oracle itself sits 8.8e-5 from its own float64 evaluation).  The comparison therefore runs under the named
+    rule "oracle-noise" of tests/parity.py -- the same rule the LoFTR production-size test uses: a confidence beyond 1e-4 of the
+    fp32 oracle must lie within north_star's 1e-4 of the EXACT value (the float64 evaluation of the oracle) while the fp32
+    oracle itself is the one that is off; such entries are listed and bounded (at most 0.3 % of the rows; measured r03: 4 of
+    3545).  In addition the GPU must be as accurate against the float64 evaluation as the reference's own fp32 evaluation
+    (<= 1.25 x the oracle's fp32-vs-fp64 deviation; measured 9.4e-5 vs 8.8e-5).
     The 96x128 fixtures from the real module hold the plain 1e-4 (tests above)."""
     cfg, sd, m = _aspan(0.2)
     data = synth.coarse_pair_batch(1, 480, 640, seed=7)
@@ -220,9 +219,9 @@ def test_aspanformer_480x640_vs_oracle(built_lib):
         finally:
             torch.set_default_dtype(torch.float32)
     assert o["i_ids"].numel() > 300
-    ex = parity.check_coarse(d, o, o["conf_matrix"], 0.2, tol_conf=2e-4)
-    parity.check_coarse_rows(d, o, ex)
     c64 = o64["conf_matrix"][0].numpy()
+    ex = parity.check_coarse(d, o, o["conf_matrix"], 0.2, exact=lambda b, i, j: c64[i, j])
+    parity.check_coarse_rows(d, o, [e for e in ex if e[0] != "oracle-noise"])
     noise = np.abs(o["conf_matrix"][0].double().numpy() - c64).max()
     hi, hj, hc = (d[k].cpu().numpy() for k in ("i_ids", "j_ids", "mconf"))
     dev64 = np.abs(hc - c64[hi, hj])
@@ -231,7 +230,8 @@ def test_aspanformer_480x640_vs_oracle(built_lib):
     print(f"[aspanformer 480x640] {len(R)} reference matches, {len(hi)} on the GPU, exempted entries: {ex}; oracle fp32-vs-fp64 "
           f"noise {noise:.2e}; GPU vs fp64 max {dev64.max():.2e}; GPU vs fp32 oracle max {dev32.max():.2e}, "
           f"{int((dev32 > parity.TOL_CONF).sum())} rows beyond 1e-4")
-    assert len(ex) <= 3 and dev64.max() <= 1.25 * noise and (dev32 > parity.TOL_CONF).sum() <= 0.003 * len(dev32)
+    noisy = [e for e in ex if e[0] == "oracle-noise"]
+    assert len(ex) - len(noisy) <= 3 and len(noisy) <= 0.003 * len(dev32) and dev64.max() <= 1.25 * noise
     assert (d["predict_flow"][0].cpu() - o["predict_flow"][0]).abs().max().item() < 2e-2
 
 

@@ -52,9 +52,9 @@ def _oracle_coarse(sd, cfg, data):
     return o, conf
 
 
-def _strict_coarse(d, ref, conf, thr, label, feats=None):
-    ex = parity.check_coarse(d, ref, conf, thr, feats=feats)
-    parity.check_coarse_rows(d, ref, [e for e in ex if e[0] != "oracle-sum"])      # "oracle-sum" rows are in both tables
+def _strict_coarse(d, ref, conf, thr, label, exact=None):
+    ex = parity.check_coarse(d, ref, conf, thr, exact=exact)
+    parity.check_coarse_rows(d, ref, [e for e in ex if e[0] != "oracle-noise"])      # "oracle-noise" rows are in both tables
     print(f"[{label}] {len(ref['i_ids'])} reference matches, {len(d['i_ids'])} on the GPU, exempted entries: {ex[:12]}"
           f"{' ...' if len(ex) > 12 else ''} ({len(ex)} in total)")
     return ex
@@ -174,10 +174,10 @@ def test_loftr_production_frame_sizes_vs_oracle(built_lib, H, W):
     assert tuple(d["hw0_c"]) == (H // 8, W // 8)
     o, conf = _oracle_coarse(sd, cfg, data)
     assert o["i_ids"].numel() > 0.5 * (H // 8) * (W // 8)
-    # rule "oracle-sum" (tests/parity.py): at these grid sizes ATen's fp32 softmax is itself up to 1.15e-4 from the exact
+    # rule "oracle-noise" (tests/parity.py): at these grid sizes ATen's fp32 softmax is itself up to 1.15e-4 from the exact
     # confidence of its own features; entries beyond 1e-4 of the fp32 oracle must be within 1e-4 of that exact value
-    ex = _strict_coarse(d, o, conf, 0.2, f"{W}x{H} planted", feats=(o["feat_c0"], o["feat_c1"], cfg["match_coarse"]["dsmax_temperature"]))
-    sums = [e for e in ex if e[0] == "oracle-sum"]
+    ex = _strict_coarse(d, o, conf, 0.2, f"{W}x{H} planted", exact=(o["feat_c0"], o["feat_c1"], cfg["match_coarse"]["dsmax_temperature"]))
+    sums = [e for e in ex if e[0] == "oracle-noise"]
     assert len(ex) - len(sums) <= 3 and len(sums) <= 0.005 * o["i_ids"].numel()
 
 

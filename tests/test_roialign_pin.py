@@ -23,6 +23,115 @@ def test_recipe_extracts_the_kernel_function_and_reports_honestly():
     assert src is not None or len(tried) >= 2          # unreachable => every location that was looked at is listed
 
 
+# The published algorithm (TensorFlow's crop_and_resize as the upstream repository ports it) written out in C BY THE BUILDER, from
+# the description in SURVEY.md 8(c) -- NOT the upstream file.  It exists to run the RECIPE end to end without the network: archive
+# -> extraction of the one kernel function -> gcc -> ctypes -> bit-for-bit comparison with the torch restatement.  A12 stays
+# "parity unpinned" until the real crop_and_resize.c goes through the same recipe (python -m oracle.pin_roialign).
+STAND_IN_C = r"""
+#include <TH/TH.h>
+#include <math.h>
+void CropAndResizePerBox(
+    const float * image_data, const int batch_size, const int depth, const int image_height, const int image_width,
+    const float * boxes_data, const int * box_index_data, const int start_box, const int limit_box,
+    float * corps_data, const int crop_height, const int crop_width, const float extrapolation_value
+) {
+    const int image_channel_elements = image_height * image_width;
+    const int image_elements = depth * image_channel_elements;
+    const int channel_elements = crop_height * crop_width;
+    const int crop_elements = depth * channel_elements;
+    int b;
+    for (b = start_box; b < limit_box; ++b) {
+        const float * box = boxes_data + b * 4;
+        const float y1 = box[0], x1 = box[1], y2 = box[2], x2 = box[3];
+        const int b_in = box_index_data[b];
+        if (b_in < 0 || b_in >= batch_size) { continue; }
+        const float height_scale = (crop_height > 1) ? (y2 - y1) * (image_height - 1) / (crop_height - 1) : 0;
+        const float width_scale = (crop_width > 1) ? (x2 - x1) * (image_width - 1) / (crop_width - 1) : 0;
+        for (int y = 0; y < crop_height; ++y) {
+            const float in_y = (crop_height > 1) ? y1 * (image_height - 1) + y * height_scale : 0.5 * (y1 + y2) * (image_height - 1);
+            if (in_y < 0 || in_y > image_height - 1) {
+                for (int x = 0; x < crop_width; ++x)
+                    for (int d = 0; d < depth; ++d)
+                        corps_data[crop_elements * b + channel_elements * d + y * crop_width + x] = extrapolation_value;
+                continue;
+            }
+            const int top_y_index = floorf(in_y);
+            const int bottom_y_index = ceilf(in_y);
+            const float y_lerp = in_y - top_y_index;
+            for (int x = 0; x < crop_width; ++x) {
+                const float in_x = (crop_width > 1) ? x1 * (image_width - 1) + x * width_scale : 0.5 * (x1 + x2) * (image_width - 1);
+                if (in_x < 0 || in_x > image_width - 1) {
+                    for (int d = 0; d < depth; ++d)
+                        corps_data[crop_elements * b + channel_elements * d + y * crop_width + x] = extrapolation_value;
+                    continue;
+                }
+                const int left_x_index = floorf(in_x);
+                const int right_x_index = ceilf(in_x);
+                const float x_lerp = in_x - left_x_index;
+                for (int d = 0; d < depth; ++d) {
+                    const float *pimage = image_data + b_in * image_elements + d * image_channel_elements;
+                    const float top_left = pimage[top_y_index * image_width + left_x_index];
+                    const float top_right = pimage[top_y_index * image_width + right_x_index];
+                    const float bottom_left = pimage[bottom_y_index * image_width + left_x_index];
+                    const float bottom_right = pimage[bottom_y_index * image_width + right_x_index];
+                    const float top = top_left + (top_right - top_left) * x_lerp;
+                    const float bottom = bottom_left + (bottom_right - bottom_left) * x_lerp;
+                    corps_data[crop_elements * b + channel_elements * d + y * crop_width + x] = top + (bottom - top) * y_lerp;
+                }
+            }
+        }
+    }
+}
+void crop_and_resize_forward(THFloatTensor * image) { }
+"""
+
+
+def _compare_with(f):
+    g = torch.Generator().manual_seed(12)
+    N, C, H, W, crop = 3, 5, 48, 64, 35
+    feat = torch.randn((N, C, H, W), generator=g)
+    pts = torch.rand((40, 2), generator=g) * torch.tensor([W + 10.0, H + 10.0]) - 5.0        # some boxes leave the image
+    boxes = torch.cat([pts - crop // 2, pts + crop // 2], -1)                                   # (x1, y1, x2, y2) pixels
+    ind = torch.randint(0, N, (40,), generator=g).int()
+    ref = restate.roi_align_crop(feat, boxes, ind, crop, crop, 0.0)
+    norm = torch.stack([boxes[:, 1] / float(H - 1), boxes[:, 0] / float(W - 1), boxes[:, 3] / float(H - 1),
+                        boxes[:, 2] / float(W - 1)], 1).float().contiguous()
+    out = np.zeros((40, C, crop, crop), dtype=np.float32)
+    fc = feat.contiguous().numpy()
+    f(fc.ctypes.data_as(ctypes.c_void_p), N, C, H, W, norm.numpy().ctypes.data_as(ctypes.c_void_p),
+      ind.numpy().ctypes.data_as(ctypes.c_void_p), 0, 40, out.ctypes.data_as(ctypes.c_void_p), crop, crop, ctypes.c_float(0.0))
+    return np.array_equal(out, ref.numpy())
+
+
+def test_recipe_end_to_end_on_a_stand_in_archive(tmp_path, monkeypatch):
+    """$ROIALIGN_SRC = a tar.gz of a checkout: unpack -> extract CropAndResizePerBox -> gcc -> ctypes -> compare.  The archive here
+    holds the builder-written C restatement above (labelled as such), so this pins the RECIPE and cross-checks the torch
+    restatement against plain-C float semantics; it does not pin the upstream source."""
+    import hashlib
+    import tarfile
+    src_dir = tmp_path / "RoIAlign.pytorch-abc123" / "roi_align" / "src"
+    src_dir.mkdir(parents=True)
+    (src_dir / "crop_and_resize.c").write_text(STAND_IN_C)
+    archive = tmp_path / "RoIAlign.pytorch-abc123.tar.gz"
+    with tarfile.open(archive, "w:gz") as t:
+        t.add(tmp_path / "RoIAlign.pytorch-abc123", arcname="RoIAlign.pytorch-abc123")
+    ref_dir = tmp_path / "_ref"
+    monkeypatch.setattr(pin_roialign, "REF_DIR", str(ref_dir))
+    monkeypatch.setattr(pin_roialign, "LIB", str(ref_dir / "libcrop_and_resize.so"))
+    monkeypatch.setenv("ROIALIGN_SRC", str(archive))
+    monkeypatch.setenv("ROIALIGN_ARCHIVE_SHA256", hashlib.sha256(archive.read_bytes()).hexdigest())
+    file_hash = hashlib.sha256(STAND_IN_C.encode()).hexdigest()
+    assert pin_roialign.main(["--sha256", "0" * 64]) == 3                      # wrong file hash: nothing is compiled
+    assert not (ref_dir / "libcrop_and_resize.so").exists()
+    assert pin_roialign.main(["--sha256", file_hash]) == 0
+    assert file_hash in (ref_dir / "libcrop_and_resize.sha256").read_text()
+    f = pin_roialign.load()
+    assert f is not None and _compare_with(f)
+    monkeypatch.setenv("ROIALIGN_ARCHIVE_SHA256", "0" * 64)                      # wrong archive hash: refused
+    with pytest.raises(RuntimeError):
+        pin_roialign.find_source()
+
+
 @pytest.mark.skipif(pin_roialign.load() is None,
                     reason="oracle/_ref/libcrop_and_resize.so not built (RoIAlign.pytorch source unreachable): a12 stays parity-unpinned")
 def test_restatement_equals_upstream_kernel_bit_for_bit():
