@@ -9,6 +9,8 @@ timeout 400 python bench.py --workload scene300 > $out/scene300.json 2> $out/sce
 timeout 300 python bench.py --workload scene300 --scene-images 60 > $out/scene60.json 2> $out/scene60.err; echo "scene60 rc=$?"
 DFSFM_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload scene300 --scene-images 60 > $out/scene60_dist.json 2> $out/scene60_dist.err; echo "scene60 dist rc=$?"
 timeout 400 python bench.py --workload hires832 --steps 6 --warmup 2 > $out/hires832.json 2> $out/hires832.err; echo "hires rc=$?"
+timeout 300 python bench.py --workload eth3d1600 --steps 5 --warmup 2 --no-cpu-baseline > $out/eth3d1600.json 2> $out/eth3d1600.err; echo "eth3d1600 rc=$?"
+timeout 300 python bench.py --workload demo1200 --steps 5 --warmup 2 --no-cpu-baseline > $out/demo1200.json 2> $out/demo1200.err; echo "demo1200 rc=$?"
 timeout 300 python bench.py --workload matchformer --steps 6 --warmup 2 > $out/matchformer.json 2> $out/mf.err; echo "mf rc=$?"
 timeout 300 python bench.py --workload aspanformer --steps 6 --warmup 2 > $out/aspanformer.json 2> $out/as.err; echo "as rc=$?"
 timeout 300 python bench.py --workload aspanformer --alt-frame 832x832 --batch 4 --steps 4 --warmup 1 > $out/aspanformer832.json 2> $out/as832.err; echo "as832 rc=$?"

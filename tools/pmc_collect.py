@@ -23,7 +23,7 @@ import sys
 from collections import defaultdict
 
 OURS = ("conv_gemm", "cm_", "la_", "roi_align", "fine_match", "layernorm", "split_rows", "direct_conv", "maxpool",
-        "add_scatter", "mk_", "mlp_", "bag_", "dfsfm", "enc_")
+        "add_scatter", "mk_", "mlp_", "bag_", "dfsfm", "enc_", "enc256")
 
 
 def ours(name: str) -> bool:
