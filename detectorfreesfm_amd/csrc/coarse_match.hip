@@ -584,19 +584,33 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
     float* s_rg = reinterpret_cast<float*>(smem + 8192);                  // [128] tile-local row gate
     float* s_cg = s_rg + SF2_BM;                                          // [128] tile-local column gate
     int* s_cnt = reinterpret_cast<int*>(s_cg + SF_BN);                    // [128] slots taken per row
+    // validity as additive penalties (0 / -inf) per accumulator row / column instead of two byte loads and a select per element
+    {
+        float rpen[2][16], cpen[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
-                const int lc = wc * 64 + j * 32 + col;
-                const float sv = ((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
-                bool ok = lr < nrow && lc < ncol;
-                if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)] && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
-                accm[i][j][r] = ok ? sv : -INFINITY;
+                bool ok = lr < nrow;
+                if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)];
+                rpen[i][r] = ok ? 0.f : -INFINITY;
             }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lc = wc * 64 + j * 32 + col;
+            bool ok = lc < ncol;
+            if (g.mask1) ok = ok && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
+            cpen[j] = ok ? 0.f : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    accm[i][j][r] = ((((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature) + rpen[i][r]) + cpen[j];
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                                         // columns: 32 lane-local rows, then the other half
         float m = -INFINITY;
@@ -647,20 +661,24 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
             const float rg = s_rg[lr];
+            const float v0 = accm[i][0][r], v1 = accm[i][1][r];          // -inf outside the matrix
+            // candidates are rare: one wave-uniform test per register row, the divergent path only where one exists
+            const bool any = fmaxf(v0 - fmaxf(rg, cg[0]), v1 - fmaxf(rg, cg[1])) > 0.f;
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float sv = accm[i][j][r];                           // -inf outside the matrix
-                if (sv > rg && sv > cg[j]) {
-                    const int slot = atomicAdd(&s_cnt[lr], 1);
-                    if (slot < g.slots)
-                        g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + wc * 64 + j * 32 + col));
+                for (int j = 0; j < 2; ++j) {
+                    const float sv = accm[i][j][r];
+                    if (sv > rg && sv > cg[j]) {
+                        const int slot = atomicAdd(&s_cnt[lr], 1);
+                        if (slot < g.slots)
+                            g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + wc * 64 + j * 32 + col));
+                    }
                 }
             }
         }
     __syncthreads();
     if (tid < nrow) g.cand_cnt[slot0 + tid] = (uint8_t)min(s_cnt[tid], g.slots);
 }
-
 
 // =====================================================================================================================
 // cm_panel_cand (r04): the single-GEMM candidate pass with the f0 PANEL RESIDENT IN REGISTERS.
@@ -708,6 +726,7 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
     const int row0 = tm * PBM + wave * 32;                   // this wave's 32 rows of f0
     constexpr int nslab_k = 8;                                // slabs per column tile: C = 256 (the launcher checks)
     int* s_cnt = reinterpret_cast<int*>(smem + NSTG * SLAB) + wave * 32;     // [4 waves][32 rows] slots taken in the current tile
+    float2* s_rs = reinterpret_cast<float2*>(smem + NSTG * SLAB + 512) + wave * 32;   // [4 waves][32 rows] row statistics of the tile
 
     // ---- B ring: slab q of this unit = column tile t_begin + q / nslab_k, channels 32 (q % nslab_k) .. + 31
     const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc((void*)(g.f1h + (int64_t)n * g.S * g.C), 0,
@@ -761,10 +780,17 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
         f32x16 accm[4], accx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) accm[j] = accx[j] = f32x16{0};
+#ifdef CM_PANEL_NOLOOP
+        if (false)
+#endif
 #pragma unroll
         for (int ks2 = 0; ks2 < nslab_k; ++ks2) {
             // ---- one slab: 2 k-steps x 4 column blocks = 4 groups of (2 blocks x [hi, lo]) and 6 MFMAs each
+#ifdef CM_PANEL_VMSLACK      // timing-only ablation: do not wait for the epilogue's stores (unsafe)
+            wait_vmcnt<12>();
+#else
             wait_vmcnt<4>();                                 // own pieces of slab next + 1 (stores in flight only add to the count)
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();                    // slab next + 1 visible; every wave is done with slab next - 1
@@ -800,20 +826,41 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- statistics / candidates of this wave's 32 x 128 block of column tile t (registers only)
+#ifdef CM_PANEL_NOEPI        // timing-only ablation (tools/build_cm_abl.sh): keep the accumulators alive, skip the epilogue
+        if (accm[0][0] + accm[1][1] + accm[2][2] + accm[3][3] + accx[0][0] + accx[3][3] == 12345.678f) g.cand_cnt[0] = 1;
+        continue;
+#endif
+        // ---- statistics / candidates of this wave's 32 x 128 block of column tile t (registers only).  Written for instruction
+        // count: the first version spent ~4000 instructions per block here (a true division, two mask byte loads and a divergent
+        // branch per element) -- more than the 192 MFMAs of the tile took.
         const int col0 = t * PBN;
         const int nrow = min(32, g.L - row0), ncol = min(PBN, g.S - col0);
         if (lane < 32) s_cnt[lane] = 0;
+        // validity as additive penalties (0 / -inf): rows past L or masked, columns past S or masked
+        float rpen[16], cpen[4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = mfma32_row(r, half);
+            bool ok = lr < nrow;
+            if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)];
+            rpen[r] = ok ? 0.f : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lc = j * 32 + col;
+            bool ok = lc < ncol;
+            if (g.mask1) ok = ok && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
+            cpen[j] = ok ? 0.f : -INFINITY;
+        }
+        // similarity = (acc * acc_mul) / temperature as ONE multiplication by acc_mul / temperature (the IEEE division costs ten
+        // instructions per element; candidates, statistics and cm_eval all see this value, which differs from the other
+        // schedules' by at most one rounding)
+        const float scale = g.acc_mul / g.temperature;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = mfma32_row(r, half), lc = j * 32 + col;
-                const float sv = ((accm[j][r] + accx[j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature;
-                bool ok = lr < nrow && lc < ncol;
-                if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)] && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
-                accm[j][r] = ok ? sv : -INFINITY;
-            }
+            for (int r = 0; r < 16; ++r)
+                accm[j][r] = ((accm[j][r] + accx[j][r] * (1.f / 2048.f)) * scale + rpen[r]) + cpen[j];
         float cg[4];
         const int part = tm * 4 + wave;                      // 32-row block index of these rows
 #pragma unroll
@@ -833,6 +880,7 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the counter reset is visible to this wave's atomics
         const int64_t slot0 = ((int64_t)n * g.ntn + t) * g.L + row0;
+        float2* rp = g.row_part + ((int64_t)n * g.ntn + t) * g.L + row0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {                       // rows: 4 lane-local columns, then the 32 lanes of the half wave
             const float v0 = accm[0][r], v1 = accm[1][r], v2 = accm[2][r], v3 = accm[3][r];
@@ -840,20 +888,28 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
             float e = (m != -INFINITY) ? (fast_exp(v0 - m) + fast_exp(v1 - m)) + (fast_exp(v2 - m) + fast_exp(v3 - m)) : 0.f;
             e = half_wave_sum(e);
             const int lr = mfma32_row(r, half);
-            if (col == 0 && lr < nrow) g.row_part[((int64_t)n * g.ntn + t) * g.L + row0 + lr] = make_float2(m, e);
+            if (col == 0) s_rs[lr] = make_float2(m, e);       // one coalesced store per tile below instead of sixteen 8-byte ones
             const float rg = (lr < nrow && m != -INFINITY) ? m + logf(g.thr * e) - 1e-3f : INFINITY;
+            // candidates are rare (at most floor(1 / thr) per row and tile, none in most tiles): ONE wave-uniform test per
+            // register row; the divergent per-element path runs only for rows that hold one
+            const bool any = fmaxf(fmaxf(v0 - fmaxf(rg, cg[0]), v1 - fmaxf(rg, cg[1])), fmaxf(v2 - fmaxf(rg, cg[2]), v3 - fmaxf(rg, cg[3]))) > 0.f;
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float sv = accm[j][r];                 // -inf outside the matrix
-                if (sv > rg && sv > cg[j]) {
-                    const int slot = atomicAdd(&s_cnt[lr], 1);
-                    if (slot < g.slots)
-                        g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + j * 32 + col));
+                for (int j = 0; j < 4; ++j) {
+                    const float sv = accm[j][r];
+                    if (sv > rg && sv > cg[j]) {
+                        const int slot = atomicAdd(&s_cnt[lr], 1);
+                        if (slot < g.slots)
+                            g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + j * 32 + col));
+                    }
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < nrow) g.cand_cnt[slot0 + lane] = (uint8_t)min(s_cnt[lane], g.slots);
+        if (lane < nrow) {
+            g.cand_cnt[slot0 + lane] = (uint8_t)min(s_cnt[lane], g.slots);
+            rp[lane] = s_rs[lane];
+        }
     }
     panel::wait_vmcnt<0>();                                  // prefetched slabs must land before the LDS allocation is released
 }
@@ -1184,8 +1240,9 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
         const int slots = thr > 0.f ? (int)floorf(1.f / (thr * 0.998f)) : CAND_SLOTS_MAX + 1;
         if (slots <= CAND_SLOTS_MAX && !force_two_pass) {
             g.cand = w.cand; g.cand_cnt = w.cand_cnt; g.slots = slots;
-            // DFSFM_CM3=0: the 128 x 128 tile kernel instead of the panel-resident one (same-box A/B switch)
-            static const bool cm3 = [] { const char* e = getenv("DFSFM_CM3"); return !e || atoi(e) != 0; }();
+            // DFSFM_CM3=1: the panel-resident kernel (r04 experiment: its correlation loop is 2.4x faster than the tile kernel's, its
+            // statistics epilogue -- no second workgroup on the CU to hide it under -- makes the whole pass slower: 0.82 vs 0.72 ms)
+            static const bool cm3 = [] { const char* e = getenv("DFSFM_CM3"); return e && atoi(e) != 0; }();
             // DFSFM_CM2=0: the 256 x 128 one-workgroup-per-CU candidate kernel (same-box A/B switch)
             static const bool cm2 = [] { const char* e = getenv("DFSFM_CM2"); return !e || atoi(e) != 0; }();
             if (cm3 && C == 256) {
@@ -1210,7 +1267,7 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
                 pa.ncr = best_ncr;
                 pa.tpr = (g.ntn + best_ncr - 1) / best_ncr;
                 static dfsfm::SmemAttr smem_attr3;
-                constexpr int SMEM3 = panel::NSTG * panel::SLAB + 4 * 32 * 4;
+                constexpr int SMEM3 = panel::NSTG * panel::SLAB + 512 + 4 * 32 * 8;
                 smem_attr3.ensure(reinterpret_cast<const void*>(&cm_panel_cand), SMEM3);
                 hipLaunchKernelGGL(cm_panel_cand, dim3((unsigned)(ntm3 * pa.ncr), N), dim3(256), SMEM3, stream, pa);
             } else if (cm2) {
