@@ -24,7 +24,12 @@ namespace {
 
 using namespace dfsfm;
 
-constexpr int MAXL = 64;       // candidate rows (left*left <= 64)
+constexpr int MAXL = 64;       // candidate slots (two 32-column MFMA blocks; the stride of the per-view result table)
+#ifdef FINE_1WG                // the r03 schedule (8-KB stages, one workgroup per CU): tools/build_fine_abl.sh
+constexpr int MAXLR = MAXL;
+#else
+constexpr int MAXLR = 52;      // candidate rows actually STORED: left is odd and left * left <= 49; slots beyond read row 51
+#endif
 constexpr int MAXWW = 256;     // window positions
 
 struct FineArgs {
@@ -63,15 +68,33 @@ struct Moments {
 // value, as many cycles as the stage's 24 MFMAs; (b) the softmax exponentials on the compensated hardware exp2 (exp_neg):
 // with one wave per SIMD nothing hides VALU time, and expf was the larger half of it; (c) a wave requests the first two
 // stages of its first view before the workgroup stages the candidate rows, so that latency runs under the prologue.
-// (d) One workgroup per CU, always (the ring alone is 96 KB).  With one wave per SIMD the wave's DMA issue, LDS reads, MFMAs and
-// softmax VALU work add up (a 4-deep ring changed nothing: the stream is issue-bound, not latency-bound).  A 4-KB-stage build
-// (KC = 32: 78 KB per workgroup, two workgroups per CU, 0.25 ms instead of 0.30 ms per 2000 tracks) was measured and NOT kept:
-// with two workgroups resident on a CU 1-14 of 2000 tracks deviated by up to 1e-4 from run to run (one view of a track at a
-// time; never with one workgroup per CU, where every run is bit-identical).  The ring contents checked out against global memory
-// in an instrumented build and the cause was not found, so the shape that is reproducible ships.
+// (d) r04: 4-KB stages (KC = 32) and 52 stored candidate rows = 79 KB of LDS per workgroup (Vq <= 5): TWO workgroups per CU, two
+// waves per SIMD -- one wave's DMA issue, LDS reads and softmax VALU work run under the other's MFMAs: 0.305 -> 0.218 ms per 2000
+// tracks (4.5 TB/s).  r03 had measured that schedule and dropped it because 1-14 of 2000 tracks changed from run to run.  ROOT CAUSE
+// (r04, tools/build_fine_abl.sh + tools/fine_determinism.py + tools/fine_which_fail.py, log in profiles/r04_fine_match_root_cause.txt):
+// not the DMA ring -- the deviations survive draining every DMA before every read, a workgroup barrier or a sleep behind the
+// wait, never issuing the out-of-range tail stages, 1 KB of slack behind the allocation, and even replacing the LDS-DMA by
+// ordinary loads + ds_write; two co-resident workgroups get disjoint LDS (tools/ubench/lds_alloc.hip).  What deviates is only the
+// `std` output (the second moments sxx, syy), by 1e-4 .. 1e-3 relative, in ~18 of 8000 (track, view) entries per run, and only when
+// two workgroups share a CU.  The compiler's SLP vectoriser had packed the moment updates into v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32 (757 packed-fp32 instructions in this kernel); with those instructions gone -- -fno-slp-vectorize, or the target
+// feature -packed-fp32-ops -- the two-workgroup build is bit-identical over 200 runs x 2000 tracks, equals the one-workgroup
+// results bit for bit, and is 7 % faster still (the guide prices packed f32 beside MFMAs as an anti-lever).  Packed-fp32 VALU
+// results are unreliable on this part while another wave of the SIMD has MFMAs in flight; with one wave per SIMD (every other
+// MFMA kernel of this library that mixes the two: scanned) it never shows.  Hence the rule for THIS file: built
+// with -fno-slp-vectorize, and the Makefile fails the build if a packed-fp32 instruction appears in its ISA.
+#ifdef FINE_1WG
+#define FINE_WAVES_PER_SIMD 1
+#else
+#define FINE_WAVES_PER_SIMD 2
+#endif
 template <int C, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
-    constexpr int KC = 64;                   // channels per stage
+__global__ __launch_bounds__(256, FINE_WAVES_PER_SIMD) void fine_match_kernel(FineArgs g) {
+#ifdef FINE_1WG
+    constexpr int KC = 64;
+#else
+    constexpr int KC = 32;                   // channels per stage: 4-KB stages, 79 KB of LDS per workgroup (Vq <= 5), two per CU
+#endif
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr int NKH = C / KC;              // DMA stages per 32-row tile
@@ -81,7 +104,8 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     constexpr int NSTG = 3;                  // ring depth per wave: two stages in flight while one is multiplied
     // (d) below: the schedule is only known to be reproducible with ONE workgroup per CU.  __launch_bounds__ does not cap
     // residency; the LDS footprint does -- the ring alone must exceed half of the CU's 160 KB, whatever C, Vq or MAXL are.
-    static_assert(2 * (4 * NSTG * STAGE) > 160 * 1024, "fine_match: the DMA ring must force one workgroup per CU");
+    // (d) below: with two workgroups per CU this translation unit must be built WITHOUT packed-fp32 VALU instructions
+    // (-fno-slp-vectorize; the Makefile checks the ISA).
     constexpr int RB = SPLIT ? KC * 2 : KC * 4;          // bytes of a row inside a stage (per plane)
     constexpr int NS = RB / 16;                          // its 16-byte slots: 16, 8 or 4
     constexpr int PLANE = 32 * RB;                       // split input: bytes of one plane of a stage
@@ -91,8 +115,8 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     auto rswz = [](int l) __attribute__((always_inline)) { return C == 128 ? (l & 15) : ((l >> 1) & 7); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* s_rh = reinterpret_cast<_Float16*>(smem);                       // [MAXL][C] hi plane, slot-swizzled; rows >= L are zero
-    _Float16* s_rl = s_rh + MAXL * C;                                         // lo plane
-    float2* s_grid = reinterpret_cast<float2*>(s_rl + MAXL * C);              // [MAXWW]
+    _Float16* s_rl = s_rh + MAXLR * C;                                        // lo plane
+    float2* s_grid = reinterpret_cast<float2*>(s_rl + MAXLR * C);             // [MAXWW]
     float* s_res = reinterpret_cast<float*>(s_grid + MAXWW);                  // [Vq][MAXL][3]
     char* s_ring = reinterpret_cast<char*>(s_res) + ((g.Vq * MAXL * 3 * 4 + 15) & ~15);   // [4 waves][NSTG stages][STAGE]
 
@@ -109,8 +133,15 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     // stage is [hi: 32 rows x RB][lo: the same]).  lane -> (row in piece, physical slot); the logical slot is on the source.
     const int drow = lane / NS, dps = lane % NS;
     __amdgpu_buffer_rsrc_t rq, rql;          // the current view's window (fp32, or hi plane) / its lo plane
+#ifdef FINE_NODMA
+    const char *vbase = nullptr, *vbase_l = nullptr;     // experiment: the same stages through ordinary loads + ds_write
+#endif
     auto open_view = [&](int n) __attribute__((always_inline)) {
         const int64_t o = ((int64_t)t * Vq + n) * WW * C;
+#ifdef FINE_NODMA
+        vbase = SPLIT ? reinterpret_cast<const char*>(g.qry_h + o) : reinterpret_cast<const char*>(g.qry + o);
+        vbase_l = SPLIT ? reinterpret_cast<const char*>(g.qry_l + o) : vbase;
+#endif
         if constexpr (SPLIT) {
             rq = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry_h + o), 0, WW * C * 2, 0x00020000);
             rql = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry_l + o), 0, WW * C * 2, 0x00020000);
@@ -129,7 +160,16 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
             const int row = (p % PP) * (64 / NS) + drow;
             const int elem = (rt * 32 + row) * C + kh * KC + (dps ^ aswz(row)) * (SPLIT ? 8 : 4);
             const unsigned off = s < nstage ? (unsigned)(elem * (SPLIT ? 2 : 4)) : 0xFFFFFF00u;
+#ifdef FINE_NODMA
+            {
+                const unsigned limit = (unsigned)(WW * C * (SPLIT ? 2 : 4));
+                uint4 v = {0u, 0u, 0u, 0u};
+                if (off + 16u <= limit) v = *reinterpret_cast<const uint4*>((p < PP ? vbase : vbase_l) + off);
+                *reinterpret_cast<uint4*>(dst + p * 1024 + lane * 16) = v;
+            }
+#else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(p < PP ? rq : rql, (lds_void*)(dst + p * 1024), 16, off, 0, 0, 0);
+#endif
         }
     };
     if (wave < Vq) {                          // the first view's first two stages fly while the candidate rows are staged
@@ -142,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
     {
         const int c0 = W / 2 - left / 2;
         const float* rbase = g.ref + (int64_t)t * WW * C;
-        for (int e = tid; e < MAXL * SLOTS; e += 256) {
+        for (int e = tid; e < MAXLR * SLOTS; e += 256) {
             const int l = e / SLOTS, q = e % SLOTS;
             half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = h;
             if (l < L && SPLIT) {
@@ -187,8 +227,28 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineArgs g) {
         f32x16 accm[2], accx[2];
         for (int s = 0; s < nstage; ++s) {
             const int rt = s / NKH, kh = s - rt * NKH;
+#ifdef FINE_NO_OOB_TAIL       // experiment: never issue the all-out-of-range (zero-fill) stages past the end of the view
+            if (s + 2 < nstage) {
+                issue(s + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            } else if (s + 1 < nstage) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#elif defined(FINE_DRAIN)        // experiment: every DMA in flight drained before every read
+            issue(s + 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             issue(s + 2);                                             // into the stage consumed in the previous iteration
 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");   // stage s has landed (s+1, s+2 may still fly)
+#endif
+#ifdef FINE_BARRIER           // experiment (every wave must own exactly one view): a workgroup barrier between the wait and the reads
+            __builtin_amdgcn_s_barrier();
+#endif
+#ifdef FINE_SLEEP             // experiment: ~512 cycles between the wait and the reads
+            __builtin_amdgcn_s_sleep(8);
+#endif
             if (kh == 0) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) { accm[b] = f32x16{0}; accx[b] = f32x16{0}; }
@@ -199,8 +259,9 @@ asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");   // stage s h
                 const int q = (kh * KC + ks * 16 + half * 8) / 8;     // fp16 slot of the reference rows
                 const half8 bh0 = *reinterpret_cast<const half8*>(s_rh + col * C + ((q ^ rswz(col)) * 8));
                 const half8 bl0 = *reinterpret_cast<const half8*>(s_rl + col * C + ((q ^ rswz(col)) * 8));
-const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
-                const half8 bl1 = *reinterpret_cast<const half8*>(s_rl + (32 + col) * C + ((q ^ rswz(32 + col)) * 8));
+const int r1 = MAXLR < MAXL ? min(32 + col, MAXLR - 1) : 32 + col;
+                const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + r1 * C + ((q ^ rswz(r1)) * 8));
+                const half8 bl1 = *reinterpret_cast<const half8*>(s_rl + r1 * C + ((q ^ rswz(r1)) * 8));
                 half8 ah, al;
                 if constexpr (SPLIT) {
                     const int so = (((ks * 2 + half) ^ aswz(col)) * 16);
@@ -227,6 +288,11 @@ const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + (32 + col) * C + ((q ^ 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // reads of this stage retired before it is refilled
             if (kh != NKH - 1) continue;
+#ifdef FINE_MFMA_SETTLE       // experiment: idle time between the tile's last MFMA and the first VALU read of its accumulators
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             // online softmax over this tile's rows r = rt*32 + mfma32_row(reg, half)
             const int rbase_t = rt * 32 + 4 * half;
             if (rbase_t < WW) {   // at least one valid row in this lane half
@@ -338,14 +404,22 @@ const half8 bh1 = *reinterpret_cast<const half8*>(s_rh + (32 + col) * C + ((q ^ 
 
 // dynamic LDS of one workgroup: candidate planes (hi, lo) + grid + per-view results + 4 waves x 3 stages x 8 KB of DMA ring
 inline size_t fine_smem_bytes(int C, int Vq) {
+#ifdef FINE_1WG
     return (size_t)MAXL * C * 4 + MAXWW * 8 + (((size_t)Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + (size_t)4 * 3 * 32 * 256;
+#else
+    return (size_t)MAXLR * C * 4 + MAXWW * 8 + (((size_t)Vq * MAXL * 3 * 4 + 15) & ~(size_t)15) + (size_t)4 * 3 * 32 * 128;
+#endif
 }
 
 template <int C, bool SPLIT>
 void launch(const FineArgs& g, hipStream_t stream) {
     static dfsfm::SmemAttr attr;
     attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C, SPLIT>), 160 * 1024);
+#ifdef FINE_SLACK             // experiment: 1 KB of unused LDS behind every workgroup's allocation
+    hipLaunchKernelGGL((fine_match_kernel<C, SPLIT>), dim3(g.T), dim3(256), fine_smem_bytes(C, g.Vq) + 1024, stream, g);
+#else
     hipLaunchKernelGGL((fine_match_kernel<C, SPLIT>), dim3(g.T), dim3(256), fine_smem_bytes(C, g.Vq), stream, g);
+#endif
 }
 
 int fine_match_any(FineArgs g, bool split, int C, hipStream_t stream, const char* what) {
@@ -354,10 +428,9 @@ int fine_match_any(FineArgs g, bool split, int C, hipStream_t stream, const char
     if (g.T < 0 || g.Vq <= 0 || g.W <= 1 || g.left <= 1) return DFSFM_E_BADARG;
     if (g.query_refined && (!g.query_pts || !g.scale_q)) return DFSFM_E_BADARG;
     if (g.ref_refined && (!g.ref_pts || !g.scale_r)) return DFSFM_E_BADARG;
-    if (g.left > g.W || g.left * g.left > MAXL || g.W * g.W > MAXWW || (g.left & 1) == 0 || (g.W & 1) == 0) return DFSFM_E_UNSUPPORTED;
+    if (g.left > g.W || g.left * g.left > MAXLR || g.W * g.W > MAXWW || (g.left & 1) == 0 || (g.W & 1) == 0) return DFSFM_E_UNSUPPORTED;
     if (C != 128 && C != 64) return DFSFM_E_UNSUPPORTED;
     if (fine_smem_bytes(C, g.Vq) > 160 * 1024) return DFSFM_E_UNSUPPORTED;   // LDS budget: Vq <= 40 at C = 128, <= 61 at C = 64
-    if (2 * fine_smem_bytes(C, g.Vq) <= 160 * 1024) return DFSFM_E_UNSUPPORTED;  // single-residency invariant (see the kernel header, (d))
     const uintptr_t al = split ? (reinterpret_cast<uintptr_t>(g.ref_h) | reinterpret_cast<uintptr_t>(g.ref_l) |
                                   reinterpret_cast<uintptr_t>(g.qry_h) | reinterpret_cast<uintptr_t>(g.qry_l))
                                : (reinterpret_cast<uintptr_t>(g.ref) | reinterpret_cast<uintptr_t>(g.qry));
