@@ -366,7 +366,7 @@ def load_pmc(result):
     """Attach the HBM traffic measured by the committed rocprofv3 --pmc passes (tools/pmc_collect.py writes
     profiles/r02_pmc_traffic.json; traffic cannot be counted from inside this process).  Corrected as the MI355X
     guide prescribes: 2*FETCH_SIZE (16-byte/lane streaming reads) + WRITE_SIZE, per launch."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_kernels_only_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_kernels_only_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -376,6 +376,7 @@ def load_pmc(result):
         rows = json.load(fh)["kernels"]
     groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
               "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",),
+              "enc256_apply_kernel": ("enc256_apply_kernel",), "enc256_kv_kernel": ("enc256_kv_kernel", "enc256_image_kernel"),
               "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_rgb_kernel", "roi_align_kernel"),
               "fine_match": ("fine_match_kernel",),
               "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact", "cm_top", "cm_eval"),
