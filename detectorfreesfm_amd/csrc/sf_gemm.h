@@ -118,15 +118,21 @@ template <int BN_, int KW, int WM = 4>
 __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * WM / 256],
                                                  f32x16 (&accx)[2][BN_ * WM / 256], int64_t m0, int n0) {
     using S_ = VS<BN_, KW, WM>;
+    constexpr int NI = 2;                                    // 32-row blocks per wave
     constexpr int WN = 8 / WM, NJ = BN_ / (32 * WN), PAD = KW / 2, BNI = S_::BN_I, NQ = WM == 8 ? 5 : WM == 4 ? 3 : 1;
     constexpr int NFULL = NQ == 1 ? 1 : NQ - 1;                 // full 16-row groups per wave (wave + 8 q); then the tail group
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kgrp = lane >> 5;
-    const int wr = wave / WN, wc = wave % WN;
+    const int row0 = (wave / WN) * 64;                       // first tile row / column of this wave's blocks
+    const int col0 = (wave % WN) * (BN_ / WN);
     const int Cin_p = g.Kpad / (KW * KW);                    // tap-padded channel count (multiple of 32)
     const int nchunk = Cin_p / BK, nS = KW * nchunk;
+    // the last 32-channel chunk of a tap holds <= 16 real channels (Cin = 196: 4): its second k-step is all padding and
+    // is neither read nor multiplied (a fourteenth of the 196-channel layers' MFMAs; worth 2.5 % of their time -- the
+    // loop is co-limited by its load segments)
+    const bool tail_half = g.Cin - (nchunk - 1) * BK <= 16;
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
@@ -178,8 +184,14 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     };
     // A piece p of a super-slab: 2q, 2q+1 = group wave + 8q (hi, lo); the last = the tail group (wave 0: hi,
     // wave 1: lo, other waves: an out-of-range piece into the 1-KB sink so every wave issues the same count)
+#ifdef SF_ABL_NODMA
+#define SF_ABL_DMA_OFF if (sf_abl_in_loop) break;
+#else
+#define SF_ABL_DMA_OFF
+#endif
 #define SDMA_A(p, astage)                                                                                          \
     do {                                                                                                            \
+        SF_ABL_DMA_OFF                                                                                              \
         if ((p) < 2 * NFULL) {                                                                                      \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(((p) & 1) ? rxl : rxh,                                         \
                                                      (lds_void*)(smem + (astage) * S_::A_STAGE + ((p) & 1) * S_::A_PLANE + \
@@ -194,6 +206,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     } while (0)
 #define SDMA_B(j, bstage)                                                                                          \
     do {                                                                                                            \
+        SF_ABL_DMA_OFF                                                                                              \
         const int ib_ = wave + 8 * (j);                                                                             \
         const int plane_ = ib_ / (BN_ / 16), grp_ = ib_ % (BN_ / 16);                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(plane_ ? rwl : rwh,                                                \
@@ -203,16 +216,16 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     } while (0)
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             accm[i][j] = f32x16{0};
             accx[i][j] = f32x16{0};
         }
-    // x coordinate of this lane's two output rows (for the left/right border of the kx taps)
-    int oxr[2];
+    // x coordinate of this lane's output rows (for the left/right border of the kx taps)
+    int oxr[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) oxr[i] = (int)((m0 + wr * 64 + i * 32 + col) % g.W);
+    for (int i = 0; i < NI; ++i) oxr[i] = (int)((m0 + row0 + i * 32 + col) % g.W);
 
     // ---- ping-pong schedule ------------------------------------------------------------------------------
     // Waves w and w+4 share a SIMD.  The two halves of the workgroup run the same slab sequence half a slab
@@ -226,21 +239,31 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     // Slab u is read in the two segments after barrier b(2u); every wave waits for its own pieces of slab u
     // (counted vmcnt) just before that barrier: waves 0-3 at the end of C(u-1), waves 4-7 at the end of L(u-1).
     const int grp = wave >> 2;
-    half8 fah[2][2], fal[2][2], fbh[2][NJ], fbl[2][NJ];             // [k-step][block] fragments of one slab
-    auto read_slab = [&](int astage, int shift, int bstage) __attribute__((always_inline)) {
+    half8 fah[2][NI], fal[2][NI], fbh[2][NJ], fbl[2][NJ];           // [k-step][block] fragments of one slab
+#ifdef SF_ABL_NOREAD
+    for (int ks = 0; ks < 2; ++ks) {
+        for (int i = 0; i < NI; ++i) { fah[ks][i] = half8{1, 2, 3, 4, 5, 6, 7, 8}; fal[ks][i] = fah[ks][i] * (_Float16)0.37; }
+        for (int j = 0; j < NJ; ++j) { fbh[ks][j] = half8{1, -2, 3, -4, 5, -6, 7, -8} * (_Float16)(lane * 0.01); fbl[ks][j] = fbh[ks][j]; }
+    }
+#endif
+    auto read_slab = [&](int astage, int shift, int bstage, bool halfc) __attribute__((always_inline)) {
         const char* sa = smem + astage * S_::A_STAGE;
         const char* sb = smem + S_::OFF_B + bstage * S_::B_STAGE;
+#ifdef SF_ABL_NOREAD
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && halfc) break;                // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = tile_off(wr * 64 + i * 32 + col + shift, ks * 2 + kgrp);
+            for (int i = 0; i < NI; ++i) {
+                const int off = tile_off(row0 + i * 32 + col + shift, ks * 2 + kgrp);
                 fah[ks][i] = *reinterpret_cast<const half8*>(sa + off);
                 fal[ks][i] = *reinterpret_cast<const half8*>(sa + S_::A_PLANE + off);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int off = tile_off(wc * (BN_ / WN) + j * 32 + col, ks * 2 + kgrp);
+                const int off = tile_off(col0 + j * 32 + col, ks * 2 + kgrp);
                 fbh[ks][j] = *reinterpret_cast<const half8*>(sb + off);
                 fbl[ks][j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
             }
@@ -250,7 +273,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
         if (shift == PAD) return;
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const bool out = (unsigned)(oxr[i] + shift - PAD) >= (unsigned)g.W;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -259,22 +282,26 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             }
         }
     };
-    auto compute_slab = [&]() __attribute__((always_inline)) {
+    auto compute_slab = [&](bool halfc) __attribute__((always_inline)) {
         // 3 products per block pair; consecutive MFMAs never share an accumulator
+#ifdef SF_ABL_NOMFMA
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && halfc) break;                // wave-uniform: one scalar branch per slab
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][i], fbh[ks][j], accm[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][i], fbl[ks][j], accx[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks][i], fbh[ks][j], accx[i][j], 0, 0, 0);
@@ -282,6 +309,9 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     };
 
     // prologue: A(0) B(0) A(1).. B(1)..  (A(0..NA-2), B(0..NB-2))
+#ifdef SF_ABL_NODMA
+    bool sf_abl_in_loop = false;
+#endif
 #pragma unroll
     for (int t = 0; t < (S_::NA > S_::NB ? S_::NA : S_::NB) - 1; ++t) {
         if (t < S_::NA - 1) {
@@ -301,16 +331,22 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     if (grp == 1) __builtin_amdgcn_s_barrier();                       // waves 4-7 sit out the first segment
     int bst = 0;                                                      // B stage of the current slab (t % NB)
     int ast = 0;                                                      // A stage of the current super-slab (S % NA)
+    int chunk = 0;                                                    // S % nchunk
+#ifdef SF_ABL_NODMA
+    sf_abl_in_loop = true;
+#endif
     for (int S = 0; S < nS; ++S) {
+        const bool half = tail_half && chunk == nchunk - 1;           // only k-step 0 of this super-slab's slabs is live
+        chunk = chunk == nchunk - 1 ? 0 : chunk + 1;
         const int anx = ast == S_::NA - 1 ? 0 : ast + 1;              // stage of A(S+1)
         const int adm = ast == 0 ? S_::NA - 1 : ast - 1;              // stage A(S+NA-1) is DMA'd into (held A(S-1))
-        auto tap = [&](auto kxc) __attribute__((always_inline)) {
+        auto tap = [&](auto kxc, bool halfc) __attribute__((always_inline)) {
             constexpr int kx = decltype(kxc)::value;
             constexpr int kxn = (kx + 1) % KW;                        // tap of the next slab
             const int t = S * KW + kx;
             const int bdm = bst == 0 ? S_::NB - 1 : bst - 1;          // stage of slab t+NB-1 (held slab t-1)
             // ---- LOAD segment of slab t ----
-            read_slab(ast, kx, bst);
+            read_slab(ast, kx, bst, halfc);
             if (kx == 0) addrA(S + S_::NA - 1);
             addrB(t + S_::NB - 1);
             if (kx == 0) { SDMA_A(0, adm); SDMA_A(1, adm); }
@@ -332,21 +368,21 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
             __builtin_amdgcn_s_barrier();
             // ---- COMPUTE segment of slab t ----
             __builtin_amdgcn_s_setprio(1);
-            compute_slab();
+            compute_slab(halfc);
             __builtin_amdgcn_s_setprio(0);
             if (grp == 0) wait_vmcnt<S_::NWAIT(kxn)>();               // waves 0-3 publish slab t+1 here
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             bst = bst == S_::NB - 1 ? 0 : bst + 1;
         };
-        tap(std::integral_constant<int, 0>{});
+        tap(std::integral_constant<int, 0>{}, half);
         if constexpr (KW > 1) {
-            tap(std::integral_constant<int, 1>{});
-            tap(std::integral_constant<int, 2>{});
+            tap(std::integral_constant<int, 1>{}, half);
+            tap(std::integral_constant<int, 2>{}, half);
         }
         if constexpr (KW > 3) {
-            tap(std::integral_constant<int, 3>{});
-            tap(std::integral_constant<int, 4>{});
+            tap(std::integral_constant<int, 3>{}, half);
+            tap(std::integral_constant<int, 4>{}, half);
         }
         ast = anx;
     }
