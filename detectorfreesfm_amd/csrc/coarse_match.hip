@@ -336,6 +336,37 @@ __device__ __forceinline__ float2 merge_stat(float2 a, float2 b) {
     return make_float2(m, a.y * fast_exp(a.x - m) + b.y * fast_exp(b.x - m));
 }
 
+// xor-16 / xor-32 lane exchanges without the LDS crossbar (gfx950: v_permlane16_swap / v_permlane32_swap): both lanes of a
+// pair end up with the two values {own, partner} in (a, b) order (row 0 | row 1, lower | upper half), so a commutative
+// combination of a and b is the same on both.
+__device__ __forceinline__ void swap16(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// Transposing butterfly over the 16 lanes of a DPP row: every lane brings 16 values x[r]; afterwards lane i holds
+// OP over the row's 16 lanes of value r = i & 15.  15 exchanges instead of the 64 of sixteen separate all-reduces: at every
+// step a lane keeps the half of its values whose index bit equals its own lane bit and sends the other half to the partner
+// that keeps those (row_mirror flips lane bit 3, row_half_mirror bit 2, the quad permutations bits 1 and 0; the lower bits
+// they flip as well do not matter before their own step).
+template <class Op>
+__device__ __forceinline__ float butterfly16(const float (&x)[16], int lane, Op op) {
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = op(b3 ? x[k + 8] : x[k], dpp_mov<0x140>(b3 ? x[k] : x[k + 8]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = op(b2 ? a[k + 4] : a[k], dpp_mov<0x141>(b2 ? a[k] : a[k + 4]));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) c[k] = op(b1 ? b[k + 2] : b[k], dpp_mov<0x4E>(b1 ? b[k] : b[k + 2]));
+    return op(b0 ? c[1] : c[0], dpp_mov<0xB1>(b0 ? c[0] : c[1]));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -603,13 +634,17 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
             if (g.mask1) ok = ok && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
             cpen[j] = ok ? 0.f : -INFINITY;
         }
+        // similarity = (acc * acc_mul) / temperature as ONE multiplication by acc_mul / temperature (r04: the IEEE division was
+        // ten instructions per element, 640 of this epilogue's ~1500; candidates, statistics and cm_eval all see this value,
+        // which differs from the two-pass kernels' by at most one rounding)
+        const float scale = g.acc_mul / g.temperature;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    accm[i][j][r] = ((((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * g.acc_mul) / g.temperature) + rpen[i][r]) + cpen[j];
+                    accm[i][j][r] = (((accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f)) * scale) + rpen[i][r]) + cpen[j];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                                         // columns: 32 lane-local rows, then the other half
@@ -625,19 +660,38 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e += fast_exp(accm[i][j][r] - m);
         }
-        const float2 st = merge_stat(make_float2(m, e), make_float2(__shfl_xor(m, 32), __shfl_xor(e, 32)));
+        float m_lo, m_hi, e_lo, e_hi;
+        swap32(m, m_lo, m_hi);
+        swap32(e, e_lo, e_hi);
+        const float2 st = merge_stat(make_float2(m_lo, e_lo), make_float2(m_hi, e_hi));
         if (half == 0) s_cp[wr * SF_BN + wc * 64 + j * 32 + col] = st;
     }
+    // rows: 2 lane-local columns, then the 32 lanes of the half wave -- as ONE transposing butterfly per 32-row block (15 DPP
+    // exchanges + one xor-16 swap leave row r's total in lanes r, r + 16 of each half; r04: sixteen separate all-reduces per block
+    // were 2 x 16 x (4 DPP steps + an LDS-crossbar exchange)); the maxima return to all lanes through 256 B of LDS per wave
+    float* s_m = reinterpret_cast<float*>(smem + 12288) + (wr * 2 + wc) * 64;       // [4 waves][64 rows]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int lr_own = i * 32 + mfma32_row(lane & 15, half);         // row of this wave's 64 whose totals this lane receives
+        float pm[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {                                    // rows: 2 lane-local columns, then 32 lanes
-            const float v0 = accm[i][0][r], v1 = accm[i][1][r];
-            const float m = half_wave_max(fmaxf(v0, v1));
-            float e = (m != -INFINITY) ? fast_exp(v0 - m) + fast_exp(v1 - m) : 0.f;
-            e = half_wave_sum(e);
-            if (col == 0) s_rp[wc * SF2_BM + wr * 64 + i * 32 + mfma32_row(r, half)] = make_float2(m, e);
+        for (int r = 0; r < 16; ++r) pm[r] = fmaxf(accm[i][0][r], accm[i][1][r]);
+        float ma, mb;
+        swap16(butterfly16(pm, lane, [](float x, float y) { return fmaxf(x, y); }), ma, mb);
+        const float m_own = fmaxf(ma, mb);
+        if ((lane & 16) == 0) s_m[lr_own] = m_own;
+        float pe[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                     // rows mfma32_row(4 q + k, half) = 8 q + 4 half + k
+            const f32x4 mr = *reinterpret_cast<const f32x4*>(s_m + i * 32 + 8 * q + 4 * half);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                pe[4 * q + k] = (mr[k] != -INFINITY) ? fast_exp(accm[i][0][4 * q + k] - mr[k]) + fast_exp(accm[i][1][4 * q + k] - mr[k]) : 0.f;
         }
+        float ea, eb;
+        swap16(butterfly16(pe, lane, [](float x, float y) { return x + y; }), ea, eb);
+        if ((lane & 16) == 0) s_rp[wc * SF2_BM + wr * 64 + lr_own] = make_float2(m_own, ea + eb);
+    }
     __syncthreads();
     if (tid < SF2_BM) {
         const float2 st = merge_stat(s_rp[tid], s_rp[SF2_BM + tid]);
@@ -655,19 +709,32 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) cg[j] = s_cg[wc * 64 + j * 32 + col];
     const int64_t slot0 = ((int64_t)n * g.ntn + tn) * g.L + row0;
+    // candidates are rare (at most floor(1 / thr) per row and tile, none in most tiles): the gates of this lane's 32 rows come
+    // back as eight 16-byte LDS reads, ONE wave-uniform test per tile decides whether the divergent per-element path runs at all
+    float rgv[2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
-            const float rg = s_rg[lr];
-            const float v0 = accm[i][0][r], v1 = accm[i][1][r];          // -inf outside the matrix
-            // candidates are rare: one wave-uniform test per register row, the divergent path only where one exists
-            const bool any = fmaxf(v0 - fmaxf(rg, cg[0]), v1 - fmaxf(rg, cg[1])) > 0.f;
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+        for (int q = 0; q < 4; ++q) {                                     // rows mfma32_row(4 q + k, half) = 8 q + 4 half + k
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_rg + wr * 64 + i * 32 + 8 * q + 4 * half);
+            rgv[i][4 * q] = v[0]; rgv[i][4 * q + 1] = v[1]; rgv[i][4 * q + 2] = v[2]; rgv[i][4 * q + 3] = v[3];
+        }
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            any = any || fmaxf(accm[i][0][r] - fmaxf(rgv[i][r], cg[0]), accm[i][1][r] - fmaxf(rgv[i][r], cg[1])) > 0.f;
+    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
+                const float rg = rgv[i][r];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float sv = accm[i][j][r];
+                    const float sv = accm[i][j][r];                       // -inf outside the matrix
                     if (sv > rg && sv > cg[j]) {
                         const int slot = atomicAdd(&s_cnt[lr], 1);
                         if (slot < g.slots)
@@ -675,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
                     }
                 }
             }
-        }
+    }
     __syncthreads();
     if (tid < nrow) g.cand_cnt[slot0 + tid] = (uint8_t)min(s_cnt[tid], g.slots);
 }
@@ -683,18 +750,19 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
 // =====================================================================================================================
 // cm_panel_cand (r04): the single-GEMM candidate pass with the f0 PANEL RESIDENT IN REGISTERS.
 // The tile kernels above re-stream both operand panels for every 128 x 128 tile (PMC r03: 1.31 GB per 8 pairs for 78.6 MB of
-// features, MFMA busy 21 %).  Here a workgroup owns 128 rows of f0 for a whole range of column tiles: wave w keeps its 32 rows x
-// 256 channels as MFMA A fragments (hi, lo: 128 registers, loaded once), and only f1 streams -- 16-KB slabs of 128 columns x 32
-// channels (hi | lo planes, 64-byte rows XOR-swizzled on the source side) through a 4-deep LDS ring that all four waves read, one
-// s_barrier per slab, the next group's fragment reads between the MFMAs of the current one (the window schedule of
-// encoder256.hip's kv kernel).  Half the operand bytes per tile and no operand staging for f0 at all.
+// features, MFMA busy 21 %; eight LDS-DMA requests per wave for 24 MFMAs).  Here a workgroup owns 128 rows of f0 for a whole range
+// of column tiles: wave w keeps its 32 rows x 256 channels as MFMA A fragments (hi, lo: 128 registers, loaded once), and only f1
+// streams -- 16-KB slabs of 128 columns x 32 channels (hi | lo planes, 64-byte rows XOR-swizzled on the source side) through a
+// 4-deep LDS ring that all four waves read, one s_barrier per slab, the next group's fragment reads between the MFMAs of the
+// current one (the window schedule of encoder256.hip's kv kernel): four requests per wave for 24 MFMAs and no staging of f0.
 // The statistics / candidate epilogue of a column tile runs per WAVE on its 32 x 128 accumulators, entirely in registers:
-//   column statistics are lane-local (+ one xor-32 exchange) and go out as one partial per 32-ROW block (col_part [N][ceil(L/32)][S]);
-//   row statistics (over the tile's 128 columns, as before) are DPP reductions over the 32 lanes of a half wave;
+//   column statistics are lane-local (+ one xor-32 swap) and go out as one partial per 32-ROW block (col_part [N][ceil(L/32)][S]);
+//   row statistics (over the tile's 128 columns, as in the tile kernels) by a transposing butterfly over the half wave;
 //   the candidate gates use the tile-local row statistics (at most floor(1 / thr) entries of a row pass: the slot bound of
 //   cm_eval is unchanged) and the WAVE-local column statistics (a 32-row block's log-sum-exp is <= the column's: still a
 //   necessary condition, merely a weaker filter than the 128-row gate; every candidate is evaluated exactly by cm_eval).
-// No __syncthreads in the epilogue: the waves only meet at the slab barriers.  Rows and confidences equal the tile kernels'.
+// No __syncthreads in the epilogue: the waves only meet at the slab barriers.  384 registers: one workgroup per CU.
+// Measured variants: a 64-column-tile version at 256 registers, two workgroups per CU, was slower than this one.
 // Work units: (row panel, column range); the number of ranges per panel is chosen so that the units fill whole rounds of CUs.
 // =====================================================================================================================
 namespace panel {
@@ -727,6 +795,8 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
     constexpr int nslab_k = 8;                                // slabs per column tile: C = 256 (the launcher checks)
     int* s_cnt = reinterpret_cast<int*>(smem + NSTG * SLAB) + wave * 32;     // [4 waves][32 rows] slots taken in the current tile
     float2* s_rs = reinterpret_cast<float2*>(smem + NSTG * SLAB + 512) + wave * 32;   // [4 waves][32 rows] row statistics of the tile
+    float* s_m = reinterpret_cast<float*>(smem + NSTG * SLAB + 1536) + wave * 32;     // [4 waves][32 rows] row maxima (broadcast)
+    float* s_g = reinterpret_cast<float*>(smem + NSTG * SLAB + 2048) + wave * 32;     // [4 waves][32 rows] row gates (broadcast)
 
     // ---- B ring: slab q of this unit = column tile t_begin + q / nslab_k, channels 32 (q % nslab_k) .. + 31
     const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc((void*)(g.f1h + (int64_t)n * g.S * g.C), 0,
@@ -873,7 +943,10 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e += fast_exp(accm[j][r] - m);
             }
-            const float2 st = merge_stat(make_float2(m, e), make_float2(__shfl_xor(m, 32), __shfl_xor(e, 32)));
+            float m_lo, m_hi, e_lo, e_hi;
+            swap32(m, m_lo, m_hi);
+            swap32(e, e_lo, e_hi);
+            const float2 st = merge_stat(make_float2(m_lo, e_lo), make_float2(m_hi, e_hi));
             const int lc = j * 32 + col;
             if (half == 0 && lc < ncol && nrow > 0) g.col_part[((int64_t)n * pa.nparts + part) * g.S + col0 + lc] = st;
             cg[j] = (lc < ncol && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
@@ -881,23 +954,62 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the counter reset is visible to this wave's atomics
         const int64_t slot0 = ((int64_t)n * g.ntn + t) * g.L + row0;
         float2* rp = g.row_part + ((int64_t)n * g.ntn + t) * g.L + row0;
+        // Row statistics over the tile's 128 columns, branch-free: lane-local maxima of the 4 columns, ONE transposing butterfly
+        // (15 DPP exchanges) + one xor-16 swap leave row r's maximum in lanes r, r + 16 of each half; the maxima go through 128 B
+        // of LDS back to all lanes (4 ds_read_b128 of broadcast addresses); the same for the sums of exponentials; one logf per
+        // lane.  (The first version ran sixteen half-wave all-reduces for the maxima and sixteen for the sums -- 4 DPP steps and
+        // an LDS-crossbar exchange each -- and a logf per row in every lane: 21 K cycles per block, 3.4x the block's MFMAs.)
+        float rgv[16];
+        {
+            const int r_own = lane & 15;                      // the register row whose totals this lane ends up with
+            const int lr_own = mfma32_row(r_own, half);
+            float pm[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {                       // rows: 4 lane-local columns, then the 32 lanes of the half wave
-            const float v0 = accm[0][r], v1 = accm[1][r], v2 = accm[2][r], v3 = accm[3][r];
-            const float m = half_wave_max(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
-            float e = (m != -INFINITY) ? (fast_exp(v0 - m) + fast_exp(v1 - m)) + (fast_exp(v2 - m) + fast_exp(v3 - m)) : 0.f;
-            e = half_wave_sum(e);
-            const int lr = mfma32_row(r, half);
-            if (col == 0) s_rs[lr] = make_float2(m, e);       // one coalesced store per tile below instead of sixteen 8-byte ones
-            const float rg = (lr < nrow && m != -INFINITY) ? m + logf(g.thr * e) - 1e-3f : INFINITY;
-            // candidates are rare (at most floor(1 / thr) per row and tile, none in most tiles): ONE wave-uniform test per
-            // register row; the divergent per-element path runs only for rows that hold one
-            const bool any = fmaxf(fmaxf(v0 - fmaxf(rg, cg[0]), v1 - fmaxf(rg, cg[1])), fmaxf(v2 - fmaxf(rg, cg[2]), v3 - fmaxf(rg, cg[3]))) > 0.f;
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+            for (int r = 0; r < 16; ++r) pm[r] = fmaxf(fmaxf(accm[0][r], accm[1][r]), fmaxf(accm[2][r], accm[3][r]));
+            float ma, mb;
+            swap16(butterfly16(pm, lane, [](float x, float y) { return fmaxf(x, y); }), ma, mb);
+            const float m_own = fmaxf(ma, mb);
+            if ((lane & 16) == 0) s_m[lr_own] = m_own;
+            float pe[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                     // rows mfma32_row(4 q + k, half) = 8 q + 4 half + k
+                const f32x4 mr = *reinterpret_cast<const f32x4*>(s_m + 8 * q + 4 * half);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * q + k;
+                    pe[r] = (mr[k] != -INFINITY) ? (fast_exp(accm[0][r] - mr[k]) + fast_exp(accm[1][r] - mr[k])) +
+                                                       (fast_exp(accm[2][r] - mr[k]) + fast_exp(accm[3][r] - mr[k])) : 0.f;
+                }
+            }
+            float ea, eb;
+            swap16(butterfly16(pe, lane, [](float x, float y) { return x + y; }), ea, eb);
+            const float e_own = ea + eb;
+            const float g_own = (lr_own < nrow && m_own != -INFINITY) ? m_own + logf(g.thr * e_own) - 1e-3f : INFINITY;
+            if ((lane & 16) == 0) {
+                s_rs[lr_own] = make_float2(m_own, e_own);
+                s_g[lr_own] = g_own;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_g + 8 * q + 4 * half);
+                rgv[4 * q] = v[0]; rgv[4 * q + 1] = v[1]; rgv[4 * q + 2] = v[2]; rgv[4 * q + 3] = v[3];
+            }
+        }
+        // candidates are rare (at most floor(1 / thr) per row and tile, none in most tiles): ONE wave-uniform test per tile; the
+        // divergent per-element path runs only in tiles that hold one
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            any = any || fmaxf(fmaxf(accm[0][r] - fmaxf(rgv[r], cg[0]), accm[1][r] - fmaxf(rgv[r], cg[1])),
+                               fmaxf(accm[2][r] - fmaxf(rgv[r], cg[2]), accm[3][r] - fmaxf(rgv[r], cg[3]))) > 0.f;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = mfma32_row(r, half);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float sv = accm[j][r];
-                    if (sv > rg && sv > cg[j]) {
+                    if (sv > rgv[r] && sv > cg[j]) {
                         const int slot = atomicAdd(&s_cnt[lr], 1);
                         if (slot < g.slots)
                             g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + j * 32 + col));
@@ -1254,6 +1366,7 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
                 int dev = 0, cus = 256;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+
                 int best_ncr = 1;
                 double best_eff = 0.0;
                 for (int ncr = 1; ncr <= g.ntn && ncr <= 16; ++ncr) {
@@ -1267,7 +1380,7 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
                 pa.ncr = best_ncr;
                 pa.tpr = (g.ntn + best_ncr - 1) / best_ncr;
                 static dfsfm::SmemAttr smem_attr3;
-                constexpr int SMEM3 = panel::NSTG * panel::SLAB + 512 + 4 * 32 * 8;
+                constexpr int SMEM3 = panel::NSTG * panel::SLAB + 512 + 4 * 32 * 8 + 2 * 4 * 32 * 4;
                 smem_attr3.ensure(reinterpret_cast<const void*>(&cm_panel_cand), SMEM3);
                 hipLaunchKernelGGL(cm_panel_cand, dim3((unsigned)(ntm3 * pa.ncr), N), dim3(256), SMEM3, stream, pa);
             } else if (cm2) {
