@@ -110,4 +110,21 @@ __device__ __forceinline__ void store4(float* out, _Float16* outh, _Float16* out
     }
 }
 
+// x + (the same variable of lane ^ 16 / lane ^ 32) without the LDS crossbar that __shfl_xor goes through (ds_bpermute_b32 and
+// an lgkmcnt wait): gfx950's v_permlane16_swap / v_permlane32_swap hand both lanes of a pair the two values in the same order,
+// and the addition is commutative, so the sum has the bits of x + __shfl_xor(x, 16 / 32) on both.
+__device__ __forceinline__ float add_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the variable of lane ^ 32
+__device__ __forceinline__ float from_xor32(float x, int lane) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(lane & 32 ? r[0] : r[1]);
+}
+
 }  // namespace dfsfm

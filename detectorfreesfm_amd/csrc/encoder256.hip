@@ -284,14 +284,12 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
         {                                                                                                             \
             float sum_ = 0.f;                                                                                         \
             _Pragma("unroll") for (int b = 0; b < NB16; ++b) _Pragma("unroll") for (int r = 0; r < 4; ++r) sum_ += VAL(b, r); \
-            sum_ += __shfl_xor(sum_, 16);                                                                             \
-            sum_ += __shfl_xor(sum_, 32);                                                                             \
+            sum_ = add_xor32(add_xor16(sum_));                                                                        \
             MEAN = sum_ / (float)EC;                                                                                  \
             float sq_ = 0.f;                                                                                          \
             _Pragma("unroll") for (int b = 0; b < NB16; ++b) _Pragma("unroll") for (int r = 0; r < 4; ++r)            \
                 sq_ += (VAL(b, r) - MEAN) * (VAL(b, r) - MEAN);                                                       \
-            sq_ += __shfl_xor(sq_, 16);                                                                               \
-            sq_ += __shfl_xor(sq_, 32);                                                                               \
+            sq_ = add_xor32(add_xor16(sq_));                                                                          \
             RSTD = 1.f / sqrtf(sq_ / (float)EC + (EPS));                                                              \
         }
         const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -342,9 +340,9 @@ __global__ __launch_bounds__(256) void enc256_apply_kernel(Apply256Args g) {
             }
             // the four lane groups' partial sums: eight independent exchanges per round instead of eight serial pairs
 #pragma unroll
-            for (int h = 0; h < NKS; ++h) zp[h] += __shfl_xor(zp[h], 16);
+            for (int h = 0; h < NKS; ++h) zp[h] = add_xor16(zp[h]);
 #pragma unroll
-            for (int h = 0; h < NKS; ++h) zp[h] += __shfl_xor(zp[h], 32);
+            for (int h = 0; h < NKS; ++h) zp[h] = add_xor32(zp[h]);
 #pragma unroll
             for (int h = 0; h < NKS; ++h) Z[h] = 1.f / (zp[h] + g.attn_eps);
         }
@@ -826,8 +824,7 @@ __global__ __launch_bounds__(256) void enc256_kv_kernel(Kv256Args g) {
             float a = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) a += ksp[((w * NKS + h) * 2 + kb) * 64 + lane];
-            a += __shfl_xor(a, 16);                 // the four lane groups hold different tokens of the same channel
-            a += __shfl_xor(a, 32);
+            a = add_xor32(add_xor16(a));            // the four lane groups hold different tokens of the same channel
             if (grp == 0) out[h * KVSZ + 1024 + 16 * kb + col] = a;
         }
     }

@@ -303,12 +303,12 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
         {                                                                                                             \
             float sum_ = 0.f;                                                                                         \
             _Pragma("unroll") for (int b = 0; b < NBLK; ++b) _Pragma("unroll") for (int r = 0; r < 16; ++r) sum_ += VAL(b, r); \
-            sum_ += __shfl_xor(sum_, 32);                                                                             \
+            sum_ = add_xor32(sum_);                                                                                   \
             MEAN = sum_ / (float)EC;                                                                                  \
             float sq_ = 0.f;                                                                                          \
             _Pragma("unroll") for (int b = 0; b < NBLK; ++b) _Pragma("unroll") for (int r = 0; r < 16; ++r)           \
                 sq_ += (VAL(b, r) - MEAN) * (VAL(b, r) - MEAN);                                                       \
-            sq_ += __shfl_xor(sq_, 32);                                                                               \
+            sq_ = add_xor32(sq_);                                                                                     \
             RSTD = 1.f / sqrtf(sq_ / (float)EC + (EPS));                                                              \
         }
         float Z[2 * NBLK];
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
                         if (q4 < 2) z0 += f * k4[e]; else z1 += f * k4[e];
                     }
                 }
-                z0 += __shfl_xor(z0, 32);
-                z1 += __shfl_xor(z1, 32);
+                z0 = add_xor32(z0);
+                z1 = add_xor32(z1);
                 Z[2 * b] = 1.f / (z0 + g.attn_eps);
                 Z[2 * b + 1] = 1.f / (z1 + g.attn_eps);
                 to_frags(v, ah[2 * b], al[2 * b], ah[2 * b + 1], al[2 * b + 1]);
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void enc_kv_kernel(KvArgs g) {
         float ks = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) ks += ksp[(w * NBLK + p) * 64 + lane];
-        ks += __shfl_xor(ks, 32);                   // the two lane halves hold the two token halves of every block
+        ks = add_xor32(ks);                         // the two lane halves hold the two token halves of every block
         char* img = g.kvimg + (int64_t)n * KVIMG;
         // apply image: fragment (b = p, t) of KV^T for enc_apply_kernel = this lane's registers 8t..8t+7, rows of the other
         // head zeroed (block-diagonal): lane = v channel d' (row of KV^T), slot j = k channel 16 t + dch(j, half)

@@ -329,16 +329,16 @@ const int r1 = MAXLR < MAXL ? min(32 + col, MAXLR - 1) : 32 + col;
         // merge the two lane halves (rows 4*half + ...) and finish: expectation and std
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const float m_o = __shfl_xor(st[b].m, 32);
+            const float m_o = from_xor32(st[b].m, lane);
             const float m_all = fmaxf(st[b].m, m_o);
             const float sc = expf(st[b].m - m_all);
             float s0 = st[b].s0 * sc, sx = st[b].sx * sc, sy = st[b].sy * sc;
             float sxx = st[b].sxx * sc, syy = st[b].syy * sc;
-            s0 += __shfl_xor(s0, 32);
-            sx += __shfl_xor(sx, 32);
-            sy += __shfl_xor(sy, 32);
-            sxx += __shfl_xor(sxx, 32);
-            syy += __shfl_xor(syy, 32);
+            s0 = add_xor32(s0);
+            sx = add_xor32(sx);
+            sy = add_xor32(sy);
+            sxx = add_xor32(sxx);
+            syy = add_xor32(syy);
             const float ex = sx / s0, ey = sy / s0;
             const float vx = sxx / s0 - ex * ex, vy = syy / s0 - ey * ey;
             const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
