@@ -5,16 +5,21 @@ exec < /dev/null
 tag=${1:-m1}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 root=$PWD
-timeout 400 python bench.py --workload scene300 > $out/scene300.json 2> $out/scene300.err; echo "scene rc=$?"
+quick=${2:-}          # "quick": skip the workloads whose kernels did not change since the last full session
+timeout 400 python bench.py --workload scene300 --no-cpu-baseline > $out/scene300.json 2> $out/scene300.err; echo "scene rc=$?"
+if [ -z "$quick" ]; then
 timeout 300 python bench.py --workload scene300 --scene-images 60 > $out/scene60.json 2> $out/scene60.err; echo "scene60 rc=$?"
 DFSFM_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload scene300 --scene-images 60 > $out/scene60_dist.json 2> $out/scene60_dist.err; echo "scene60 dist rc=$?"
-timeout 400 python bench.py --workload hires832 --steps 6 --warmup 2 > $out/hires832.json 2> $out/hires832.err; echo "hires rc=$?"
+fi
+timeout 400 python bench.py --workload hires832 --steps 6 --warmup 2 --no-cpu-baseline > $out/hires832.json 2> $out/hires832.err; echo "hires rc=$?"
 timeout 300 python bench.py --workload eth3d1600 --steps 5 --warmup 2 --no-cpu-baseline > $out/eth3d1600.json 2> $out/eth3d1600.err; echo "eth3d1600 rc=$?"
 timeout 300 python bench.py --workload demo1200 --steps 5 --warmup 2 --no-cpu-baseline > $out/demo1200.json 2> $out/demo1200.err; echo "demo1200 rc=$?"
-timeout 300 python bench.py --workload matchformer --steps 6 --warmup 2 > $out/matchformer.json 2> $out/mf.err; echo "mf rc=$?"
-timeout 300 python bench.py --workload aspanformer --steps 6 --warmup 2 > $out/aspanformer.json 2> $out/as.err; echo "as rc=$?"
+timeout 300 python bench.py --workload matchformer --steps 6 --warmup 2 --no-cpu-baseline > $out/matchformer.json 2> $out/mf.err; echo "mf rc=$?"
+timeout 300 python bench.py --workload aspanformer --steps 6 --warmup 2 --no-cpu-baseline > $out/aspanformer.json 2> $out/as.err; echo "as rc=$?"
+if [ -z "$quick" ]; then
 timeout 300 python bench.py --workload aspanformer --alt-frame 832x832 --batch 4 --steps 4 --warmup 1 > $out/aspanformer832.json 2> $out/as832.err; echo "as832 rc=$?"
 timeout 300 python bench.py --workload scene300 --scene-matcher aspanformer --scene-images 40 > $out/scene40_aspanformer.json 2> $out/scene40_as.err; echo "scene40 aspan rc=$?"
+fi
 cd /tmp
 for w in coarse refine; do
   timeout 600 env PYTHONPATH=$root rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$w -o $w -- python $root/tools/profile_step.py $w 4 > $root/$out/prof_$w.log 2>&1
