@@ -427,6 +427,30 @@ __device__ __forceinline__ void sf_epilogue(const ConvArgs& g, char* smem, f32x1
     sf_epilogue_rows<BN_, BM_, NT>(g, tile, m0, n0, tid);
 }
 
+// Epilogue of the 16 x 16 x 32 main loop (sf_same_mainloop16): block (i, j) of wave (wr, wc) holds rows wr 64 + 16 i + 4 (lane >> 4) + r,
+// column wc WCOLS + 16 j + (lane & 15) in register r.  The four lane groups of a store instruction hit rows 4 apart (bank offsets
+// 0 / 16 / 32 / 48 with the 132-float pitch) with 16 consecutive columns each: conflict-free.
+template <int BN_, int BM_ = BM2, int NT = 512>
+__device__ __forceinline__ void sf_epilogue16(const ConvArgs& g, char* smem, f32x4 (&accm)[4][BN_ * BM_ / (16 * NT)],
+                                              f32x4 (&accx)[4][BN_ * BM_ / (16 * NT)], int64_t m0, int n0, int tid, int wr, int wc,
+                                              int lane) {
+    constexpr int TILE_LD_ = BN_ + 4;
+    constexpr int NJ = BN_ * BM_ / (16 * NT);                // 16-wide column blocks per wave
+    constexpr int WCOLS = NJ * 16;
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(wr * 64 + i * 16 + 4 * (lane >> 4) + r) * TILE_LD_ + wc * WCOLS + j * 16 + (lane & 15)] =
+                    accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
+    __syncthreads();
+    sf_epilogue_rows<BN_, BM_, NT>(g, tile, m0, n0, tid);
+}
+
 template <int BN_>
 __global__ __launch_bounds__(512, 1) void conv_gemm_sf_kernel(ConvArgs g) {
     using T = V2<BN_>;
@@ -652,6 +676,20 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
     if (tile_id >= g.ntiles) return;
     const int64_t m0 = (int64_t)(tile_id / ntn) * S_::BM;
     const int n0 = (tile_id % ntn) * BN_;
+#ifndef SF_NO_M16
+    if constexpr (WM == 4 || WM == 8) {      // the 256 x BN and 512 x 64 tiles: v_mfma_f32_16x16x32_f16 (sf_gemm.h, M16)
+        f32x4 am[4][2 * NJ], ax[4][2 * NJ];
+        sf_same_mainloop16<BN_, KW, WM>(g, smem, am, ax, m0, n0);
+#ifdef SF_ABL_NOEPI16
+        float sacc = 0.f;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 2 * NJ; ++j) for (int r = 0; r < 4; ++r) sacc += am[i][j][r] + ax[i][j][r];
+        if (sacc == 12345.678f) g.out[0] = sacc;
+        return;
+#endif
+        sf_epilogue16<BN_, S_::BM>(g, smem, am, ax, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane);
+        return;
+    }
+#endif
     f32x16 accm[2][NJ], accx[2][NJ];
     sf_same_mainloop<BN_, KW, WM>(g, smem, accm, accx, m0, n0);
     sf_epilogue<BN_, S_::BM>(g, smem, accm, accx, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane & 31, lane >> 5);

@@ -42,6 +42,9 @@ struct ConvArgs {
 // ds_read_b128 fragment reads of 16 different rows conflict-free (64-byte rows, 4 rows per bank row)
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
+// the same tile with the row swizzle of the 16 x 16 x 32 fragment pattern (16 rows x 4 slots per read instruction)
+__device__ __forceinline__ int tile_off16(int row, int slot) { return row * 64 + ((slot ^ ((row >> 1) & 3)) << 4); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -114,12 +117,19 @@ struct VS {
     static_assert(KW == 1 ? (NA == NB) : true, "1x1: A(t) and B(t) are issued in the same load segment");
 };
 
-template <int BN_, int KW, int WM = 4>
-__device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * WM / 256],
-                                                 f32x16 (&accx)[2][BN_ * WM / 256], int64_t m0, int n0) {
+// M16: the same wave tile on v_mfma_f32_16x16x32_f16 (4 x 2 NJ blocks of 16 x 16, one 32-wide k-step per slab) instead of
+// v_mfma_f32_32x32x16_f16 (2 x NJ blocks of 32 x 32, two k-steps).  Same LDS fragment reads (a fragment is 1 KB either way), same
+// accumulator registers, twice the MFMA instructions at half the cycles each -- and, in the POWER-limited regime these kernels run
+// in, 15 % more sustained MFMA rate on random operands (tools/ubench/mfma_order.hip: 1.97 vs 1.72 PFLOP/s).  The fragment of a
+// 16 x 16 x 32 MFMA is 16 rows x all four 16-byte slots of a 64-byte LDS row (lane = row + 16 slot), so the tiles use the row
+// swizzle (r >> 1) & 3 -- conflict-free for that pattern at every tap shift -- instead of (r >> 2) & 3.
+template <int BN_, int KW, int WM, bool M16, class AccArr>
+__device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* smem, AccArr& accm, AccArr& accx, int64_t m0, int n0) {
     using S_ = VS<BN_, KW, WM>;
-    constexpr int NI = 2;                                    // 32-row blocks per wave
-    constexpr int WN = 8 / WM, NJ = BN_ / (32 * WN), PAD = KW / 2, BNI = S_::BN_I, NQ = WM == 8 ? 5 : WM == 4 ? 3 : 1;
+    constexpr int WN = 8 / WM, PAD = KW / 2, BNI = S_::BN_I, NQ = WM == 8 ? 5 : WM == 4 ? 3 : 1;
+    constexpr int NI = M16 ? 4 : 2;                          // row blocks per wave (16 / 32 rows)
+    constexpr int NJ = M16 ? BN_ / (16 * WN) : BN_ / (32 * WN);
+    constexpr int RB = M16 ? 16 : 32;                        // rows / columns of an MFMA block
     constexpr int NFULL = NQ == 1 ? 1 : NQ - 1;                 // full 16-row groups per wave (wave + 8 q); then the tail group
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,7 +142,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     // the last 32-channel chunk of a tap holds <= 16 real channels (Cin = 196: 4): its second k-step is all padding and
     // is neither read nor multiplied (a fourteenth of the 196-channel layers' MFMAs; worth 2.5 % of their time -- the
     // loop is co-limited by its load segments)
-    const bool tail_half = g.Cin - (nchunk - 1) * BK <= 16;
+    const bool tail_half = !M16 && g.Cin - (nchunk - 1) * BK <= 16;
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
@@ -140,7 +150,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.wl, 0, g.wbytes, 0x00020000);
 
     const int lrow = lane >> 2;
-    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    const int lslot = (lane & 3) ^ (M16 ? (lane >> 3) & 3 : (lane >> 4) & 3);   // logical slot of this lane's physical slot: the row swizzle
     // A rows of this lane: groups wave + 8 q and (waves 0/1 only: hi/lo plane of) the tail group 8 * NFULL
     int ay[5];                                                   // NQ used
     int64_t abase[5];
@@ -219,13 +229,14 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            accm[i][j] = f32x16{0};
-            accx[i][j] = f32x16{0};
+            using V = std::remove_reference_t<decltype(accm[0][0])>;
+            accm[i][j] = V{0};
+            accx[i][j] = V{0};
         }
     // x coordinate of this lane's output rows (for the left/right border of the kx taps)
     int oxr[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) oxr[i] = (int)((m0 + row0 + i * 32 + col) % g.W);
+    for (int i = 0; i < NI; ++i) oxr[i] = (int)((m0 + row0 + i * RB + (M16 ? lane & 15 : col)) % g.W);
 
     // ---- ping-pong schedule ------------------------------------------------------------------------------
     // Waves w and w+4 share a SIMD.  The two halves of the workgroup run the same slab sequence half a slab
@@ -239,9 +250,10 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     // Slab u is read in the two segments after barrier b(2u); every wave waits for its own pieces of slab u
     // (counted vmcnt) just before that barrier: waves 0-3 at the end of C(u-1), waves 4-7 at the end of L(u-1).
     const int grp = wave >> 2;
-    half8 fah[2][NI], fal[2][NI], fbh[2][NJ], fbl[2][NJ];           // [k-step][block] fragments of one slab
+    constexpr int NKS = M16 ? 1 : 2;                                 // k-steps per slab
+    half8 fah[NKS][NI], fal[NKS][NI], fbh[NKS][NJ], fbl[NKS][NJ];   // [k-step][block] fragments of one slab
 #ifdef SF_ABL_NOREAD
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
         for (int i = 0; i < NI; ++i) { fah[ks][i] = half8{1, 2, 3, 4, 5, 6, 7, 8}; fal[ks][i] = fah[ks][i] * (_Float16)0.37; }
         for (int j = 0; j < NJ; ++j) { fbh[ks][j] = half8{1, -2, 3, -4, 5, -6, 7, -8} * (_Float16)(lane * 0.01); fbl[ks][j] = fbh[ks][j]; }
     }
@@ -252,8 +264,23 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
 #ifdef SF_ABL_NOREAD
         return;
 #endif
+        if constexpr (M16) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int i = 0; i < NI; ++i) {
+                const int off = tile_off16(row0 + i * 16 + (lane & 15) + shift, lane >> 4);
+                fah[0][i] = *reinterpret_cast<const half8*>(sa + off);
+                fal[0][i] = *reinterpret_cast<const half8*>(sa + S_::A_PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int off = tile_off16(col0 + j * 16 + (lane & 15), lane >> 4);
+                fbh[0][j] = *reinterpret_cast<const half8*>(sb + off);
+                fbl[0][j] = *reinterpret_cast<const half8*>(sb + S_::B_PLANE + off);
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
             if (ks == 1 && halfc) break;                // wave-uniform
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -276,7 +303,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
         for (int i = 0; i < NI; ++i) {
             const bool out = (unsigned)(oxr[i] + shift - PAD) >= (unsigned)g.W;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 fah[ks][i] = out ? z : fah[ks][i];
                 fal[ks][i] = out ? z : fal[ks][i];
             }
@@ -287,8 +314,28 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
 #ifdef SF_ABL_NOMFMA
         return;
 #endif
+        if constexpr (M16) {
+            // accumulate IN PLACE (inline asm ties destination and addend): left to the register allocator, the 16 x 16 x 32
+            // builtin got a destination different from its addend across the unrolled taps and the kernel spilled 44 registers.
+            // Consecutive MFMAs never share an accumulator (reuse distance 16), so no software wait states are needed here; the
+            // first VALU read of the results is behind the workgroup barrier of the epilogue.
+#define SF_MFMA16(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) SF_MFMA16(accm[i][j], fah[0][i], fbh[0][j]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) SF_MFMA16(accx[i][j], fah[0][i], fbl[0][j]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) SF_MFMA16(accx[i][j], fal[0][i], fbh[0][j]);
+#undef SF_MFMA16
+        } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
             if (ks == 1 && halfc) break;                // wave-uniform: one scalar branch per slab
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -305,6 +352,7 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks][i], fbh[ks][j], accx[i][j], 0, 0, 0);
+        }
         }
     };
 
@@ -390,6 +438,18 @@ __device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, 
     wait_vmcnt<0>();
 #undef SDMA_A
 #undef SDMA_B
+}
+
+template <int BN_, int KW, int WM = 4>
+__device__ __forceinline__ void sf_same_mainloop(const ConvArgs& g, char* smem, f32x16 (&accm)[2][BN_ * WM / 256],
+                                                 f32x16 (&accx)[2][BN_ * WM / 256], int64_t m0, int n0) {
+    sf_same_mainloop_impl<BN_, KW, WM, false>(g, smem, accm, accx, m0, n0);
+}
+// the 16 x 16 x 32 form: 4 x (BN_ WM / 128) accumulator blocks of 4 registers
+template <int BN_, int KW, int WM = 4>
+__device__ __forceinline__ void sf_same_mainloop16(const ConvArgs& g, char* smem, f32x4 (&accm)[4][BN_ * WM / 128],
+                                                   f32x4 (&accx)[4][BN_ * WM / 128], int64_t m0, int n0) {
+    sf_same_mainloop_impl<BN_, KW, WM, true>(g, smem, accm, accx, m0, n0);
 }
 
 // =================================================================================================
