@@ -123,7 +123,7 @@ def kernel_rooflines(dev, batch):
     flops = 2.0 * nimg * 240 * 320 * 128 * 9 * 128
     out.append(_rl("conv_gemm_sf_same_kernel<128,3> (3x3, 128->128 @240x320)", "mfma", flops, ms, f"{nimg} images",
                    mfma_flops_executed_frac=3.0 * flops / ms / 1e9 / MFMA_F16_PEAK_TF,
-                   step_share="~46% of the coarse step and ~27% of the refinement step (profiles/r03_*_step_kernel_stats.csv)"))
+                   step_share="~47% of the coarse step and ~27% of the refinement step (profiles/r04_*_step_kernel_stats.csv)"))
     del x, xs, pw
     # K10 + K1 of the refinement head: one fused encoder layer (csrc/encoder_fused.hip) on the query tokens of a 2000-track x
     # 4-view bag: enc_kv_kernel (source tokens -> per-track attention state) + enc_apply_kernel (the rest of the layer).
