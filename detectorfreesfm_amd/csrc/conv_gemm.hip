@@ -676,20 +676,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_sf_same_kernel(ConvArgs g) {
     if (tile_id >= g.ntiles) return;
     const int64_t m0 = (int64_t)(tile_id / ntn) * S_::BM;
     const int n0 = (tile_id % ntn) * BN_;
-#ifndef SF_NO_M16
     if constexpr (WM == 4 || WM == 8) {      // the 256 x BN and 512 x 64 tiles: v_mfma_f32_16x16x32_f16 (sf_gemm.h, M16)
         f32x4 am[4][2 * NJ], ax[4][2 * NJ];
         sf_same_mainloop16<BN_, KW, WM>(g, smem, am, ax, m0, n0);
-#ifdef SF_ABL_NOEPI16
-        float sacc = 0.f;
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 2 * NJ; ++j) for (int r = 0; r < 4; ++r) sacc += am[i][j][r] + ax[i][j][r];
-        if (sacc == 12345.678f) g.out[0] = sacc;
-        return;
-#endif
         sf_epilogue16<BN_, S_::BM>(g, smem, am, ax, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane);
         return;
     }
-#endif
     f32x16 accm[2][NJ], accx[2][NJ];
     sf_same_mainloop<BN_, KW, WM>(g, smem, accm, accx, m0, n0);
     sf_epilogue<BN_, S_::BM>(g, smem, accm, accx, m0, n0, tid, wave / S_::WN, wave % S_::WN, lane & 31, lane >> 5);

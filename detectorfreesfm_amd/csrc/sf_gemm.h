@@ -194,14 +194,8 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     };
     // A piece p of a super-slab: 2q, 2q+1 = group wave + 8q (hi, lo); the last = the tail group (wave 0: hi,
     // wave 1: lo, other waves: an out-of-range piece into the 1-KB sink so every wave issues the same count)
-#ifdef SF_ABL_NODMA
-#define SF_ABL_DMA_OFF if (sf_abl_in_loop) break;
-#else
-#define SF_ABL_DMA_OFF
-#endif
 #define SDMA_A(p, astage)                                                                                          \
     do {                                                                                                            \
-        SF_ABL_DMA_OFF                                                                                              \
         if ((p) < 2 * NFULL) {                                                                                      \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(((p) & 1) ? rxl : rxh,                                         \
                                                      (lds_void*)(smem + (astage) * S_::A_STAGE + ((p) & 1) * S_::A_PLANE + \
@@ -216,7 +210,6 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     } while (0)
 #define SDMA_B(j, bstage)                                                                                          \
     do {                                                                                                            \
-        SF_ABL_DMA_OFF                                                                                              \
         const int ib_ = wave + 8 * (j);                                                                             \
         const int plane_ = ib_ / (BN_ / 16), grp_ = ib_ % (BN_ / 16);                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(plane_ ? rwl : rwh,                                                \
@@ -252,18 +245,9 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     const int grp = wave >> 2;
     constexpr int NKS = M16 ? 1 : 2;                                 // k-steps per slab
     half8 fah[NKS][NI], fal[NKS][NI], fbh[NKS][NJ], fbl[NKS][NJ];   // [k-step][block] fragments of one slab
-#ifdef SF_ABL_NOREAD
-    for (int ks = 0; ks < NKS; ++ks) {
-        for (int i = 0; i < NI; ++i) { fah[ks][i] = half8{1, 2, 3, 4, 5, 6, 7, 8}; fal[ks][i] = fah[ks][i] * (_Float16)0.37; }
-        for (int j = 0; j < NJ; ++j) { fbh[ks][j] = half8{1, -2, 3, -4, 5, -6, 7, -8} * (_Float16)(lane * 0.01); fbl[ks][j] = fbh[ks][j]; }
-    }
-#endif
     auto read_slab = [&](int astage, int shift, int bstage, bool halfc) __attribute__((always_inline)) {
         const char* sa = smem + astage * S_::A_STAGE;
         const char* sb = smem + S_::OFF_B + bstage * S_::B_STAGE;
-#ifdef SF_ABL_NOREAD
-        return;
-#endif
         if constexpr (M16) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -311,9 +295,6 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     };
     auto compute_slab = [&](bool halfc) __attribute__((always_inline)) {
         // 3 products per block pair; consecutive MFMAs never share an accumulator
-#ifdef SF_ABL_NOMFMA
-        return;
-#endif
         if constexpr (M16) {
             // accumulate IN PLACE (inline asm ties destination and addend): left to the register allocator, the 16 x 16 x 32
             // builtin got a destination different from its addend across the unrolled taps and the kernel spilled 44 registers.
@@ -357,9 +338,6 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     };
 
     // prologue: A(0) B(0) A(1).. B(1)..  (A(0..NA-2), B(0..NB-2))
-#ifdef SF_ABL_NODMA
-    bool sf_abl_in_loop = false;
-#endif
 #pragma unroll
     for (int t = 0; t < (S_::NA > S_::NB ? S_::NA : S_::NB) - 1; ++t) {
         if (t < S_::NA - 1) {
@@ -380,9 +358,6 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     int bst = 0;                                                      // B stage of the current slab (t % NB)
     int ast = 0;                                                      // A stage of the current super-slab (S % NA)
     int chunk = 0;                                                    // S % nchunk
-#ifdef SF_ABL_NODMA
-    sf_abl_in_loop = true;
-#endif
     for (int S = 0; S < nS; ++S) {
         const bool half = tail_half && chunk == nchunk - 1;           // only k-step 0 of this super-slab's slabs is live
         chunk = chunk == nchunk - 1 ? 0 : chunk + 1;
