@@ -850,17 +850,10 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
         f32x16 accm[4], accx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) accm[j] = accx[j] = f32x16{0};
-#ifdef CM_PANEL_NOLOOP
-        if (false)
-#endif
 #pragma unroll
         for (int ks2 = 0; ks2 < nslab_k; ++ks2) {
             // ---- one slab: 2 k-steps x 4 column blocks = 4 groups of (2 blocks x [hi, lo]) and 6 MFMAs each
-#ifdef CM_PANEL_VMSLACK      // timing-only ablation: do not wait for the epilogue's stores (unsafe)
-            wait_vmcnt<12>();
-#else
             wait_vmcnt<4>();                                 // own pieces of slab next + 1 (stores in flight only add to the count)
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();                    // slab next + 1 visible; every wave is done with slab next - 1
@@ -896,10 +889,6 @@ __global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#ifdef CM_PANEL_NOEPI        // timing-only ablation (tools/build_cm_abl.sh): keep the accumulators alive, skip the epilogue
-        if (accm[0][0] + accm[1][1] + accm[2][2] + accm[3][3] + accx[0][0] + accx[3][3] == 12345.678f) g.cand_cnt[0] = 1;
-        continue;
-#endif
         // ---- statistics / candidates of this wave's 32 x 128 block of column tile t (registers only).  Written for instruction
         // count: the first version spent ~4000 instructions per block here (a true division, two mask byte loads and a divergent
         // branch per element) -- more than the 192 MFMAs of the tile took.

@@ -44,20 +44,11 @@ constexpr int KVIMG = 32 * 1024 + 1024;  // bytes per sequence: 16 KV^T fragment
 constexpr int KVSZ = 32 * 32 + 32;       // floats per (n, chunk, head) of the chunk partials: KV[d][v] then Ksum[d] (K1's layout)
 constexpr int SMEM_APPLY = RING + 4 * STG + 4 * EC * 4 + 4 * 2048;   // + LayerNorm gamma / beta + Ksum of a wave's two sequences
 
-// Timing-only ablation switches (tools/build_enc256_abl.sh builds them into csrc/abl/; results are WRONG with any of them set):
-// ENC256_NOMFMA the matrix instructions of the slab stream become register moves, ENC256_NODMA no ring refill, ENC256_NOBAR no
-// per-slab barrier, ENC256_NOREAD the weight fragments are not re-read from LDS.
 __device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 mfma16s(const half8 a, const half8 b, const f32x4 c) {
-#ifdef ENC256_NOMFMA
-    f32x4 r = c;
-    r[0] += (float)a[0] + (float)b[0];
-    return r;
-#else
+__device__ __forceinline__ f32x4 mfma16s(const half8 a, const half8 b, const f32x4 c) {     // the slab stream's MFMAs
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#endif
 }
 
 // Two consecutive accumulator blocks (lane (n, g): a[r] = channel 16 (2 s) + 4 g + r, b[r] = channel 16 (2 s + 1) + 4 g + r of
@@ -91,11 +82,7 @@ __device__ __forceinline__ int stg_off(int t, int c) { return t * 512 + ((c ^ (t
 // issue: read-then-multiply per slab serialised the two (first version: 65 us per 64-token tile for 20 us of MFMA issue).  One s_barrier per slab as before; it now means "every wave's pieces of slab next + 1 have landed AND every wave
 // has the fragments of slab next in registers" (lgkmcnt(0) before it), so the refill cannot overtake a reader.  Callers alternate
 // the two register sets (the slab sequence of a tile is static and even).
-#ifdef ENC256_NODMA
-#define ENC256_REFILL(ring, gn, piece) do { (void)(gn); ++piece; } while (0)
-#else
 #define ENC256_REFILL(ring, gn, piece) (ring).issue_piece((gn), (piece)++)
-#endif
 template <int NB, int KPS, int B0>
 __device__ __forceinline__ void slab_step(SlabRing& ring, int lane, f32x4 (&am)[NB16], f32x4 (&ax)[NB16], const half8* bh,
                                           const half8* bl, const half8 (&cur)[16], half8 (&nxt)[16]) {
@@ -103,9 +90,7 @@ __device__ __forceinline__ void slab_step(SlabRing& ring, int lane, f32x4 (&am)[
     wait_vmcnt<(NSTG - 2) * 4>();                   // this wave's pieces of slab next + 1 (next + 2, next + 3 may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its fragment reads of slab next are complete
     __builtin_amdgcn_sched_barrier(0);
-#ifndef ENC256_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
     const char* nslab = ring.ring + ((ring.next + 1) % NSTG) * SLAB + lane * 16;
     const unsigned gn = ring.next + NSTG;           // into the slot slab `next` was read from
@@ -115,11 +100,7 @@ __device__ __forceinline__ void slab_step(SlabRing& ring, int lane, f32x4 (&am)[
     // LDS sustains (4 waves x 4 cycles per 16-cycle MFMA).  sched_barriers pin the order.
     int m = 0, piece = 0;
     auto after = [&]() __attribute__((always_inline)) {
-#ifndef ENC256_NOREAD
         if (m < 16) nxt[m] = *reinterpret_cast<const half8*>(nslab + m * 1024);
-#else
-        if (m < 16) nxt[m] = cur[m];
-#endif
         if (m % 6 == 3) ENC256_REFILL(ring, gn, piece);
         ++m;
         __builtin_amdgcn_sched_barrier(0);

@@ -25,7 +25,7 @@ namespace {
 using namespace dfsfm;
 
 constexpr int MAXL = 64;       // candidate slots (two 32-column MFMA blocks; the stride of the per-view result table)
-#ifdef FINE_1WG                // the r03 schedule (8-KB stages, one workgroup per CU): tools/build_fine_abl.sh
+#ifdef FINE_1WG                // the r03 schedule (8-KB stages, one workgroup per CU)
 constexpr int MAXLR = MAXL;
 #else
 constexpr int MAXLR = 52;      // candidate rows actually STORED: left is odd and left * left <= 49; slots beyond read row 51
@@ -71,7 +71,8 @@ struct Moments {
 // (d) r04: 4-KB stages (KC = 32) and 52 stored candidate rows = 79 KB of LDS per workgroup (Vq <= 5): TWO workgroups per CU, two
 // waves per SIMD -- one wave's DMA issue, LDS reads and softmax VALU work run under the other's MFMAs: 0.305 -> 0.218 ms per 2000
 // tracks (4.5 TB/s).  r03 had measured that schedule and dropped it because 1-14 of 2000 tracks changed from run to run.  ROOT CAUSE
-// (r04, tools/build_fine_abl.sh + tools/fine_determinism.py + tools/fine_which_fail.py, log in profiles/r04_fine_match_root_cause.txt):
+// (r04: a 13-variant matrix of temporary build switches, tools/fine_determinism.py + tools/fine_which_fail.py, log in
+// profiles/r04_fine_match_root_cause.txt; the switches have left this file again):
 // not the DMA ring -- the deviations survive draining every DMA before every read, a workgroup barrier or a sleep behind the
 // wait, never issuing the out-of-range tail stages, 1 KB of slack behind the allocation, and even replacing the LDS-DMA by
 // ordinary loads + ds_write; two co-resident workgroups get disjoint LDS (tools/ubench/lds_alloc.hip).  What deviates is only the
@@ -133,15 +134,8 @@ __global__ __launch_bounds__(256, FINE_WAVES_PER_SIMD) void fine_match_kernel(Fi
     // stage is [hi: 32 rows x RB][lo: the same]).  lane -> (row in piece, physical slot); the logical slot is on the source.
     const int drow = lane / NS, dps = lane % NS;
     __amdgpu_buffer_rsrc_t rq, rql;          // the current view's window (fp32, or hi plane) / its lo plane
-#ifdef FINE_NODMA
-    const char *vbase = nullptr, *vbase_l = nullptr;     // experiment: the same stages through ordinary loads + ds_write
-#endif
     auto open_view = [&](int n) __attribute__((always_inline)) {
         const int64_t o = ((int64_t)t * Vq + n) * WW * C;
-#ifdef FINE_NODMA
-        vbase = SPLIT ? reinterpret_cast<const char*>(g.qry_h + o) : reinterpret_cast<const char*>(g.qry + o);
-        vbase_l = SPLIT ? reinterpret_cast<const char*>(g.qry_l + o) : vbase;
-#endif
         if constexpr (SPLIT) {
             rq = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry_h + o), 0, WW * C * 2, 0x00020000);
             rql = __builtin_amdgcn_make_buffer_rsrc((void*)(g.qry_l + o), 0, WW * C * 2, 0x00020000);
@@ -160,16 +154,7 @@ __global__ __launch_bounds__(256, FINE_WAVES_PER_SIMD) void fine_match_kernel(Fi
             const int row = (p % PP) * (64 / NS) + drow;
             const int elem = (rt * 32 + row) * C + kh * KC + (dps ^ aswz(row)) * (SPLIT ? 8 : 4);
             const unsigned off = s < nstage ? (unsigned)(elem * (SPLIT ? 2 : 4)) : 0xFFFFFF00u;
-#ifdef FINE_NODMA
-            {
-                const unsigned limit = (unsigned)(WW * C * (SPLIT ? 2 : 4));
-                uint4 v = {0u, 0u, 0u, 0u};
-                if (off + 16u <= limit) v = *reinterpret_cast<const uint4*>((p < PP ? vbase : vbase_l) + off);
-                *reinterpret_cast<uint4*>(dst + p * 1024 + lane * 16) = v;
-            }
-#else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(p < PP ? rq : rql, (lds_void*)(dst + p * 1024), 16, off, 0, 0, 0);
-#endif
         }
     };
     if (wave < Vq) {                          // the first view's first two stages fly while the candidate rows are staged
@@ -227,28 +212,8 @@ __global__ __launch_bounds__(256, FINE_WAVES_PER_SIMD) void fine_match_kernel(Fi
         f32x16 accm[2], accx[2];
         for (int s = 0; s < nstage; ++s) {
             const int rt = s / NKH, kh = s - rt * NKH;
-#ifdef FINE_NO_OOB_TAIL       // experiment: never issue the all-out-of-range (zero-fill) stages past the end of the view
-            if (s + 2 < nstage) {
-                issue(s + 2);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-            } else if (s + 1 < nstage) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-#elif defined(FINE_DRAIN)        // experiment: every DMA in flight drained before every read
-            issue(s + 2);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             issue(s + 2);                                             // into the stage consumed in the previous iteration
-asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");   // stage s has landed (s+1, s+2 may still fly)
-#endif
-#ifdef FINE_BARRIER           // experiment (every wave must own exactly one view): a workgroup barrier between the wait and the reads
-            __builtin_amdgcn_s_barrier();
-#endif
-#ifdef FINE_SLEEP             // experiment: ~512 cycles between the wait and the reads
-            __builtin_amdgcn_s_sleep(8);
-#endif
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");   // stage s has landed (s+1, s+2 may still fly)
             if (kh == 0) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) { accm[b] = f32x16{0}; accx[b] = f32x16{0}; }
@@ -288,11 +253,6 @@ const int r1 = MAXLR < MAXL ? min(32 + col, MAXLR - 1) : 32 + col;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // reads of this stage retired before it is refilled
             if (kh != NKH - 1) continue;
-#ifdef FINE_MFMA_SETTLE       // experiment: idle time between the tile's last MFMA and the first VALU read of its accumulators
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             // online softmax over this tile's rows r = rt*32 + mfma32_row(reg, half)
             const int rbase_t = rt * 32 + 4 * half;
             if (rbase_t < WW) {   // at least one valid row in this lane half
@@ -415,11 +375,7 @@ template <int C, bool SPLIT>
 void launch(const FineArgs& g, hipStream_t stream) {
     static dfsfm::SmemAttr attr;
     attr.ensure(reinterpret_cast<const void*>(&fine_match_kernel<C, SPLIT>), 160 * 1024);
-#ifdef FINE_SLACK             // experiment: 1 KB of unused LDS behind every workgroup's allocation
-    hipLaunchKernelGGL((fine_match_kernel<C, SPLIT>), dim3(g.T), dim3(256), fine_smem_bytes(C, g.Vq) + 1024, stream, g);
-#else
     hipLaunchKernelGGL((fine_match_kernel<C, SPLIT>), dim3(g.T), dim3(256), fine_smem_bytes(C, g.Vq), stream, g);
-#endif
 }
 
 int fine_match_any(FineArgs g, bool split, int C, hipStream_t stream, const char* what) {

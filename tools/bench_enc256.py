@@ -1,5 +1,5 @@
 """Times dfsfm_encoder256_apply_f32 (and the state kernels) at the coarse transformer's shapes.  With DFSFM_LIB_PATH pointing at
-an ablation build (tools/build_enc256_abl.sh) the numbers are the timing breakdown of DESIGN.md section 3 (results are wrong)."""
+an ablation build (temporary switches of round 4, since removed from csrc/encoder256.hip) the numbers are the timing breakdown of DESIGN.md section 3 (results are wrong)."""
 import os
 import sys
 

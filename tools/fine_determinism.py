@@ -1,6 +1,6 @@
 """Run-to-run reproducibility of fine_match at BASELINE configs[2] (2000 tracks x 4 views): N runs, tracks whose outputs differ
 from run 0 (any bit of coords / std / best_index), and the timing.  With DFSFM_LIB_PATH = an experiment build
-(tools/build_fine_abl.sh) this is the root-cause experiment of DESIGN.md section 3 (K11-K12)."""
+(temporary build switches of round 4, since removed from csrc/fine_match.hip; -DFINE_1WG remains) this is the root-cause experiment of DESIGN.md section 3 (K11-K12)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
