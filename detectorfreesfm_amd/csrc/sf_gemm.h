@@ -298,8 +298,10 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
         if constexpr (M16) {
             // accumulate IN PLACE (inline asm ties destination and addend): left to the register allocator, the 16 x 16 x 32
             // builtin got a destination different from its addend across the unrolled taps and the kernel spilled 44 registers.
-            // Consecutive MFMAs never share an accumulator (reuse distance 16), so no software wait states are needed here; the
-            // first VALU read of the results is behind the workgroup barrier of the epilogue.
+            // Consecutive MFMAs never share an accumulator (reuse distance 16), so no software wait states are needed here.  The
+            // compiler's hazard recogniser does not look inside the asm, so the two VALU <-> MFMA hazards are kept away by
+            // construction: the accumulators are zeroed in the prologue, a whole ring fill before the first MFMA reads them, and the
+            // first VALU read of the results is behind the barriers that end the K loop and open the epilogue.
 #define SF_MFMA16(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
 #pragma unroll
             for (int i = 0; i < NI; ++i)
