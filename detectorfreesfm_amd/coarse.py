@@ -15,7 +15,7 @@ the FPN top-down branch (dead when fine.enable=False, resnet_fpn.py:110-116) and
 """
 import math
 
-import os
+
 
 import torch
 
@@ -50,12 +50,13 @@ def _fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
     return (w.double() * s[:, None, None, None]).contiguous(), (bn_b.double() - mean.double() * s).contiguous()
 
 
-# DFSFM_FUSED_ENCODER=0 keeps d_model-128 layers on the five-GEMM path as well (same-box A/B switch, read once at import)
-FUSED_ENCODER = os.environ.get("DFSFM_FUSED_ENCODER", "1") != "0"
-# DFSFM_FUSED_ENCODER256=0: the same switch for the d_model-256 layers of the coarse transformer (csrc/encoder256.hip);
-# DFSFM_FUSED_KV256=0 keeps their source side on the k | v projection GEMM + K1's partial sums (encoder256_state)
-FUSED_ENCODER256 = os.environ.get("DFSFM_FUSED_ENCODER256", "1") != "0"
-FUSED_KV256 = os.environ.get("DFSFM_FUSED_KV256", "1") != "0"
+# Module flags (no environment reads): False keeps d_model-128 layers on the five-GEMM path that MatchFormer / ASpanFormer use
+# for their other widths; FUSED_ENCODER256 the same for the d_model-256 layers of the coarse transformer (csrc/encoder256.hip);
+# FUSED_KV256 = False keeps only their source side on the k | v projection GEMM + K1's partial sums (encoder256_state).  Every
+# setting is a tested path: tests/test_gpu_encoder256.py and tests/test_gpu_encoder_fused.py run the layers both ways.
+FUSED_ENCODER = True
+FUSED_ENCODER256 = True
+FUSED_KV256 = True
 
 
 class EncoderLayerWeights:
@@ -198,7 +199,9 @@ def backbone_tokens_hip(x, H):
 class HipLoFTR(ParamModule):
     def __init__(self, config: dict):
         super().__init__()
-        self.same_conv = os.environ.get("DFSFM_SAME_CONV", "1") != "0"   # A/B switch for the tap-reuse conv kernel
+        # tap-reuse ("same") schedule for the stride-1 3x3 convs; False packs them for the flattened-K kernel (set before the
+        # first forward; tests/test_gpu_e2e.py::test_flattened_k_conv_schedule_equals_same_schedule)
+        self.same_conv = True
         if config["match_coarse"]["match_type"] != "dual_softmax":
             raise NotImplementedError("only the dual_softmax coarse matcher is on the hot path")
         if config["fine"]["enable"]:

@@ -462,11 +462,10 @@ extern "C" int dfsfm_span_attention_f32(const float* q, int64_t ldq, int64_t sq,
     a.sq = sq; a.sk = sk; a.sv = sv; a.sflow = (int64_t)H0 * W0 * 4; a.so = (int64_t)h * w * ldo; a.kv_swap = kv_swap;
     const int smem = (SP_M * SP_LD + 4 * SP_C + 4 * 8 * SP_M + SP_M * 4 + SP_M * 4) * 4;
     static dfsfm::SmemAttr attr, attr_w;
-    static const int force = [] { const char* e = getenv("DFSFM_SPAN_WIDE"); return e ? atoi(e) : -1; }();   // A/B switch
     const bool aligned = ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
                          sk % 4 == 0 && sv % 4 == 0;
     const dim3 grid((unsigned)((h / 2) * (w / 2)), (unsigned)N);
-    if (aligned && force != 0) {
+    if (aligned) {      // 16-byte gathers; rows that are not 16-byte aligned (column slices at odd offsets) take the 4-byte kernel
         attr_w.ensure(reinterpret_cast<const void*>(span_attention_kernel<true>), smem);
         hipLaunchKernelGGL(span_attention_kernel<true>, grid, dim3(256), smem, static_cast<hipStream_t>(stream_), a);
     } else {

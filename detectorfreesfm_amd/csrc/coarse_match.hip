@@ -39,7 +39,7 @@ constexpr int SMEM_TILE = BM * TILE_LD * 4;                  // 66048 B
 constexpr int SMEM_STATS = (BM + BN) * (8 + 4);              // row/col (max,sum) + candidate gates
 constexpr int SMEM_BYTES = SMEM_TILE + SMEM_STATS;           // 68096 B -> 2 workgroups / CU
 
-enum { MODE_STATS = 0, MODE_SELECT = 1, MODE_CONF = 2, MODE_CAND = 3 };
+enum { MODE_STATS = 0, MODE_SELECT = 1, MODE_CONF = 2 };
 constexpr int CAND_SLOTS_MAX = 8;                             // candidate slots per (row, column tile) the workspace is sized for
 
 struct GemmArgs {
@@ -299,7 +299,7 @@ struct GemmSfArgs {
     unsigned int* col_best;
     const uint8_t* mask0;    // optional padding masks [N][L], [N][S] (1 = valid): masked rows / columns take no part
     const uint8_t* mask1;    //     (the reference fills their similarities with -1e9, coarse_matching.py:110-113)
-    float2* cand;            // MODE_CAND: [N][ntn][L][slots] (sim, column index bits) of entries that pass the tile-local gates
+    float2* cand;            // cm_gemm_sf2_cand: [N][ntn][L][slots] (sim, column index bits) of entries that pass the tile-local gates
     uint8_t* cand_cnt;       //            [N][ntn][L] number of valid slots
     int slots;
 };
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
 
     // lane holds sim[row = wr*64 + i*32 + mfma32_row(r,half)][col = wc*64 + j*32 + (lane&31)]
     const int nrow = min(SF_BM, g.L - row0), ncol = min(SF_BN, g.S - col0);
-    if (MODE == MODE_STATS || MODE == MODE_CAND) {
+    if (MODE == MODE_STATS) {
         // Statistics straight from the accumulator registers: a lane's 16 registers of one block are 16 rows of ONE
         // column (column sums are lane-local), and the 32 lanes of a half wave hold the 32 columns of one row (row
         // sums are a 32-lane butterfly).  Only the per-wave partials go through LDS.
@@ -460,58 +460,15 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
                 e = half_wave_sum(e);
                 if (col == 0) s_rp[wc * SF_BM + wr * 64 + i * 32 + mfma32_row(r, half)] = make_float2(m, e);
             }
-        // MODE_CAND (single-GEMM path, thr >= 1/8): besides the partial statistics, remember every entry that could still
-        // reach conf > thr.  conf = p_row * p_col > thr needs p_row > thr and p_col > thr; the log-sum-exp of a whole
-        // row / column is >= that of its part inside this tile, so an entry that fails the gate built from the TILE's
-        // statistics (s > max + log(thr * sum) - 1e-3, the gate cm_gemm_sf<SELECT> applies with the global statistics)
-        // fails the global one too: the survivors are a superset of the true candidates, at most floor(1 / (thr e^-1e-3))
-        // per row and tile, and the exact decision is taken later from their stored fp32 similarities (cm_eval).
-        float* s_rg = reinterpret_cast<float*>(smem + 8192);              // [SF_BM] tile-local row gate
-        float* s_cg = s_rg + SF_BM;                                       // [SF_BN] tile-local column gate
-        int* s_cnt = reinterpret_cast<int*>(s_cg + SF_BN);                // [SF_BM] slots taken per row
         __syncthreads();
         if (tid < SF_BM) {
             const float2 st = merge_stat(s_rp[tid], s_rp[SF_BM + tid]);
             if (tid < nrow) g.row_part[((int64_t)n * g.ntn + tn) * g.L + row0 + tid] = st;
-            if (MODE == MODE_CAND) {
-                s_rg[tid] = (tid < nrow && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
-                s_cnt[tid] = 0;
-            }
         } else {
             const int c = (tid - SF_BM) & (SF_BN - 1), h = (tid - SF_BM) >> 7;   // column c, 128-row half h
             const float2 st = merge_stat(s_cp[(2 * h) * SF_BN + c], s_cp[(2 * h + 1) * SF_BN + c]);
             if (c < ncol)        // an empty half (rows past L) leaves the neutral partial (-inf, 0)
                 g.col_part[((int64_t)n * g.nhalf + tm * 2 + h) * g.S + col0 + c] = st;
-            if (MODE == MODE_CAND && h == 0) {
-                const float2 all = merge_stat(st, merge_stat(s_cp[2 * SF_BN + c], s_cp[3 * SF_BN + c]));
-                s_cg[c] = (c < ncol && all.x != -INFINITY) ? all.x + logf(g.thr * all.y) - 1e-3f : INFINITY;
-            }
-        }
-        if (MODE == MODE_CAND) {
-            __syncthreads();
-            float cg[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) cg[j] = s_cg[wc * 64 + j * 32 + col];
-            const int64_t slot0 = ((int64_t)n * g.ntn + tn) * g.L + row0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = wr * 64 + i * 32 + mfma32_row(r, half);
-                    const float rg = s_rg[lr];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float sv = accm[i][j][r];                       // -inf outside the matrix
-                        if (sv > rg && sv > cg[j]) {
-                            const int slot = atomicAdd(&s_cnt[lr], 1);
-                            if (slot < g.slots)
-                                g.cand[(slot0 + lr) * g.slots + slot] =
-                                    make_float2(sv, __int_as_float(col0 + wc * 64 + j * 32 + col));
-                        }
-                    }
-                }
-            __syncthreads();
-            if (tid < nrow) g.cand_cnt[slot0 + tid] = (uint8_t)min(s_cnt[tid], g.slots);
         }
         return;
     }
@@ -582,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void cm_gemm_sf(GemmSfArgs g) {
 // Single-GEMM candidate pass on the 128 x 128 / two-workgroups-per-CU schedule (dfsfm_sf::sf2_mainloop): the statistics /
 // candidate epilogue of one workgroup runs under the correlation main loop of the co-resident one (with K = 256 the 512-thread
 // kernel above spends ~10 us in its main loop and ~7 us in this epilogue with nothing else on the CU), and the tiles are half
-// as tall.  Same arithmetic, same statistics, same candidates: rows and confidences are identical to cm_gemm_sf<MODE_CAND>.
+// as tall.  Same arithmetic, same statistics, same candidates: rows and confidences are identical to the two-pass path (cm_gemm_sf<STATS> + <SELECT>).
 constexpr int SF2_BM = 128;
 __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -745,274 +702,6 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
     }
     __syncthreads();
     if (tid < nrow) g.cand_cnt[slot0 + tid] = (uint8_t)min(s_cnt[tid], g.slots);
-}
-
-// =====================================================================================================================
-// cm_panel_cand (r04): the single-GEMM candidate pass with the f0 PANEL RESIDENT IN REGISTERS.
-// The tile kernels above re-stream both operand panels for every 128 x 128 tile (PMC r03: 1.31 GB per 8 pairs for 78.6 MB of
-// features, MFMA busy 21 %; eight LDS-DMA requests per wave for 24 MFMAs).  Here a workgroup owns 128 rows of f0 for a whole range
-// of column tiles: wave w keeps its 32 rows x 256 channels as MFMA A fragments (hi, lo: 128 registers, loaded once), and only f1
-// streams -- 16-KB slabs of 128 columns x 32 channels (hi | lo planes, 64-byte rows XOR-swizzled on the source side) through a
-// 4-deep LDS ring that all four waves read, one s_barrier per slab, the next group's fragment reads between the MFMAs of the
-// current one (the window schedule of encoder256.hip's kv kernel): four requests per wave for 24 MFMAs and no staging of f0.
-// The statistics / candidate epilogue of a column tile runs per WAVE on its 32 x 128 accumulators, entirely in registers:
-//   column statistics are lane-local (+ one xor-32 swap) and go out as one partial per 32-ROW block (col_part [N][ceil(L/32)][S]);
-//   row statistics (over the tile's 128 columns, as in the tile kernels) by a transposing butterfly over the half wave;
-//   the candidate gates use the tile-local row statistics (at most floor(1 / thr) entries of a row pass: the slot bound of
-//   cm_eval is unchanged) and the WAVE-local column statistics (a 32-row block's log-sum-exp is <= the column's: still a
-//   necessary condition, merely a weaker filter than the 128-row gate; every candidate is evaluated exactly by cm_eval).
-// No __syncthreads in the epilogue: the waves only meet at the slab barriers.  384 registers: one workgroup per CU.
-// Measured variants: a 64-column-tile version at 256 registers, two workgroups per CU, was slower than this one.
-// Work units: (row panel, column range); the number of ranges per panel is chosen so that the units fill whole rounds of CUs.
-// =====================================================================================================================
-namespace panel {
-constexpr int PBM = 128, PBN = 128, SLAB = 16384, NSTG = 4, KSL = 32;   // slab = 128 columns x 32 channels x (hi, lo)
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void lds_void;
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-}  // namespace panel
-
-struct PanelArgs {
-    GemmSfArgs g;
-    int ncr;                 // column ranges per row panel
-    int tpr;                 // column tiles per range
-    int nparts;              // ceil(L / 32): column partials per pair
-};
-
-__global__ __launch_bounds__(256) void cm_panel_cand(PanelArgs pa) {
-    using namespace panel;
-    const GemmSfArgs& g = pa.g;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, half = lane >> 5;
-    const int n = blockIdx.y;
-    const int tm = blockIdx.x / pa.ncr, cr = blockIdx.x % pa.ncr;
-    const int t_begin = cr * pa.tpr, t_end = min(g.ntn, t_begin + pa.tpr);
-    if (t_begin >= t_end) return;
-    const int row0 = tm * PBM + wave * 32;                   // this wave's 32 rows of f0
-    constexpr int nslab_k = 8;                                // slabs per column tile: C = 256 (the launcher checks)
-    int* s_cnt = reinterpret_cast<int*>(smem + NSTG * SLAB) + wave * 32;     // [4 waves][32 rows] slots taken in the current tile
-    float2* s_rs = reinterpret_cast<float2*>(smem + NSTG * SLAB + 512) + wave * 32;   // [4 waves][32 rows] row statistics of the tile
-    float* s_m = reinterpret_cast<float*>(smem + NSTG * SLAB + 1536) + wave * 32;     // [4 waves][32 rows] row maxima (broadcast)
-    float* s_g = reinterpret_cast<float*>(smem + NSTG * SLAB + 2048) + wave * 32;     // [4 waves][32 rows] row gates (broadcast)
-
-    // ---- B ring: slab q of this unit = column tile t_begin + q / nslab_k, channels 32 (q % nslab_k) .. + 31
-    const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc((void*)(g.f1h + (int64_t)n * g.S * g.C), 0,
-                                                                         (unsigned)((int64_t)g.S * g.C * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc((void*)(g.f1l + (int64_t)n * g.S * g.C), 0,
-                                                                         (unsigned)((int64_t)g.S * g.C * 2), 0x00020000);
-    const unsigned bbytes = (unsigned)((int64_t)g.S * g.C * 2);
-    const int prow = lane >> 2, pchunk = lane & 3;           // DMA lane geometry: a 1-KB piece = 16 rows x 64 B of one plane
-    // this lane's byte offset inside a (tile, slab): row prow of a 16-row group, logical chunk of its physical slot
-    const unsigned lane_src = (unsigned)((prow * g.C + ((pchunk ^ ((prow >> 2) & 3)) << 3)) * 2);
-    // piece 4 * wave + i of slab ks2 (0..7) of column tile t: the ring stage is ks2 & 3 (8 slabs per tile: static in the
-    // unrolled slab loop below, like every index derived from ks2)
-    auto issue_piece = [&](int t, int ks2, int i) __attribute__((always_inline)) {
-        const int p = 4 * wave + i, plane = p >> 3, rg = p & 7;
-        const int64_t srow0 = (int64_t)t * PBN + rg * 16;
-        const unsigned off = (t < t_end && srow0 + prow < g.S) ? (unsigned)((srow0 * g.C + ks2 * KSL) * 2) + lane_src : bbytes;
-        char* dst = smem + (ks2 & 3) * SLAB + plane * 8192 + rg * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(plane ? rbl : rbh, (lds_void*)dst, 16, off, 0, 0, 0);
-    };
-#pragma unroll
-    for (int q = 0; q < NSTG - 1; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_piece(t_begin, q, i);
-
-    // ---- A panel: this wave's 32 rows x C channels as MFMA A fragments (lane (row, kgrp): channels 16 s + 8 kgrp + j)
-    half8 ah[16], al[16];
-    {
-        const int64_t r = (int64_t)row0 + col;
-        const bool ok = r < g.L;
-        const _Float16* ph = g.f0h + ((int64_t)n * g.L + (ok ? r : 0)) * g.C + 8 * half;
-        const _Float16* pl = g.f0l + ((int64_t)n * g.L + (ok ? r : 0)) * g.C + 8 * half;
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) {
-            ah[s_] = ok ? *reinterpret_cast<const half8*>(ph + 16 * s_) : z;
-            al[s_] = ok ? *reinterpret_cast<const half8*>(pl + 16 * s_) : z;
-        }
-    }
-    wait_vmcnt<0>();
-    __syncthreads();                                         // slabs 0-2 of every wave have landed
-    // B fragment (block j = 32 columns, k-step ks of the slab, plane): lane (col, kgrp) <- row 32 j + col, chunk 2 ks + kgrp
-    auto bfrag = [&](const char* slab, int j, int ks, int plane) __attribute__((always_inline)) {
-        const int r = 32 * j + col;
-        return *reinterpret_cast<const half8*>(slab + plane * 8192 + r * 64 + (((2 * ks + half) ^ ((r >> 2) & 3)) << 4));
-    };
-    half8 wa[4], wb[4];                                      // fragment window: group being multiplied / being fetched
-    {   // group 0 of slab 0: [bh(j0), bl(j0), bh(j1), bl(j1)] of k-step 0
-        wa[0] = bfrag(smem, 0, 0, 0); wa[1] = bfrag(smem, 0, 0, 1); wa[2] = bfrag(smem, 1, 0, 0); wa[3] = bfrag(smem, 1, 0, 1);
-    }
-    for (int t = t_begin; t < t_end; ++t) {
-        f32x16 accm[4], accx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) accm[j] = accx[j] = f32x16{0};
-#pragma unroll
-        for (int ks2 = 0; ks2 < nslab_k; ++ks2) {
-            // ---- one slab: 2 k-steps x 4 column blocks = 4 groups of (2 blocks x [hi, lo]) and 6 MFMAs each
-            wait_vmcnt<4>();                                 // own pieces of slab next + 1 (stores in flight only add to the count)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();                    // slab next + 1 visible; every wave is done with slab next - 1
-            __builtin_amdgcn_sched_barrier(0);
-            const char* cslab = smem + (ks2 & 3) * SLAB;
-            const char* nslab = smem + ((ks2 + 1) & 3) * SLAB;
-            const int rt = t + ((ks2 + 3) >> 3), rk = (ks2 + 3) & 7;     // the slab that refills the stage of slab ks2 - 1
-            const half8 a0h = ah[2 * ks2], a0l = al[2 * ks2], a1h = ah[2 * ks2 + 1], a1l = al[2 * ks2 + 1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ks = q >> 1, j0 = 2 * (q & 1), j1 = j0 + 1;
-                half8(&c)[4] = (q & 1) ? wb : wa;
-                half8(&nx)[4] = (q & 1) ? wa : wb;
-                const char* src = q < 3 ? cslab : nslab;
-                const int nks = q < 3 ? (q + 1) >> 1 : 0, nj0 = q < 3 ? 2 * ((q + 1) & 1) : 0;
-                const half8 xh = ks ? a1h : a0h, xl = ks ? a1l : a0l;
-                accm[j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, c[0], accm[j0], 0, 0, 0);
-                nx[0] = bfrag(src, nj0, nks, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                accx[j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, c[1], accx[j0], 0, 0, 0);
-                nx[1] = bfrag(src, nj0, nks, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                accm[j1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, c[2], accm[j1], 0, 0, 0);
-                issue_piece(rt, rk, q);
-                __builtin_amdgcn_sched_barrier(0);
-                accx[j1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, c[3], accx[j1], 0, 0, 0);
-                nx[2] = bfrag(src, nj0 + 1, nks, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                accx[j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, c[0], accx[j0], 0, 0, 0);
-                nx[3] = bfrag(src, nj0 + 1, nks, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                accx[j1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, c[2], accx[j1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- statistics / candidates of this wave's 32 x 128 block of column tile t (registers only).  Written for instruction
-        // count: the first version spent ~4000 instructions per block here (a true division, two mask byte loads and a divergent
-        // branch per element) -- more than the 192 MFMAs of the tile took.
-        const int col0 = t * PBN;
-        const int nrow = min(32, g.L - row0), ncol = min(PBN, g.S - col0);
-        if (lane < 32) s_cnt[lane] = 0;
-        // validity as additive penalties (0 / -inf): rows past L or masked, columns past S or masked
-        float rpen[16], cpen[4];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = mfma32_row(r, half);
-            bool ok = lr < nrow;
-            if (g.mask0) ok = ok && g.mask0[(int64_t)n * g.L + min(row0 + lr, g.L - 1)];
-            rpen[r] = ok ? 0.f : -INFINITY;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lc = j * 32 + col;
-            bool ok = lc < ncol;
-            if (g.mask1) ok = ok && g.mask1[(int64_t)n * g.S + min(col0 + lc, g.S - 1)];
-            cpen[j] = ok ? 0.f : -INFINITY;
-        }
-        // similarity = (acc * acc_mul) / temperature as ONE multiplication by acc_mul / temperature (the IEEE division costs ten
-        // instructions per element; candidates, statistics and cm_eval all see this value, which differs from the other
-        // schedules' by at most one rounding)
-        const float scale = g.acc_mul / g.temperature;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                accm[j][r] = ((accm[j][r] + accx[j][r] * (1.f / 2048.f)) * scale + rpen[r]) + cpen[j];
-        float cg[4];
-        const int part = tm * 4 + wave;                      // 32-row block index of these rows
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                        // columns: 16 lane-local rows, then the other lane half
-            float m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, accm[j][r]);
-            float e = 0.f;
-            if (m != -INFINITY) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) e += fast_exp(accm[j][r] - m);
-            }
-            float m_lo, m_hi, e_lo, e_hi;
-            swap32(m, m_lo, m_hi);
-            swap32(e, e_lo, e_hi);
-            const float2 st = merge_stat(make_float2(m_lo, e_lo), make_float2(m_hi, e_hi));
-            const int lc = j * 32 + col;
-            if (half == 0 && lc < ncol && nrow > 0) g.col_part[((int64_t)n * pa.nparts + part) * g.S + col0 + lc] = st;
-            cg[j] = (lc < ncol && st.x != -INFINITY) ? st.x + logf(g.thr * st.y) - 1e-3f : INFINITY;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the counter reset is visible to this wave's atomics
-        const int64_t slot0 = ((int64_t)n * g.ntn + t) * g.L + row0;
-        float2* rp = g.row_part + ((int64_t)n * g.ntn + t) * g.L + row0;
-        // Row statistics over the tile's 128 columns, branch-free: lane-local maxima of the 4 columns, ONE transposing butterfly
-        // (15 DPP exchanges) + one xor-16 swap leave row r's maximum in lanes r, r + 16 of each half; the maxima go through 128 B
-        // of LDS back to all lanes (4 ds_read_b128 of broadcast addresses); the same for the sums of exponentials; one logf per
-        // lane.  (The first version ran sixteen half-wave all-reduces for the maxima and sixteen for the sums -- 4 DPP steps and
-        // an LDS-crossbar exchange each -- and a logf per row in every lane: 21 K cycles per block, 3.4x the block's MFMAs.)
-        float rgv[16];
-        {
-            const int r_own = lane & 15;                      // the register row whose totals this lane ends up with
-            const int lr_own = mfma32_row(r_own, half);
-            float pm[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pm[r] = fmaxf(fmaxf(accm[0][r], accm[1][r]), fmaxf(accm[2][r], accm[3][r]));
-            float ma, mb;
-            swap16(butterfly16(pm, lane, [](float x, float y) { return fmaxf(x, y); }), ma, mb);
-            const float m_own = fmaxf(ma, mb);
-            if ((lane & 16) == 0) s_m[lr_own] = m_own;
-            float pe[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                     // rows mfma32_row(4 q + k, half) = 8 q + 4 half + k
-                const f32x4 mr = *reinterpret_cast<const f32x4*>(s_m + 8 * q + 4 * half);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int r = 4 * q + k;
-                    pe[r] = (mr[k] != -INFINITY) ? (fast_exp(accm[0][r] - mr[k]) + fast_exp(accm[1][r] - mr[k])) +
-                                                       (fast_exp(accm[2][r] - mr[k]) + fast_exp(accm[3][r] - mr[k])) : 0.f;
-                }
-            }
-            float ea, eb;
-            swap16(butterfly16(pe, lane, [](float x, float y) { return x + y; }), ea, eb);
-            const float e_own = ea + eb;
-            const float g_own = (lr_own < nrow && m_own != -INFINITY) ? m_own + logf(g.thr * e_own) - 1e-3f : INFINITY;
-            if ((lane & 16) == 0) {
-                s_rs[lr_own] = make_float2(m_own, e_own);
-                s_g[lr_own] = g_own;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(s_g + 8 * q + 4 * half);
-                rgv[4 * q] = v[0]; rgv[4 * q + 1] = v[1]; rgv[4 * q + 2] = v[2]; rgv[4 * q + 3] = v[3];
-            }
-        }
-        // candidates are rare (at most floor(1 / thr) per row and tile, none in most tiles): ONE wave-uniform test per tile; the
-        // divergent per-element path runs only in tiles that hold one
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            any = any || fmaxf(fmaxf(accm[0][r] - fmaxf(rgv[r], cg[0]), accm[1][r] - fmaxf(rgv[r], cg[1])),
-                               fmaxf(accm[2][r] - fmaxf(rgv[r], cg[2]), accm[3][r] - fmaxf(rgv[r], cg[3]))) > 0.f;
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = mfma32_row(r, half);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sv = accm[j][r];
-                    if (sv > rgv[r] && sv > cg[j]) {
-                        const int slot = atomicAdd(&s_cnt[lr], 1);
-                        if (slot < g.slots)
-                            g.cand[(slot0 + lr) * g.slots + slot] = make_float2(sv, __int_as_float(col0 + j * 32 + col));
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < nrow) {
-            g.cand_cnt[slot0 + lane] = (uint8_t)min(s_cnt[lane], g.slots);
-            rp[lane] = s_rs[lane];
-        }
-    }
-    panel::wait_vmcnt<0>();                                  // prefetched slabs must land before the LDS allocation is released
 }
 
 // Merge per-tile (max, sumexp) partials; clear row_best / col_best.
@@ -1231,9 +920,9 @@ struct Workspace {
 };
 
 Workspace carve(void* base, int N, int L, int S) {
-    // col_part holds one partial per row block: 128 rows (ceil(L/128) for cm_gemm, 2*ceil(L/256) for cm_gemm_sf) or 32 rows
-    // (cm_panel_cand: ceil(L/32)); sized for the latter
-    const int ntm = (L + 31) / 32, ntn = (S + BN - 1) / BN;
+    // col_part holds one partial per 128-row block: ceil(L/128) for cm_gemm and cm_gemm_sf2_cand, 2*ceil(L/256) (>= that) for
+    // the two half tiles of cm_gemm_sf
+    const int ntm = 2 * ((L + SF_BM - 1) / SF_BM), ntn = (S + BN - 1) / BN;
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1344,51 +1033,17 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
         g.mask0 = mask0; g.mask1 = mask1;
         // Single-GEMM path: at most floor(1 / (thr e^-1e-3)) entries of a row (or column) can pass the row gate, so for
         // thr >= 1/8 a fixed number of candidate slots per (row, column tile) holds every possible match and the second
-        // correlation pass is replaced by an O(candidates) evaluation.  DFSFM_CM_TWOPASS=1 forces the two-pass path (A/B).
-        static const bool force_two_pass = [] { const char* e = getenv("DFSFM_CM_TWOPASS"); return e && atoi(e) != 0; }();
+        // correlation pass is replaced by an O(candidates) evaluation (thr < 1/8 takes the two-pass path below).
         const int slots = thr > 0.f ? (int)floorf(1.f / (thr * 0.998f)) : CAND_SLOTS_MAX + 1;
-        if (slots <= CAND_SLOTS_MAX && !force_two_pass) {
+        if (slots <= CAND_SLOTS_MAX) {
             g.cand = w.cand; g.cand_cnt = w.cand_cnt; g.slots = slots;
-            // DFSFM_CM3=1: the panel-resident kernel (r04 experiment: its correlation loop is 2.4x faster than the tile kernel's, its
-            // statistics epilogue -- no second workgroup on the CU to hide it under -- makes the whole pass slower: 0.82 vs 0.72 ms)
-            static const bool cm3 = [] { const char* e = getenv("DFSFM_CM3"); return e && atoi(e) != 0; }();
-            // DFSFM_CM2=0: the 256 x 128 one-workgroup-per-CU candidate kernel (same-box A/B switch)
-            static const bool cm2 = [] { const char* e = getenv("DFSFM_CM2"); return !e || atoi(e) != 0; }();
-            if (cm3 && C == 256) {
-                PanelArgs pa{};
-                pa.g = g;
-                const int ntm3 = (L + panel::PBM - 1) / panel::PBM;
-                pa.nparts = nparts = (L + 31) / 32;
-                // column ranges per panel: the split whose unit count wastes the least of its last round of CUs
-                int dev = 0, cus = 256;
-                (void)hipGetDevice(&dev);
-                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-
-                int best_ncr = 1;
-                double best_eff = 0.0;
-                for (int ncr = 1; ncr <= g.ntn && ncr <= 16; ++ncr) {
-                    const int tpr = (g.ntn + ncr - 1) / ncr;
-                    const int64_t units = (int64_t)N * ntm3 * ncr;
-                    const int64_t rounds = (units + cus - 1) / cus;
-                    // time ~ rounds x tiles per unit (+ one tile's worth of fixed cost per unit: A panel load, ring fill)
-                    const double eff = ((double)N * ntm3 * g.ntn) / ((double)rounds * cus * (tpr + 1.0));
-                    if (eff > best_eff + 1e-9) { best_eff = eff; best_ncr = ncr; }
-                }
-                pa.ncr = best_ncr;
-                pa.tpr = (g.ntn + best_ncr - 1) / best_ncr;
-                static dfsfm::SmemAttr smem_attr3;
-                constexpr int SMEM3 = panel::NSTG * panel::SLAB + 512 + 4 * 32 * 8 + 2 * 4 * 32 * 4;
-                smem_attr3.ensure(reinterpret_cast<const void*>(&cm_panel_cand), SMEM3);
-                hipLaunchKernelGGL(cm_panel_cand, dim3((unsigned)(ntm3 * pa.ncr), N), dim3(256), SMEM3, stream, pa);
-            } else if (cm2) {
+            {
                 const int ntm2 = (L + SF2_BM - 1) / SF2_BM;
                 g.ntiles = (unsigned)(ntm2 * g.ntn);
                 g.nhalf = nparts = ntm2;
                 static dfsfm::SmemAttr smem_attr2;
                 smem_attr2.ensure(reinterpret_cast<const void*>(&cm_gemm_sf2_cand), dfsfm_sf::V2S<1>::SMEM);
                 hipLaunchKernelGGL(cm_gemm_sf2_cand, dim3((g.ntiles + 7) / 8 * 8, N), dim3(256), dfsfm_sf::V2S<1>::SMEM, stream, g);
-            } else {
-                launch_gemm_sf<MODE_CAND>(g, N, stream);
             }
             hipLaunchKernelGGL(cm_reduce_stats, dim3((L + S + 255) / 256, N), dim3(256), 0, stream, w.row_part,
                                w.col_part, w.row_stat, w.col_stat, w.row_best, w.col_best, L, S, nparts, g.ntn);

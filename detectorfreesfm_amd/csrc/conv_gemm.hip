@@ -1048,16 +1048,6 @@ void launch_lin(const ConvArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(linear_gemm_sf_kernel<NA_>, grid, dim3(T::NT), T::SMEM, stream, a);
 }
 
-// DFSFM_LIN2: 1 (default) = 128 x 128 / two-workgroups-per-CU schedule for linear layers with Cout > 64, A ring 3 deep;
-// 2 = the same with a 2-deep A ring; 0 = the 512-thread schedule everywhere (A/B control).
-int lin2_mode() {
-    static const int mode = [] {
-        const char* e = getenv("DFSFM_LIN2");
-        return e ? atoi(e) : 1;
-    }();
-    return mode;
-}
-
 }  // namespace
 
 extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, int64_t sxn, int64_t sxh,
@@ -1135,11 +1125,11 @@ extern "C" int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const voi
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1, 128x256 tile)");
         }
         if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {    // 1x1 / linear: the same schedule with one tap
-            if (Cout > 64 && (!ln_gamma || Cout == 128) && lin2_mode() != 0) {
-                if (lin2_mode() == 2) launch_lin<2>(g, stream); else launch_lin<3>(g, stream);
+            if (Cout > 64) {       // 128 x 128 tiles, two workgroups per CU (a fused LayerNorm here means Cout == 128: one N tile)
+                launch_lin<3>(g, stream);
                 return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(linear, 128x128 tile)");
             }
-            if (Cout <= 64) launch_same<64, 1>(g, stream); else launch_same<128, 1>(g, stream);
+            launch_same<64, 1>(g, stream);
             return dfsfm::check_launch("dfsfm_conv2d_nhwc_f32(1x1)");
         }
         if (Cout <= 64) launch_v2<64>(g, stream);

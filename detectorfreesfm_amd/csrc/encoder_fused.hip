@@ -786,8 +786,7 @@ extern "C" int dfsfm_encoder_apply_f32(const void* x_hi, const void* x_lo, int64
     g.ntiles = (int)((M + 127) / 128);
     g.dbg = debug;
     g.dbg_stage = debug_stage;
-    static const int stagger = [] { const char* e = getenv("DFSFM_ENC_STAGGER"); return e ? atoi(e) : 2; }();   // A/B knob
-    g.stagger = g.ntiles > 4 * 256 ? stagger : 0;       // only worth it when every workgroup walks several tiles
+    g.stagger = g.ntiles > 4 * 256 ? 2 : 0;             // only worth it when every workgroup walks several tiles
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

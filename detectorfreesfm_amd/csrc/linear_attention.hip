@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void la_kv_finalize(const float* __restrict__ 
 // Rows per kv_partial workgroup: aim for ~512 workgroups (one resident wave of 2 per CU), at least
 // 64 rows each.
 int chunk_rows(int N, int S) {
-    static const int wgs = [] { const char* e = getenv("DFSFM_LA_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // A/B knob (>= 1)
+    constexpr int wgs = 512;
     int64_t want = ((int64_t)S * N + wgs - 1) / wgs;
     int rows = (int)((want + 31) / 32 * 32);
     if (rows < 64) rows = 64;

@@ -775,8 +775,7 @@ class SplitAct:
 # (Cin, kh, kw, Cout) -> (stride, pad) served by dfsfm_conv2d_direct_f32, and the shapes routed to it by default
 # (the 7x7 stem measures faster on the implicit-GEMM kernel: 0.43 vs 0.65 ms at 16 x 480x640)
 _DIRECT_SHAPES = {(1, 7, 7, 128): (2, 3), (3, 3, 3, 64): (1, 1)}
-# DFSFM_DIRECT_CONV=0 routes conv1_1 to the implicit-GEMM kernel as well (A/B switch, read once at import)
-_DIRECT_DEFAULT = {(3, 3, 3, 64)} if os.environ.get("DFSFM_DIRECT_CONV", "1") != "0" else set()
+_DIRECT_DEFAULT = {(3, 3, 3, 64)}
 
 
 class PackedDense:

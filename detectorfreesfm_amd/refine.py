@@ -22,7 +22,6 @@ Output-identical work the reference wastes is skipped ("dea
 * padded view slots (image index -1) are never cropped or convolved: they are masked everywhere
   downstream, the reference feeds them a copy of the last patch (MultiviewMatcher.py:253-266).
 """
-import os
 
 import torch
 import torch.nn.functional as F      # _bicubic_rows: PyTorch's own interpolation coefficients, on the host
@@ -46,7 +45,9 @@ def _bicubic_rows(n_in: int, n_out: int, lo: int, hi: int) -> torch.Tensor:
 class HipMultiviewMatcher(ParamModule):
     def __init__(self, config: dict, test: bool = True, max_backbone_patches: int = 16384, **_unused):
         super().__init__()
-        self.same_conv = os.environ.get("DFSFM_SAME_CONV", "1") != "0"   # A/B switch for the tap-reuse conv kernel
+        # tap-reuse ("same") schedule for the stride-1 3x3 / 5x5 convs; False packs them for the flattened-K kernel (set before
+        # the first forward; tests/test_gpu_e2e.py::test_flattened_k_conv_schedule_equals_same_schedule)
+        self.same_conv = True
         if not test:
             raise NotImplementedError("training path is out of scope; build with test=True")
         bb = config["backbone"]
@@ -71,8 +72,9 @@ class HipMultiviewMatcher(ParamModule):
             # equals the reference's pad-2 convolution of the full map only while that halo stays inside the patch
             raise NotImplementedError(f"window_size {W} too close to crop_size {crop}: need crop >= window + 6")
         self.config = config
-        # patches per S2DNet pass; DFSFM_BACKBONE_PATCHES overrides it for A/B runs of the chunk size
-        self.max_backbone_patches = int(os.environ.get("DFSFM_BACKBONE_PATCHES", max_backbone_patches))
+        # patches per S2DNet pass (bounds the activation buffers; results do not depend on it:
+        # tests/test_gpu_e2e.py::test_refine_backbone_patch_chunks_are_invisible)
+        self.max_backbone_patches = int(max_backbone_patches)
         self.register_spec(multiview_param_spec(config))
         self.register_buffer("_mean", torch.tensor(IMAGENET_MEAN), persistent=False)
         self.register_buffer("_std", torch.tensor(IMAGENET_STD), persistent=False)

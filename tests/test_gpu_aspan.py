@@ -72,6 +72,25 @@ def test_span_attention_vs_reference(built_lib, hw, hw_k, s):
     assert err.mean().item() < 1e-6 and err.max().item() < 5e-4
 
 
+def test_span_attention_unaligned_rows_take_the_4_byte_gathers(built_lib):
+    """Key / value rows whose row pitch is not a multiple of 16 bytes cannot use the 16-byte gathers: the entry point then runs
+    span_attention_kernel<false> (4-byte taps).  Same products and sums per element -> the result must equal the aligned launch
+    bit for bit."""
+    g = torch.Generator().manual_seed(21)
+    hw, s = (12, 16), 2
+    H0, W0 = hw[0] * s, hw[1] * s
+    q = torch.randn((hw[0] * hw[1], 256), generator=g).to(DEV)
+    kv = torch.randn((hw[0] * hw[1], 2 * 256 + 2), generator=g).to(DEV)          # pitch 514 floats: rows are 8-byte aligned only
+    flow = torch.cat([torch.rand((H0 * W0, 1), generator=g) * 36 - 2, torch.rand((H0 * W0, 1), generator=g) * 28 - 2,
+                      torch.randn((H0 * W0, 2), generator=g) - 1.0], 1).contiguous().to(DEV)
+    so = torch.tensor([[a - 3.5, b - 3.5] for a in range(8) for b in range(8)]).to(DEV)
+    k_u, v_u = kv[:, :256], kv[:, 258:514]
+    assert k_u.stride(0) % 4 != 0
+    narrow = ops.span_attention(q, hw, k_u, v_u, hw, flow, (H0, W0), so, 8, [2, 8], 5)
+    wide = ops.span_attention(q, hw, k_u.contiguous(), v_u.contiguous(), hw, flow, (H0, W0), so, 8, [2, 8], 5)
+    assert torch.equal(narrow, wide)
+
+
 def test_span_attention_batched_swap(built_lib):
     """Two row-stacked images in one launch, image n sampling the keys / values of image n ^ 1 (how a pair of equal frames runs)."""
     g = torch.Generator().manual_seed(11)

@@ -194,6 +194,111 @@ def test_loftr_640x480_planted_vs_oracle(built_lib):
     assert len(ex) <= 3
 
 
+def _batched_vs_oracle(nb, H, W, seed, label, min_rows_per_pair):
+    """The batch ``bench.py`` times, held to the oracle: ONE ``HipLoFTR.forward`` over ``nb`` same-shape pairs against ONE
+    batched oracle forward -- the reference sends same-shape frames through the backbone as one 2N batch
+    (third_party/LoFTR/src/loftr/loftr.py:45-47) and runs the self layers on N-sequence batches
+    (loftr_module/transformer.py:90-97), so batch size is part of the configuration: it changes the launch shapes here
+    (`use_ln160(M)`, the chunking of enc256_kv, K3's tile count and workspace carving).  Checked pair by pair under the plain
+    north_star rules (no oracle-noise rule): rows identical, confidences within 1e-4."""
+    cfg, sd, m = _loftr(0.2)
+    data = synth.coarse_pair_batch(nb, H, W, seed=seed)
+    d = synth.to_device(data, DEV)
+    m(d)
+    o, conf = _oracle_coarse(sd, cfg, data)
+    total_ex = []
+    hb, ob = d["b_ids"].cpu(), o["b_ids"]
+    for p in range(nb):
+        hs, os_ = (hb == p), (ob == p)
+        hp = {k: d[k].cpu()[hs] for k in MATCH_KEYS}
+        op = {k: o[k][os_] for k in MATCH_KEYS if k in o}
+        hp["b_ids"], op["b_ids"] = torch.zeros_like(hp["b_ids"]), torch.zeros_like(op["b_ids"])
+        assert op["i_ids"].numel() > min_rows_per_pair, (p, op["i_ids"].numel())
+        total_ex += _strict_coarse(hp, op, conf[p:p + 1], 0.2, f"{label} pair {p}")
+    assert len(total_ex) <= 3 * nb and not any(e[0] == "oracle-noise" for e in total_ex)
+    # whole-table layout as the plugin reads it: ascending (b, i), every pair present
+    key = d["b_ids"].cpu() * (H // 8) * (W // 8) + d["i_ids"].cpu()
+    assert (key[1:] > key[:-1]).all() and set(hb.tolist()) == set(range(nb))
+
+
+def test_loftr_benched_batch8_640x480_vs_oracle(built_lib):
+    """BASELINE configs[1] exactly as ``bench.py`` steps it (rank 0, first rotating batch: ``coarse_pair_batch(8, 480, 640,
+    seed=1000)``, planted weights, thr 0.2): all 8 pairs against the batched oracle."""
+    _batched_vs_oracle(8, 480, 640, 1000, "bench batch 8x640x480", 3000)
+
+
+def test_loftr_benched_batch4_832_vs_oracle(built_lib):
+    """``bench.py --workload hires832`` step (configs[4] frame size, 4 pairs, seed 500) against the batched oracle."""
+    _batched_vs_oracle(4, 832, 832, 500, "bench batch 4x832x832", 6000)
+
+
+def test_flattened_k_conv_schedule_equals_same_schedule(built_lib):
+    """``model.same_conv = False`` packs the stride-1 3x3 / 5x5 convolutions for the flattened-K kernel instead of the
+    tap-reuse schedule (another summation order of the same products): both matchers must still meet the oracle under the
+    north_star rules, and agree with the default schedule to rounding."""
+    cfg, sd, m = _loftr(0.2)
+    alt = HipLoFTR(cfg)
+    alt.same_conv = False
+    alt.load_state_dict(sd, strict=True)
+    alt = alt.eval().to(DEV)
+    data = synth.coarse_pair_batch(2, 96, 128, seed=1000)
+    d, e = synth.to_device(data, DEV), synth.to_device(data, DEV)
+    m(d)
+    alt(e)
+    assert not any(pw.tap_padded for pw in _packed_convs(alt)) and any(pw.tap_padded for pw in _packed_convs(m))
+    o, conf = _oracle_coarse(sd, cfg, data)
+    assert o["i_ids"].numel() > 100
+    assert len(_strict_coarse(e, o, conf, 0.2, "flattened-K backbone")) <= 2
+    assert _same_tables({k: d[k].cpu() for k in MATCH_KEYS}, {k: e[k].cpu() for k in MATCH_KEYS}, 0.2) > 100
+
+    rcfg, rsd, rm = _refiner(1)
+    ralt = HipMultiviewMatcher(rcfg, test=True)
+    ralt.same_conv = False
+    ralt.load_state_dict(rsd, strict=True)
+    ralt = ralt.eval().to(DEV)
+    rdata = synth.refine_bag(T=40, V=4, H=120, W=160, seed=2300, variable_lengths=True)
+    rd = synth.to_device(rdata, DEV)
+    ralt(rd)
+    with torch.no_grad():
+        ro = restate.multiview_matcher_forward(rsd, rcfg, rdata)
+    assert len(_strict_refine(rd, ro, rdata, 7, "flattened-K S2DNet")) <= 2
+
+
+def _packed_convs(model):
+    P = model._packed
+    found = []
+
+    def walk(x):
+        if hasattr(x, "tap_padded"):
+            found.append(x)
+        elif isinstance(x, dict):
+            for v in x.values():
+                walk(v)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                walk(v)
+    walk(P)
+    return found
+
+
+def test_refine_backbone_patch_chunks_are_invisible(built_lib):
+    """``max_backbone_patches`` bounds S2DNet's activation buffers by running the patches in chunks; patches are independent
+    and no kernel's summation order depends on how many share a launch, so a 64-patch chunking must reproduce the one-pass
+    result exactly."""
+    cfg, sd, m = _refiner(1)
+    small = HipMultiviewMatcher(cfg, test=True, max_backbone_patches=64)
+    small.load_state_dict(sd, strict=True)
+    small = small.eval().to(DEV)
+    data = synth.refine_bag(T=96, V=4, H=120, W=160, seed=2400, variable_lengths=True)
+    a, b = synth.to_device(data, DEV), synth.to_device(data, DEV)
+    m(a)
+    small(b)
+    assert small.max_backbone_patches == 64 and m.max_backbone_patches > 96 * 4
+    assert torch.equal(a["query_points_refined"], b["query_points_refined"])
+    assert torch.equal(a["reference_points_refined"][-1], b["reference_points_refined"][-1])
+    assert torch.equal(a["std"][-1], b["std"][-1])
+
+
 def test_loftr_features_vs_oracle_640x480(built_lib):
     """BASELINE config 2 frame size: transformer output features vs the oracle (1e-4 relative)."""
     for planted in (False, True):

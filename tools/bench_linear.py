@@ -1,6 +1,6 @@
-"""Linear-layer shapes of both transformers on dfsfm_conv2d_nhwc_f32 (1x1 case); run with DFSFM_LIN2=0/1/2 to A/B the
-512-thread schedule against the 128x128 two-workgroups-per-CU schedule.  usage: python tools/bench_linear.py"""
-import os, sys, torch
+"""Linear-layer shapes of both transformers on dfsfm_conv2d_nhwc_f32 (1x1 case: the 128x128 two-workgroups-per-CU schedule;
+the 512-thread schedule it was A/B'd against in r02 has left the library).  usage: python tools/bench_linear.py"""
+import sys, torch
 sys.path.insert(0, '.')
 from detectorfreesfm_amd import ops
 dev = 'cuda:0'
@@ -19,7 +19,6 @@ shapes = [  # (label, rows, K, N, mode)   mode: f32 out / split relu / ln
     ("refine mlp.0 (qry)", 1800000, 256, 256, "relu"), ("refine mlp.2+LN (qry)", 1800000, 256, 128, "ln"),
     ("refine qkv (ref)", 450000, 128, 384, "f32"), ("refine mlp.0 (ref)", 450000, 256, 256, "relu"),
 ]
-print("DFSFM_LIN2 =", os.environ.get("DFSFM_LIN2", "(default 1)"))
 tot = 0
 for label, rows, K, N, mode in shapes:
     x = torch.randn((rows, K), generator=g).to(dev)
