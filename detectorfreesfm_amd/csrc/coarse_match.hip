@@ -26,6 +26,7 @@
 // conflict-free; next k-slab is prefetched into registers while the MFMAs run.
 #include "common.h"
 #include "sf_gemm.h"
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 
@@ -302,6 +303,7 @@ struct GemmSfArgs {
     float2* cand;            // cm_gemm_sf2_cand: [N][ntn][L][slots] (sim, column index bits) of entries that pass the tile-local gates
     uint8_t* cand_cnt;       //            [N][ntn][L] number of valid slots
     int slots;
+    int sb;                  // cm_gemm_sf2_cand: tile rows per traversal group (L2-aware tile order)
 };
 
 // exp for the softmax denominators of the split path: v_exp_f32(x * log2 e).  The argument is <= 0; the product's
@@ -550,7 +552,14 @@ __global__ __launch_bounds__(256, 2) void cm_gemm_sf2_cand(GemmSfArgs g) {
     const int n = blockIdx.y;
     const unsigned t_id = dfsfm_sf::xcd_band_tile(blockIdx.x, gridDim.x >> 3);
     if (t_id >= g.ntiles) return;
-    const int tm = t_id / g.ntn, tn = t_id % g.ntn;
+    // L2-aware traversal (r05).  XCD x runs the contiguous range [x T/8, (x+1) T/8) of a tile ORDER, 64 tiles at a time (32 CUs x 2
+    // workgroups).  In row-major order those 64 tiles are 1.7 tile rows x all 38 column tiles: every tile row re-streams the whole
+    // f1 panel (4.9 MB per pair at 4800 rows, more than an XCD's 4-MB L2) -- 1.22 GB fetched per 8 pairs for 79 MB of features
+    // (profiles/r04_pmc_traffic.json).  The order used here walks row GROUPS of g.sb tile rows column tile by column tile
+    // (tn outer, tm inner): the group's f0 rows (sb x 128 KB) stay in L2 while f1 streams past once per group.
+    const unsigned gsz = (unsigned)(g.sb * g.ntn), grp = t_id / gsz, rem = t_id - grp * gsz;
+    const int rows_g = min(g.sb, g.nhalf - (int)grp * g.sb);              // g.nhalf = tile rows (one column partial per tile row)
+    const int tn = (int)rem / rows_g, tm = (int)grp * g.sb + (int)rem % rows_g;
     const int row0 = tm * SF2_BM, col0 = tn * SF_BN;
 
     dfsfm_sf::ConvArgs a{};
@@ -1041,6 +1050,9 @@ int coarse_match_impl(const float* feat0, const float* feat1, const _Float16* f0
                 const int ntm2 = (L + SF2_BM - 1) / SF2_BM;
                 g.ntiles = (unsigned)(ntm2 * g.ntn);
                 g.nhalf = nparts = ntm2;
+                // tile rows per traversal group: about one group per XCD range (8 ranges), at most 12 (1.5 MB of f0 at C = 256
+                // in a 4-MB L2 that f1 is streaming through)
+                g.sb = std::min(12, std::max(1, (ntm2 + 7) / 8));
                 static dfsfm::SmemAttr smem_attr2;
                 smem_attr2.ensure(reinterpret_cast<const void*>(&cm_gemm_sf2_cand), dfsfm_sf::V2S<1>::SMEM);
                 hipLaunchKernelGGL(cm_gemm_sf2_cand, dim3((g.ntiles + 7) / 8 * 8, N), dim3(256), dfsfm_sf::V2S<1>::SMEM, stream, g);

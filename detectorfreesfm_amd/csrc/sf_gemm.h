@@ -299,9 +299,9 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
             // accumulate IN PLACE (inline asm ties destination and addend): left to the register allocator, the 16 x 16 x 32
             // builtin got a destination different from its addend across the unrolled taps and the kernel spilled 44 registers.
             // Consecutive MFMAs never share an accumulator (reuse distance 16), so no software wait states are needed here.  The
-            // compiler's hazard recogniser does not look inside the asm, so the two VALU <-> MFMA hazards are kept away by
-            // construction: the accumulators are zeroed in the prologue, a whole ring fill before the first MFMA reads them, and the
-            // first VALU read of the results is behind the barriers that end the K loop and open the epilogue.
+            // compiler's hazard recogniser does not look inside the asm: the accumulators are zeroed in the prologue, a whole ring
+            // fill (hundreds of cycles, with s_waitcnt + s_barrier in between) before the first MFMA reads them, and the K loop
+            // ends with an explicit s_nop run before any VALU instruction may read the results (end of this function).
 #define SF_MFMA16(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -413,6 +413,11 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();                       // pairs with the extra barrier of waves 4-7
     wait_vmcnt<0>();
+    // The inline-asm MFMAs are invisible to the compiler's hazard recogniser: close the region explicitly.  An XDL write of a
+    // 16 x 16 x 32 (8-pass) MFMA must be 11 - 18 wait states ahead of a VALU read / overlapped write of its destination
+    // (MI355X guide, MFMA hazards); a barrier every wave has already reached is one issue slot, not a delay.  20 wait states per
+    // TILE (not per slab) make the accumulators safe to read whatever the caller's epilogue starts with.
+    if constexpr (M16) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #undef SDMA_A
 #undef SDMA_B
 }

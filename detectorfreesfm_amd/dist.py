@@ -95,7 +95,26 @@ def shard_pairs_tiled(pairs: Sequence[Tuple[int, int]], n_images: int, world_siz
             best = (worst, out)
         if worst <= 1.02 * ideal:
             break
-    return best[1]
+    worst, out = best
+    if worst > 1.02 * ideal:
+        # Sparse / star-shaped pair lists (covisibility graphs) can leave every block grid off balance: level the ranks by moving
+        # single pairs from the heaviest ranks to the lightest ones.  A moved pair may bring one or two more images to its new rank;
+        # the blocks themselves stay where they were dealt, so the image locality of the deal is kept up to those pairs.
+        out = [list(o) for o in out]
+        load = [len(o) for o in out]
+        order = sorted(range(world_size), key=lambda r: -load[r])
+        for r in order:
+            while load[r] > ideal:
+                to = min(range(world_size), key=lambda q: (load[q], q))
+                if load[to] + 1 > ideal or to == r:
+                    break
+                n = min(load[r] - ideal, ideal - load[to])
+                out[to].extend(out[r][-n:])
+                del out[r][-n:]
+                load[r] -= n
+                load[to] += n
+        out = [sorted(o) for o in out]
+    return out
 
 
 _WORD_DTYPES = (torch.float32, torch.int32)
@@ -113,9 +132,9 @@ def collect_tables(tables: List[torch.Tensor], group=None, root=None, dtype=torc
     packed=True: returns ``(rows [sum M, W], counts int32 [n_tables])`` device tensors instead of a list of views -- no
     second host read and no per-table Python object (what a per-step caller such as bench.py wants; the list form splits
     ``rows`` by ``counts`` with one ``torch.split`` per rank).
-    Every argument error (a dtype that is not a 4-byte word, tables of mixed width) is detected BEFORE the first collective
-    and travels in the metadata, so all ranks raise together instead of one rank raising while the others wait inside the
-    collective.
+    Every argument error (a dtype that is not a 4-byte word, tables of mixed width on one rank or of different widths on
+    different ranks) is detected BEFORE the payload collective from the metadata every rank holds, so all ranks raise together
+    instead of one rank raising while the others wait inside the collective.
     The reference moves the same tables as pickled numpy arrays through Ray's object store
     (src/coarse_match/coarse_match.py:127-140; multiview_match.py:39-62)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -143,6 +162,10 @@ def collect_tables(tables: List[torch.Tensor], group=None, root=None, dtype=torc
         what = {1: "tables travel as 4-byte words (float32 / int32)", 2: "tables must be [M, W] with one width per rank"}
         raise TypeError("collect_tables: " + "; ".join(f"rank {r}: {what[e]}" for r, e in bad))
     wmax = max(m[1] for m in metas)
+    odd = [(r, m[1]) for r, m in enumerate(metas) if m[1] and m[1] != wmax]
+    if odd:                                                                       # widths are per call, not per rank
+        raise TypeError("collect_tables: table widths differ between ranks: " +
+                        ", ".join(f"rank {r}: {w}" for r, w in odd) + f" vs {wmax}")
     # this rank's words: [row counts (n_tables) | rows (total x width)]
     counts = torch.tensor([t.shape[0] for t in tables], dtype=torch.int32, device=dev)
     words = torch.cat([counts] + [t.contiguous().view(torch.int32).reshape(-1) for t in tables if t.shape[0]]) if tables \
@@ -154,7 +177,7 @@ def collect_tables(tables: List[torch.Tensor], group=None, root=None, dtype=torc
         rows = [buf[offs[r] + metas[r][0]:offs[r] + lens[r]].view(dtype).view(metas[r][2], metas[r][1])
                 for r in range(ws)]
         if packed:
-            keep = [x for x, m in zip(rows, metas) if m[1] == wmax and m[2]]
+            keep = [x for x, m in zip(rows, metas) if m[2]]                       # widths were checked equal above
             return (torch.cat(keep) if keep else torch.empty((0, wmax), dtype=dtype, device=dev)), torch.cat(cnts)
         host = torch.cat(cnts).tolist() if sum(m[0] for m in metas) else []      # host read 2: the row counts
         out, k = [], 0

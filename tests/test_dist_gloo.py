@@ -1,4 +1,4 @@
-"""Multi-process path on CPU (gloo, world_size 2): static sharding + all-gather of match tables."""
+"""Multi-process path on CPU (gloo, world_size 2 and 8): static sharding + the collectives of the match tables."""
 import os
 
 import torch
@@ -189,6 +189,132 @@ def test_refine_scene_sharded_world2():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2] > 40
+
+
+def _worker8(rank, world, port, q):
+    """collect_tables at the target world size (8 ranks, gloo): every form, ranks WITHOUT tables, both error paths."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(200)
+    per_rank = [0 if r in (2, 6) else 1 + (r % 3) for r in range(world)]              # ranks 2 and 6 hold no table at all
+    all_tables = [[torch.rand((int(torch.randint(0, 7, (1,), generator=g)), 5), generator=g) for _ in range(n)] for n in per_rank]
+    flat = [t for ts in all_tables for t in ts]
+    mine = all_tables[rank]
+    ok = True
+    got = ddist.collect_tables(mine, root=None)                                       # list form on every rank
+    ok = ok and len(got) == len(flat) and all(torch.equal(a, b) for a, b in zip(got, flat))
+    rows, cnt = ddist.collect_tables(mine, root=None, packed=True)                    # packed form on every rank
+    ok = ok and torch.equal(rows, torch.cat(flat)) and cnt.tolist() == [t.shape[0] for t in flat]
+    for root in (0, 5, 6):                                                            # gather-to-root, incl. a root without tables
+        got = ddist.collect_tables(mine, root=root)
+        ok = ok and ((got is None) if rank != root else (len(got) == len(flat) and all(torch.equal(a, b) for a, b in zip(got, flat))))
+        pk = ddist.collect_tables(mine, root=root, packed=True)
+        ok = ok and ((pk is None) if rank != root else (torch.equal(pk[0], torch.cat(flat)) and pk[1].tolist() == [t.shape[0] for t in flat]))
+    ints = [torch.full((rank % 4, 4), rank, dtype=torch.int32)] if rank % 2 else []   # int32 rows, half the ranks empty
+    gi = ddist.collect_tables(ints, root=None, dtype=torch.int32)
+    ok = ok and len(gi) == 4 and all(t.dtype == torch.int32 for t in gi) and [int(t.shape[0]) for t in gi] == [1, 3, 1, 3] \
+        and [int(t[0, 0]) for t in gi] == [1, 3, 5, 7]
+    none = ddist.collect_tables([], root=None)                                        # nobody has anything
+    ok = ok and none == []
+    # error on ONE rank -> the same TypeError on ALL ranks, nobody left inside the payload collective
+    for bad_rank, bad in ((3, [torch.ones((2, 5), dtype=torch.float64)]), (7, [torch.ones(2, 5), torch.ones(2, 4)])):
+        for root in (None, 0):
+            try:
+                ddist.collect_tables(bad if rank == bad_rank else mine, root=root)
+                ok = False
+            except TypeError as e:
+                ok = ok and f"rank {bad_rank}" in str(e)
+    # widths that differ BETWEEN ranks (each rank consistent in itself): raised everywhere as well, in every form
+    odd = [torch.ones(3, 4)] if rank == 4 else mine
+    for kw in ({"root": None}, {"root": None, "packed": True}, {"root": 0}):
+        try:
+            ddist.collect_tables(odd, **kw)
+            ok = False
+        except TypeError as e:
+            ok = ok and "rank 4: 4" in str(e)
+    after = ddist.collect_tables(mine, root=None)                                     # the group is still usable afterwards
+    ok = ok and len(after) == len(flat)
+    q.put((rank, bool(ok), len(got) if got is not None else -1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, port, timeout):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=timeout) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_collect_tables_world8():
+    res = _spawn(_worker8, 8, 35500 + os.getpid() % 2000, 300)
+    assert len(res) == 8 and all(ok for _, ok, _ in res), res
+
+
+def _scene_worker8(rank, world, port, q):
+    """plugin.match_scene_sharded on 8 gloo ranks, 24 images / 276 exhaustive pairs, tiled shards (CPU stand-ins behind
+    ``ops``): every rank ends with all 276 tables in pair-list order; the tiled and the contiguous sharding give the same
+    rows; a sample of pairs equals the single-process path; a rank touches ~ half the images."""
+    import numpy as np
+    from cpu_standins import cpu_ops
+    from detectorfreesfm_amd import HipLoFTR, plugin, synth
+    from detectorfreesfm_amd.config import loftr_coarse_only_config
+    from detectorfreesfm_amd.params import loftr_param_spec, planted_loftr_state_dict
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = loftr_coarse_only_config(0.2)
+    m = HipLoFTR(cfg).eval()
+    m.load_state_dict(planted_loftr_state_dict(loftr_param_spec(cfg), 0), strict=True)
+    base = synth.coarse_pair_batch(12, 48, 64, seed=1000)
+    images = torch.cat([base["image0"], base["image1"]], 0)            # 24 images -> 276 exhaustive pairs
+    names = [f"scene/img{k:02d}.jpg" for k in range(24)]
+    pairs = ddist.exhaustive_pairs(24)
+    shards = ddist.shard_pairs_tiled(pairs, 24, world)
+    ok = sorted(k for s in shards for k in s) == list(range(276)) and max(len(s) for s in shards) <= 36
+    ok = ok and max(len({x for k in s for x in pairs[k]}) for s in shards) <= 16   # contiguous shards of this list: up to 24
+    with cpu_ops(), torch.no_grad():
+        matches, kp, sc, upd = plugin.match_scene_sharded(m, images, names, " ", batch=4)            # tiled, on EVERY rank
+        on_root = plugin.match_scene_sharded(m, images, names, " ", batch=4, root=0, shard="contiguous")
+        ok = ok and (on_root is None) == (rank != 0)
+        ok = ok and list(matches) == [f"{names[i]} {names[j]}" for i, j in pairs]
+        if rank == 0:
+            c = on_root[0]
+            ok = ok and list(c) == list(matches) and all(
+                np.array_equal(c[k][:, :4], matches[k][:, :4]) and np.allclose(c[k][:, 4], matches[k][:, 4], atol=1e-4) for k in matches)
+            sample = [pairs[k] for k in range(0, 276, 23)]
+            ref = plugin.match_scene_cached(m, images, sample, batch=4)
+            for (i, j), t in ref.items():
+                g = matches[f"{names[i]} {names[j]}"]
+                ok = ok and np.array_equal(g[:, :4], t[:, :4]) and np.allclose(g[:, 4], t[:, 4], atol=1e-4)
+            ok = ok and all(len(kp[n]) > 0 for n in names)
+    q.put((rank, bool(ok), sum(len(t) for t in matches.values())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_sharded_tiled_world8():
+    res = _spawn(_scene_worker8, 8, 37500 + os.getpid() % 2000, 900)
+    assert len(res) == 8 and all(ok for _, ok, _ in res), res
+    assert len({n for _, _, n in res}) == 1 and res[0][2] > 3000       # every rank holds the same full set of tables
+
+
+def test_tiled_pair_shards_level_sparse_lists():
+    """A star-shaped covisibility list (one hub image paired with everything + a thin band) defeats every block grid; the
+    pair-level levelling keeps the shards within one pair of the ideal."""
+    n = 200
+    pairs = [(0, j) for j in range(1, n)] + [(i, i + 1) for i in range(1, n - 1)] + [(i, i + 2) for i in range(1, n - 2)]
+    for ws in (3, 8):
+        sh = ddist.shard_pairs_tiled(pairs, n, ws)
+        assert sorted(k for s in sh for k in s) == list(range(len(pairs)))
+        ideal = -(-len(pairs) // ws)
+        assert max(len(s) for s in sh) <= max(ideal, int(1.02 * ideal)), [len(s) for s in sh]
 
 
 def test_single_process_passthrough():
