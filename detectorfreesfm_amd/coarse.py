@@ -101,13 +101,22 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
     D = C // nhead
     S = src.hi.shape[1]
     xs_x = xs.cols(0, C)
-    if w.fused is not None and nhead == 8 and L >= 32 and (out_x is not None or out_xs is not None):
+    fused128 = w.fused is not None and nhead == 8 and L >= 32 and (out_x is not None or out_xs is not None)
+    fused256 = w.fused256 is not None and nhead == 8 and L >= 16 and (out_x is not None or out_xs is not None)
+    if (fused128 or fused256) and ops.range_check_active():
+        # Range guard of the fused kernels: they split q, k, v, the message, norm1(merge) and the ReLU hidden layer in
+        # REGISTERS with a saturating clamp -- nothing a producer-side check can see.  While a range sweep is open (the first call
+        # after load_state_dict) or DFSFM_DEBUG_RANGE is on, the same layer ALSO runs on the five-GEMM path below, whose every
+        # intermediate is a checked producer; its results are discarded (scratch output; the unused [norm1] half of ``xs``).
+        scratch = ops.SplitAct.empty_rows((N, L), C, xs.hi.device)
+        _encoder_layer_unfused(w, xs, src, None, scratch, nhead, x_mask, source_mask, q_group, kv_group, is_self)
+    if fused128:
         # two launches: source tokens -> per-sequence attention state; x tokens -> layer output.  q, k, v, the message, the
         # merged message and the MLP's hidden layer never reach memory (the second half of ``xs`` stays unused)
         state = ops.encoder_kv(src, w.fused, source_mask, kv_group)
         ops.encoder_apply(xs_x, w.fused, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
         return out_x
-    if w.fused256 is not None and nhead == 8 and L >= 16 and (out_x is not None or out_xs is not None):
+    if fused256:
         # source side: k | v projection fused with K1's partial sums (+ the small image kernel); query side: q, attention,
         # merge, LayerNorm, MLP, LayerNorm and the residual in one kernel.  q, k, v, the message, [x | norm1] and the hidden
         # layer never reach memory; the second half of ``xs`` stays unused
@@ -118,6 +127,16 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
             state = ops.encoder256_state(kv[..., :C], kv[..., C:], source_mask, kv_group)
         ops.encoder256_apply(xs_x, w.fused256, state, S, x_mask, q_group, out_split=out_xs, out=out_x)
         return out_x
+    return _encoder_layer_unfused(w, xs, src, out_x, out_xs, nhead, x_mask, source_mask, q_group, kv_group, is_self)
+
+
+def _encoder_layer_unfused(w, xs, src, out_x, out_xs, nhead, x_mask, source_mask, q_group, kv_group, is_self):
+    """The five-GEMM + K1 form of ``encoder_layer_split`` (every intermediate reaches memory through a range-checked producer)."""
+    N, L, C2 = xs.hi.shape
+    C = C2 // 2
+    D = C // nhead
+    S = src.hi.shape[1]
+    xs_x = xs.cols(0, C)
     if is_self:
         qkv = ops.linear(xs_x, w.pqkv).view(N, L, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
@@ -125,6 +144,14 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
         q = ops.linear(xs_x, w.pq).view(N, L, C)
         kv = ops.linear(src, w.pkv).view(N, S, 2 * C)
         k, v = kv[..., :C], kv[..., C:]
+    if ops.range_check_active() and (w.fused is not None or w.fused256 is not None):
+        # what only the fused kernels hold as split planes: phi(q) = elu(q) + 1 <= |q| + 1, phi(k), v / S, and the per-head state
+        # KV = sum_s phi(k_s) v_s / S, a mean over the source tokens and therefore bounded by max phi(k) * max |v|
+        qa, ka, va = q.abs().max(), k.abs().max(), v.abs().max()
+        ops.range_note("fused encoder layer: phi(q)", qa + 1.0)
+        ops.range_note("fused encoder layer: phi(k)", ka + 1.0)
+        ops.range_note("fused encoder layer: v", va)
+        ops.range_note("fused encoder layer: KV state bound max phi(k) * max |v|", (ka + 1.0) * va)
     msg = ops.linear_attention(q.unflatten(-1, (nhead, D)), k.unflatten(-1, (nhead, D)),
                                v.unflatten(-1, (nhead, D)), x_mask, source_mask, q_group, kv_group, out_split=True)
     fuse_ln = C in (64, 128, 256)    # a row fits one workgroup tile: LayerNorm runs in the GEMM epilogue

@@ -20,6 +20,12 @@ FP16_MAX = 65504.0
 #   reads them back ONCE at the end of the call; a saturated activation raises there instead of silently clamping.  Later
 #   calls pay nothing.  DFSFM_RANGE_SWEEP=0 switches it off.
 # * DFSFM_DEBUG_RANGE=1 / set_debug_range(True): every producer checks every launch at once (one host sync per launch).
+# * Coverage.  The fused encoder layers (encoder_fused.hip, encoder256.hip) split q, k, v, the message, norm1(merge) and the MLP's
+#   hidden layer in registers: no producer sees those.  While either guard is active (``range_check_active``) the layer therefore
+#   ALSO runs on its five-GEMM form, where each of them is a checked producer (coarse.encoder_layer_split) -- the first call after a
+#   weight load pays one extra transformer pass, later calls nothing.  What the default guard does NOT cover: range depends on the
+#   INPUT as well as on the weights, and only the first call's input is swept; a deployment that wants every call checked sets
+#   DFSFM_DEBUG_RANGE=1 (or wraps calls in ``range_sweep``) and pays for it.
 _debug_range = os.environ.get("DFSFM_DEBUG_RANGE", "0") == "1"
 RANGE_SWEEP = os.environ.get("DFSFM_RANGE_SWEEP", "1") != "0"
 _sweep = None            # list of (producer, abs-max device scalar) while a sweep is open
@@ -33,7 +39,7 @@ def set_debug_range(on: bool):
 def check_split_range(sa, what: str):
     """Raises if a split-plane tensor holds a saturated element: split_f32 clamps hi to +-65504, the largest finite
     fp16, so |hi| == 65504 means the fp32 value was out of the representable range (or exactly on its edge)."""
-    if sa.hi.numel() and float(sa.hi.abs().max()) >= FP16_MAX:
+    if sa.hi.numel() and not (float(sa.hi.float().abs().max()) < FP16_MAX):          # NaN fails the test as well
         raise _lib.DfsfmError(f"{what}: activation outside the split-plane range |v| < {FP16_MAX:.0f} "
                               "(the fp16x2 representation would saturate; rescale the layer)")
 
@@ -46,11 +52,28 @@ def _range(sa, what: str):
         _sweep.append((what, sa.hi.abs().max()))
 
 
+def range_note(what: str, value):
+    """Queue (or, in debug mode, check at once) a device scalar that must stay below 65504: bounds on quantities that only the
+    fused kernels ever hold as split planes (q, k, v, the per-head KV state), computed from the fp32 tensors of the five-GEMM form."""
+    if _debug_range:
+        if not (float(value) < FP16_MAX):
+            raise _lib.DfsfmError(f"{what}: outside the split-plane range |v| < {FP16_MAX:.0f} (the fused encoder layer would saturate)")
+    elif _sweep is not None:
+        _sweep.append((what, value))
+
+
+def range_check_active() -> bool:
+    """True while split-plane producers are being checked (an open sweep or DFSFM_DEBUG_RANGE): callers that normally keep
+    intermediates in registers (the fused encoder layers) then ALSO run their memory-going form so the guard sees them."""
+    return _debug_range or _sweep is not None
+
+
 class range_sweep:
     """Context manager: collect the abs-max of every split-plane tensor produced inside, check them with one host read."""
 
-    def __init__(self, label: str):
-        self.label, self.mine = label, False
+    def __init__(self, label: str, report=None):
+        """report: optional list that receives (producer, abs-max) of everything the sweep saw (tools/verify_checkpoint.py)."""
+        self.label, self.mine, self.report = label, False, report
 
     def __enter__(self):
         global _sweep
@@ -65,7 +88,9 @@ class range_sweep:
         items, _sweep = _sweep, None
         if et is None and items:
             mx = torch.stack([v.float() for _, v in items]).cpu()
-            bad = sorted({n for (n, _), m in zip(items, mx.tolist()) if m >= FP16_MAX})
+            if self.report is not None:
+                self.report.extend((n, m) for (n, _), m in zip(items, mx.tolist()))
+            bad = sorted({n for (n, _), m in zip(items, mx.tolist()) if not (m < FP16_MAX)})       # NaN / inf count as out of range
             if bad:
                 raise _lib.DfsfmError(f"{self.label}: activations outside the split-plane range |v| < {FP16_MAX:.0f} after "
                                       f"{', '.join(bad)} (the fp16x2 representation saturates there; these weights need a "
