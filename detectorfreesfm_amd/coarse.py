@@ -352,10 +352,11 @@ class HipLoFTR(ParamModule):
 
     @torch.no_grad()
     @ops.first_call_range_sweep
-    def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None, mask0=None, mask1=None):
+    def match_tokens(self, tok0, tok1, hw0_c, hw1_c, hw0_i, scale0=None, scale1=None, mask0=None, mask1=None, defer=False):
         """Positional encoding + transformer + coarse matching on cached backbone tokens of N pairs
         (tok0 [N,L,C], tok1 [N,S,C]; optional padding masks [N,h0c,w0c] / [N,h1c,w1c]); the same dict of matches
-        ``forward`` leaves in ``data``."""
+        ``forward`` leaves in ``data`` -- or, with ``defer=True``, an ``ops.PendingMatches`` whose ``result()`` is that dict
+        (no host read inside the call: the scene loop launches the next batch first)."""
         P = self._packed or self._pack()
         self._feat_split = None
         m0, m1 = self._flat_masks(mask0, mask1, tok0.shape[0], tuple(hw0_c), tuple(hw1_c), tok0.device)
@@ -364,7 +365,9 @@ class HipLoFTR(ParamModule):
         self._feat_split = None
         mc = self.config["match_coarse"]
         return ops.coarse_match(f0, f1, tuple(hw0_c), tuple(hw1_c), mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
-                                scale0, scale1, hw0_i[0] / hw0_c[0], mask0=m0, mask1=m1)
+                                scale0, scale1, hw0_i[0] / hw0_c[0], mask0=m0, mask1=m1, defer=defer)
+
+    supports_defer = True      # plugin.match_scene_cached pipelines the batches of a scene through ``match_tokens(defer=True)``
 
     @staticmethod
     def _flat_masks(mask0, mask1, N, hw0_c, hw1_c, dev):
@@ -390,8 +393,11 @@ class HipLoFTR(ParamModule):
 
     @torch.no_grad()
     @ops.first_call_range_sweep
-    def forward(self, data: dict):
-        """Updates ``data`` in place like LoFTR.forward (loftr.py:29-73, fine.enable=False)."""
+    def forward(self, data: dict, defer: bool = False):
+        """Updates ``data`` in place like LoFTR.forward (loftr.py:29-73, fine.enable=False) and returns None.
+        ``defer=True`` (an extension for callers that loop over batches: ``plugin.match_scene_cached``, ``bench.py``'s pipelined
+        rate) queues the whole forward WITHOUT the host read of the match count and returns ``finish``: calling it later -- after
+        the next batch has been launched -- fills the match keys of ``data``."""
         img0, img1 = data["image0"], data["image1"]
         data.update({"bs": img0.size(0), "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
         self._feat_split = None
@@ -407,10 +413,17 @@ class HipLoFTR(ParamModule):
                      "hw1_f": torch.Size((img1.shape[2] // 2, img1.shape[3] // 2))})
         mc = self.config["match_coarse"]
         scale = data["hw0_i"][0] / hw0_c[0]
-        m = ops.coarse_match(f0, f1, hw0_c, hw1_c, mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
-                             data.get("scale0"), data.get("scale1"), scale, mask0=m0, mask1=m1)
-        data.update({"b_ids": m["b_ids"], "i_ids": m["i_ids"], "j_ids": m["j_ids"],
-                     "gt_mask": m["mconf"] == 0, "m_bids": m["b_ids"], "mkpts0_c": m["mkpts0_c"],
-                     "mkpts1_c": m["mkpts1_c"], "mconf": m["mconf"],
-                     "mkpts0_f": m["mkpts0_c"], "mkpts1_f": m["mkpts1_c"]})
+        pending = ops.coarse_match(f0, f1, hw0_c, hw1_c, mc["thr"], mc["border_rm"], mc["dsmax_temperature"],
+                                   data.get("scale0"), data.get("scale1"), scale, mask0=m0, mask1=m1, defer=True)
+
+        def finish():
+            m = pending.result()
+            data.update({"b_ids": m["b_ids"], "i_ids": m["i_ids"], "j_ids": m["j_ids"],
+                         "gt_mask": m["mconf"] == 0, "m_bids": m["b_ids"], "mkpts0_c": m["mkpts0_c"],
+                         "mkpts1_c": m["mkpts1_c"], "mconf": m["mconf"],
+                         "mkpts0_f": m["mkpts0_c"], "mkpts1_f": m["mkpts1_c"]})
+            return data
+        if defer:
+            return finish
+        finish()
         return None

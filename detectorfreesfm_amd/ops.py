@@ -221,12 +221,27 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, 
     return res
 
 
+class PendingMatches:
+    """Match tables of a ``coarse_match(..., defer=True)`` call whose row count is still on the device: full-capacity buffers + the
+    count scalar.  ``result()`` performs the one host read (like ``torch.where`` in the reference) and returns the sliced dict.  A
+    caller that loops over batches launches batch k + 1 before it asks for batch k's result, so the device never idles on the read."""
+
+    def __init__(self, ids, mconf, mk, count):
+        self.ids, self.mconf, self.mk, self.count = ids, mconf, mk, count
+
+    def result(self):
+        M = int(self.count.item())
+        return {"b_ids": self.ids[0, :M], "i_ids": self.ids[1, :M], "j_ids": self.ids[2, :M], "mconf": self.mconf[:M],
+                "mkpts0_c": self.mk[0, :M], "mkpts1_c": self.mk[1, :M]}
+
+
 @_on_device
 def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None,
-                 coarse_scale=8.0, mask0=None, mask1=None):
+                 coarse_scale=8.0, mask0=None, mask1=None, defer=False):
     """K3+K4+K5.  feat0 [N,L,C], feat1 [N,S,C]: fp32 contiguous tensors, or SplitAct planes (contiguous, C a
     power of 4) -- the correlation then runs on the fp16x2-split MFMA path.  Returns a dict with
-    b_ids,i_ids,j_ids (int64 [M]), mconf [M], mkpts0_c, mkpts1_c [M,2] in ascending (b,i) order."""
+    b_ids,i_ids,j_ids (int64 [M]), mconf [M], mkpts0_c, mkpts1_c [M,2] in ascending (b,i) order; ``defer=True`` returns a
+    ``PendingMatches`` instead (no host synchronisation inside the call)."""
     split = isinstance(feat0, SplitAct)
     if split != isinstance(feat1, SplitAct):
         raise _lib.DfsfmError("coarse_match: feat0 and feat1 must both be fp32 or both be split planes")
@@ -277,9 +292,8 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=No
     else:
         rc = lib.dfsfm_coarse_match_f32(_ptr(feat0), _ptr(feat1), *tail)
         _lib.check(rc, "dfsfm_coarse_match_f32")
-    M = int(count.item())          # data-dependent size, like torch.where in the reference
-    return {"b_ids": ids[0, :M], "i_ids": ids[1, :M], "j_ids": ids[2, :M], "mconf": mconf[:M],
-            "mkpts0_c": mk[0, :M], "mkpts1_c": mk[1, :M]}
+    pending = PendingMatches(ids, mconf, mk, count)
+    return pending if defer else pending.result()      # data-dependent size, like torch.where in the reference
 
 
 @_on_device

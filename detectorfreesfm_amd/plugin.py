@@ -233,13 +233,11 @@ def match_scene_cached(matcher, images, pairs, batch=8, scales=None, to_host=Tru
     toks = torch.cat(toks, 0) if toks else None
     hw_i = tuple(images.shape[2:])
     out = {}
-    for lo in range(0, len(pairs), batch):
-        chunk = pairs[lo:lo + batch]
-        i0 = torch.tensor([slot[int(p[0])] for p in chunk], device=dev)
-        i1 = torch.tensor([slot[int(p[1])] for p in chunk], device=dev)
-        s0 = None if scales is None else scales[[int(p[0]) for p in chunk]]
-        s1 = None if scales is None else scales[[int(p[1]) for p in chunk]]
-        m = matcher.match_tokens(toks[i0], toks[i1], hw_c, hw_c, hw_i, s0, s1)
+    defer = bool(getattr(matcher, "supports_defer", False))
+
+    def collect(chunk, m):
+        if defer:
+            m = m.result()                        # the one host read of this batch -- after the NEXT batch has been launched
         rows = torch.cat([m["mkpts0_c"], m["mkpts1_c"], m["mconf"][:, None]], -1)
         counts = torch.bincount(m["b_ids"], minlength=len(chunk)).tolist()       # rows come in ascending b order
         parts = rows.split(counts)
@@ -247,6 +245,23 @@ def match_scene_cached(matcher, images, pairs, batch=8, scales=None, to_host=Tru
             parts = [p.cpu().numpy() for p in parts]
         for pr, tab in zip(chunk, parts):
             out[tuple(pr)] = tab
+
+    waiting = None
+    for lo in range(0, len(pairs), batch):
+        chunk = pairs[lo:lo + batch]
+        i0 = torch.tensor([slot[int(p[0])] for p in chunk], device=dev)
+        i1 = torch.tensor([slot[int(p[1])] for p in chunk], device=dev)
+        s0 = None if scales is None else scales[[int(p[0]) for p in chunk]]
+        s1 = None if scales is None else scales[[int(p[1]) for p in chunk]]
+        if defer:       # software pipeline of depth one: the device works on batch k + 1 while the host reads batch k's tables
+            m = matcher.match_tokens(toks[i0], toks[i1], hw_c, hw_c, hw_i, s0, s1, defer=True)
+            if waiting is not None:
+                collect(*waiting)
+            waiting = (chunk, m)
+        else:
+            collect(chunk, matcher.match_tokens(toks[i0], toks[i1], hw_c, hw_c, hw_i, s0, s1))
+    if waiting is not None:
+        collect(*waiting)
     return out
 
 

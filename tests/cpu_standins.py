@@ -36,7 +36,11 @@ def _la(q, k, v, q_mask=None, kv_mask=None, q_group=1, kv_group=1, eps=1e-6, out
 
 
 def _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0=None, scale1=None, coarse_scale=8.0,
-        mask0=None, mask1=None):
+        mask0=None, mask1=None, defer=False):
+    if defer:       # ops.PendingMatches: the result is asked for later
+        out = _cm(feat0, feat1, hw0_c, hw1_c, thr, border, temperature, scale0, scale1, coarse_scale, mask0, mask1)
+        import types
+        return types.SimpleNamespace(result=lambda: out)
     from detectorfreesfm_amd.ops import SplitAct
     if isinstance(feat0, SplitAct):       # split planes carry the fp32 value to 2^-22: correlate what they hold
         feat0, feat1 = feat0.float(), feat1.float()

@@ -22,7 +22,7 @@ timeout 300 python bench.py --workload scene300 --scene-matcher aspanformer --sc
 fi
 cd /tmp
 for w in coarse refine; do
-  timeout 600 env PYTHONPATH=$root rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$w -o $w -- python $root/tools/profile_step.py $w 4 > $root/$out/prof_$w.log 2>&1
+  timeout 600 env PYTHONPATH=$root rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$w -o $w -- python $root/tools/profile_step.py $w 10 > $root/$out/prof_$w.log 2>&1
   f=$(find $root/$out/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $root/$out/${w}_step_kernel_stats.csv
   rm -rf $root/$out/prof_$w
 done

@@ -20,10 +20,20 @@ import os
 import shlex
 import subprocess
 import sys
+import time
 from collections import defaultdict
 
 OURS = ("conv_gemm", "cm_", "la_", "roi_align", "fine_match", "layernorm", "split_rows", "direct_conv", "maxpool",
         "add_scatter", "mk_", "mlp_", "bag_", "dfsfm", "enc_", "enc256")
+
+
+def lib_sha256():
+    """sha256 of the library build the passes ran on (bench.py compares it with the build it times: ``traffic_build_matches``)."""
+    import hashlib
+    path = os.environ.get("DFSFM_LIB_PATH") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "detectorfreesfm_amd", "csrc", "libdfsfm_hip.so")
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
 
 
 def ours(name: str) -> bool:
@@ -79,6 +89,7 @@ def main():
     with open(args.out, "w") as fh:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of `" + args.target +
                            "`, averages per launch; FETCH_SIZE doubled per the MI355X guide (16 B/lane streaming reads)",
+                   "library_sha256": lib_sha256(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
                    "kernels": rows}, fh, indent=1)
     print(f"{args.out}: {len(rows)} kernels")
 
