@@ -414,10 +414,21 @@ __device__ __forceinline__ void sf_same_mainloop_impl(const ConvArgs& g, char* s
     if (grp == 0) __builtin_amdgcn_s_barrier();                       // pairs with the extra barrier of waves 4-7
     wait_vmcnt<0>();
     // The inline-asm MFMAs are invisible to the compiler's hazard recogniser: close the region explicitly.  An XDL write of a
-    // 16 x 16 x 32 (8-pass) MFMA must be 11 - 18 wait states ahead of a VALU read / overlapped write of its destination
-    // (MI355X guide, MFMA hazards); a barrier every wave has already reached is one issue slot, not a delay.  20 wait states per
-    // TILE (not per slab) make the accumulators safe to read whatever the caller's epilogue starts with.
-    if constexpr (M16) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    // 16 x 16 x 32 MFMA (4 passes) must be 7 wait states ahead of a VALU read / overlapped write of its destination on gfx950
+    // (passes + 3; tools/studies/mfma_hazard_scan.py); a barrier every wave has already reached is one issue slot, not a delay.
+    // The s_nop alone is not enough: asm volatile orders memory, not registers, and the compiler hoisted the epilogue's first
+    // accumulator reads ABOVE it (r05, seen in the ISA).  Every accumulator therefore passes through an empty asm as "+v" after the
+    // nop: volatile asms keep their order, and a value redefined there cannot be read before it.  8 wait states per TILE.
+    if constexpr (M16) {
+        asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                asm volatile("" : "+v"(accm[i][j]));
+                asm volatile("" : "+v"(accx[i][j]));
+            }
+    }
 #undef SDMA_A
 #undef SDMA_B
 }

@@ -194,7 +194,7 @@ def test_loftr_640x480_planted_vs_oracle(built_lib):
     assert len(ex) <= 3
 
 
-def _batched_vs_oracle(nb, H, W, seed, label, min_rows_per_pair):
+def _batched_vs_oracle(nb, H, W, seed, label, min_rows_per_pair, noise_rule=False):
     """The batch ``bench.py`` times, held to the oracle: ONE ``HipLoFTR.forward`` over ``nb`` same-shape pairs against ONE
     batched oracle forward -- the reference sends same-shape frames through the backbone as one 2N batch
     (third_party/LoFTR/src/loftr/loftr.py:45-47) and runs the self layers on N-sequence batches
@@ -214,8 +214,11 @@ def _batched_vs_oracle(nb, H, W, seed, label, min_rows_per_pair):
         op = {k: o[k][os_] for k in MATCH_KEYS if k in o}
         hp["b_ids"], op["b_ids"] = torch.zeros_like(hp["b_ids"]), torch.zeros_like(op["b_ids"])
         assert op["i_ids"].numel() > min_rows_per_pair, (p, op["i_ids"].numel())
-        total_ex += _strict_coarse(hp, op, conf[p:p + 1], 0.2, f"{label} pair {p}")
-    assert len(total_ex) <= 3 * nb and not any(e[0] == "oracle-noise" for e in total_ex)
+        exact = (o["feat_c0"][p:p + 1], o["feat_c1"][p:p + 1], cfg["match_coarse"]["dsmax_temperature"]) if noise_rule else None
+        total_ex += _strict_coarse(hp, op, conf[p:p + 1], 0.2, f"{label} pair {p}", exact=exact)
+    noise = [e for e in total_ex if e[0] == "oracle-noise"]
+    assert len(total_ex) - len(noise) <= 3 * nb
+    assert len(noise) <= (0.005 * o["i_ids"].numel() if noise_rule else 0)
     # whole-table layout as the plugin reads it: ascending (b, i), every pair present
     key = d["b_ids"].cpu() * (H // 8) * (W // 8) + d["i_ids"].cpu()
     assert (key[1:] > key[:-1]).all() and set(hb.tolist()) == set(range(nb))
@@ -230,6 +233,14 @@ def test_loftr_benched_batch8_640x480_vs_oracle(built_lib):
 def test_loftr_benched_batch4_832_vs_oracle(built_lib):
     """``bench.py --workload hires832`` step (configs[4] frame size, 4 pairs, seed 500) against the batched oracle."""
     _batched_vs_oracle(4, 832, 832, 500, "bench batch 4x832x832", 6000)
+
+
+def test_loftr_benched_batch2_1600x1064_vs_oracle(built_lib):
+    """``bench.py --workload eth3d1600`` step (the frame size of hydra_configs/eth3d_sfm/dfsfm.yaml:76, 2 pairs, seed 500: L = S =
+    26 600) against the batched oracle.  At this grid size ATen's fp32 softmax is itself up to 1.15e-4 from the exact confidence of
+    its own features (tests/parity.py rule "oracle-noise", profiles/r04_loftr_hires_noise_study.txt): entries beyond 1e-4 of the
+    fp32 oracle must be within 1e-4 of the float64 value -- the one test of the three bench batches that needs the rule."""
+    _batched_vs_oracle(2, 1064, 1600, 500, "bench batch 2x1600x1064", 8000, noise_rule=True)
 
 
 def test_flattened_k_conv_schedule_equals_same_schedule(built_lib):

@@ -1,7 +1,7 @@
 """Static scan of a gfx950 ISA listing (hipcc -S --cuda-device-only) for the software-managed hazard "XDL (MFMA) write of D -> VALU
 read / write of the same registers": the hardware does not interlock it, the compiler's hazard recogniser must keep N independent
-issue states between the two (8-pass MFMA: 11 states, 16-pass: 19 -- LLVM GCNHazardRecognizer::checkMAIVALUHazards; MI355X guide:
-"8-pass XDL: 12 states").  For every v_mfma the script walks forward inside the kernel body until the first instruction that touches a
+issue states between the two (passes + 3 on gfx950: 4-pass 16x16x32 -> 7, 8-pass 32x32x16 -> 11, 16-pass fp32 32x32x2 -> 19 -- LLVM
+GCNHazardRecognizer::checkMAIVALUHazards; MI355X guide: "8-pass XDL: 12 states").  For every v_mfma the script walks forward inside the kernel body until the first instruction that touches a
 destination register (skipping MFMAs that take D whole as their C operand: the accumulate chain needs 0) and records the number of
 states in between, separately for packed-fp32 consumers (v_pk_*_f32) and all others.
 
@@ -28,12 +28,17 @@ def regs(operand_text):
 
 
 def passes(op):
-    # gfx950 dense f16/bf16: 32x32x16 = 16 passes (64 cycles / 4), 16x16x32 = 8 passes; f32 32x32x2 = 16, 16x16x4 = 8
-    if "32x32" in op:
-        return 16
-    if "16x16" in op:
+    # gfx950: a pass is 4 cycles.  32x32x16 f16/bf16 = 32 cycles = 8 passes, 16x16x32 f16/bf16 = 16 cycles = 4 passes;
+    # fp32-input 32x32x2 = 16 passes, 16x16x4 = 8 passes
+    if "32x32x16" in op:
         return 8
-    return 4
+    if "16x16x32" in op:
+        return 4
+    if "32x32x2" in op:
+        return 16
+    if "16x16x4" in op:
+        return 8
+    return 16 if "32x32" in op else 8
 
 
 def scan(path):
@@ -46,7 +51,7 @@ def scan(path):
             continue
         ops_ = text[len(op):].split(",")
         dst = regs(ops_[0])
-        need = {16: 19, 8: 11, 4: 7}[passes(op)]
+        need = passes(op) + 3                    # LLVM GFX940_XDL_N_PassWriteVgprVALUMemExpReadWaitStates: passes + 2, + 1 on gfx950
         states = 0
         for ln2, t2 in ins[k + 1:k + 400]:
             op2 = t2.split()[0]
