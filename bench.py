@@ -367,16 +367,6 @@ def build_refiner(dev):
     return refiner.eval().to(dev)
 
 
-def lib_sha256():
-    import hashlib
-    from detectorfreesfm_amd import _lib
-    try:
-        with open(_lib.LIB_PATH, "rb") as fh:
-            return hashlib.sha256(fh.read()).hexdigest()
-    except OSError:
-        return None
-
-
 def load_pmc(result):
     """Attach the HBM traffic measured by the committed rocprofv3 --pmc passes (tools/pmc_collect.py writes
     profiles/r02_pmc_traffic.json; traffic cannot be counted from inside this process).  Corrected as the MI355X
@@ -392,8 +382,10 @@ def load_pmc(result):
         pmc = json.load(fh)
     rows = pmc["kernels"]
     # the PMC passes are a separate run (counters cannot be read from inside this process): say whether they were collected on
-    # the library build that is being timed now (tools/pmc_collect.py stamps the sha256 of libdfsfm_hip.so into the file)
-    result["traffic_build_matches"] = bool(pmc.get("library_sha256")) and pmc.get("library_sha256") == lib_sha256()
+    # the library SOURCES that are being timed now (tools/pmc_collect.py stamps _lib.source_sha256() into the file; the .so itself
+    # is not bit-reproducible across build directories)
+    from detectorfreesfm_amd import _lib
+    result["traffic_build_matches"] = bool(pmc.get("library_source_sha256")) and pmc.get("library_source_sha256") == _lib.source_sha256()
     result["traffic_file"] = f"profiles/{name}"
     groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
               "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",),

@@ -142,3 +142,21 @@ def check(rc: int, what: str):
         if rc == -4:
             extra = ": " + (lib().dfsfm_last_error_string() or b"").decode()
         raise DfsfmError(f"{what} failed with {_ERRORS.get(rc, rc)}{extra}")
+
+
+def source_sha256() -> str:
+    """sha256 over the library's SOURCES (csrc/*.hip, *.h, Makefile, exports.map, include/dfsfm_hip.h; names and contents, sorted): the
+    identity of a build that survives a rebuild -- the .so itself is not bit-reproducible across build directories.  Measurement files
+    that cannot be produced by the timed process itself (the rocprofv3 PMC passes) carry it, and bench.py compares."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   [os.path.join(_HERE, "csrc", "Makefile"), os.path.join(_HERE, "csrc", "exports.map"),
+                    os.path.join(os.path.dirname(_HERE), "include", "dfsfm_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()

@@ -273,12 +273,14 @@ class HipLoFTR(ParamModule):
         return backbone_tokens_hip(x, P["hip"])
 
     # -- K2/K1: LocalFeatureTransformer.forward (transformer.py:80-101) -------------------------
-    def _transformer(self, f0, f1, P, pe0=None, pe1=None, mask0=None, mask1=None):
+    def _transformer(self, f0, f1, P, pe0=None, pe1=None, mask0=None, mask1=None, want_f32=True):
         """f0 [N,L,C], f1 [N,S,C] (+ optional positional-encoding tables added on the way in) -> updated
         features (contiguous fp32).  When both images have the same grid they share buffers so that
         self layers run as ONE batch of 2N sequences.  Split planes [.,.,2C] = [x | norm1(message)] ping-pong, fp32 only
         for the result (encoder_layer_split).  mask0 [N,L] / mask1 [N,S] (uint8 / bool, 1 = valid): the padding masks of
-        transformer.py:80-97 -- query mask and source mask of every layer's linear attention (K1)."""
+        transformer.py:80-97 -- query mask and source mask of every layer's linear attention (K1).
+        want_f32=False: the last layer writes only the split planes the correlation reads (``self._feat_split``); the fp32 copy of the
+        final features (79 MB per 8 pairs) is for callers of ``coarse_features`` and is not produced; returns (None, None)."""
         nhead = self.config["coarse"]["nhead"]
         names = self.config["coarse"]["layer_names"]
         N, L, C = f0.shape
@@ -308,7 +310,7 @@ class HipLoFTR(ParamModule):
         for li, (w, name) in enumerate(zip(P["enc"], names)):
             last = li == len(names) - 1
             oxs = fin if last else tuple(None if b is None else b.cols(0, C) for b in XSn)
-            if last:
+            if last and want_f32:
                 out = new_f32(C)            # fp32 copy of the final features only
             if name == "self":
                 if same:   # both images through one batched call
@@ -325,8 +327,9 @@ class HipLoFTR(ParamModule):
         self._feat_split = (fin[1], fin[2])
         return out[1], out[2]
 
-    def coarse_features(self, image0, image1, mask0=None, mask1=None):
-        """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c)."""
+    def coarse_features(self, image0, image1, mask0=None, mask1=None, want_f32=True):
+        """Backbone + positional encoding + transformer -> (feat_c0 [N,L,C], feat_c1 [N,S,C], hw0_c, hw1_c); with ``want_f32=False``
+        the features exist only as the split planes in ``self._feat_split`` (what ``forward`` correlates) and the first two are None."""
         P = self._packed or self._pack()
         bs = image0.size(0)
         same = image0.shape[2:] == image1.shape[2:]
@@ -337,7 +340,7 @@ class HipLoFTR(ParamModule):
             c0, c1 = self._backbone_hip(image0, P), self._backbone_hip(image1, P)
         hw0_c, hw1_c = tuple(c0.shape[1:3]), tuple(c1.shape[1:3])
         f0, f1 = self._transformer(c0.flatten(1, 2), c1.flatten(1, 2), P, self._pe_tokens(hw0_c),
-                                   self._pe_tokens(hw1_c), mask0, mask1)     # pos-enc added while splitting
+                                   self._pe_tokens(hw1_c), mask0, mask1, want_f32)     # pos-enc added while splitting
         return f0, f1, hw0_c, hw1_c
 
     # -- "backbone once per image" (the reference re-runs the CNN for every pair an image is in)
@@ -360,7 +363,7 @@ class HipLoFTR(ParamModule):
         P = self._packed or self._pack()
         self._feat_split = None
         m0, m1 = self._flat_masks(mask0, mask1, tok0.shape[0], tuple(hw0_c), tuple(hw1_c), tok0.device)
-        f0, f1 = self._transformer(tok0, tok1, P, self._pe_tokens(tuple(hw0_c)), self._pe_tokens(tuple(hw1_c)), m0, m1)
+        self._transformer(tok0, tok1, P, self._pe_tokens(tuple(hw0_c)), self._pe_tokens(tuple(hw1_c)), m0, m1, want_f32=False)
         f0, f1 = self._feat_split
         self._feat_split = None
         mc = self.config["match_coarse"]
@@ -405,7 +408,7 @@ class HipLoFTR(ParamModule):
         if "mask0" in data:     # padded frames (loftr.py:61-65): masks through every attention, the dual-softmax, the border
             hw0, hw1 = (img0.shape[2] // 8, img0.shape[3] // 8), (img1.shape[2] // 8, img1.shape[3] // 8)
             m0, m1 = self._flat_masks(data["mask0"], data.get("mask1"), img0.size(0), hw0, hw1, img0.device)
-        f0, f1, hw0_c, hw1_c = self.coarse_features(img0, img1, m0, m1)
+        _, _, hw0_c, hw1_c = self.coarse_features(img0, img1, m0, m1, want_f32=False)
         f0, f1 = self._feat_split              # correlate the split planes the last LayerNorm wrote
         self._feat_split = None
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),

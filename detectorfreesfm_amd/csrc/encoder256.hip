@@ -675,7 +675,10 @@ __global__ __launch_bounds__(256) void enc256_kv_kernel(Kv256Args g) {
 
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
-    const float Sf = (float)g.S;
+    // v / S as one multiplication by 1 / S (r05: the IEEE division was ten VALU instructions per element of a per-head epilogue that runs
+    // beside nothing -- one wave per SIMD; the quotient differs from the division's by at most one rounding, 6e-8 relative, inside the
+    // 2^-22 of the split operands it is multiplied into next)
+    const float inv_S = 1.f / (float)g.S;
     // the chunk's mask entries once into LDS (as byte loads inside the block loop every entry was its own drain of the DMA queue)
     uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + RING + 4 * STG);
     const int m_lo = s_begin / g.kv_group;
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(256) void enc256_kv_kernel(Kv256Args g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     kf[r] = phi_fast(dm[b][r] + dx[b][r] * (1.f / 2048.f)) * tm[r];
-                    vf[r] = ((dm[2 + b][r] + dx[2 + b][r] * (1.f / 2048.f)) * tm[r]) / Sf;
+                    vf[r] = ((dm[2 + b][r] + dx[2 + b][r] * (1.f / 2048.f)) * tm[r]) * inv_S;
                     ksum[h][b] += kf[r];
                 }
                 to_frag16(kf, zz, kfh[b], kfl[b]);        // slots 4..7 (the other 16 k positions of the MFMA) stay zero

@@ -27,13 +27,11 @@ OURS = ("conv_gemm", "cm_", "la_", "roi_align", "fine_match", "layernorm", "spli
         "add_scatter", "mk_", "mlp_", "bag_", "dfsfm", "enc_", "enc256")
 
 
-def lib_sha256():
-    """sha256 of the library build the passes ran on (bench.py compares it with the build it times: ``traffic_build_matches``)."""
-    import hashlib
-    path = os.environ.get("DFSFM_LIB_PATH") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                             "detectorfreesfm_amd", "csrc", "libdfsfm_hip.so")
-    with open(path, "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()
+def source_sha256():
+    """Identity of the library build the passes ran on (bench.py compares it with the sources it times: ``traffic_build_matches``)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from detectorfreesfm_amd import _lib
+    return _lib.source_sha256()
 
 
 def ours(name: str) -> bool:
@@ -89,7 +87,7 @@ def main():
     with open(args.out, "w") as fh:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of `" + args.target +
                            "`, averages per launch; FETCH_SIZE doubled per the MI355X guide (16 B/lane streaming reads)",
-                   "library_sha256": lib_sha256(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
+                   "library_source_sha256": source_sha256(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
                    "kernels": rows}, fh, indent=1)
     print(f"{args.out}: {len(rows)} kernels")
 
