@@ -485,6 +485,29 @@ def test_multiview_config3_T2000_ragged(built_lib):
     assert torch.equal(d["query_points_refined"][0].cpu()[imm], data["query_points"][0][imm])     # unmovable => centre
 
 
+def test_multiview_benched_bag_vs_oracle(built_lib):
+    """The refinement bag ``bench.py`` steps (configs[2]: ``synth.refine_bag(2000, 5, 480, 640, seed=2000)``, every view valid, seeded
+    weights 1 -- `secondary` of the bench line) held to the oracle: tracks are independent units (attention batch dimension = track,
+    src/MultiviewMatcher/matcher_module/transformer.py:132-178), so a seeded sample of 128 tracks of the full launch is compared with
+    the oracle run on those tracks alone; the whole bag is checked for finiteness and the +-7.5 px search window."""
+    cfg, sd, m = _refiner(1)
+    data = synth.refine_bag(2000, 5, 480, 640, seed=2000)
+    d = synth.to_device(data, DEV)
+    m(d)
+    q, r = d["query_points_refined"], d["reference_points_refined"][-1]
+    assert q.shape == (1, 2000, 2) and r.shape == (1, 4, 2000, 2) and torch.isfinite(q).all() and torch.isfinite(r).all()
+    assert (r.cpu() - data["reference_points_coarse"]).abs().max().item() <= 7.5
+    g = torch.Generator().manual_seed(11)
+    idx = torch.sort(torch.randperm(2000, generator=g)[:128])[0]
+    sub = _subset_bag(data, idx)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, sub)
+    dsub = {"query_points_refined": q[:, idx.to(DEV)], "reference_points_refined": [r[:, :, idx.to(DEV)]],
+            "std": [d["std"][-1][:, :, idx.to(DEV)]]}
+    flips = _strict_refine(dsub, o, sub, 7, "bench bag 2000 x 5 (128-track sample)")
+    assert len(flips) <= 2
+
+
 def test_multiview_chunk16000_equals_two_chunks(built_lib):
     """BASELINE config 5 refinement chunk (chunk_size = 16000 tracks, 5 views): tracks are independent units and no
     kernel's summation order depends on how many tracks share a launch, so one 16000-track bag must reproduce its
