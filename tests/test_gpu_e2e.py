@@ -528,6 +528,15 @@ def test_multiview_chunk16000_equals_two_chunks(built_lib):
         assert torch.equal(h["query_points_refined"], q[:, lo:hi])
         assert (h["reference_points_refined"][-1] - r[:, :, lo:hi]).abs().max().item() <= 1e-6
         assert (h["std"][-1] - s[:, :, lo:hi]).abs().max().item() <= 1e-6
+    # ... and the 16000-track launch itself against the ORACLE (r05): a seeded sample of 64 of its tracks, spread over the whole chunk
+    # (first / last tiles of the persistent encoder grid, the S2DNet pass boundary at 16384 patches), run through the oracle alone
+    g = torch.Generator().manual_seed(5)
+    idx = torch.sort(torch.cat([torch.tensor([0, 1, 3275, 3276, 3277, 15998, 15999]), torch.randperm(T, generator=g)[:57]]).unique())[0]
+    sub = _subset_bag(data, idx)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, sub)
+    dsub = {"query_points_refined": q[:, idx.to(DEV)], "reference_points_refined": [r[:, :, idx.to(DEV)]], "std": [s[:, :, idx.to(DEV)]]}
+    assert len(_strict_refine(dsub, o, sub, 7, f"chunk 16000 ({len(idx)}-track sample)")) <= 2
 
 
 def test_refine_plugin_surface(built_lib, tmp_path):
@@ -668,6 +677,34 @@ def test_scene_matching_cached_tokens_equals_pairwise(built_lib):
         assert not bad, bad[:5]
         total += len(B)
     assert total > 100
+
+
+def test_scene_path_640x480_vs_oracle(built_lib):
+    """BASELINE configs[3] at its frame size, against the ORACLE (r05): the first five frames of ``bench.py --workload scene300``'s camera
+    sweep (same generator), all ten pairs through ``plugin.match_scene_cached`` -- backbone once per image, pairs of DIFFERENT images
+    sharing a transformer batch, the pipelined match-count read -- and every per-pair table against the oracle's forward on that pair
+    under the north_star rules."""
+    cfg, sd, m = _loftr(0.2)
+    g = torch.Generator().manual_seed(4242)
+    base = torch.rand((1, 1, 480, 640), generator=g)
+    images = torch.cat([torch.roll(base, shifts=(8 * (k % 7), 8 * k), dims=(2, 3)) + 0.02 * torch.randn((1, 1, 480, 640), generator=g)
+                        for k in range(5)], 0)
+    pairs = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+    tables = plugin.match_scene_cached(m, images, pairs, batch=4, to_host=False)      # 4 + 4 + 2 pairs: a partial last batch
+    total = 0
+    for (i, j) in pairs:
+        data = {"image0": images[i:i + 1], "image1": images[j:j + 1]}
+        o, conf = _oracle_coarse(sd, cfg, data)
+        t = tables[(i, j)].cpu()
+        # rows are (x0, y0, x1, y1, conf) on the 8-px coarse grid at scale 1: recover the cell indices
+        w_c = 640 // 8
+        hip = {"b_ids": torch.zeros(len(t), dtype=torch.long), "i_ids": (t[:, 1] / 8).long() * w_c + (t[:, 0] / 8).long(),
+               "j_ids": (t[:, 3] / 8).long() * w_c + (t[:, 2] / 8).long(), "mconf": t[:, 4],
+               "mkpts0_f": t[:, 0:2], "mkpts1_f": t[:, 2:4]}
+        ex = _strict_coarse(hip, o, conf, 0.2, f"scene pair {(i, j)}")
+        assert len(ex) <= 3
+        total += int(o["i_ids"].numel())
+    assert total > 10 * 2000
 
 
 def test_refine_scene_worker_vs_oracle(built_lib):
