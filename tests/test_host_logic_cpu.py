@@ -33,6 +33,33 @@ def test_coarse_host_logic():
     assert (d["m_bids"] == d["b_ids"]).all() and d["hw0_c"] == torch.Size((12, 16))
 
 
+def test_forward_defer_and_pipelined_scene_loop():
+    """``forward(data, defer=True)`` queues the forward and returns ``finish``; the match keys appear in ``data`` only when it is called
+    and equal the synchronous call's; ``plugin.match_scene_cached`` (which pipelines the batches of a scene through
+    ``match_tokens(defer=True)``) gives the tables of one-pair-at-a-time calls, incl. a partial last batch."""
+    cfg = loftr_coarse_only_config(1e-3)
+    sd = random_state_dict(loftr_param_spec(cfg), 0)
+    m = HipLoFTR(cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    data = synth.coarse_pair_batch(2, 96, 128, seed=1000)
+    with cpu_ops():
+        a, b = dict(data), dict(data)
+        assert m(a) is None and "mconf" in a
+        finish = m(b, defer=True)
+        assert callable(finish) and "mconf" not in b and "hw0_c" in b           # shapes are known at once, the table is not
+        assert finish() is b
+        for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f", "gt_mask", "m_bids"):
+            assert torch.equal(a[k], b[k]), k
+        assert m.supports_defer
+        images = torch.cat([data["image0"], data["image1"], data["image0"].flip(-1)[:1]], 0)   # 5 images, 10 pairs, batches of 4 + 4 + 2
+        pairs = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+        piped = plugin.match_scene_cached(m, images, pairs, batch=4)
+        assert list(piped) == pairs
+        for p in pairs[::3]:
+            one = plugin.match_scene_cached(m, images, [p], batch=4)[p]
+            assert np.array_equal(piped[p][:, :4], one[:, :4]) and np.allclose(piped[p][:, 4], one[:, 4], atol=1e-4)   # batch composition: summation order
+
+
 def test_coarse_different_image_sizes():
     cfg = loftr_coarse_only_config(1e-3)
     sd = random_state_dict(loftr_param_spec(cfg), 3)
