@@ -1,0 +1,474 @@
+// Thread-level pieces of the device JPEG decoder (csrc/jpeg_decode.hip) -- gfx950 (MI355X).
+//
+// Every function here is what ONE thread of a kernel does, written against plain pointers, so the same text also compiles
+// with g++ as the CPU lane model of the decoder (tests/jpeg_emul.cpp: the kernels' grids become loops; tests/test_jpeg_cpu.py
+// holds it to the oracle and to libjpeg-turbo before anything runs on a GPU).  See jpeg_decode.hip for the algorithm.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define JD_FN __device__ __forceinline__
+#define JD_HD __host__ __device__ __forceinline__
+#define JD_UNROLL _Pragma("unroll")
+#else
+#define JD_UNROLL
+#define JD_FN static inline
+#define JD_HD static inline
+#endif
+
+namespace jd {
+
+constexpr int MAX_BLK = 6;                 // blocks per MCU (4:2:0: Y Y Y Y Cb Cr)
+constexpr int SCAN_T = 1024;               // threads of the single-workgroup scans
+constexpr int DC_GROUP = 16;               // MCUs per thread of the DC prediction passes
+constexpr uint64_t NO_STATE = ~0ull;
+
+struct Params {
+    // ---- the scan and its tables (device) ------------------------------------------------------------------------
+    const uint8_t* scan;                   // entropy-coded bytes, raw: stuffed zeros and RSTn markers still in place
+    const uint16_t* lut;                   // [4][65536]: (code length << 8) | symbol for every 16-bit prefix, 0 = no code
+    const uint16_t* qt;                    // [3][64] quantisation steps of each component, natural (row-major) order
+    const uint32_t* seg_beg;               // [nseg] raw byte range of each restart segment's data (markers excluded)
+    const uint32_t* seg_end;
+    const int32_t* seg_chunk0;             // [nseg] first chunk of the segment
+    const int32_t* chunk_seg;              // [nchunks]
+    int32_t nseg, nchunks, chunk_bytes;
+    // ---- frame geometry ------------------------------------------------------------------------------------------
+    int32_t nb;                            // blocks per MCU
+    int32_t blk_comp[MAX_BLK], blk_bx[MAX_BLK], blk_by[MAX_BLK], blk_dc[MAX_BLK], blk_ac[MAX_BLK];
+    int32_t ncomp, comp_h[3], comp_v[3], comp_j0[3];
+    int32_t hmax, vmax;
+    int32_t mcux, nmcu, restart;           // MCUs per row, in the frame, per restart interval (0 = none)
+    int32_t nblocks;
+    int32_t width, height;
+    int32_t plane_w[3], plane_h[3];        // padded component planes (samples)
+    int32_t real_w[3], real_h[3];          // ceil(width h / hmax), ceil(height v / vmax): the samples that exist
+    int32_t out_channels;                  // 1: luma plane, 3: RGB
+    // ---- workspace (device) --------------------------------------------------------------------------------------
+    uint64_t* exit_state;                  // [nchunks] decoder state at the first symbol that starts at / after the chunk's end
+    uint64_t* last_entry;                  // [nchunks] entry state the stored exit was computed from
+    int32_t* nblk;                         // [nchunks] blocks completed by symbols that start inside the chunk
+    int32_t* blk0;                         // [nchunks] exclusive prefix of nblk
+    int32_t* work;                         // [64] chunks decoded by sweep i (0 = fixed point reached)
+    int32_t* status;                       // [4] work of the last sweep, invalid codes, segments with a wrong block count, sweeps used
+    int16_t* coef;                         // [nblocks][64] natural order; DC differences until the prediction pass
+    int32_t* dc_part;                      // [ngroups][4] (sum Y, Cb, Cr since the last reset in the group; has reset)
+    int32_t* dc_base;                      // [ngroups][4]
+    uint8_t* plane[3];                     // colour output only
+    uint8_t* out;
+    int64_t out_stride;
+};
+
+JD_FN uint64_t pack_state(uint64_t pos, uint32_t b, uint32_t z) { return (pos << 16) | ((uint64_t)b << 8) | z; }
+
+// ---- bit reader over the raw (stuffed) bytes of one restart segment ------------------------------------------------
+// A position is (raw index of the DATA byte that holds the next unread bit, bits of it already read); it never points at
+// a stuffed zero: the byte after a data 0xFF is skipped by rule, on both the fetch and the position side.  Past the
+// segment's end the reader feeds zeros and positions keep advancing, so every loop that runs "until the position passes
+// X" terminates whatever the bits say.
+struct Reader {
+    const uint8_t* d;
+    uint32_t lim;
+    uint32_t raw, o;
+    uint64_t acc;                          // nbytes data bytes from `raw` on, left aligned
+    uint32_t nbytes;
+    uint32_t nxt;
+};
+JD_FN void reader_init(Reader& r, const uint8_t* d, uint32_t lim, uint64_t pos) {
+    r.d = d;
+    r.lim = lim;
+    r.raw = (uint32_t)(pos >> 3);
+    r.o = (uint32_t)(pos & 7);
+    r.acc = 0;
+    r.nbytes = 0;
+    r.nxt = r.raw;
+}
+JD_FN void reader_fetch(Reader& r) {
+    uint32_t b = 0;
+    if (r.nxt < r.lim) b = r.d[r.nxt];
+    r.nxt += b == 0xFF ? 2 : 1;
+    r.acc |= (uint64_t)b << (56 - 8 * r.nbytes);
+    r.nbytes += 1;
+}
+JD_FN uint32_t reader_peek(Reader& r, uint32_t n) {      // 1 <= n <= 32
+    while (r.nbytes * 8 < r.o + n) reader_fetch(r);
+    return (uint32_t)((r.acc << r.o) >> (64 - n));
+}
+JD_FN void reader_skip(Reader& r, uint32_t n) {          // the n bits were peeked before
+    r.o += n;
+    while (r.o >= 8) {
+        const uint32_t b = (uint32_t)(r.acc >> 56);
+        r.acc <<= 8;
+        r.nbytes -= 1;
+        r.o -= 8;
+        r.raw += b == 0xFF ? 2 : 1;
+    }
+}
+JD_FN uint64_t reader_pos(const Reader& r) { return (uint64_t)r.raw * 8 + r.o; }
+
+JD_FN int extend(uint32_t v, uint32_t s) { return s && v < (1u << (s - 1)) ? (int)v - (int)(1u << s) + 1 : (int)v; }
+
+__attribute__((unused)) static const uint8_t ZIGZAG_HOST[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+#if defined(__HIPCC__)
+__device__ __constant__ uint8_t ZIGZAG_DEV[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+#define JD_ZIGZAG ZIGZAG_DEV
+#define JD_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define JD_LOAD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define JD_STORE64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define JD_ZIGZAG ZIGZAG_HOST
+#define JD_ATOMIC_ADD(p, v) (*(p) += (v))
+#define JD_LOAD64(p) (*(p))
+#define JD_STORE64(p, v) (*(p) = (v))
+#endif
+
+// ---- chunk geometry ---------------------------------------------------------------------------------------------
+struct Chunk {
+    int32_t seg;
+    uint32_t beg, end, lim;                // raw bytes [beg, end) of the chunk; lim = end of the segment
+    bool first, last;                      // of its segment
+};
+JD_FN Chunk chunk_of(const Params& P, int c) {
+    Chunk k;
+    k.seg = P.chunk_seg[c];
+    const int i = c - P.seg_chunk0[k.seg];
+    k.lim = P.seg_end[k.seg];
+    k.beg = P.seg_beg[k.seg] + (uint32_t)i * (uint32_t)P.chunk_bytes;
+    const uint32_t e = k.beg + (uint32_t)P.chunk_bytes;
+    k.end = e < k.lim ? e : k.lim;
+    k.first = i == 0;
+    k.last = k.end == k.lim;
+    return k;
+}
+// the state a decoder is ASSUMED to be in at the first byte of a chunk before anything is known: on a byte boundary, at
+// the DC coefficient of the MCU's first block.  (A stuffed zero is not a data byte: step over it.)
+JD_FN uint64_t default_entry(const Params& P, const Chunk& k) {
+    uint32_t s = k.beg;
+    if (!k.first && s < k.lim && P.scan[s] == 0 && P.scan[s - 1] == 0xFF) s += 1;
+    return pack_state((uint64_t)s * 8, 0, 0);
+}
+
+// ---- the Huffman decoder of one chunk ----------------------------------------------------------------------------
+// Decodes the symbols that START inside [entry position, chunk end): DC size + difference when z == 0, AC run / size (EOB,
+// ZRL) otherwise (ITU T.81 F.2.2; libjpeg-turbo jdhuff.c decode_mcu).  WRITE: coefficients go to coef[block][natural index]
+// (DC as its difference), blocks from blk on, at most up to blk_limit.  An invalid prefix costs one bit and is counted:
+// on a mis-synchronised path that is routine, on the final path it means a corrupt file.
+struct ChunkResult {
+    uint64_t exit;
+    int32_t nblk, nbad;
+};
+template <bool WRITE>
+JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit) {
+    Reader r;
+    reader_init(r, P.scan, k.lim, entry >> 16);
+    uint32_t b = (uint32_t)(entry >> 8) & 0xFF, z = (uint32_t)entry & 0xFF;
+    const uint64_t end_pos = (uint64_t)k.end * 8;
+    ChunkResult res;
+    res.nblk = 0;
+    res.nbad = 0;
+    while (reader_pos(r) < end_pos && (!WRITE || blk < blk_limit)) {
+        const uint16_t* lut = P.lut + (size_t)(z == 0 ? P.blk_dc[b] : P.blk_ac[b]) * 65536;
+        const uint32_t e = lut[reader_peek(r, 16)];
+        const uint32_t len = e >> 8;
+        if (len == 0) {
+            reader_skip(r, 1);
+            res.nbad += 1;
+            continue;
+        }
+        reader_skip(r, len);
+        const uint32_t sym = e & 0xFF;
+        if (z == 0) {
+            const uint32_t s = sym & 15;
+            if (sym > 15) res.nbad += 1;
+            int v = 0;
+            if (s) {
+                v = extend(reader_peek(r, s), s);
+                reader_skip(r, s);
+            }
+            if (WRITE) P.coef[(int64_t)blk * 64] = (int16_t)v;
+            z = 1;
+        } else {
+            const uint32_t run = sym >> 4, s = sym & 15;
+            if (s == 0) {
+                z = run == 15 ? z + 16 : 64;                   // ZRL / EOB
+            } else {
+                z += run;
+                const int v = extend(reader_peek(r, s), s);
+                reader_skip(r, s);
+                if (WRITE && z < 64) P.coef[(int64_t)blk * 64 + JD_ZIGZAG[z]] = (int16_t)v;
+                z += 1;
+            }
+        }
+        if (z >= 64) {
+            z = 0;
+            b = b + 1 == (uint32_t)P.nb ? 0 : b + 1;
+            res.nblk += 1;
+            blk += 1;
+        }
+    }
+    res.exit = pack_state(reader_pos(r), b, z);
+    return res;
+}
+
+// ---- kernels, one thread each --------------------------------------------------------------------------------------
+JD_FN void init_thread(const Params& P, int c) {
+    uint64_t e = NO_STATE;
+    if (c + 1 < P.nchunks && P.chunk_seg[c + 1] == P.chunk_seg[c]) e = default_entry(P, chunk_of(P, c + 1));
+    P.exit_state[c] = e;
+    P.last_entry[c] = NO_STATE;
+    P.nblk[c] = 0;
+}
+
+// One relaxation sweep: chunk c decodes from the exit state its predecessor currently reports (in the same launch that may
+// be the old or the new one: both are proposals) unless that is the entry its stored result was computed from.  Chunk 0 of a
+// segment starts from the truth, so after sweep i the first i + 1 chunks of every segment are final; because Huffman
+// streams self-synchronise, a wrong entry usually leads to the right exit within the chunk and the fixed point arrives
+// after a handful of sweeps.  A sweep that decodes nothing IS the fixed point (every stored result matches its entry).
+JD_FN void sweep_thread(const Params& P, int c, int sweep) {
+    const Chunk k = chunk_of(P, c);
+    const uint64_t entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : JD_LOAD64(&P.exit_state[c - 1]);
+    if (entry == P.last_entry[c]) return;
+    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0);
+    JD_STORE64(&P.exit_state[c], res.exit);
+    P.last_entry[c] = entry;
+    P.nblk[c] = res.nblk;
+    JD_ATOMIC_ADD(&P.work[sweep], 1);
+}
+
+// Exclusive prefix of nblk over all chunks, one workgroup: spans, scan of the span sums, spans again.
+JD_FN int32_t scan_span(const Params& P) { return (P.nchunks + SCAN_T - 1) / SCAN_T; }
+JD_FN void scan_phase_a(const Params& P, int t, int32_t* part) {
+    const int span = scan_span(P);
+    int32_t s = 0;
+    for (int c = t * span; c < (t + 1) * span && c < P.nchunks; ++c) s += P.nblk[c];
+    part[t] = s;
+}
+JD_FN void scan_phase_b(int32_t* part) {                    // thread 0
+    int32_t run = 0;
+    for (int t = 0; t < SCAN_T; ++t) {
+        const int32_t s = part[t];
+        part[t] = run;
+        run += s;
+    }
+}
+JD_FN void scan_phase_c(const Params& P, int t, const int32_t* part) {
+    const int span = scan_span(P);
+    int32_t run = part[t];
+    for (int c = t * span; c < (t + 1) * span && c < P.nchunks; ++c) {
+        P.blk0[c] = run;
+        run += P.nblk[c];
+    }
+}
+
+JD_FN void write_thread(const Params& P, int c) {
+    const Chunk k = chunk_of(P, c);
+    const uint64_t entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : P.exit_state[c - 1];
+    const int32_t per_seg = P.restart ? P.restart * P.nb : P.nblocks;
+    const int32_t seg_blk0 = k.seg * per_seg;
+    int32_t limit = seg_blk0 + per_seg;
+    if (limit > P.nblocks) limit = P.nblocks;
+    const int32_t blk = seg_blk0 + P.blk0[c] - P.blk0[P.seg_chunk0[k.seg]];
+    if (blk >= limit && !k.last) return;
+    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit);
+    if (res.nbad) JD_ATOMIC_ADD(&P.status[1], res.nbad);
+    if (k.last && blk + res.nblk != limit) JD_ATOMIC_ADD(&P.status[2], 1);
+}
+
+// DC prediction (T.81 F.2.1.3.1: DC = previous DC of the same component + difference, reset to 0 at every restart):
+// pass 1 sums the differences of DC_GROUP MCUs per component, a single-workgroup scan turns the sums into the prediction
+// each group starts from, pass 3 rewrites the differences as values.
+JD_HD int32_t dc_ngroups(const Params& P) { return (P.nmcu + DC_GROUP - 1) / DC_GROUP; }
+JD_FN bool mcu_resets(const Params& P, int m) { return m == 0 || (P.restart && m % P.restart == 0); }
+JD_FN void dc_sum_thread(const Params& P, int g) {
+    int32_t sum[3] = {0, 0, 0};
+    int32_t reset = 0;
+    for (int m = g * DC_GROUP; m < (g + 1) * DC_GROUP && m < P.nmcu; ++m) {
+        if (mcu_resets(P, m)) {
+            sum[0] = sum[1] = sum[2] = 0;
+            reset = 1;
+        }
+        for (int j = 0; j < P.nb; ++j) sum[P.blk_comp[j]] += P.coef[((int64_t)m * P.nb + j) * 64];
+    }
+    int32_t* o = P.dc_part + 4 * g;
+    o[0] = sum[0];
+    o[1] = sum[1];
+    o[2] = sum[2];
+    o[3] = reset;
+}
+JD_FN int32_t dc_span(const Params& P) { return (dc_ngroups(P) + SCAN_T - 1) / SCAN_T; }
+// phase a: thread t folds its span of groups into one (sum since the last reset, has reset) tuple in part[4 t ..]
+JD_FN void dc_scan_phase_a(const Params& P, int t, int32_t* part) {
+    const int span = dc_span(P), ng = dc_ngroups(P);
+    int32_t sum[3] = {0, 0, 0}, reset = 0;
+    for (int g = t * span; g < (t + 1) * span && g < ng; ++g) {
+        const int32_t* p = P.dc_part + 4 * g;
+        if (p[3]) {
+            sum[0] = p[0]; sum[1] = p[1]; sum[2] = p[2];
+            reset = 1;
+        } else {
+            sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2];
+        }
+    }
+    part[4 * t] = sum[0]; part[4 * t + 1] = sum[1]; part[4 * t + 2] = sum[2]; part[4 * t + 3] = reset;
+}
+JD_FN void dc_scan_phase_b(int32_t* part) {                 // thread 0: part[t] := prediction at the start of span t
+    int32_t run[3] = {0, 0, 0};
+    for (int t = 0; t < SCAN_T; ++t) {
+        int32_t* p = part + 4 * t;
+        const int32_t s0 = p[0], s1 = p[1], s2 = p[2], reset = p[3];
+        p[0] = run[0]; p[1] = run[1]; p[2] = run[2];
+        if (reset) { run[0] = s0; run[1] = s1; run[2] = s2; }
+        else { run[0] += s0; run[1] += s1; run[2] += s2; }
+    }
+}
+JD_FN void dc_scan_phase_c(const Params& P, int t, const int32_t* part) {
+    const int span = dc_span(P), ng = dc_ngroups(P);
+    int32_t run[3] = {part[4 * t], part[4 * t + 1], part[4 * t + 2]};
+    for (int g = t * span; g < (t + 1) * span && g < ng; ++g) {
+        const int32_t* p = P.dc_part + 4 * g;
+        int32_t* o = P.dc_base + 4 * g;
+        o[0] = run[0]; o[1] = run[1]; o[2] = run[2];
+        if (p[3]) { run[0] = p[0]; run[1] = p[1]; run[2] = p[2]; }
+        else { run[0] += p[0]; run[1] += p[1]; run[2] += p[2]; }
+    }
+}
+JD_FN void dc_apply_thread(const Params& P, int g) {
+    int32_t pred[3] = {P.dc_base[4 * g], P.dc_base[4 * g + 1], P.dc_base[4 * g + 2]};
+    for (int m = g * DC_GROUP; m < (g + 1) * DC_GROUP && m < P.nmcu; ++m) {
+        if (mcu_resets(P, m)) pred[0] = pred[1] = pred[2] = 0;
+        for (int j = 0; j < P.nb; ++j) {
+            int16_t* d = P.coef + ((int64_t)m * P.nb + j) * 64;
+            pred[P.blk_comp[j]] += *d;
+            *d = (int16_t)pred[P.blk_comp[j]];
+        }
+    }
+}
+
+// ---- jidctint.c: jpeg_idct_islow -----------------------------------------------------------------------------------
+// Loeffler-Ligtenberg-Moschytz with 13-bit constants: a column pass that keeps 2 extra bits, a row pass, the 1024-entry
+// range-limit table indexed modulo (jdmaster.c prepare_range_limit_table) written out as arithmetic.  The library's
+// zero-AC shortcuts give the same numbers as the full butterfly, so there are none here.
+JD_FN void idct_1d(const int32_t in0, const int32_t in1, const int32_t in2, const int32_t in3, const int32_t in4,
+                   const int32_t in5, const int32_t in6, const int32_t in7, int32_t* o) {
+    int32_t z1 = (in2 + in6) * 4433;                        // FIX(0.541196100)
+    const int32_t t2 = z1 + in6 * (-15137);                 // FIX(1.847759065)
+    const int32_t t3 = z1 + in2 * 6270;                     // FIX(0.765366865)
+    const int32_t t0 = (in0 + in4) * 8192, t1 = (in0 - in4) * 8192;
+    const int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    int32_t a0 = in7, a1 = in5, a2 = in3, a3 = in1;
+    z1 = a0 + a3;
+    int32_t z2 = a1 + a2, z3 = a0 + a2, z4 = a1 + a3;
+    const int32_t z5 = (z3 + z4) * 9633;                    // FIX(1.175875602)
+    a0 *= 2446;                                             // FIX(0.298631336)
+    a1 *= 16819;                                            // FIX(2.053119869)
+    a2 *= 25172;                                            // FIX(3.072711026)
+    a3 *= 12299;                                            // FIX(1.501321110)
+    z1 *= -7373;                                            // FIX(0.899976223)
+    z2 *= -20995;                                           // FIX(2.562915447)
+    z3 = z3 * -16069 + z5;                                  // FIX(1.961570560)
+    z4 = z4 * -3196 + z5;                                   // FIX(0.390180644)
+    a0 += z1 + z3;
+    a1 += z2 + z4;
+    a2 += z2 + z3;
+    a3 += z1 + z4;
+    o[0] = t10 + a3; o[7] = t10 - a3;
+    o[1] = t11 + a2; o[6] = t11 - a2;
+    o[2] = t12 + a1; o[5] = t12 - a1;
+    o[3] = t13 + a0; o[4] = t13 - a0;
+}
+JD_FN uint8_t range_limit(int32_t x) {
+    const int32_t i = x & 1023;
+    if (i < 512) return (uint8_t)(i + 128 > 255 ? 255 : i + 128);
+    const int32_t v = i - 1024 + 128;
+    return (uint8_t)(v < 0 ? 0 : v);
+}
+JD_FN void idct_thread(const Params& P, int blk) {
+    const int m = blk / P.nb, j = blk - m * P.nb;
+    const int comp = P.blk_comp[j];
+    if (P.out_channels == 1 && comp != 0) return;
+    const int row0 = ((m / P.mcux) * P.comp_v[comp] + P.blk_by[j]) * 8, col0 = ((m % P.mcux) * P.comp_h[comp] + P.blk_bx[j]) * 8;
+    if (P.out_channels == 1 && (row0 >= P.height || col0 >= P.width)) return;
+    const int16_t* cf = P.coef + (int64_t)blk * 64;
+    const uint16_t* q = P.qt + comp * 64;
+    int32_t ws[64], o[8];
+    JD_UNROLL
+    for (int c = 0; c < 8; ++c) {
+        idct_1d((int32_t)cf[c] * q[c], (int32_t)cf[8 + c] * q[8 + c], (int32_t)cf[16 + c] * q[16 + c],
+                (int32_t)cf[24 + c] * q[24 + c], (int32_t)cf[32 + c] * q[32 + c], (int32_t)cf[40 + c] * q[40 + c],
+                (int32_t)cf[48 + c] * q[48 + c], (int32_t)cf[56 + c] * q[56 + c], o);
+        JD_UNROLL
+        for (int r = 0; r < 8; ++r) ws[r * 8 + c] = (o[r] + (1 << 10)) >> 11;          // DESCALE(CONST_BITS - PASS1_BITS)
+    }
+    uint8_t* dst;
+    int64_t stride;
+    int rows = 8, cols = 8;
+    if (P.out_channels == 1) {
+        dst = P.out + (int64_t)row0 * P.out_stride + col0;
+        stride = P.out_stride;
+        if (P.height - row0 < rows) rows = P.height - row0;
+        if (P.width - col0 < cols) cols = P.width - col0;
+    } else {
+        dst = P.plane[comp] + (int64_t)row0 * P.plane_w[comp] + col0;
+        stride = P.plane_w[comp];
+    }
+    JD_UNROLL
+    for (int r = 0; r < 8; ++r) {
+        idct_1d(ws[r * 8], ws[r * 8 + 1], ws[r * 8 + 2], ws[r * 8 + 3], ws[r * 8 + 4], ws[r * 8 + 5], ws[r * 8 + 6], ws[r * 8 + 7], o);
+        uint8_t px[8];
+        JD_UNROLL
+        for (int c = 0; c < 8; ++c) px[c] = range_limit((o[c] + (1 << 17)) >> 18);      // CONST_BITS + PASS1_BITS + 3
+        if (r < rows) {
+            if (cols == 8) {                                    // blocks start on 8-byte columns of rows the caller aligned or not:
+                JD_UNROLL                                       // byte stores keep any out_stride legal
+                for (int c = 0; c < 8; ++c) dst[r * stride + c] = px[c];
+            } else {
+                JD_UNROLL
+                for (int c = 0; c < 8; ++c)
+                    if (c < cols) dst[r * stride + c] = px[c];
+            }
+        }
+    }
+}
+
+// ---- jdsample.c fancy upsampling + jdcolor.c ycc_rgb_convert, one output pixel -----------------------------------------
+JD_FN int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+JD_FN int chroma_at(const Params& P, int comp, int x, int y) {
+    const uint8_t* pl = P.plane[comp];
+    const int pw = P.plane_w[comp], rw = P.real_w[comp], rh = P.real_h[comp];
+    const int hr = P.hmax / P.comp_h[comp], vr = P.vmax / P.comp_v[comp];
+    if (hr == 1 && vr == 1) return pl[(int64_t)y * pw + x];
+    const int cx = x >> 1;
+    if (vr == 1) {                                          // h2v1_fancy_upsample: 3/4 nearer + 1/4 further, edges replicated
+        const uint8_t* row = pl + (int64_t)y * pw;
+        const int cur = row[cx];
+        return (x & 1) ? (3 * cur + row[clampi(cx + 1, 0, rw - 1)] + 2) >> 2 : (3 * cur + row[clampi(cx - 1, 0, rw - 1)] + 1) >> 2;
+    }
+    // h2v2_fancy_upsample: column sums 3 nearer row + further row (the row above the first / below the last real row is a copy
+    // of it, jdmainct.c), then 3/4 : 1/4 across, rounding 8 / 7 alternating
+    const int cy = y >> 1;
+    const int fy = clampi((y & 1) ? cy + 1 : cy - 1, 0, rh - 1);
+    const uint8_t* r0 = pl + (int64_t)cy * pw;
+    const uint8_t* r1 = pl + (int64_t)fy * pw;
+    const int cur = 3 * r0[cx] + r1[cx];
+    const int ox = clampi((x & 1) ? cx + 1 : cx - 1, 0, rw - 1);
+    return (3 * cur + 3 * r0[ox] + r1[ox] + ((x & 1) ? 7 : 8)) >> 4;
+}
+JD_FN void color_thread(const Params& P, int x, int y) {
+    const int Y = P.plane[0][(int64_t)y * P.plane_w[0] + x];
+    uint8_t* o = P.out + (int64_t)y * P.out_stride + 3 * x;
+    if (P.ncomp == 1) {
+        o[0] = o[1] = o[2] = (uint8_t)Y;
+        return;
+    }
+    const int cb = chroma_at(P, 1, x, y) - 128, cr = chroma_at(P, 2, x, y) - 128;
+    // build_ycc_rgb_table: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+    o[0] = (uint8_t)clampi(Y + ((91881 * cr + 32768) >> 16), 0, 255);
+    o[1] = (uint8_t)clampi(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0, 255);
+    o[2] = (uint8_t)clampi(Y + ((116130 * cb + 32768) >> 16), 0, 255);
+}
+
+}  // namespace jd

@@ -1,0 +1,140 @@
+// Baseline JPEG decode on the device -- gfx950 (MI355X).  The last host-side stage of SURVEY.md 8(f) rank 1 ("image feeding").
+//
+// Replaces, for baseline Huffman JPEGs (SOF0 / SOF1, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart markers or not):
+//     cv2.imread(path, cv2.IMREAD_GRAYSCALE)        src/dataset/utils.py:127, 183   -> the luma plane
+//     cv2.imread(path, cv2.IMREAD_COLOR) + BGR2RGB  src/dataset/utils.py:86-92      -> RGB
+// i.e. libjpeg-turbo's default decompression path (jdhuff.c, jidctint.c, jdsample.c, jdcolor.c), byte for byte
+// (oracle/jpeg_baseline.c is the sequential restatement; tests pin both to the library itself).
+//
+// The entropy-coded scan is ONE bit string with no index: symbol k+1 starts where symbol k ends.  What makes it parallel is
+// that Huffman streams self-synchronise -- a decoder started at a wrong bit falls into step with the true one after a few
+// symbols -- so the scan is cut into fixed chunks (128 bytes of raw data by default) with one thread each:
+//   init      every chunk's exit state := "next chunk starts on its first byte, at the DC of block 0"
+//   sweep x n chunk c decodes from its predecessor's current exit state (position, block-in-MCU, coefficient index) and
+//             publishes its own; chunks whose entry did not change since their last decode do nothing.  The first chunk
+//             of a segment starts from the truth, so this is a fixed-point iteration that is exact when a sweep decodes
+//             nothing, and self-synchronisation makes that happen after a few sweeps instead of nchunks
+//             (Weissenberger & Schmidt's scheme for GPU Huffman / JPEG decoding, restated for 64-lane waves: no
+//             intra-block phases, the relaxation runs in place in global memory, 8-byte states are single transactions).
+//             Restart markers (DRI) cut the scan into independent segments: more starting points that are true.
+//   scan      exclusive prefix of the blocks each chunk completes -> the block every chunk starts in
+//   write     decode once more, now storing coefficients (zig-zag undone, DC as differences) into coef[block][64]
+//   dc        per-component prefix sum of the DC differences in scan order (reset at restarts): 3 small launches
+//   idct      one thread per 8x8 block: dequantise + jpeg_idct_islow; the luma plane goes straight to the output
+//   colour    (RGB only) fancy upsampling of Cb / Cr + YCbCr -> RGB per output pixel
+// All integer / byte work, HBM- and latency-bound; no LDS staging is needed for a stream this small (a 0.5 MB file is 4000
+// threads), the Huffman tables are 16-bit-prefix LUTs that live in L2.
+//
+// The marker segments (tables, frame header, restart positions) are parsed on the host (detectorfreesfm_amd/jpeg.py): a few
+// hundred bytes of control data.  Progressive, arithmetic-coded, 12-bit, CMYK and multi-scan files are refused there
+// (DFSFM_E_UNSUPPORTED at this level), and the caller decides who decodes them.
+#include "common.h"
+#include "jpeg_core.h"
+#include "jpeg_host.h"
+
+namespace {
+
+using jd::Params;
+using jd::Layout;
+using jd::derive;
+using jd::layout_of;
+
+__global__ __launch_bounds__(256) void jd_init_kernel(Params P) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < P.nchunks) jd::init_thread(P, c);
+}
+__global__ __launch_bounds__(256) void jd_sweep_kernel(Params P, int sweep) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < P.nchunks) jd::sweep_thread(P, c, sweep);
+}
+__global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
+    __shared__ int32_t part[jd::SCAN_T];
+    jd::scan_phase_a(P, threadIdx.x, part);
+    __syncthreads();
+    if (threadIdx.x == 0) jd::scan_phase_b(part);
+    __syncthreads();
+    jd::scan_phase_c(P, threadIdx.x, part);
+}
+__global__ __launch_bounds__(256) void jd_write_kernel(Params P) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < P.nchunks) jd::write_thread(P, c);
+}
+__global__ __launch_bounds__(256) void jd_dc_sum_kernel(Params P) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < jd::dc_ngroups(P)) jd::dc_sum_thread(P, g);
+}
+__global__ __launch_bounds__(jd::SCAN_T) void jd_dc_scan_kernel(Params P) {
+    __shared__ int32_t part[4 * jd::SCAN_T];
+    jd::dc_scan_phase_a(P, threadIdx.x, part);
+    __syncthreads();
+    if (threadIdx.x == 0) jd::dc_scan_phase_b(part);
+    __syncthreads();
+    jd::dc_scan_phase_c(P, threadIdx.x, part);
+}
+__global__ __launch_bounds__(256) void jd_dc_apply_kernel(Params P) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < jd::dc_ngroups(P)) jd::dc_apply_thread(P, g);
+}
+__global__ __launch_bounds__(64) void jd_idct_kernel(Params P) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < P.nblocks) jd::idct_thread(P, b);
+}
+__global__ __launch_bounds__(256) void jd_color_kernel(Params P) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < P.width && y < P.height) jd::color_thread(P, x, y);
+}
+__global__ void jd_status_kernel(Params P, int sweeps) {
+    P.status[0] = P.work[sweeps - 1];
+    int used = 0;
+    for (int i = 0; i < sweeps; ++i)
+        if (P.work[i]) used = i + 1;
+    P.status[3] = used;                                          // sweeps of this call that still decoded something
+}
+
+}  // namespace
+
+extern "C" size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int out_channels) {
+    if (!frame_host || (out_channels != 1 && out_channels != 3)) return 0;
+    Params P{};
+    if (!derive(*frame_host, P)) return 0;
+    return layout_of(P, out_channels).total;
+}
+
+extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* frame_host,
+                                    const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* seg_beg,
+                                    const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg,
+                                    uint8_t* out, int64_t out_stride, int out_channels, int sweeps, int resume,
+                                    int32_t* status, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!scan || !frame_host || !huff_lut || !qt || !seg_beg || !seg_end || !seg_chunk0 || !chunk_seg || !out || !status ||
+        !workspace)
+        return DFSFM_E_BADARG;
+    if (scan_bytes <= 0 || scan_bytes >= (1ll << 31) || (out_channels != 1 && out_channels != 3) || sweeps < 1 || sweeps > 64)
+        return DFSFM_E_BADARG;
+    Params P{};
+    if (!derive(*frame_host, P)) return DFSFM_E_UNSUPPORTED;
+    if (out_stride < (int64_t)P.width * out_channels) return DFSFM_E_BADARG;
+    const Layout L = layout_of(P, out_channels);
+    if (workspace_bytes < L.total) return DFSFM_E_WORKSPACE;
+    jd::bind(P, L, static_cast<char*>(workspace), scan, huff_lut, qt, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
+             out_channels, status);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    const unsigned gc = (unsigned)((P.nchunks + 255) / 256);
+    (void)hipMemsetAsync(P.work, 0, 64 * 4, stream);
+    (void)hipMemsetAsync(status, 0, 4 * 4, stream);
+    if (!resume) hipLaunchKernelGGL(jd_init_kernel, dim3(gc), dim3(256), 0, stream, P);
+    for (int s = 0; s < sweeps; ++s) hipLaunchKernelGGL(jd_sweep_kernel, dim3(gc), dim3(256), 0, stream, P, s);
+    hipLaunchKernelGGL(jd_status_kernel, dim3(1), dim3(1), 0, stream, P, sweeps);
+    hipLaunchKernelGGL(jd_scan_kernel, dim3(1), dim3(jd::SCAN_T), 0, stream, P);
+    (void)hipMemsetAsync(P.coef, 0, (size_t)P.nblocks * 128, stream);
+    hipLaunchKernelGGL(jd_write_kernel, dim3(gc), dim3(256), 0, stream, P);
+    const unsigned gg = (unsigned)((jd::dc_ngroups(P) + 255) / 256);
+    hipLaunchKernelGGL(jd_dc_sum_kernel, dim3(gg), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(jd_dc_scan_kernel, dim3(1), dim3(jd::SCAN_T), 0, stream, P);
+    hipLaunchKernelGGL(jd_dc_apply_kernel, dim3(gg), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(jd_idct_kernel, dim3((unsigned)((P.nblocks + 63) / 64)), dim3(64), 0, stream, P);
+    if (out_channels == 3)
+        hipLaunchKernelGGL(jd_color_kernel, dim3((unsigned)((P.width + 63) / 64), (unsigned)((P.height + 3) / 4)), dim3(256), 0,
+                           stream, P);
+    return dfsfm::check_launch("dfsfm_jpeg_decode_u8");
+}

@@ -5,7 +5,9 @@ cv2, resize it with PIL's LANCZOS filter (``resize_image(..., "pil_LANCZOS")``, 
 (``pad_bottom_right``, :30-52) and turn it into a float tensor in [0, 1] (``grayscale2tensor`` / ``rgb2tensor``,
 :55-59), all on one host core per image.  Here everything after the decode runs on the GPU: the decoded uint8 frame is
 copied once (1 byte per pixel) and ``dfsfm_resample_u8`` returns PIL's bytes exactly (fixed-point arithmetic, see
-csrc/image_resize.hip) already converted, padded and masked.  The entropy decode itself (cv2.imread) stays on the host.
+csrc/image_resize.hip) already converted, padded and masked.  Since r05 the decode itself runs on the GPU too for baseline
+JPEG files (``jpeg.decode`` -> csrc/jpeg_decode.hip, bytes identical to libjpeg-turbo, the library behind cv2.imread); other
+files keep the reference's host decode (``decode="auto"``).
 
 ``read_grayscale`` / ``read_rgb`` keep the reference's signature and return values; ``path`` may also be an already
 decoded uint8 array / tensor ([H,W] or [H,W,3] RGB), which is what a maintainer passes after ``cv2.imread``.
@@ -114,13 +116,12 @@ def resize_lanczos(image_u8, size, device=None):
 _warned_pil_decode = False
 
 
-def _decode(path, color: bool):
-    """Host entropy decode for callers that pass a file name.  The reference decodes with ``cv2.imread(path,
-    IMREAD_GRAYSCALE)`` / ``IMREAD_COLOR`` + BGR->RGB (src/dataset/utils.py:92-96, 150-153): OpenCV applies the EXIF
-    orientation, decodes JPEG luma directly for gray and uses its own rounding for colour->gray.  With cv2 importable the
-    same calls are made here.  Without it (this image) Pillow decodes -- EXIF orientation is applied to match cv2, but
-    gray / colour bytes of a JPEG can differ by an LSB from OpenCV's decoder, so this branch is NOT parity-pinned; it warns
-    once and INTEGRATION.md says so.  Everything after the decode is byte-exact (tests pass decoded frames)."""
+def _decode_host(path, color: bool):
+    """Host decode, the reference's own: ``cv2.imread(path, IMREAD_GRAYSCALE)`` / ``IMREAD_COLOR`` + BGR->RGB
+    (src/dataset/utils.py:86-92, 127).  Without cv2 (this image) Pillow decodes -- the same libjpeg-turbo underneath: for a JPEG
+    ``draft('L')`` selects the library's grey output (the luma plane, what OpenCV asks for too) instead of an RGB -> L conversion,
+    and the EXIF orientation is applied as cv2.imread does.  Other formats (PNG ...) go through Pillow's own converters and are
+    NOT parity-pinned to OpenCV; that case warns once."""
     try:
         import cv2
     except ImportError:
@@ -135,22 +136,48 @@ def _decode(path, color: bool):
         if im is None:
             raise FileNotFoundError(str(path))
         return im
-    global _warned_pil_decode
-    if not _warned_pil_decode:
-        import warnings
-        warnings.warn("detectorfreesfm_amd.images: cv2 is not installed, decoding files with Pillow -- the decode step is not "
-                      "parity-pinned to the reference's cv2.imread (pass decoded frames, or install OpenCV)", RuntimeWarning)
-        _warned_pil_decode = True
     from PIL import Image, ImageOps
     with Image.open(str(path)) as im:
+        if im.format == "JPEG":
+            if not color:
+                im.draft("L", im.size)
+        else:
+            global _warned_pil_decode
+            if not _warned_pil_decode:
+                import warnings
+                warnings.warn("detectorfreesfm_amd.images: cv2 is not installed, decoding a non-JPEG file with Pillow -- this "
+                              "decode is not parity-pinned to the reference's cv2.imread (pass decoded frames, or install "
+                              "OpenCV)", RuntimeWarning)
+                _warned_pil_decode = True
         im = ImageOps.exif_transpose(im)                     # cv2.imread honours the EXIF orientation
         return np.asarray(im.convert("RGB" if color else "L"))
 
 
-def _read(image, color, resize, resize_no_larger_than, df, pad_to, ret_scales, ret_pad_mask, device):
+def _decode(path, color: bool, device=None, decode: str = "auto"):
+    """A file name -> decoded uint8 frame.  ``decode``: "device" = ``jpeg.decode`` (csrc/jpeg_decode.hip: baseline JPEGs, bytes
+    identical to libjpeg-turbo / cv2.imread; anything else raises ``jpeg.UnsupportedJpeg``), "host" = the reference's host decode
+    (``_decode_host``), "auto" (default) = the device for the files it takes, the host for the rest (progressive JPEGs, PNG ...)."""
+    if decode not in ("auto", "device", "host"):
+        raise ValueError("decode is 'auto', 'device' or 'host'")
+    if decode != "host":
+        from . import jpeg
+        with open(str(path), "rb") as f:
+            buf = f.read()
+        if decode == "device" and not jpeg.is_jpeg(buf):
+            raise jpeg.UnsupportedJpeg("not a JPEG file")
+        if jpeg.is_jpeg(buf):
+            try:
+                return jpeg.decode(buf, color, device if device is not None else "cuda")
+            except jpeg.UnsupportedJpeg:
+                if decode == "device":
+                    raise
+    return _decode_host(path, color)
+
+
+def _read(image, color, resize, resize_no_larger_than, df, pad_to, ret_scales, ret_pad_mask, device, decode="auto"):
     resize = tuple(resize) if resize is not None else None
     if isinstance(image, (str, bytes)) or hasattr(image, "__fspath__"):
-        image = _decode(image, color)
+        image = _decode(image, color, device, decode)
     device = torch.device(device if device is not None else (image.device if isinstance(image, torch.Tensor) and image.is_cuda else "cuda"))
     img = _as_device_u8(image, device)
     if (img.dim() == 3) != color:
@@ -178,17 +205,17 @@ def _read(image, color, resize, resize_no_larger_than, df, pad_to, ret_scales, r
 
 
 def read_grayscale(path, resize=None, resize_no_larger_than=False, resize_float=False, df=None, client=None, pad_to=None,
-                   ret_scales=False, ret_pad_mask=False, augmentor=None, device=None):
+                   ret_scales=False, ret_pad_mask=False, augmentor=None, device=None, decode="auto"):
     """src/dataset/utils.py:123-160 with the frame resized / padded / converted on the GPU: returns ts_image [1,h,w]
     fp32 on the device (+ scales, original_hw on the host, + the padding mask on the device) like the reference."""
     if client is not None or augmentor is not None:
         raise NotImplementedError("petrel clients and augmentors are training-time options of the reference")
-    return _read(path, False, resize, resize_no_larger_than, df, pad_to, ret_scales, ret_pad_mask, device)
+    return _read(path, False, resize, resize_no_larger_than, df, pad_to, ret_scales, ret_pad_mask, device, decode)
 
 
 def read_rgb(path, resize=None, resize_no_larger_than=False, resize_float=False, df=None, client=None, pad_to=None,
-             ret_scales=False, ret_pad_mask=False, augmentor=None, device=None):
+             ret_scales=False, ret_pad_mask=False, augmentor=None, device=None, decode="auto"):
     """src/dataset/utils.py:80-121 likewise: ts_image [3,h,w] fp32 on the device."""
     if client is not None or augmentor is not None:
         raise NotImplementedError("petrel clients and augmentors are training-time options of the reference")
-    return _read(path, True, resize, resize_no_larger_than, df, pad_to, ret_scales, ret_pad_mask, device)
+    return _read(path, True, resize, resize_no_larger_than, df, pad_to, ret_scales, ret_pad_mask, device, decode)

@@ -1,0 +1,334 @@
+"""Baseline JPEG decode on the device: the decode in front of ``images.read_grayscale`` / ``read_rgb``.
+
+The reference decodes every frame on the host with ``cv2.imread(path, IMREAD_GRAYSCALE)`` (src/dataset/utils.py:127, 183) or
+``cv2.imread(path, IMREAD_COLOR)`` + BGR2RGB (:86-92), i.e. libjpeg-turbo with its defaults.  ``decode(buf, color, device)``
+returns the same bytes from ``dfsfm_jpeg_decode_u8`` (csrc/jpeg_decode.hip): the host parses the marker segments (tables, frame
+header, restart positions: ``plan``), the entropy decode, the inverse DCT, the chroma upsampling and the colour conversion
+run on the GPU.  EXIF orientation is applied as cv2.imread does (index bookkeeping on the decoded bytes).
+
+What the device path takes: baseline / extended-sequential Huffman files (SOF0, SOF1), 8 bit, one interleaved scan, grey or
+YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling, with or without restart markers -- what cameras and ``cv2.imwrite`` / Pillow write
+by default, and all eight frames of the reference's example scene.  Everything else (progressive, arithmetic, 12 bit, CMYK / RGB
+colour spaces, 4:4:0 / 4:1:1, multi-scan) raises ``UnsupportedJpeg``; ``images._decode`` then falls back to the host decoder the
+reference itself uses.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from functools import lru_cache
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+CHUNK_BYTES = 128            # raw scan bytes per decoder thread
+DEFAULT_SWEEPS = 12          # relaxation sweeps per call before the first status check
+
+ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
+                   21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60,
+                   61, 54, 47, 55, 62, 63], dtype=np.int64)
+
+
+class UnsupportedJpeg(Exception):
+    """Not a file the device decoder takes (the message says why)."""
+
+
+class CorruptJpeg(Exception):
+    pass
+
+
+class Frame(ctypes.Structure):
+    """``dfsfm_jpeg_frame`` of include/dfsfm_hip.h."""
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ncomp", ctypes.c_int32),
+                ("h", ctypes.c_int32 * 3), ("v", ctypes.c_int32 * 3),
+                ("dc_slot", ctypes.c_int32 * 3), ("ac_slot", ctypes.c_int32 * 3),
+                ("restart", ctypes.c_int32), ("nseg", ctypes.c_int32), ("nchunks", ctypes.c_int32),
+                ("chunk_bytes", ctypes.c_int32)]
+
+
+@dataclass
+class Plan:
+    """Everything ``dfsfm_jpeg_decode_u8`` takes besides the output, as host arrays."""
+    frame: Frame
+    scan: np.ndarray                 # uint8: the entropy-coded bytes of the scan (raw)
+    lut_key: bytes                   # the DHT payloads the LUT was built from (cache key)
+    lut: np.ndarray                  # uint16 [4, 65536]
+    qt: np.ndarray                   # uint16 [3, 64] natural order
+    seg_beg: np.ndarray              # uint32 [nseg]
+    seg_end: np.ndarray
+    seg_chunk0: np.ndarray           # int32 [nseg]
+    chunk_seg: np.ndarray            # int32 [nchunks]
+    orientation: int = 1
+    sampling: List[Tuple[int, int]] = field(default_factory=list)
+
+    @property
+    def width(self):
+        return int(self.frame.width)
+
+    @property
+    def height(self):
+        return int(self.frame.height)
+
+
+def huffman_lut(bits: bytes, vals: bytes) -> np.ndarray:
+    """(code length << 8) | symbol for every 16-bit prefix; codes as ITU T.81 Annex C generates them from BITS / HUFFVAL."""
+    lut = np.zeros(65536, dtype=np.uint16)
+    code, k = 0, 0
+    for length in range(1, 17):
+        for _ in range(bits[length - 1]):
+            if k >= len(vals) or code >= (1 << length):
+                raise CorruptJpeg("bad Huffman table")
+            lo = code << (16 - length)
+            lut[lo:lo + (1 << (16 - length))] = (length << 8) | vals[k]
+            code += 1
+            k += 1
+        code <<= 1
+    return lut
+
+
+@lru_cache(maxsize=32)
+def _lut_block(key: bytes) -> np.ndarray:
+    """[4, 65536] for up to four (class, bits, vals) tables serialised in ``key``."""
+    out = np.zeros((4, 65536), dtype=np.uint16)
+    o, slot = 0, 0
+    while o < len(key):
+        n = sum(key[o:o + 16])
+        out[slot] = huffman_lut(key[o:o + 16], key[o + 16:o + 16 + n])
+        o += 16 + n
+        slot += 1
+    return out
+
+
+def _exif_orientation(seg: bytes) -> int:
+    t = seg[6:]
+    if len(t) < 8 or t[:2] not in (b"II", b"MM"):
+        return 1
+    bo = "little" if t[:2] == b"II" else "big"
+    ifd = int.from_bytes(t[4:8], bo)
+    if ifd + 2 > len(t):
+        return 1
+    n = int.from_bytes(t[ifd:ifd + 2], bo)
+    for e in range(n):
+        o = ifd + 2 + 12 * e
+        if o + 12 > len(t):
+            break
+        if int.from_bytes(t[o:o + 2], bo) == 0x0112:
+            v = int.from_bytes(t[o + 8:o + 10], bo)
+            return v if 1 <= v <= 8 else 1
+    return 1
+
+
+def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
+    """Parse the marker segments of a JPEG file (bytes / uint8 array) and cut its scan into decoder chunks."""
+    data = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray, memoryview)) else np.ascontiguousarray(buf, dtype=np.uint8)
+    b = data.tobytes() if not isinstance(buf, bytes) else buf
+    n = len(b)
+    if n < 4 or b[0] != 0xFF or b[1] != 0xD8:
+        raise CorruptJpeg("no SOI marker")
+    qts = {}
+    huff = {}                        # (class, id) -> (bits, vals)
+    sof = None
+    restart = 0
+    orientation = 1
+    jfif = False
+    adobe = None
+    p = 2
+    scan_start = None
+    sos = None
+    while p + 4 <= n:
+        if b[p] != 0xFF:
+            raise CorruptJpeg("marker expected")
+        while p < n and b[p] == 0xFF:
+            p += 1
+        m = b[p]
+        p += 1
+        if m == 0xD8 or 0xD0 <= m <= 0xD7 or m == 0x01:
+            continue
+        if m == 0xD9:
+            raise CorruptJpeg("EOI before SOS")
+        ln = (b[p] << 8) | b[p + 1]
+        if ln < 2 or p + ln > n:
+            raise CorruptJpeg("truncated marker segment")
+        seg = b[p + 2:p + ln]
+        if m == 0xDB:
+            i = 0
+            while i < len(seg):
+                pq, tq = seg[i] >> 4, seg[i] & 15
+                i += 1
+                if pq:
+                    q = np.frombuffer(seg[i:i + 128], dtype=">u2").astype(np.uint16)
+                    i += 128
+                else:
+                    q = np.frombuffer(seg[i:i + 64], dtype=np.uint8).astype(np.uint16)
+                    i += 64
+                if q.size != 64 or tq > 3:
+                    raise CorruptJpeg("bad DQT")
+                nat = np.zeros(64, dtype=np.uint16)
+                nat[ZIGZAG] = q
+                qts[tq] = nat
+        elif m == 0xC4:
+            i = 0
+            while i < len(seg):
+                tc, th = seg[i] >> 4, seg[i] & 15
+                bits = seg[i + 1:i + 17]
+                cnt = sum(bits)
+                vals = seg[i + 17:i + 17 + cnt]
+                if len(bits) != 16 or len(vals) != cnt or tc > 1 or th > 3:
+                    raise CorruptJpeg("bad DHT")
+                huff[(tc, th)] = (bytes(bits), bytes(vals))
+                i += 17 + cnt
+        elif m in (0xC0, 0xC1, 0xC2):
+            if seg[0] != 8:
+                raise UnsupportedJpeg(f"{seg[0]}-bit samples")
+            sof = dict(progressive=m == 0xC2, height=(seg[1] << 8) | seg[2], width=(seg[3] << 8) | seg[4], ncomp=seg[5],
+                       comps=[(seg[6 + 3 * c], seg[7 + 3 * c] >> 4, seg[7 + 3 * c] & 15, seg[8 + 3 * c]) for c in range(seg[5])])
+        elif 0xC3 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            raise UnsupportedJpeg("lossless / differential / arithmetic-coded JPEG")
+        elif m == 0xDD:
+            restart = (seg[0] << 8) | seg[1]
+        elif m == 0xE0 and seg[:5] == b"JFIF\0":
+            jfif = True
+        elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
+            adobe = seg[11]
+        elif m == 0xE1 and seg[:6] == b"Exif\0\0":
+            orientation = _exif_orientation(seg)
+        elif m == 0xDA:
+            sos = seg
+            scan_start = p + ln
+            break
+        p += ln
+    if sof is None or sos is None:
+        raise CorruptJpeg("no frame / scan header")
+    if sof["progressive"]:
+        raise UnsupportedJpeg("progressive JPEG")
+    ncomp = sof["ncomp"]
+    if ncomp not in (1, 3):
+        raise UnsupportedJpeg(f"{ncomp} components")
+    if sos[0] != ncomp:
+        raise UnsupportedJpeg("multi-scan sequential JPEG")
+    if sof["width"] == 0 or sof["height"] == 0:
+        raise UnsupportedJpeg("frame size given by a DNL marker")
+    fr = Frame()
+    fr.width, fr.height, fr.ncomp = sof["width"], sof["height"], ncomp
+    qt = np.ones((3, 64), dtype=np.uint16)
+    tables = []                      # distinct (class, id) in slot order
+    sampling = []
+    for c in range(ncomp):
+        cid, h, v, tq = sof["comps"][c]
+        if sos[1 + 2 * c] != cid:
+            raise UnsupportedJpeg("scan components out of frame order")
+        td, ta = sos[2 + 2 * c] >> 4, sos[2 + 2 * c] & 15
+        if tq not in qts or (0, td) not in huff or (1, ta) not in huff:
+            raise CorruptJpeg("missing table")
+        qt[c] = qts[tq]
+        for key in ((0, td), (1, ta)):
+            if key not in tables:
+                tables.append(key)
+        fr.dc_slot[c], fr.ac_slot[c] = tables.index((0, td)), tables.index((1, ta))
+        fr.h[c], fr.v[c] = (1, 1) if ncomp == 1 else (h, v)
+        sampling.append((h, v))
+    if len(tables) > 4:
+        raise UnsupportedJpeg("more than four Huffman tables in one scan")
+    if ncomp == 3:
+        ids = [c[0] for c in sof["comps"]]
+        ycc = True                   # jdapimin.c default_decompress_parms
+        if not jfif and adobe == 0:
+            ycc = False
+        if not jfif and adobe is None and ids == [ord("R"), ord("G"), ord("B")]:
+            ycc = False
+        if not ycc:
+            raise UnsupportedJpeg("RGB-coded JPEG")
+        if sampling[1] != (1, 1) or sampling[2] != (1, 1) or sampling[0] not in ((1, 1), (2, 1), (2, 2)):
+            raise UnsupportedJpeg(f"sampling {sampling}")
+    hmax, vmax = fr.h[0], fr.v[0]
+    mcux = -(-fr.width // (8 * hmax))
+    mcuy = -(-fr.height // (8 * vmax))
+    nmcu = mcux * mcuy
+
+    # ---- the scan: up to the first marker that is not RSTn; restart markers cut it into segments -------------------------
+    d = data[scan_start:]
+    ff = np.flatnonzero(d[:-1] == 0xFF)
+    nxt = d[ff + 1]
+    mark = ff[(nxt != 0) & (nxt != 0xFF)]                       # FF FF is fill, FF 00 a stuffed data byte
+    ends = mark[~((d[mark + 1] >= 0xD0) & (d[mark + 1] <= 0xD7))]
+    scan_len = int(ends[0]) if ends.size else d.size
+    rst = mark[(mark < scan_len) & (d[mark + 1] >= 0xD0) & (d[mark + 1] <= 0xD7)]
+    if restart:
+        nseg = -(-nmcu // restart)
+        if rst.size != nseg - 1:
+            raise CorruptJpeg(f"{rst.size} restart markers for {nseg} intervals")
+    else:
+        if rst.size:
+            raise CorruptJpeg("restart markers without DRI")
+        nseg = 1
+    seg_beg = np.concatenate([[0], rst + 2]).astype(np.uint32)
+    seg_end = np.concatenate([rst, [scan_len]]).astype(np.uint32)
+    # fill bytes (FF FF .. before a marker) belong to no segment
+    for s in range(nseg):
+        e = int(seg_end[s])
+        while e > int(seg_beg[s]) and d[e - 1] == 0xFF:
+            e -= 1
+        seg_end[s] = e
+    if np.any(seg_end <= seg_beg):
+        raise CorruptJpeg("empty restart interval")
+    per = -(-(seg_end - seg_beg).astype(np.int64) // chunk_bytes)
+    seg_chunk0 = np.concatenate([[0], np.cumsum(per)[:-1]]).astype(np.int32)
+    chunk_seg = np.repeat(np.arange(nseg, dtype=np.int32), per)
+    fr.restart, fr.nseg, fr.nchunks, fr.chunk_bytes = restart, nseg, int(chunk_seg.size), chunk_bytes
+    key = b"".join(huff[t][0] + huff[t][1] for t in tables)
+    return Plan(frame=fr, scan=np.ascontiguousarray(d[:scan_len]), lut_key=key, lut=_lut_block(key), qt=qt, seg_beg=seg_beg,
+                seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling)
+
+
+def is_jpeg(buf) -> bool:
+    return len(buf) >= 3 and buf[0] == 0xFF and buf[1] == 0xD8 and buf[2] == 0xFF
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device side
+# ---------------------------------------------------------------------------------------------------------------------
+_lut_cache = {}
+
+
+def _device_lut(pl: Plan, device):
+    import torch
+    key = (pl.lut_key, str(device))
+    t = _lut_cache.get(key)
+    if t is None:
+        if len(_lut_cache) > 16:
+            _lut_cache.clear()
+        t = _lut_cache[key] = torch.from_numpy(pl.lut.view(np.int16)).to(device)
+    return t
+
+
+def apply_orientation(img, orientation: int):
+    """EXIF orientation the way cv2.imread applies it (loadsave.cpp ExifTransform); ``img`` [H,W] or [H,W,3] tensor."""
+    if orientation == 2:
+        img = img.flip(1)
+    elif orientation == 3:
+        img = img.flip(0, 1)
+    elif orientation == 4:
+        img = img.flip(0)
+    elif orientation == 5:
+        img = img.transpose(0, 1)
+    elif orientation == 6:
+        img = img.transpose(0, 1).flip(1)
+    elif orientation == 7:
+        img = img.transpose(0, 1).flip(0, 1)
+    elif orientation == 8:
+        img = img.transpose(0, 1).flip(0)
+    return img.contiguous()
+
+
+def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_bytes: int = CHUNK_BYTES, orient: bool = True,
+           return_info: bool = False):
+    """The bytes of ``cv2.imread(IMREAD_GRAYSCALE)`` ([H,W] uint8, ``color=False``) / of ``cv2.imread(IMREAD_COLOR)`` after
+    BGR2RGB ([H,W,3], ``color=True``) as a device tensor.  Raises ``UnsupportedJpeg`` for files outside the device path and
+    ``CorruptJpeg`` for streams that do not decode; reads 16 bytes of status back once per call (more sweeps follow only if the
+    fixed point was not reached, which the default covers for every file seen so far)."""
+    import torch
+    from . import ops
+    pl = plan(buf, chunk_bytes)
+    device = torch.device(device)
+    out, info = ops.jpeg_decode(pl, _device_lut(pl, device) if device.type == "cuda" else None, 3 if color else 1, device, sweeps)
+    if orient and pl.orientation != 1:
+        out = apply_orientation(out, pl.orientation)
+    return (out, info) if return_info else out

@@ -8,6 +8,7 @@ import functools
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -739,6 +740,64 @@ def resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pad
                                       ph, pw, _ptr(lut), _stream())
     _lib.check(rc, "dfsfm_resample_u8")
     return o8, of, mk
+
+
+def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 12, max_calls: int = 8):
+    """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``): uploads the scan and its small tables in ONE copy, runs the
+    chunk-parallel entropy decode + IDCT (+ upsampling / colour conversion) and returns (uint8 [H,W] or [H,W,3] device tensor,
+    dict(sweeps, calls)).  ``lut``: the [4,65536] Huffman prefix tables on the device (jpeg._device_lut caches them by DHT
+    content).  Reads the 16-byte status back once per call: a file whose relaxation has not reached its fixed point after
+    ``sweeps`` passes is continued (resume) with twice as many; corrupt streams raise."""
+    from . import jpeg as _jpeg
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
+    _require_cuda(lut)
+    if lut.dtype != torch.int16 or tuple(lut.shape) != (4, 65536) or not lut.is_contiguous():
+        raise _lib.DfsfmError("jpeg_decode: lut is the contiguous [4, 65536] 16-bit prefix table")
+    if out_channels not in (1, 3):
+        raise _lib.DfsfmError("jpeg_decode: out_channels is 1 (luma) or 3 (RGB)")
+    with torch.cuda.device(device):
+        L = _lib.lib()
+        fr = pl.frame
+        nbytes = L.dfsfm_jpeg_decode_workspace(ctypes.byref(fr), out_channels)
+        if nbytes == 0:
+            raise _jpeg.UnsupportedJpeg("frame outside the device decoder (dfsfm_jpeg_decode_workspace)")
+        # one host buffer = one H2D copy: [scan | qt | seg_beg | seg_end | seg_chunk0 | chunk_seg], each part 16-byte aligned
+        parts = [pl.scan, pl.qt.reshape(-1).view(np.uint8), pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8),
+                 pl.seg_chunk0.view(np.uint8), pl.chunk_seg.view(np.uint8)]
+        offs, o = [], 0
+        for a in parts:
+            offs.append(o)
+            o = (o + a.size + 15) // 16 * 16
+        host = torch.empty((o,), dtype=torch.uint8, pin_memory=True)
+        hv = host.numpy()
+        for a, at in zip(parts, offs):
+            hv[at:at + a.size] = a
+        devbuf = host.to(device, non_blocking=True)
+        base = devbuf.data_ptr()
+        ptrs = [ctypes.c_void_p(base + at) for at in offs]
+        out = torch.empty((fr.height, fr.width) if out_channels == 1 else (fr.height, fr.width, 3), dtype=torch.uint8, device=device)
+        status = torch.empty((4,), dtype=torch.int32, device=device)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        calls, total, used = 0, 0, 0
+        while True:
+            rc = L.dfsfm_jpeg_decode_u8(ptrs[0], pl.scan.size, ctypes.byref(fr), _ptr(lut), ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                                        ptrs[5], _ptr(out), out.stride(0), out_channels, sweeps, int(calls > 0), _ptr(status),
+                                        _ptr(ws), nbytes, _stream())
+            _lib.check(rc, "dfsfm_jpeg_decode_u8")
+            calls += 1
+            total += sweeps
+            st = status.tolist()
+            used = total - sweeps + st[3] if st[3] else used
+            if st[0] == 0:
+                break
+            if calls >= max_calls:
+                raise _jpeg.CorruptJpeg(f"entropy decode did not reach its fixed point in {total} sweeps")
+            sweeps = min(64, 2 * sweeps)
+        if st[1] or st[2]:
+            raise _jpeg.CorruptJpeg(f"corrupt scan: {st[1]} invalid codes, {st[2]} restart intervals with a wrong block count")
+        return out, dict(sweeps=total, sweeps_used=used, calls=calls)
 
 
 @_on_device

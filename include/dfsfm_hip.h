@@ -445,6 +445,45 @@ int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, 
                                float attn_eps, void* out_hi, void* out_lo, int64_t ldo, float* out32, int64_t ldo32,
                                float* debug, int debug_stage, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Baseline JPEG decode (csrc/jpeg_decode.hip) -- the decode in front of dfsfm_resample_u8
+ * Replaces, for baseline Huffman files (SOF0 / SOF1, 8 bit; grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0; with or without DRI)
+ *   cv2.imread(path, cv2.IMREAD_GRAYSCALE)         src/dataset/utils.py:127 (read_grayscale), :183
+ *   cv2.imread(path, cv2.IMREAD_COLOR) + BGR2RGB   src/dataset/utils.py:86-92 (read_rgb)
+ * = libjpeg-turbo's default decompression (jdhuff.c decode_mcu, jidctint.c jpeg_idct_islow, jdsample.c fancy
+ * upsampling, jdcolor.c ycc_rgb_convert): out_channels 1 gives the luma plane (what IMREAD_GRAYSCALE returns, no
+ * colour conversion), 3 gives RGB; bytes identical to the library.  EXIF orientation is the caller's (a transpose / flip).
+ *
+ * The host parses the marker segments (detectorfreesfm_amd/jpeg.py) and passes
+ *   frame_host  the frame header as plain ints (below); nseg / nchunks / chunk_bytes describe how the scan is cut
+ *   scan        the entropy-coded bytes of the single interleaved scan, raw (stuffed zeros, RSTn markers in place)
+ *   huff_lut    [4][65536] uint16: (code length << 8) | symbol for every 16-bit prefix, 0 where no code matches;
+ *               slots named by dc_slot / ac_slot
+ *   qt          [3][64] uint16 quantisation steps per component, natural (row-major) order
+ *   seg_beg / seg_end [nseg] raw byte range of each restart interval's data (no markers); seg_chunk0 [nseg] its first
+ *               chunk; chunk_seg [nchunks] the segment of a chunk; chunk i of a segment covers chunk_bytes raw bytes
+ * Decoding is a fixed-point iteration over the chunks (`sweeps` relaxation passes, see the kernel file); status[0] == 0
+ * says the fixed point was reached -- otherwise call again with resume = 1 (the workspace keeps the state) and more
+ * sweeps.  status[1] = invalid codes on the final path, status[2] = restart intervals with a wrong block count (a corrupt
+ * file; `out` is then unspecified), status[3] = sweeps of this call that still decoded something.  status is 4 device
+ * int32, read by the caller when convenient: no host sync here.
+ * out [height][out_stride] bytes, out_stride >= width * out_channels.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfsfm_jpeg_frame {
+    int32_t width, height;
+    int32_t ncomp;                   /* 1 (grey) or 3 (Y, Cb, Cr) */
+    int32_t h[3], v[3];              /* sampling factors; chroma must be 1 x 1, luma 1x1 / 2x1 / 2x2 */
+    int32_t dc_slot[3], ac_slot[3];  /* huff_lut slot (0..3) of each component's DC / AC table */
+    int32_t restart;                 /* MCUs per restart interval (DRI), 0 = none */
+    int32_t nseg, nchunks, chunk_bytes;
+} dfsfm_jpeg_frame;
+size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int out_channels);   /* 0 = unsupported frame */
+int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* frame_host,
+                         const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* seg_beg, const uint32_t* seg_end,
+                         const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out, int64_t out_stride,
+                         int out_channels, int sweeps, int resume, int32_t* status, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

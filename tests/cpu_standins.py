@@ -398,6 +398,21 @@ def _enc256_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=N
     return None
 
 
+def _jpeg_decode(pl, lut, out_channels, device, sweeps=12, max_calls=8):
+    """ops.jpeg_decode on the CPU lane model of the decoder (tests/jpeg_emul.cpp: the device thread functions compiled with g++),
+    thread order reversed so that every sweep sees only the previous sweep's states, like a launch whose threads all start
+    together."""
+    import jpeg_emul
+    out, info = jpeg_emul.decode(pl, out_channels == 3, sweeps=sweeps, order=1, max_calls=max_calls)
+    st = info["status"]
+    from detectorfreesfm_amd import jpeg
+    if st[0] != 0:
+        raise jpeg.CorruptJpeg("entropy decode did not reach its fixed point")
+    if st[1] or st[2]:
+        raise jpeg.CorruptJpeg(f"corrupt scan: {st[1]} invalid codes, {st[2]} restart intervals with a wrong block count")
+    return torch.from_numpy(out), dict(sweeps=info["sweeps"], calls=info["calls"])
+
+
 @contextlib.contextmanager
 def cpu_ops():
     from detectorfreesfm_amd import ops
@@ -406,7 +421,9 @@ def cpu_ops():
                                           "maxpool3x3s2_nhwc", "split_rows", "linear_ln", "merge_keypoints", "resample_separable", "dwconv3x3",
                                           "bilinear_up", "resample_u8", "avgpool", "full_attention",
                                           "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear",
-                                          "encoder_kv", "encoder_apply", "encoder256_state", "encoder256_apply", "encoder256_kv")}
+                                          "encoder_kv", "encoder_apply", "encoder256_state", "encoder256_apply", "encoder256_kv",
+                                          "jpeg_decode")}
+    ops.jpeg_decode = _jpeg_decode
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool

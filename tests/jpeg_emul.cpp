@@ -1,0 +1,72 @@
+// CPU lane model of the device JPEG decoder: the SAME thread functions as csrc/jpeg_decode.hip (csrc/jpeg_core.h) and the same
+// host geometry (csrc/jpeg_host.h), compiled with g++; every kernel launch becomes a loop over its threads, in the launch
+// order of dfsfm_jpeg_decode_u8.  `order` permutes the thread order of the sweeps (0 ascending, 1 descending, 2 a fixed
+// shuffle): the relaxation must reach the same fixed point whatever the hardware's scheduling does.
+// Test infrastructure (tests/test_jpeg_cpu.py builds it into tests/_build/); not part of the product library.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "jpeg_core.h"
+#include "jpeg_host.h"
+
+extern "C" size_t jd_emul_workspace(const dfsfm_jpeg_frame* f, int out_channels) {
+    jd::Params P{};
+    if (!jd::derive(*f, P)) return 0;
+    return jd::layout_of(P, out_channels).total;
+}
+
+// returns 0, or the DFSFM_E_* code the real entry point would; sweeps_used (may be null) receives, per sweep, the chunks decoded
+extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* f, const uint16_t* lut,
+                              const uint16_t* qt, const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0,
+                              const int32_t* chunk_seg, uint8_t* out, int64_t out_stride, int out_channels, int sweeps,
+                              int resume, int32_t* status, void* workspace, size_t workspace_bytes, int order,
+                              int32_t* work_out) {
+    jd::Params P{};
+    if (!jd::derive(*f, P)) return DFSFM_E_UNSUPPORTED;
+    if (out_stride < (int64_t)P.width * out_channels || sweeps < 1 || sweeps > 64) return DFSFM_E_BADARG;
+    const jd::Layout L = jd::layout_of(P, out_channels);
+    if (workspace_bytes < L.total) return DFSFM_E_WORKSPACE;
+    jd::bind(P, L, static_cast<char*>(workspace), scan, lut, qt, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
+             out_channels, status);
+    std::memset(P.work, 0, 64 * 4);
+    std::memset(status, 0, 16);
+    std::vector<int> perm(P.nchunks);
+    for (int c = 0; c < P.nchunks; ++c) perm[c] = order == 1 ? P.nchunks - 1 - c : c;
+    if (order == 2) {
+        uint32_t s = 12345;
+        for (int c = P.nchunks - 1; c > 0; --c) {
+            s = s * 1664525u + 1013904223u;
+            std::swap(perm[c], perm[(s >> 8) % (uint32_t)(c + 1)]);
+        }
+    }
+    if (!resume)
+        for (int c = 0; c < P.nchunks; ++c) jd::init_thread(P, c);
+    for (int s = 0; s < sweeps; ++s)
+        for (int i = 0; i < P.nchunks; ++i) jd::sweep_thread(P, perm[i], s);
+    status[0] = P.work[sweeps - 1];
+    for (int i = 0; i < sweeps; ++i)
+        if (P.work[i]) status[3] = i + 1;
+    if (work_out) std::memcpy(work_out, P.work, 64 * 4);
+    {
+        std::vector<int32_t> part(jd::SCAN_T);
+        for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_a(P, t, part.data());
+        jd::scan_phase_b(part.data());
+        for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_c(P, t, part.data());
+    }
+    std::memset(P.coef, 0, (size_t)P.nblocks * 128);
+    for (int c = 0; c < P.nchunks; ++c) jd::write_thread(P, c);
+    const int ng = jd::dc_ngroups(P);
+    for (int g = 0; g < ng; ++g) jd::dc_sum_thread(P, g);
+    {
+        std::vector<int32_t> part(4 * jd::SCAN_T);
+        for (int t = 0; t < jd::SCAN_T; ++t) jd::dc_scan_phase_a(P, t, part.data());
+        jd::dc_scan_phase_b(part.data());
+        for (int t = 0; t < jd::SCAN_T; ++t) jd::dc_scan_phase_c(P, t, part.data());
+    }
+    for (int g = 0; g < ng; ++g) jd::dc_apply_thread(P, g);
+    for (int b = 0; b < P.nblocks; ++b) jd::idct_thread(P, b);
+    if (out_channels == 3)
+        for (int y = 0; y < P.height; ++y)
+            for (int x = 0; x < P.width; ++x) jd::color_thread(P, x, y);
+    return 0;
+}

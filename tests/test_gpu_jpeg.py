@@ -1,0 +1,96 @@
+"""Device JPEG decode (csrc/jpeg_decode.hip through the C ABI) against the oracle (oracle/jpeg_baseline.c) and against
+libjpeg-turbo itself (the installed Pillow): bytes identical for every supported sampling / restart / table layout, odd sizes,
+EXIF orientations, a 12-megapixel frame; corrupt and unsupported files raise; the readers take file names."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_jpeg_cpu import cases, encode, pil_gray, pil_rgb, synth   # noqa: E402
+from detectorfreesfm_amd import _lib, images, jpeg                   # noqa: E402
+from oracle import restate_jpeg as rj                                # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_device_decode_matches_oracle_and_libjpeg_turbo():
+    n = 0
+    for key, buf in cases([(1, 1), (8, 8), (7, 5), (17, 33), (100, 75), (241, 319)]):
+        for color in (False, True):
+            ref = rj.decode(buf, color)
+            assert np.array_equal(ref, pil_rgb(buf) if color else pil_gray(buf)), key
+            out, info = jpeg.decode(buf, color, DEV, chunk_bytes=32 if n % 2 else 128, return_info=True)
+            assert out.dtype == torch.uint8 and out.is_cuda
+            assert np.array_equal(out.cpu().numpy(), ref), (key, color, info)
+        n += 1
+    assert n > 200
+
+
+def test_camera_sized_frames_and_sweep_counts():
+    """640x480 / 1600x1200 / 4000x3000 frames, 4:2:0 and 4:4:4, with and without restart markers: identical bytes; the relaxation
+    settles within the default sweep budget (one call) on all of them."""
+    for (h, w, kw) in [(480, 640, dict(quality=90, subsampling=2)), (1200, 1600, dict(quality=85, subsampling=2)),
+                       (1200, 1600, dict(quality=95, subsampling=0)), (1200, 1600, dict(quality=85, subsampling=1, restart_marker_rows=1)),
+                       (3000, 4000, dict(quality=90, subsampling=2))]:
+        buf = encode(synth(h, w, True, seed=h), **kw)
+        for color in (False, True):
+            out, info = jpeg.decode(buf, color, DEV, return_info=True)
+            assert np.array_equal(out.cpu().numpy(), rj.decode(buf, color)), (h, w, kw, color)
+            assert info["calls"] <= 2, info
+    buf = encode(synth(1200, 1600, False, seed=5), quality=80)             # a grey file, as RGB too
+    assert np.array_equal(jpeg.decode(buf, True, DEV).cpu().numpy(), rj.decode(buf, True))
+    assert np.array_equal(jpeg.decode(buf, False, DEV).cpu().numpy(), rj.decode(buf, False))
+
+
+def test_few_sweeps_resume_to_the_same_bytes():
+    buf = encode(synth(480, 640, True, seed=9), quality=90, subsampling=2)
+    ref = rj.decode(buf, True)
+    out, info = jpeg.decode(buf, True, DEV, sweeps=1, return_info=True)
+    assert info["calls"] > 1 and np.array_equal(out.cpu().numpy(), ref)
+    again = jpeg.decode(buf, True, DEV, sweeps=64)
+    assert torch.equal(out, again)
+
+
+def test_orientation_corrupt_and_unsupported():
+    from PIL import Image, ImageOps
+    img = synth(40, 56)
+    for orientation in (1, 3, 6, 8, 5):
+        exif = Image.Exif()
+        exif[0x0112] = orientation
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=90, exif=exif)
+        want = np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(b.getvalue()))).convert("RGB"))
+        assert np.array_equal(jpeg.decode(b.getvalue(), True, DEV).cpu().numpy(), want)
+    good = encode(synth(120, 160), quality=85, subsampling=2)
+    pl = jpeg.plan(good)
+    start = good.index(pl.scan.tobytes()[:16])
+    with pytest.raises(jpeg.CorruptJpeg):
+        jpeg.decode(good[:start + pl.scan.size // 2] + b"\xff\xd9", False, DEV)
+    with pytest.raises(jpeg.UnsupportedJpeg):
+        jpeg.decode(encode(img, progressive=True), False, DEV)
+    # the C ABI refuses bad arguments before anything is launched
+    L = _lib.lib()
+    assert L.dfsfm_jpeg_decode_workspace(None, 1) == 0
+    assert L.dfsfm_jpeg_decode_u8(None, 0, None, None, None, None, None, None, None, None, 0, 1, 1, 0, None, None, 0, None) == -1
+
+
+def test_readers_take_file_names(tmp_path):
+    img = synth(300, 400)
+    p = tmp_path / "frame.jpg"
+    p.write_bytes(encode(img, quality=88, subsampling=2))
+    pp = tmp_path / "prog.jpg"
+    pp.write_bytes(encode(img, quality=88, progressive=True))
+    for path in (p, pp):                                                   # device decode / host fallback: the same luma plane
+        a = images.read_grayscale(str(path), resize=(256,), df=8, device=DEV)
+        b = images.read_grayscale(pil_gray(path.read_bytes()), resize=(256,), df=8, device=DEV)
+        assert torch.equal(a, b)
+    a = images.read_rgb(str(p), resize=(256,), df=8, device=DEV, decode="device")
+    b = images.read_rgb(pil_rgb(p.read_bytes()), resize=(256,), df=8, device=DEV)
+    assert torch.equal(a, b)
+    with pytest.raises(jpeg.UnsupportedJpeg):
+        images.read_grayscale(str(pp), device=DEV, decode="device")

@@ -92,14 +92,18 @@ def test_golden_is_what_the_reference_returns_now():
 
 
 def test_example_jpeg_through_the_readers():
-    """One of the reference's example JPEGs, decoded by PIL, through oracle and product (emulated kernel) at the
-    pipeline's setting (larger side 640, df 8): the two agree and equal Pillow's own resize."""
+    """One of the reference's example JPEGs through oracle and product at the pipeline's setting (larger side 640, df 8): the
+    product decodes the FILE (jpeg.decode on the CPU lane model of the device decoder) to the luma plane -- what
+    cv2.imread(IMREAD_GRAYSCALE) and Pillow's draft('L') both get from libjpeg-turbo -- and then agrees with the oracle reader
+    and with Pillow's own resize of those bytes."""
     from PIL import Image
     root = "/root/reference/SfM_dataset/example_dataset/example_scene/images"
     if not os.path.isdir(root):
         pytest.skip("reference example scene not present")
     path = os.path.join(root, sorted(os.listdir(root))[0])
-    gray = np.asarray(Image.open(path).convert("L"))
+    im = Image.open(path)
+    im.draft("L", im.size)
+    gray = np.asarray(im)
     h, w = gray.shape
     o_img, o_scales, o_hw, _ = rr.read_image(gray, resize=(640,), df=8)
     w_new, h_new = rr.process_resize(w, h, (640,), 8)

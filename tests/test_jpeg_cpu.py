@@ -1,0 +1,238 @@
+"""JPEG decode, CPU side: (1) the oracle (oracle/jpeg_baseline.c, the sequential restatement of libjpeg-turbo's default
+decompression path = what the reference's cv2.imread calls run) is pinned byte for byte to libjpeg-turbo itself through the
+installed Pillow; (2) the CPU lane model of the DEVICE decoder (tests/jpeg_emul.cpp: the thread functions of csrc/jpeg_core.h
+compiled with g++, kernels as loops, three thread orders) is held to the oracle on every supported sampling / restart / table
+combination, through the resume path, and on the reference's own example-scene files where /root/reference is mounted;
+(3) the host parser (detectorfreesfm_amd/jpeg.py) refuses what the device path does not take and reads the EXIF orientation."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import jpeg_emul                                                     # noqa: E402
+from cpu_standins import cpu_ops                                     # noqa: E402
+from detectorfreesfm_amd import images, jpeg                         # noqa: E402
+from oracle import restate_jpeg as rj                                # noqa: E402
+
+REF_SCENE = "/root/reference/SfM_dataset/example_dataset/example_scene/images"
+
+
+def synth(h, w, color=True, seed=0):
+    """Smooth structure + noise + a bright patch + salt: long and short Huffman codes, big and small DC steps."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 100 * np.sin(x / 17. + k) * np.cos(y / 23. - k) for k in range(3)], -1)
+    base += rng.normal(0, 12, (h, w, 3))
+    base[h // 3:h // 2, w // 4:w // 2] += 80
+    base = (base + (rng.random((h, w, 1)) > 0.995) * 120).clip(0, 255).astype(np.uint8)
+    return base if color else np.ascontiguousarray(base[..., 0])
+
+
+def encode(img, **kw):
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def pil_gray(buf):
+    im = Image.open(io.BytesIO(buf))
+    im.draft("L", im.size)                       # libjpeg-turbo's own JCS_GRAYSCALE output: what cv2.IMREAD_GRAYSCALE asks for
+    return np.asarray(im)
+
+
+def pil_rgb(buf):
+    return np.asarray(Image.open(io.BytesIO(buf)).convert("RGB"))
+
+
+def cases(sizes, subs=(0, 1, 2, "gray"), qualities=(5, 50, 92), restarts=(0, 1, 5), optimize=(False, True)):
+    k = 0
+    for (h, w) in sizes:
+        for sub in subs:
+            for q in qualities:
+                for rst in restarts:
+                    opt = optimize[k % len(optimize)]
+                    k += 1
+                    kw = dict(quality=q, optimize=opt)
+                    if sub != "gray":
+                        kw["subsampling"] = sub
+                    if rst:
+                        kw["restart_marker_blocks"] = rst
+                    try:
+                        yield (h, w, sub, q, rst, opt), encode(synth(h, w, sub != "gray", seed=k), **kw)
+                    except OSError:              # Pillow's encoder buffer is too small for a few quality-100 optimised files
+                        continue
+
+
+def test_oracle_pinned_to_libjpeg_turbo():
+    n = 0
+    for key, buf in cases([(1, 1), (8, 8), (7, 5), (16, 16), (17, 33), (100, 75), (241, 319)], qualities=(5, 50, 92, 100)):
+        assert np.array_equal(rj.decode(buf, False), pil_gray(buf)), key
+        assert np.array_equal(rj.decode(buf, True), pil_rgb(buf)), key
+        n += 1
+    assert n > 300
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENE), reason="reference example scene not present")
+def test_oracle_and_lane_model_on_the_reference_scene():
+    """The reference's only data fixture: eight 4:2:0 baseline JPEGs.  Oracle == libjpeg-turbo, lane model == oracle, with
+    every sweep seeing only the previous sweep's states (order 1) at two chunk sizes."""
+    for name in sorted(os.listdir(REF_SCENE)):
+        buf = open(os.path.join(REF_SCENE, name), "rb").read()
+        g, c = rj.decode(buf, False), rj.decode(buf, True)
+        assert np.array_equal(g, pil_gray(buf)) and np.array_equal(c, pil_rgb(buf)), name
+        for cb, color in ((128, False), (256, True)):
+            out, info = jpeg_emul.decode(jpeg.plan(buf, cb), color, sweeps=12, order=1)
+            assert info["status"][:3].tolist() == [0, 0, 0], (name, info)
+            assert np.array_equal(out, c if color else g), name
+
+
+def test_lane_model_matches_oracle_on_every_supported_layout():
+    n = 0
+    for key, buf in cases([(1, 1), (8, 8), (7, 5), (17, 33), (100, 75), (241, 319)]):
+        pl = jpeg.plan(buf, 64 if n % 2 else 16)
+        for color in (False, True):
+            ref = rj.decode(buf, color)
+            out, info = jpeg_emul.decode(pl, color, sweeps=3, order=n % 3)          # 3 sweeps per call: the resume path
+            assert info["status"][:3].tolist() == [0, 0, 0], (key, info)
+            assert np.array_equal(out, ref), (key, color, info)
+        n += 1
+    assert n > 200
+
+
+def test_thread_order_does_not_change_the_fixed_point():
+    buf = encode(synth(480, 640, True, seed=3), quality=90, subsampling=2)
+    pl = jpeg.plan(buf)
+    ref = rj.decode(buf, True)
+    sweeps = []
+    for order in (0, 1, 2):
+        out, info = jpeg_emul.decode(pl, True, sweeps=64, order=order)
+        assert np.array_equal(out, ref) and info["calls"] == 1
+        sweeps.append(info["sweeps"])
+    assert sweeps[0] == 1                    # ascending order = sequential decode: one sweep
+    assert 1 < sweeps[1] <= 64               # previous-sweep states only: a handful (self-synchronisation), not nchunks
+    assert pl.frame.nchunks > 200
+
+
+def test_huffman_lut_is_the_canonical_code():
+    buf = encode(synth(64, 64), quality=75, optimize=True)
+    pl = jpeg.plan(buf)
+    # every code of every table: the prefix range maps to (length, symbol); everything else is 0
+    o = 0
+    for slot in range(4):
+        if o >= len(pl.lut_key):
+            assert not pl.lut[slot].any()
+            continue
+        bits = pl.lut_key[o:o + 16]
+        nv = sum(bits)
+        vals = pl.lut_key[o + 16:o + 16 + nv]
+        o += 16 + nv
+        code, k, covered = 0, 0, 0
+        for length in range(1, 17):
+            for _ in range(bits[length - 1]):
+                lo, hi = code << (16 - length), (code + 1) << (16 - length)
+                assert (pl.lut[slot][lo:hi] == ((length << 8) | vals[k])).all()
+                covered += hi - lo
+                code += 1
+                k += 1
+            code <<= 1
+        assert int((pl.lut[slot] != 0).sum()) == covered
+
+
+def test_parser_refuses_what_the_device_path_does_not_take():
+    img = synth(64, 48)
+    with pytest.raises(jpeg.UnsupportedJpeg):
+        jpeg.plan(encode(img, progressive=True))
+    with pytest.raises(jpeg.UnsupportedJpeg):
+        b = io.BytesIO()
+        Image.fromarray(img).convert("CMYK").save(b, "JPEG")
+        jpeg.plan(b.getvalue())
+    with pytest.raises(jpeg.CorruptJpeg):
+        jpeg.plan(b"\x89PNG\r\n\x1a\n" + bytes(64))
+    good = encode(img, quality=80)
+    with pytest.raises(jpeg.CorruptJpeg):
+        jpeg.plan(good[:200])                                           # cut inside the tables
+    assert not jpeg.is_jpeg(b"\x89PNG") and jpeg.is_jpeg(good)
+    info = rj.info(encode(img, progressive=True))
+    assert info["progressive"] and not info["supported"]
+    with cpu_ops():
+        with pytest.raises(jpeg.UnsupportedJpeg):
+            jpeg.decode(encode(img, progressive=True), False, device="cpu")
+
+
+def test_corrupt_scans_terminate_and_are_order_independent():
+    """Bit errors inside the entropy-coded bytes.  JPEG has no checksum: most flips just change coefficients, some change the
+    block count of the segment (status[2]) or hit a prefix no code has (status[1]).  What must hold for ALL of them: the
+    relaxation terminates, nothing is written out of bounds (the lane model runs under the kernels' own bounds), and the result
+    -- image AND status -- is the same whatever order the threads of a sweep run in (the fixed point is unique)."""
+    buf = bytearray(encode(synth(120, 160), quality=85, subsampling=2))
+    pl0 = jpeg.plan(bytes(buf))
+    start = bytes(buf).index(pl0.scan.tobytes()[:16])
+    rng = np.random.default_rng(1)
+    flagged = 0
+    for trial in range(40):
+        bad = bytearray(buf)
+        for pos in rng.integers(start + 8, start + pl0.scan.size - 8, 1 + trial % 6):
+            if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+                if bad[pos] == 0xFF:
+                    bad[pos] = 0xFE
+        pl = jpeg.plan(bytes(bad), 32)
+        outs = [jpeg_emul.decode(pl, False, sweeps=8, order=o) for o in (0, 1, 2)]
+        for out, info in outs:
+            assert out.shape == (120, 160) and info["status"][0] == 0
+            assert np.array_equal(out, outs[0][0]) and info["status"][:3].tolist() == outs[0][1]["status"][:3].tolist()
+        flagged += int(outs[0][1]["status"][1] != 0 or outs[0][1]["status"][2] != 0)
+    assert flagged >= 1
+    # a truncated scan: blocks are missing, every caller sees it
+    cut = bytes(buf[:start + pl0.scan.size // 2]) + b"\xff\xd9"
+    out, info = jpeg_emul.decode(jpeg.plan(cut), False, sweeps=16, order=1)
+    assert info["status"][2] != 0
+    with cpu_ops():
+        with pytest.raises(jpeg.CorruptJpeg):
+            jpeg.decode(cut, False, device="cpu")
+
+
+def test_exif_orientation_like_cv2_imread():
+    img = synth(40, 56)
+    from PIL import ImageOps
+    for orientation in range(1, 9):
+        exif = Image.Exif()
+        exif[0x0112] = orientation
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=90, exif=exif)
+        buf = b.getvalue()
+        assert jpeg.plan(buf).orientation == orientation and rj.info(buf)["orientation"] == orientation
+        want = np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(buf))).convert("RGB"))
+        assert np.array_equal(rj.apply_orientation(rj.decode(buf, True), orientation), want)
+        with cpu_ops():
+            got = jpeg.decode(buf, True, device="cpu")
+        assert np.array_equal(got.numpy(), want), orientation
+
+
+def test_readers_decode_files_on_the_product_path(tmp_path):
+    """images.read_grayscale / read_rgb given a FILE NAME: decode='auto' sends a baseline JPEG through jpeg.decode (here on the
+    lane model) and equals the reader fed the library's own decode; a progressive file falls back to the host decoder; the
+    'device' setting refuses it."""
+    img = synth(150, 200)
+    p = tmp_path / "frame.jpg"
+    p.write_bytes(encode(img, quality=88, subsampling=2))
+    pp = tmp_path / "prog.jpg"
+    pp.write_bytes(encode(img, quality=88, progressive=True))
+    with cpu_ops():
+        a = images.read_grayscale(str(p), resize=(96,), df=8, device="cpu")
+        b = images.read_grayscale(pil_gray(p.read_bytes()), resize=(96,), df=8, device="cpu")
+        assert np.array_equal(a.numpy(), b.numpy())
+        a = images.read_rgb(str(p), resize=(96,), df=8, device="cpu", decode="device")
+        b = images.read_rgb(pil_rgb(p.read_bytes()), resize=(96,), df=8, device="cpu")
+        assert np.array_equal(a.numpy(), b.numpy())
+        a = images.read_grayscale(str(pp), resize=(96,), df=8, device="cpu")            # auto -> host (Pillow here: the luma plane)
+        b = images.read_grayscale(pil_gray(pp.read_bytes()), resize=(96,), df=8, device="cpu")
+        assert np.array_equal(a.numpy(), b.numpy())
+        with pytest.raises(jpeg.UnsupportedJpeg):
+            images.read_grayscale(str(pp), device="cpu", decode="device")
+        a = images.read_grayscale(str(p), resize=(96,), df=8, device="cpu", decode="host")
+        assert np.array_equal(a.numpy(), images.read_grayscale(pil_gray(p.read_bytes()), resize=(96,), df=8, device="cpu").numpy())
