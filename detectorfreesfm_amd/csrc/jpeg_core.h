@@ -73,6 +73,8 @@ struct Reader {
     uint64_t acc;                          // nbytes data bytes from `raw` on, left aligned
     uint32_t nbytes;
     uint32_t nxt;
+    uint64_t win;                          // the aligned 8 raw bytes at wbase (one global load per 8 bytes of scan)
+    uint32_t wbase;
 };
 JD_FN void reader_init(Reader& r, const uint8_t* d, uint32_t lim, uint64_t pos) {
     r.d = d;
@@ -82,10 +84,19 @@ JD_FN void reader_init(Reader& r, const uint8_t* d, uint32_t lim, uint64_t pos) 
     r.acc = 0;
     r.nbytes = 0;
     r.nxt = r.raw;
+    r.win = 0;
+    r.wbase = 0xFFFFFFFFu;
 }
 JD_FN void reader_fetch(Reader& r) {
     uint32_t b = 0;
-    if (r.nxt < r.lim) b = r.d[r.nxt];
+    if (r.nxt < r.lim) {
+        const uint32_t wb = r.nxt & ~7u;
+        if (wb != r.wbase) {                                   // `scan` is 8-byte aligned and readable to the next multiple of 8
+            r.win = *reinterpret_cast<const uint64_t*>(r.d + wb);
+            r.wbase = wb;
+        }
+        b = (uint32_t)(r.win >> (8 * (r.nxt & 7))) & 0xFF;
+    }
     r.nxt += b == 0xFF ? 2 : 1;
     r.acc |= (uint64_t)b << (56 - 8 * r.nbytes);
     r.nbytes += 1;
@@ -152,6 +163,18 @@ JD_FN uint64_t default_entry(const Params& P, const Chunk& k) {
     return pack_state((uint64_t)s * 8, 0, 0);
 }
 
+// ---- two-level Huffman lookup ----------------------------------------------------------------------------------------
+// The 16-bit-prefix tables (4 x 128 KB) live in L2; a workgroup keeps their first L1_BITS levels in LDS: entry i of a slot is
+// the table's entry for prefix i << (16 - L1_BITS) when that code is no longer than L1_BITS bits (then all 2^(16 - L1_BITS)
+// continuations agree), else 0 = "ask the big table".  Almost every symbol of a photograph is answered from LDS.
+constexpr int L1_BITS = 10;
+constexpr int L1_SIZE = 4 << L1_BITS;
+JD_FN uint16_t l1_entry(const uint16_t* lut, int i) {
+    const int slot = i >> L1_BITS, prefix = i & ((1 << L1_BITS) - 1);
+    const uint16_t e = lut[(size_t)slot * 65536 + ((size_t)prefix << (16 - L1_BITS))];
+    return (e >> 8) <= L1_BITS ? e : (uint16_t)0;
+}
+
 // ---- the Huffman decoder of one chunk ----------------------------------------------------------------------------
 // Decodes the symbols that START inside [entry position, chunk end): DC size + difference when z == 0, AC run / size (EOB,
 // ZRL) otherwise (ITU T.81 F.2.2; libjpeg-turbo jdhuff.c decode_mcu).  WRITE: coefficients go to coef[block][natural index]
@@ -162,7 +185,7 @@ struct ChunkResult {
     int32_t nblk, nbad;
 };
 template <bool WRITE>
-JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit) {
+JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint16_t* l1) {
     Reader r;
     reader_init(r, P.scan, k.lim, entry >> 16);
     uint32_t b = (uint32_t)(entry >> 8) & 0xFF, z = (uint32_t)entry & 0xFF;
@@ -171,8 +194,10 @@ JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, 
     res.nblk = 0;
     res.nbad = 0;
     while (reader_pos(r) < end_pos && (!WRITE || blk < blk_limit)) {
-        const uint16_t* lut = P.lut + (size_t)(z == 0 ? P.blk_dc[b] : P.blk_ac[b]) * 65536;
-        const uint32_t e = lut[reader_peek(r, 16)];
+        const uint32_t slot = (uint32_t)(z == 0 ? P.blk_dc[b] : P.blk_ac[b]);
+        const uint32_t pk = reader_peek(r, 16);
+        uint32_t e = l1[(slot << L1_BITS) | (pk >> (16 - L1_BITS))];
+        if (e == 0) e = P.lut[(size_t)slot * 65536 + pk];
         const uint32_t len = e >> 8;
         if (len == 0) {
             reader_skip(r, 1);
@@ -228,11 +253,14 @@ JD_FN void init_thread(const Params& P, int c) {
 // segment starts from the truth, so after sweep i the first i + 1 chunks of every segment are final; because Huffman
 // streams self-synchronise, a wrong entry usually leads to the right exit within the chunk and the fixed point arrives
 // after a handful of sweeps.  A sweep that decodes nothing IS the fixed point (every stored result matches its entry).
-JD_FN void sweep_thread(const Params& P, int c, int sweep) {
+JD_FN bool sweep_needs(const Params& P, int c, uint64_t& entry) {
     const Chunk k = chunk_of(P, c);
-    const uint64_t entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : JD_LOAD64(&P.exit_state[c - 1]);
-    if (entry == P.last_entry[c]) return;
-    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0);
+    entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : JD_LOAD64(&P.exit_state[c - 1]);
+    return entry != P.last_entry[c];
+}
+JD_FN void sweep_thread(const Params& P, int c, int sweep, uint64_t entry, const uint16_t* l1) {
+    const Chunk k = chunk_of(P, c);
+    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, l1);
     JD_STORE64(&P.exit_state[c], res.exit);
     P.last_entry[c] = entry;
     P.nblk[c] = res.nblk;
@@ -247,14 +275,28 @@ JD_FN void scan_phase_a(const Params& P, int t, int32_t* part) {
     for (int c = t * span; c < (t + 1) * span && c < P.nchunks; ++c) s += P.nblk[c];
     part[t] = s;
 }
-JD_FN void scan_phase_b(int32_t* part) {                    // thread 0
+// the SCAN_T span sums -> their exclusive prefix, in three short phases instead of one thread walking 1024 LDS words:
+// b1 thread g < SCAN_G scans its SCAN_T / SCAN_G entries in place and leaves the group total in grp[g]; b2 thread 0 scans the
+// SCAN_G totals; b3 every thread adds its group's offset.
+constexpr int SCAN_G = 32;
+JD_FN void scan_phase_b1(int32_t* part, int32_t* grp, int g) {
     int32_t run = 0;
-    for (int t = 0; t < SCAN_T; ++t) {
+    for (int t = g * (SCAN_T / SCAN_G); t < (g + 1) * (SCAN_T / SCAN_G); ++t) {
         const int32_t s = part[t];
         part[t] = run;
         run += s;
     }
+    grp[g] = run;
 }
+JD_FN void scan_phase_b2(int32_t* grp) {                    // thread 0
+    int32_t run = 0;
+    for (int g = 0; g < SCAN_G; ++g) {
+        const int32_t s = grp[g];
+        grp[g] = run;
+        run += s;
+    }
+}
+JD_FN void scan_phase_b3(int32_t* part, const int32_t* grp, int t) { part[t] += grp[t / (SCAN_T / SCAN_G)]; }
 JD_FN void scan_phase_c(const Params& P, int t, const int32_t* part) {
     const int span = scan_span(P);
     int32_t run = part[t];
@@ -264,7 +306,7 @@ JD_FN void scan_phase_c(const Params& P, int t, const int32_t* part) {
     }
 }
 
-JD_FN void write_thread(const Params& P, int c) {
+JD_FN void write_thread(const Params& P, int c, const uint16_t* l1) {
     const Chunk k = chunk_of(P, c);
     const uint64_t entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : P.exit_state[c - 1];
     const int32_t per_seg = P.restart ? P.restart * P.nb : P.nblocks;
@@ -273,7 +315,7 @@ JD_FN void write_thread(const Params& P, int c) {
     if (limit > P.nblocks) limit = P.nblocks;
     const int32_t blk = seg_blk0 + P.blk0[c] - P.blk0[P.seg_chunk0[k.seg]];
     if (blk >= limit && !k.last) return;
-    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit);
+    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit, l1);
     if (res.nbad) JD_ATOMIC_ADD(&P.status[1], res.nbad);
     if (k.last && blk + res.nblk != limit) JD_ATOMIC_ADD(&P.status[2], 1);
 }
@@ -315,14 +357,37 @@ JD_FN void dc_scan_phase_a(const Params& P, int t, int32_t* part) {
     }
     part[4 * t] = sum[0]; part[4 * t + 1] = sum[1]; part[4 * t + 2] = sum[2]; part[4 * t + 3] = reset;
 }
-JD_FN void dc_scan_phase_b(int32_t* part) {                 // thread 0: part[t] := prediction at the start of span t
-    int32_t run[3] = {0, 0, 0};
-    for (int t = 0; t < SCAN_T; ++t) {
+// (sum, reset) tuples compose: folding a tuple into a running prediction gives  reset ? sum : prediction + sum.  Same three
+// phases as above: b1 replaces every tuple of a group by the fold of the tuples BEFORE it in the group and leaves the group's
+// own fold in grp; b2 turns the group folds into the prediction each group starts from; b3 applies it.
+JD_FN void dc_fold(int32_t* acc, const int32_t* t) {        // acc := acc followed by t
+    if (t[3]) { acc[0] = t[0]; acc[1] = t[1]; acc[2] = t[2]; acc[3] = 1; }
+    else { acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; }
+}
+JD_FN void dc_scan_phase_b1(int32_t* part, int32_t* grp, int g) {
+    int32_t run[4] = {0, 0, 0, 0};
+    for (int t = g * (SCAN_T / SCAN_G); t < (g + 1) * (SCAN_T / SCAN_G); ++t) {
         int32_t* p = part + 4 * t;
-        const int32_t s0 = p[0], s1 = p[1], s2 = p[2], reset = p[3];
+        const int32_t cur[4] = {p[0], p[1], p[2], p[3]};
+        p[0] = run[0]; p[1] = run[1]; p[2] = run[2]; p[3] = run[3];
+        dc_fold(run, cur);
+    }
+    grp[4 * g] = run[0]; grp[4 * g + 1] = run[1]; grp[4 * g + 2] = run[2]; grp[4 * g + 3] = run[3];
+}
+JD_FN void dc_scan_phase_b2(int32_t* grp) {                 // thread 0: grp[g] := prediction at the start of group g
+    int32_t run[4] = {0, 0, 0, 0};
+    for (int g = 0; g < SCAN_G; ++g) {
+        int32_t* p = grp + 4 * g;
+        const int32_t cur[4] = {p[0], p[1], p[2], p[3]};
         p[0] = run[0]; p[1] = run[1]; p[2] = run[2];
-        if (reset) { run[0] = s0; run[1] = s1; run[2] = s2; }
-        else { run[0] += s0; run[1] += s1; run[2] += s2; }
+        dc_fold(run, cur);
+    }
+}
+JD_FN void dc_scan_phase_b3(int32_t* part, const int32_t* grp, int t) {   // part[t] := prediction at the start of span t
+    int32_t* p = part + 4 * t;
+    if (!p[3]) {
+        const int32_t* c = grp + 4 * (t / (SCAN_T / SCAN_G));
+        p[0] += c[0]; p[1] += c[1]; p[2] += c[2];
     }
 }
 JD_FN void dc_scan_phase_c(const Params& P, int t, const int32_t* part) {

@@ -22,8 +22,9 @@
 //   dc        per-component prefix sum of the DC differences in scan order (reset at restarts): 3 small launches
 //   idct      one thread per 8x8 block: dequantise + jpeg_idct_islow; the luma plane goes straight to the output
 //   colour    (RGB only) fancy upsampling of Cb / Cr + YCbCr -> RGB per output pixel
-// All integer / byte work, HBM- and latency-bound; no LDS staging is needed for a stream this small (a 0.5 MB file is 4000
-// threads), the Huffman tables are 16-bit-prefix LUTs that live in L2.
+// All integer / byte work, and latency-bound: a thread's next lookup depends on its last.  So the chain is kept short -- the
+// scan is read as aligned 8-byte words (one global load per 8 bytes), the Huffman tables are 16-bit-prefix LUTs in L2 whose
+// first 10 levels every workgroup copies into 8 KB of LDS (where almost every symbol of a photograph is answered).
 //
 // The marker segments (tables, frame header, restart positions) are parsed on the host (detectorfreesfm_amd/jpeg.py): a few
 // hundred bytes of control data.  Progressive, arithmetic-coded, 12-bit, CMYK and multi-scan files are refused there
@@ -44,30 +45,47 @@ __global__ __launch_bounds__(256) void jd_init_kernel(Params P) {
     if (c < P.nchunks) jd::init_thread(P, c);
 }
 __global__ __launch_bounds__(256) void jd_sweep_kernel(Params P, int sweep) {
+    __shared__ uint16_t l1[jd::L1_SIZE];
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < P.nchunks) jd::sweep_thread(P, c, sweep);
+    uint64_t entry = 0;
+    const bool need = c < P.nchunks && jd::sweep_needs(P, c, entry);
+    if (!__syncthreads_or(need)) return;                     // a settled stretch of the scan: nothing to look up
+    for (int i = threadIdx.x; i < jd::L1_SIZE; i += 256) l1[i] = jd::l1_entry(P.lut, i);
+    __syncthreads();
+    if (need) jd::sweep_thread(P, c, sweep, entry, l1);
 }
 __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
-    __shared__ int32_t part[jd::SCAN_T];
+    __shared__ int32_t part[jd::SCAN_T], grp[jd::SCAN_G];
     jd::scan_phase_a(P, threadIdx.x, part);
     __syncthreads();
-    if (threadIdx.x == 0) jd::scan_phase_b(part);
+    if (threadIdx.x < jd::SCAN_G) jd::scan_phase_b1(part, grp, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) jd::scan_phase_b2(grp);
+    __syncthreads();
+    jd::scan_phase_b3(part, grp, threadIdx.x);
     __syncthreads();
     jd::scan_phase_c(P, threadIdx.x, part);
 }
 __global__ __launch_bounds__(256) void jd_write_kernel(Params P) {
+    __shared__ uint16_t l1[jd::L1_SIZE];
+    for (int i = threadIdx.x; i < jd::L1_SIZE; i += 256) l1[i] = jd::l1_entry(P.lut, i);
+    __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < P.nchunks) jd::write_thread(P, c);
+    if (c < P.nchunks) jd::write_thread(P, c, l1);
 }
 __global__ __launch_bounds__(256) void jd_dc_sum_kernel(Params P) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < jd::dc_ngroups(P)) jd::dc_sum_thread(P, g);
 }
 __global__ __launch_bounds__(jd::SCAN_T) void jd_dc_scan_kernel(Params P) {
-    __shared__ int32_t part[4 * jd::SCAN_T];
+    __shared__ int32_t part[4 * jd::SCAN_T], grp[4 * jd::SCAN_G];
     jd::dc_scan_phase_a(P, threadIdx.x, part);
     __syncthreads();
-    if (threadIdx.x == 0) jd::dc_scan_phase_b(part);
+    if (threadIdx.x < jd::SCAN_G) jd::dc_scan_phase_b1(part, grp, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) jd::dc_scan_phase_b2(grp);
+    __syncthreads();
+    jd::dc_scan_phase_b3(part, grp, threadIdx.x);
     __syncthreads();
     jd::dc_scan_phase_c(P, threadIdx.x, part);
 }
@@ -108,6 +126,7 @@ extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, con
     if (!scan || !frame_host || !huff_lut || !qt || !seg_beg || !seg_end || !seg_chunk0 || !chunk_seg || !out || !status ||
         !workspace)
         return DFSFM_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(scan) & 7) != 0) return DFSFM_E_BADARG;      // the bit reader loads aligned 8-byte words
     if (scan_bytes <= 0 || scan_bytes >= (1ll << 31) || (out_channels != 1 && out_channels != 3) || sweeps < 1 || sweeps > 64)
         return DFSFM_E_BADARG;
     Params P{};

@@ -274,7 +274,9 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
     chunk_seg = np.repeat(np.arange(nseg, dtype=np.int32), per)
     fr.restart, fr.nseg, fr.nchunks, fr.chunk_bytes = restart, nseg, int(chunk_seg.size), chunk_bytes
     key = b"".join(huff[t][0] + huff[t][1] for t in tables)
-    return Plan(frame=fr, scan=np.ascontiguousarray(d[:scan_len]), lut_key=key, lut=_lut_block(key), qt=qt, seg_beg=seg_beg,
+    padded = np.zeros((scan_len + 15) // 8 * 8, dtype=np.uint8)      # the bit reader loads aligned 8-byte words: readable past the end
+    padded[:scan_len] = d[:scan_len]
+    return Plan(frame=fr, scan=padded[:scan_len], lut_key=key, lut=_lut_block(key), qt=qt, seg_beg=seg_beg,
                 seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling)
 
 

@@ -456,7 +456,8 @@ int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, 
  *
  * The host parses the marker segments (detectorfreesfm_amd/jpeg.py) and passes
  *   frame_host  the frame header as plain ints (below); nseg / nchunks / chunk_bytes describe how the scan is cut
- *   scan        the entropy-coded bytes of the single interleaved scan, raw (stuffed zeros, RSTn markers in place)
+ *   scan        the entropy-coded bytes of the single interleaved scan, raw (stuffed zeros, RSTn markers in place);
+ *               8-byte aligned, the allocation readable up to the next multiple of 8 past scan_bytes
  *   huff_lut    [4][65536] uint16: (code length << 8) | symbol for every 16-bit prefix, 0 where no code matches;
  *               slots named by dc_slot / ac_slot
  *   qt          [3][64] uint16 quantisation steps per component, natural (row-major) order

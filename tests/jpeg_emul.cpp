@@ -39,28 +39,37 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
             std::swap(perm[c], perm[(s >> 8) % (uint32_t)(c + 1)]);
         }
     }
+    std::vector<uint16_t> l1(jd::L1_SIZE);                    // the kernels' LDS copy of the tables' first levels
+    for (int i = 0; i < jd::L1_SIZE; ++i) l1[i] = jd::l1_entry(P.lut, i);
     if (!resume)
         for (int c = 0; c < P.nchunks; ++c) jd::init_thread(P, c);
     for (int s = 0; s < sweeps; ++s)
-        for (int i = 0; i < P.nchunks; ++i) jd::sweep_thread(P, perm[i], s);
+        for (int i = 0; i < P.nchunks; ++i) {
+            uint64_t entry = 0;
+            if (jd::sweep_needs(P, perm[i], entry)) jd::sweep_thread(P, perm[i], s, entry, l1.data());
+        }
     status[0] = P.work[sweeps - 1];
     for (int i = 0; i < sweeps; ++i)
         if (P.work[i]) status[3] = i + 1;
     if (work_out) std::memcpy(work_out, P.work, 64 * 4);
     {
-        std::vector<int32_t> part(jd::SCAN_T);
+        std::vector<int32_t> part(jd::SCAN_T), grp(jd::SCAN_G);
         for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_a(P, t, part.data());
-        jd::scan_phase_b(part.data());
+        for (int g = 0; g < jd::SCAN_G; ++g) jd::scan_phase_b1(part.data(), grp.data(), g);
+        jd::scan_phase_b2(grp.data());
+        for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_b3(part.data(), grp.data(), t);
         for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_c(P, t, part.data());
     }
     std::memset(P.coef, 0, (size_t)P.nblocks * 128);
-    for (int c = 0; c < P.nchunks; ++c) jd::write_thread(P, c);
+    for (int c = 0; c < P.nchunks; ++c) jd::write_thread(P, c, l1.data());
     const int ng = jd::dc_ngroups(P);
     for (int g = 0; g < ng; ++g) jd::dc_sum_thread(P, g);
     {
-        std::vector<int32_t> part(4 * jd::SCAN_T);
+        std::vector<int32_t> part(4 * jd::SCAN_T), grp(4 * jd::SCAN_G);
         for (int t = 0; t < jd::SCAN_T; ++t) jd::dc_scan_phase_a(P, t, part.data());
-        jd::dc_scan_phase_b(part.data());
+        for (int g = 0; g < jd::SCAN_G; ++g) jd::dc_scan_phase_b1(part.data(), grp.data(), g);
+        jd::dc_scan_phase_b2(grp.data());
+        for (int t = 0; t < jd::SCAN_T; ++t) jd::dc_scan_phase_b3(part.data(), grp.data(), t);
         for (int t = 0; t < jd::SCAN_T; ++t) jd::dc_scan_phase_c(P, t, part.data());
     }
     for (int g = 0; g < ng; ++g) jd::dc_apply_thread(P, g);

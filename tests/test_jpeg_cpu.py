@@ -117,6 +117,17 @@ def test_thread_order_does_not_change_the_fixed_point():
     assert pl.frame.nchunks > 200
 
 
+def test_large_frame_multi_entry_scan_spans():
+    """A frame large enough that the single-workgroup scans (block counts over the chunks, DC predictions over the MCU groups)
+    give every thread a SPAN of entries: 30 000 MCUs, restart intervals that end inside spans, 16-byte chunks."""
+    for kw, cb in ((dict(quality=90, subsampling=0, restart_marker_rows=7), 16), (dict(quality=85, subsampling=2), 32)):
+        buf = encode(synth(1200, 1600, True, seed=11), **kw)
+        pl = jpeg.plan(buf, cb)
+        assert pl.frame.nchunks > 4 * 1024
+        out, info = jpeg_emul.decode(pl, True, sweeps=64, order=1)
+        assert info["status"][:3].tolist() == [0, 0, 0] and np.array_equal(out, rj.decode(buf, True))
+
+
 def test_huffman_lut_is_the_canonical_code():
     buf = encode(synth(64, 64), quality=75, optimize=True)
     pl = jpeg.plan(buf)
