@@ -742,6 +742,18 @@ def resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pad
     return o8, of, mk
 
 
+_jpeg_stage = [None]
+
+
+def _jpeg_staging(nbytes: int):
+    """A grow-only pinned host buffer for the one upload of a decode call (allocating pinned memory per call costs more than the
+    decode).  Safe to reuse: every jpeg_decode call ends with a host read of its status, i.e. after its upload."""
+    buf = _jpeg_stage[0]
+    if buf is None or buf.numel() < nbytes:
+        buf = _jpeg_stage[0] = torch.empty((max(nbytes * 5 // 4, 1 << 20),), dtype=torch.uint8, pin_memory=True)
+    return buf[:nbytes]
+
+
 def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 12, max_calls: int = 8):
     """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``): uploads the scan and its small tables in ONE copy, runs the
     chunk-parallel entropy decode + IDCT (+ upsampling / colour conversion) and returns (uint8 [H,W] or [H,W,3] device tensor,
@@ -770,7 +782,7 @@ def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 12, max_calls:
         for a in parts:
             offs.append(o)
             o = (o + a.size + 15) // 16 * 16
-        host = torch.empty((o,), dtype=torch.uint8, pin_memory=True)
+        host = _jpeg_staging(o)                             # pinned; free again when this call's status read returns
         hv = host.numpy()
         for a, at in zip(parts, offs):
             hv[at:at + a.size] = a
