@@ -20,21 +20,25 @@ namespace jd {
 
 constexpr int MAX_BLK = 6;                 // blocks per MCU (4:2:0: Y Y Y Y Cb Cr)
 constexpr int SCAN_T = 1024;               // threads of the single-workgroup scans
-constexpr int DC_GROUP = 16;               // MCUs per thread of the DC prediction passes
+constexpr int DC_GROUP = 4;                // MCUs per thread of the DC prediction passes
 constexpr uint64_t NO_STATE = ~0ull;
 
 struct Params {
     // ---- the scan and its tables (device) ------------------------------------------------------------------------
-    const uint8_t* scan;                   // entropy-coded bytes, raw: stuffed zeros and RSTn markers still in place
+    const uint8_t* scan;                   // entropy-coded bytes as in the file: stuffed zeros and RSTn markers still in place
+    int32_t scan_bytes;
+    const uint32_t* block_base;            // [ceil(scan_bytes / UNSTUFF_BLOCK)] entropy bytes in front of each block of `scan`
+    uint8_t* clean;                        // workspace: the scan without stuffed zeros, markers and fill bytes (+ 16 bytes of pad)
     const uint16_t* lut;                   // [4][65536]: (code length << 8) | symbol for every 16-bit prefix, 0 = no code
     const uint16_t* qt;                    // [3][64] quantisation steps of each component, natural (row-major) order
-    const uint32_t* seg_beg;               // [nseg] raw byte range of each restart segment's data (markers excluded)
+    const uint32_t* seg_beg;               // [nseg] byte range of each restart segment in `clean`
     const uint32_t* seg_end;
     const int32_t* seg_chunk0;             // [nseg] first chunk of the segment
     const int32_t* chunk_seg;              // [nchunks]
     int32_t nseg, nchunks, chunk_bytes;
     // ---- frame geometry ------------------------------------------------------------------------------------------
     int32_t nb;                            // blocks per MCU
+    uint32_t dc_pack, ac_pack, comp_pack;  // 4 bits per block-in-MCU: LUT slot of its DC / AC table, its component
     int32_t blk_comp[MAX_BLK], blk_bx[MAX_BLK], blk_by[MAX_BLK], blk_dc[MAX_BLK], blk_ac[MAX_BLK];
     int32_t ncomp, comp_h[3], comp_v[3], comp_j0[3];
     int32_t hmax, vmax;
@@ -61,61 +65,97 @@ struct Params {
 
 JD_FN uint64_t pack_state(uint64_t pos, uint32_t b, uint32_t z) { return (pos << 16) | ((uint64_t)b << 8) | z; }
 
-// ---- bit reader over the raw (stuffed) bytes of one restart segment ------------------------------------------------
-// A position is (raw index of the DATA byte that holds the next unread bit, bits of it already read); it never points at
-// a stuffed zero: the byte after a data 0xFF is skipped by rule, on both the fetch and the position side.  Past the
-// segment's end the reader feeds zeros and positions keep advancing, so every loop that runs "until the position passes
-// X" terminates whatever the bits say.
+// ---- pass 0: the scan without its byte stuffing -----------------------------------------------------------------------
+// In the file every data byte 0xFF is followed by a stuffed 0x00, restart intervals end in FF D0..D7 (possibly after FF fill
+// bytes).  A decoder that has to step over those while it tracks bit positions spends more instructions on that than on
+// Huffman codes, so the scan is compacted once: a byte stays unless it is a stuffed zero (00 after FF), the FF of a marker /
+// fill byte (FF not followed by 00) or a marker's code (D0..D7 after FF).  A workgroup takes UNSTUFF_BLOCK bytes, 16 per
+// thread; the number of kept bytes in front of each block comes from the host, which has seen every FF anyway (jpeg.plan).
+constexpr int UNSTUFF_BLOCK = 4096;
+JD_FN uint32_t unstuff_mask(const Params& P, int blk, int t, uint64_t& w0, uint64_t& w1) {   // bit j set: byte 16 t + j of the block stays
+    const int64_t r0 = (int64_t)blk * UNSTUFF_BLOCK + 16 * t;
+    w0 = w1 = 0;
+    if (r0 >= P.scan_bytes) return 0;
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(P.scan + r0);     // `scan` is 16-byte aligned and readable to the next multiple of 16
+    w0 = src[0];
+    w1 = src[1];
+    uint32_t keep = 0;
+    uint32_t prev = r0 > 0 ? P.scan[r0 - 1] : 0;
+    uint32_t cur = (uint32_t)w0 & 0xFF;
+    for (int j = 0; j < 16; ++j) {
+        const int64_t i = r0 + j;
+        if (i >= P.scan_bytes) break;
+        uint32_t next;
+        if (j < 15) next = (uint32_t)((j + 1 < 8 ? w0 >> (8 * (j + 1)) : w1 >> (8 * (j - 7))) & 0xFF);
+        else next = i + 1 < P.scan_bytes ? P.scan[i + 1] : 0xD9;
+        if (i + 1 >= P.scan_bytes) next = 0xD9;               // what follows the scan is a marker
+        const bool drop = (prev == 0xFF && (cur == 0 || (cur >= 0xD0 && cur <= 0xD7))) || (cur == 0xFF && next != 0);
+        if (!drop) keep |= 1u << j;
+        prev = cur;
+        cur = next;
+    }
+    return keep;
+}
+JD_FN void unstuff_store(const Params& P, int blk, uint32_t keep, uint64_t w0, uint64_t w1, uint32_t before) {
+    uint8_t* o = P.clean + P.block_base[blk] + before;      // `before`: kept bytes of the block in front of this thread
+    for (int j = 0; j < 16; ++j)
+        if (keep >> j & 1) *o++ = (uint8_t)((j < 8 ? w0 >> (8 * j) : w1 >> (8 * (j - 8))) & 0xFF);
+}
+// exclusive prefix of the 256 per-thread counts of a block, the same three phases as the chunk scan below
+constexpr int UNSTUFF_T = UNSTUFF_BLOCK / 16, UNSTUFF_G = 16;
+JD_FN void unstuff_scan_b1(uint32_t* cnt, uint32_t* grp, int g) {
+    uint32_t run = 0;
+    for (int t = g * (UNSTUFF_T / UNSTUFF_G); t < (g + 1) * (UNSTUFF_T / UNSTUFF_G); ++t) {
+        const uint32_t c = cnt[t];
+        cnt[t] = run;
+        run += c;
+    }
+    grp[g] = run;
+}
+JD_FN void unstuff_scan_b2(uint32_t* grp) {
+    uint32_t run = 0;
+    for (int g = 0; g < UNSTUFF_G; ++g) {
+        const uint32_t c = grp[g];
+        grp[g] = run;
+        run += c;
+    }
+}
+
+// ---- bit reader over the compacted scan --------------------------------------------------------------------------------
+// 64-bit window, left aligned, refilled 32 bits at a time from aligned big-endian words: at least 32 valid bits at the start
+// of every symbol cover the longest code (16) plus the longest value (15).  Positions are bits of `clean`.  Past a segment's
+// end the reader sees the next segment (or the pad): every loop is bounded by positions, not by what the bits say.
 struct Reader {
-    const uint8_t* d;
-    uint32_t lim;
-    uint32_t raw, o;
-    uint64_t acc;                          // nbytes data bytes from `raw` on, left aligned
-    uint32_t nbytes;
-    uint32_t nxt;
-    uint64_t win;                          // the aligned 8 raw bytes at wbase (one global load per 8 bytes of scan)
-    uint32_t wbase;
+    const uint32_t* d;
+    uint32_t i;                            // next word to load
+    uint64_t acc;
+    int32_t nbits;
 };
-JD_FN void reader_init(Reader& r, const uint8_t* d, uint32_t lim, uint64_t pos) {
-    r.d = d;
-    r.lim = lim;
-    r.raw = (uint32_t)(pos >> 3);
-    r.o = (uint32_t)(pos & 7);
-    r.acc = 0;
-    r.nbytes = 0;
-    r.nxt = r.raw;
-    r.win = 0;
-    r.wbase = 0xFFFFFFFFu;
+JD_FN uint32_t load_be32(const uint32_t* p) {
+    const uint32_t w = *p;
+    return (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
 }
-JD_FN void reader_fetch(Reader& r) {
-    uint32_t b = 0;
-    if (r.nxt < r.lim) {
-        const uint32_t wb = r.nxt & ~7u;
-        if (wb != r.wbase) {                                   // `scan` is 8-byte aligned and readable to the next multiple of 8
-            r.win = *reinterpret_cast<const uint64_t*>(r.d + wb);
-            r.wbase = wb;
-        }
-        b = (uint32_t)(r.win >> (8 * (r.nxt & 7))) & 0xFF;
-    }
-    r.nxt += b == 0xFF ? 2 : 1;
-    r.acc |= (uint64_t)b << (56 - 8 * r.nbytes);
-    r.nbytes += 1;
+JD_FN void reader_init(Reader& r, const uint8_t* clean, uint64_t pos) {
+    r.d = reinterpret_cast<const uint32_t*>(clean);
+    r.i = (uint32_t)(pos >> 5);
+    const uint32_t sh = (uint32_t)(pos & 31);
+    r.acc = (uint64_t)load_be32(r.d + r.i) << (32 + sh);
+    r.nbits = 32 - (int32_t)sh;
+    r.i += 1;
 }
-JD_FN uint32_t reader_peek(Reader& r, uint32_t n) {      // 1 <= n <= 32
-    while (r.nbytes * 8 < r.o + n) reader_fetch(r);
-    return (uint32_t)((r.acc << r.o) >> (64 - n));
-}
-JD_FN void reader_skip(Reader& r, uint32_t n) {          // the n bits were peeked before
-    r.o += n;
-    while (r.o >= 8) {
-        const uint32_t b = (uint32_t)(r.acc >> 56);
-        r.acc <<= 8;
-        r.nbytes -= 1;
-        r.o -= 8;
-        r.raw += b == 0xFF ? 2 : 1;
+JD_FN void reader_fill(Reader& r) {                      // afterwards nbits >= 32
+    if (r.nbits < 32) {
+        r.acc |= (uint64_t)load_be32(r.d + r.i) << (32 - r.nbits);
+        r.nbits += 32;
+        r.i += 1;
     }
 }
-JD_FN uint64_t reader_pos(const Reader& r) { return (uint64_t)r.raw * 8 + r.o; }
+JD_FN uint32_t reader_peek32(const Reader& r) { return (uint32_t)(r.acc >> 32); }
+JD_FN void reader_skip(Reader& r, uint32_t n) {          // n <= 32 bits that were valid
+    r.acc <<= n;
+    r.nbits -= (int32_t)n;
+}
+JD_FN uint64_t reader_pos(const Reader& r) { return (uint64_t)r.i * 32 - (uint64_t)r.nbits; }
 
 JD_FN int extend(uint32_t v, uint32_t s) { return s && v < (1u << (s - 1)) ? (int)v - (int)(1u << s) + 1 : (int)v; }
 
@@ -140,7 +180,7 @@ __device__ __constant__ uint8_t ZIGZAG_DEV[64] = {
 // ---- chunk geometry ---------------------------------------------------------------------------------------------
 struct Chunk {
     int32_t seg;
-    uint32_t beg, end, lim;                // raw bytes [beg, end) of the chunk; lim = end of the segment
+    uint32_t beg, end, lim;                // bytes [beg, end) of `clean`; lim = end of the segment
     bool first, last;                      // of its segment
 };
 JD_FN Chunk chunk_of(const Params& P, int c) {
@@ -156,12 +196,8 @@ JD_FN Chunk chunk_of(const Params& P, int c) {
     return k;
 }
 // the state a decoder is ASSUMED to be in at the first byte of a chunk before anything is known: on a byte boundary, at
-// the DC coefficient of the MCU's first block.  (A stuffed zero is not a data byte: step over it.)
-JD_FN uint64_t default_entry(const Params& P, const Chunk& k) {
-    uint32_t s = k.beg;
-    if (!k.first && s < k.lim && P.scan[s] == 0 && P.scan[s - 1] == 0xFF) s += 1;
-    return pack_state((uint64_t)s * 8, 0, 0);
-}
+// the DC coefficient of the MCU's first block
+JD_FN uint64_t default_entry(const Chunk& k) { return pack_state((uint64_t)k.beg * 8, 0, 0); }
 
 // ---- two-level Huffman lookup ----------------------------------------------------------------------------------------
 // The 16-bit-prefix tables (4 x 128 KB) live in L2; a workgroup keeps their first L1_BITS levels in LDS: entry i of a slot is
@@ -187,46 +223,36 @@ struct ChunkResult {
 template <bool WRITE>
 JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint16_t* l1) {
     Reader r;
-    reader_init(r, P.scan, k.lim, entry >> 16);
+    reader_init(r, P.clean, entry >> 16);
     uint32_t b = (uint32_t)(entry >> 8) & 0xFF, z = (uint32_t)entry & 0xFF;
     const uint64_t end_pos = (uint64_t)k.end * 8;
     ChunkResult res;
     res.nblk = 0;
     res.nbad = 0;
     while (reader_pos(r) < end_pos && (!WRITE || blk < blk_limit)) {
-        const uint32_t slot = (uint32_t)(z == 0 ? P.blk_dc[b] : P.blk_ac[b]);
-        const uint32_t pk = reader_peek(r, 16);
-        uint32_t e = l1[(slot << L1_BITS) | (pk >> (16 - L1_BITS))];
-        if (e == 0) e = P.lut[(size_t)slot * 65536 + pk];
+        reader_fill(r);
+        const uint32_t pk = reader_peek32(r);
+        const bool is_dc = z == 0;
+        const uint32_t slot = ((is_dc ? P.dc_pack : P.ac_pack) >> (4 * b)) & 15;
+        uint32_t e = l1[(slot << L1_BITS) | (pk >> (32 - L1_BITS))];
+        if (e == 0) e = P.lut[(size_t)slot * 65536 + (pk >> 16)];
         const uint32_t len = e >> 8;
-        if (len == 0) {
+        if (len == 0) {                                        // no code has this prefix
             reader_skip(r, 1);
             res.nbad += 1;
             continue;
         }
-        reader_skip(r, len);
         const uint32_t sym = e & 0xFF;
-        if (z == 0) {
-            const uint32_t s = sym & 15;
-            if (sym > 15) res.nbad += 1;
-            int v = 0;
-            if (s) {
-                v = extend(reader_peek(r, s), s);
-                reader_skip(r, s);
-            }
-            if (WRITE) P.coef[(int64_t)blk * 64] = (int16_t)v;
-            z = 1;
+        if (is_dc && sym > 15) res.nbad += 1;
+        const uint32_t s = sym & 15, run = is_dc ? 0 : sym >> 4;
+        const uint32_t v = (uint32_t)(((uint64_t)(pk << len)) >> (32 - s));     // the s bits after the code (0 for s = 0)
+        reader_skip(r, len + s);                               // <= 16 + 15 of the >= 32 valid bits
+        if (!is_dc && s == 0) {
+            z = run == 15 ? z + 16 : 64;                       // ZRL / EOB
         } else {
-            const uint32_t run = sym >> 4, s = sym & 15;
-            if (s == 0) {
-                z = run == 15 ? z + 16 : 64;                   // ZRL / EOB
-            } else {
-                z += run;
-                const int v = extend(reader_peek(r, s), s);
-                reader_skip(r, s);
-                if (WRITE && z < 64) P.coef[(int64_t)blk * 64 + JD_ZIGZAG[z]] = (int16_t)v;
-                z += 1;
-            }
+            z += run;
+            if (WRITE && z < 64) P.coef[(int64_t)blk * 64 + JD_ZIGZAG[z]] = (int16_t)extend(v, s);
+            z += 1;
         }
         if (z >= 64) {
             z = 0;
@@ -242,7 +268,7 @@ JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, 
 // ---- kernels, one thread each --------------------------------------------------------------------------------------
 JD_FN void init_thread(const Params& P, int c) {
     uint64_t e = NO_STATE;
-    if (c + 1 < P.nchunks && P.chunk_seg[c + 1] == P.chunk_seg[c]) e = default_entry(P, chunk_of(P, c + 1));
+    if (c + 1 < P.nchunks && P.chunk_seg[c + 1] == P.chunk_seg[c]) e = default_entry(chunk_of(P, c + 1));
     P.exit_state[c] = e;
     P.last_entry[c] = NO_STATE;
     P.nblk[c] = 0;
@@ -333,7 +359,7 @@ JD_FN void dc_sum_thread(const Params& P, int g) {
             sum[0] = sum[1] = sum[2] = 0;
             reset = 1;
         }
-        for (int j = 0; j < P.nb; ++j) sum[P.blk_comp[j]] += P.coef[((int64_t)m * P.nb + j) * 64];
+        for (int j = 0; j < P.nb; ++j) sum[(P.comp_pack >> (4 * j)) & 15] += P.coef[((int64_t)m * P.nb + j) * 64];
     }
     int32_t* o = P.dc_part + 4 * g;
     o[0] = sum[0];
@@ -407,8 +433,9 @@ JD_FN void dc_apply_thread(const Params& P, int g) {
         if (mcu_resets(P, m)) pred[0] = pred[1] = pred[2] = 0;
         for (int j = 0; j < P.nb; ++j) {
             int16_t* d = P.coef + ((int64_t)m * P.nb + j) * 64;
-            pred[P.blk_comp[j]] += *d;
-            *d = (int16_t)pred[P.blk_comp[j]];
+            const int comp = (P.comp_pack >> (4 * j)) & 15;
+            pred[comp] += *d;
+            *d = (int16_t)pred[comp];
         }
     }
 }

@@ -8,7 +8,9 @@
 //
 // The entropy-coded scan is ONE bit string with no index: symbol k+1 starts where symbol k ends.  What makes it parallel is
 // that Huffman streams self-synchronise -- a decoder started at a wrong bit falls into step with the true one after a few
-// symbols -- so the scan is cut into fixed chunks (128 bytes of raw data by default) with one thread each:
+// symbols -- so the (compacted) scan is cut into fixed chunks (128 bytes by default) with one thread each:
+//   unstuff   the scan is compacted once (stuffed zeros, restart markers and fill bytes out), so that bit positions are plain
+//             offsets and the decoder's inner loop has no byte-level special cases
 //   init      every chunk's exit state := "next chunk starts on its first byte, at the DC of block 0"
 //   sweep x n chunk c decodes from its predecessor's current exit state (position, block-in-MCU, coefficient index) and
 //             publishes its own; chunks whose entry did not change since their last decode do nothing.  The first chunk
@@ -22,9 +24,12 @@
 //   dc        per-component prefix sum of the DC differences in scan order (reset at restarts): 3 small launches
 //   idct      one thread per 8x8 block: dequantise + jpeg_idct_islow; the luma plane goes straight to the output
 //   colour    (RGB only) fancy upsampling of Cb / Cr + YCbCr -> RGB per output pixel
-// All integer / byte work, and latency-bound: a thread's next lookup depends on its last.  So the chain is kept short -- the
-// scan is read as aligned 8-byte words (one global load per 8 bytes), the Huffman tables are 16-bit-prefix LUTs in L2 whose
-// first 10 levels every workgroup copies into 8 KB of LDS (where almost every symbol of a photograph is answered).
+// All integer / byte work, and latency-bound: a thread's next lookup depends on its last.  So the chain is kept short -- one
+// 32-bit window per symbol covers the code AND its value bits (one lookup, one shift), the window refills from aligned words
+// of the compacted scan, DC and AC symbols share one path (no divergence between lanes at different coefficients), the
+// Huffman tables are 16-bit-prefix LUTs in L2 whose first 10 levels every workgroup copies into 8 KB of LDS (where almost
+// every symbol of a photograph is answered).  v1 of this file decoded the stuffed bytes in place: 1.5 us per byte and thread
+// (profiles/r05_jpeg_v1_kernel_stats.csv).
 //
 // The marker segments (tables, frame header, restart positions) are parsed on the host (detectorfreesfm_amd/jpeg.py): a few
 // hundred bytes of control data.  Progressive, arithmetic-coded, 12-bit, CMYK and multi-scan files are refused there
@@ -40,6 +45,18 @@ using jd::Layout;
 using jd::derive;
 using jd::layout_of;
 
+__global__ __launch_bounds__(jd::UNSTUFF_T) void jd_unstuff_kernel(Params P) {
+    __shared__ uint32_t cnt[jd::UNSTUFF_T], grp[jd::UNSTUFF_G];
+    uint64_t w0, w1;
+    const uint32_t keep = jd::unstuff_mask(P, blockIdx.x, threadIdx.x, w0, w1);
+    cnt[threadIdx.x] = __popc(keep);
+    __syncthreads();
+    if (threadIdx.x < jd::UNSTUFF_G) jd::unstuff_scan_b1(cnt, grp, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) jd::unstuff_scan_b2(grp);
+    __syncthreads();
+    jd::unstuff_store(P, blockIdx.x, keep, w0, w1, cnt[threadIdx.x] + grp[threadIdx.x / (jd::UNSTUFF_T / jd::UNSTUFF_G)]);
+}
 __global__ __launch_bounds__(256) void jd_init_kernel(Params P) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < P.nchunks) jd::init_thread(P, c);
@@ -111,37 +128,41 @@ __global__ void jd_status_kernel(Params P, int sweeps) {
 
 }  // namespace
 
-extern "C" size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int out_channels) {
-    if (!frame_host || (out_channels != 1 && out_channels != 3)) return 0;
+extern "C" size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int64_t scan_bytes, int out_channels) {
+    if (!frame_host || scan_bytes <= 0 || scan_bytes >= (1ll << 31) || (out_channels != 1 && out_channels != 3)) return 0;
     Params P{};
     if (!derive(*frame_host, P)) return 0;
-    return layout_of(P, out_channels).total;
+    return layout_of(P, scan_bytes, out_channels).total;
 }
 
 extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* frame_host,
-                                    const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* seg_beg,
-                                    const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg,
+                                    const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* block_base,
+                                    const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg,
                                     uint8_t* out, int64_t out_stride, int out_channels, int sweeps, int resume,
                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!scan || !frame_host || !huff_lut || !qt || !seg_beg || !seg_end || !seg_chunk0 || !chunk_seg || !out || !status ||
+    if (!scan || !frame_host || !huff_lut || !qt || !block_base || !seg_beg || !seg_end || !seg_chunk0 || !chunk_seg || !out || !status ||
         !workspace)
         return DFSFM_E_BADARG;
-    if ((reinterpret_cast<uintptr_t>(scan) & 7) != 0) return DFSFM_E_BADARG;      // the bit reader loads aligned 8-byte words
+    if ((reinterpret_cast<uintptr_t>(scan) & 15) != 0) return DFSFM_E_BADARG;     // the compaction pass loads aligned 16-byte pieces
     if (scan_bytes <= 0 || scan_bytes >= (1ll << 31) || (out_channels != 1 && out_channels != 3) || sweeps < 1 || sweeps > 64)
         return DFSFM_E_BADARG;
     Params P{};
     if (!derive(*frame_host, P)) return DFSFM_E_UNSUPPORTED;
     if (out_stride < (int64_t)P.width * out_channels) return DFSFM_E_BADARG;
-    const Layout L = layout_of(P, out_channels);
+    const Layout L = layout_of(P, scan_bytes, out_channels);
     if (workspace_bytes < L.total) return DFSFM_E_WORKSPACE;
-    jd::bind(P, L, static_cast<char*>(workspace), scan, huff_lut, qt, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
+    jd::bind(P, L, static_cast<char*>(workspace), scan, scan_bytes, huff_lut, qt, block_base, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
              out_channels, status);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
     const unsigned gc = (unsigned)((P.nchunks + 255) / 256);
     (void)hipMemsetAsync(P.work, 0, 64 * 4, stream);
     (void)hipMemsetAsync(status, 0, 4 * 4, stream);
-    if (!resume) hipLaunchKernelGGL(jd_init_kernel, dim3(gc), dim3(256), 0, stream, P);
+    if (!resume) {
+        const unsigned gu = (unsigned)((scan_bytes + jd::UNSTUFF_BLOCK - 1) / jd::UNSTUFF_BLOCK);
+        hipLaunchKernelGGL(jd_unstuff_kernel, dim3(gu), dim3(jd::UNSTUFF_T), 0, stream, P);
+        hipLaunchKernelGGL(jd_init_kernel, dim3(gc), dim3(256), 0, stream, P);
+    }
     for (int s = 0; s < sweeps; ++s) hipLaunchKernelGGL(jd_sweep_kernel, dim3(gc), dim3(256), 0, stream, P, s);
     hipLaunchKernelGGL(jd_status_kernel, dim3(1), dim3(1), 0, stream, P, sweeps);
     hipLaunchKernelGGL(jd_scan_kernel, dim3(1), dim3(jd::SCAN_T), 0, stream, P);

@@ -9,7 +9,7 @@
 namespace jd {
 
 struct Layout {
-    size_t exit_state, last_entry, nblk, blk0, work, coef, dc_part, dc_base, plane[3], total;
+    size_t clean, exit_state, last_entry, nblk, blk0, work, coef, dc_part, dc_base, plane[3], total;
 };
 
 // geometry the frame header implies; false = not a frame this decoder takes
@@ -49,6 +49,12 @@ inline bool derive(const dfsfm_jpeg_frame& f, Params& P) {
         P.real_h[c] = (f.height * P.comp_v[c] + vmax - 1) / vmax;
     }
     P.nb = j;
+    P.dc_pack = P.ac_pack = P.comp_pack = 0;
+    for (int i = 0; i < j; ++i) {
+        P.dc_pack |= (uint32_t)P.blk_dc[i] << (4 * i);
+        P.ac_pack |= (uint32_t)P.blk_ac[i] << (4 * i);
+        P.comp_pack |= (uint32_t)P.blk_comp[i] << (4 * i);
+    }
     P.nblocks = P.nmcu * P.nb;
     P.restart = f.restart;
     P.nseg = f.nseg;
@@ -59,10 +65,11 @@ inline bool derive(const dfsfm_jpeg_frame& f, Params& P) {
     return true;
 }
 
-inline Layout layout_of(const Params& P, int out_channels) {
+inline Layout layout_of(const Params& P, int64_t scan_bytes, int out_channels) {
     Layout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) / 256 * 256; return at; };
+    L.clean = take((size_t)scan_bytes + 64);                   // compacted scan + words the bit reader may touch past its end
     L.exit_state = take((size_t)P.nchunks * 8);
     L.last_entry = take((size_t)P.nchunks * 8);
     L.nblk = take((size_t)P.nchunks * 4);
@@ -79,10 +86,13 @@ inline Layout layout_of(const Params& P, int out_channels) {
 }
 
 
-inline void bind(Params& P, const Layout& L, char* ws, const uint8_t* scan, const uint16_t* huff_lut, const uint16_t* qt,
-                 const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out,
+inline void bind(Params& P, const Layout& L, char* ws, const uint8_t* scan, int64_t scan_bytes, const uint16_t* huff_lut,
+                 const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out,
                  int64_t out_stride, int out_channels, int32_t* status) {
     P.scan = scan;
+    P.scan_bytes = (int32_t)scan_bytes;
+    P.block_base = block_base;
+    P.clean = reinterpret_cast<uint8_t*>(ws + L.clean);
     P.lut = huff_lut;
     P.qt = qt;
     P.seg_beg = seg_beg;

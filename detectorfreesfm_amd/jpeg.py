@@ -19,8 +19,9 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-CHUNK_BYTES = 128            # raw scan bytes per decoder thread
-DEFAULT_SWEEPS = 12          # relaxation sweeps per call before the first status check
+CHUNK_BYTES = 128            # bytes of the compacted scan per decoder thread
+DEFAULT_SWEEPS = 16          # relaxation sweeps per call before the first status check
+UNSTUFF_BLOCK = 4096         # csrc/jpeg_core.h
 
 ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
                    21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60,
@@ -48,11 +49,12 @@ class Frame(ctypes.Structure):
 class Plan:
     """Everything ``dfsfm_jpeg_decode_u8`` takes besides the output, as host arrays."""
     frame: Frame
-    scan: np.ndarray                 # uint8: the entropy-coded bytes of the scan (raw)
+    scan: np.ndarray                 # uint8: the entropy-coded bytes of the scan as in the file
     lut_key: bytes                   # the DHT payloads the LUT was built from (cache key)
     lut: np.ndarray                  # uint16 [4, 65536]
     qt: np.ndarray                   # uint16 [3, 64] natural order
-    seg_beg: np.ndarray              # uint32 [nseg]
+    block_base: np.ndarray           # uint32 [ceil(len(scan) / 4096)] entropy bytes in front of each block of the scan
+    seg_beg: np.ndarray              # uint32 [nseg] byte range of each restart interval in the compacted scan
     seg_end: np.ndarray
     seg_chunk0: np.ndarray           # int32 [nseg]
     chunk_seg: np.ndarray            # int32 [nchunks]
@@ -245,12 +247,16 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
 
     # ---- the scan: up to the first marker that is not RSTn; restart markers cut it into segments -------------------------
     d = data[scan_start:]
-    ff = np.flatnonzero(d[:-1] == 0xFF)
-    nxt = d[ff + 1]
+    ff = np.flatnonzero(d == 0xFF)
+    nxt = np.where(ff + 1 < d.size, d[np.minimum(ff + 1, d.size - 1)], 0xD9)
     mark = ff[(nxt != 0) & (nxt != 0xFF)]                       # FF FF is fill, FF 00 a stuffed data byte
-    ends = mark[~((d[mark + 1] >= 0xD0) & (d[mark + 1] <= 0xD7))]
+    ends = mark[~((nxt[(nxt != 0) & (nxt != 0xFF)] >= 0xD0) & (nxt[(nxt != 0) & (nxt != 0xFF)] <= 0xD7))]
     scan_len = int(ends[0]) if ends.size else d.size
-    rst = mark[(mark < scan_len) & (d[mark + 1] >= 0xD0) & (d[mark + 1] <= 0xD7)]
+    inside = ff < scan_len
+    ff, nxt = ff[inside], nxt[inside]
+    nxt = np.where(ff + 1 < scan_len, nxt, 0xD9)                # what follows the scan is a marker
+    is_rst = (nxt >= 0xD0) & (nxt <= 0xD7)
+    rst = ff[is_rst]
     if restart:
         nseg = -(-nmcu // restart)
         if rst.size != nseg - 1:
@@ -259,14 +265,14 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
         if rst.size:
             raise CorruptJpeg("restart markers without DRI")
         nseg = 1
-    seg_beg = np.concatenate([[0], rst + 2]).astype(np.uint32)
-    seg_end = np.concatenate([rst, [scan_len]]).astype(np.uint32)
-    # fill bytes (FF FF .. before a marker) belong to no segment
-    for s in range(nseg):
-        e = int(seg_end[s])
-        while e > int(seg_beg[s]) and d[e - 1] == 0xFF:
-            e -= 1
-        seg_end[s] = e
+    # bytes the device's compaction pass drops (csrc/jpeg_core.h unstuff_mask, the same three rules): the stuffed zero after a
+    # data FF, the FF of a marker / fill byte (an FF not followed by 00), the code byte of a restart marker
+    drops = np.sort(np.concatenate([ff[nxt == 0] + 1, ff[nxt != 0], rst + 1]))
+    clean = lambda x: np.asarray(x, dtype=np.int64) - np.searchsorted(drops, x, side="left")
+    nblocks = -(-scan_len // UNSTUFF_BLOCK)
+    block_base = clean(np.arange(nblocks, dtype=np.int64) * UNSTUFF_BLOCK).astype(np.uint32)
+    seg_beg = clean(np.concatenate([[0], rst + 2])).astype(np.uint32)
+    seg_end = clean(np.concatenate([rst, [scan_len]])).astype(np.uint32)
     if np.any(seg_end <= seg_beg):
         raise CorruptJpeg("empty restart interval")
     per = -(-(seg_end - seg_beg).astype(np.int64) // chunk_bytes)
@@ -274,9 +280,9 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
     chunk_seg = np.repeat(np.arange(nseg, dtype=np.int32), per)
     fr.restart, fr.nseg, fr.nchunks, fr.chunk_bytes = restart, nseg, int(chunk_seg.size), chunk_bytes
     key = b"".join(huff[t][0] + huff[t][1] for t in tables)
-    padded = np.zeros((scan_len + 15) // 8 * 8, dtype=np.uint8)      # the bit reader loads aligned 8-byte words: readable past the end
+    padded = np.zeros((scan_len + 31) // 16 * 16, dtype=np.uint8)    # the compaction pass loads aligned 16-byte pieces
     padded[:scan_len] = d[:scan_len]
-    return Plan(frame=fr, scan=padded[:scan_len], lut_key=key, lut=_lut_block(key), qt=qt, seg_beg=seg_beg,
+    return Plan(frame=fr, scan=padded[:scan_len], lut_key=key, lut=_lut_block(key), qt=qt, block_base=block_base, seg_beg=seg_beg,
                 seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling)
 
 

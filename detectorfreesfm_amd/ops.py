@@ -754,7 +754,7 @@ def _jpeg_staging(nbytes: int):
     return buf[:nbytes]
 
 
-def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 12, max_calls: int = 8):
+def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 16, max_calls: int = 8):
     """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``): uploads the scan and its small tables in ONE copy, runs the
     chunk-parallel entropy decode + IDCT (+ upsampling / colour conversion) and returns (uint8 [H,W] or [H,W,3] device tensor,
     dict(sweeps, calls)).  ``lut``: the [4,65536] Huffman prefix tables on the device (jpeg._device_lut caches them by DHT
@@ -772,11 +772,11 @@ def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 12, max_calls:
     with torch.cuda.device(device):
         L = _lib.lib()
         fr = pl.frame
-        nbytes = L.dfsfm_jpeg_decode_workspace(ctypes.byref(fr), out_channels)
+        nbytes = L.dfsfm_jpeg_decode_workspace(ctypes.byref(fr), pl.scan.size, out_channels)
         if nbytes == 0:
             raise _jpeg.UnsupportedJpeg("frame outside the device decoder (dfsfm_jpeg_decode_workspace)")
-        # one host buffer = one H2D copy: [scan | qt | seg_beg | seg_end | seg_chunk0 | chunk_seg], each part 16-byte aligned
-        parts = [pl.scan, pl.qt.reshape(-1).view(np.uint8), pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8),
+        # one host buffer = one H2D copy: [scan | qt | block_base | seg_beg | seg_end | seg_chunk0 | chunk_seg], 16-byte aligned parts
+        parts = [pl.scan, pl.qt.reshape(-1).view(np.uint8), pl.block_base.view(np.uint8), pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8),
                  pl.seg_chunk0.view(np.uint8), pl.chunk_seg.view(np.uint8)]
         offs, o = [], 0
         for a in parts:
@@ -795,7 +795,7 @@ def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 12, max_calls:
         calls, total, used = 0, 0, 0
         while True:
             rc = L.dfsfm_jpeg_decode_u8(ptrs[0], pl.scan.size, ctypes.byref(fr), _ptr(lut), ptrs[1], ptrs[2], ptrs[3], ptrs[4],
-                                        ptrs[5], _ptr(out), out.stride(0), out_channels, sweeps, int(calls > 0), _ptr(status),
+                                        ptrs[5], ptrs[6], _ptr(out), out.stride(0), out_channels, sweeps, int(calls > 0), _ptr(status),
                                         _ptr(ws), nbytes, _stream())
             _lib.check(rc, "dfsfm_jpeg_decode_u8")
             calls += 1

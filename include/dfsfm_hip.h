@@ -456,13 +456,16 @@ int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, 
  *
  * The host parses the marker segments (detectorfreesfm_amd/jpeg.py) and passes
  *   frame_host  the frame header as plain ints (below); nseg / nchunks / chunk_bytes describe how the scan is cut
- *   scan        the entropy-coded bytes of the single interleaved scan, raw (stuffed zeros, RSTn markers in place);
- *               8-byte aligned, the allocation readable up to the next multiple of 8 past scan_bytes
+ *   scan        the entropy-coded bytes of the single interleaved scan as in the file (stuffed zeros, RSTn markers and
+ *               fill bytes in place); 16-byte aligned, the allocation readable up to the next multiple of 16
+ *   block_base  [ceil(scan_bytes / 4096)] uint32: entropy bytes in front of each 4096-byte block of `scan` (a byte counts
+ *               unless it is a 00 after FF, an FF not followed by 00, or D0..D7 after FF) -- the first kernel compacts
+ *               the scan with them
  *   huff_lut    [4][65536] uint16: (code length << 8) | symbol for every 16-bit prefix, 0 where no code matches;
  *               slots named by dc_slot / ac_slot
  *   qt          [3][64] uint16 quantisation steps per component, natural (row-major) order
- *   seg_beg / seg_end [nseg] raw byte range of each restart interval's data (no markers); seg_chunk0 [nseg] its first
- *               chunk; chunk_seg [nchunks] the segment of a chunk; chunk i of a segment covers chunk_bytes raw bytes
+ *   seg_beg / seg_end [nseg] byte range of each restart interval in the COMPACTED scan; seg_chunk0 [nseg] its first
+ *               chunk; chunk_seg [nchunks] the segment of a chunk; chunk i of a segment covers chunk_bytes compacted bytes
  * Decoding is a fixed-point iteration over the chunks (`sweeps` relaxation passes, see the kernel file); status[0] == 0
  * says the fixed point was reached -- otherwise call again with resume = 1 (the workspace keeps the state) and more
  * sweeps.  status[1] = invalid codes on the final path, status[2] = restart intervals with a wrong block count (a corrupt
@@ -478,10 +481,10 @@ typedef struct dfsfm_jpeg_frame {
     int32_t restart;                 /* MCUs per restart interval (DRI), 0 = none */
     int32_t nseg, nchunks, chunk_bytes;
 } dfsfm_jpeg_frame;
-size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int out_channels);   /* 0 = unsupported frame */
+size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int64_t scan_bytes, int out_channels);   /* 0 = unsupported */
 int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* frame_host,
-                         const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* seg_beg, const uint32_t* seg_end,
-                         const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out, int64_t out_stride,
+                         const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg,
+                         const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out, int64_t out_stride,
                          int out_channels, int sweeps, int resume, int32_t* status, void* workspace,
                          size_t workspace_bytes, void* stream);
 

@@ -9,24 +9,25 @@
 #include "jpeg_core.h"
 #include "jpeg_host.h"
 
-extern "C" size_t jd_emul_workspace(const dfsfm_jpeg_frame* f, int out_channels) {
+extern "C" size_t jd_emul_workspace(const dfsfm_jpeg_frame* f, int64_t scan_bytes, int out_channels) {
     jd::Params P{};
     if (!jd::derive(*f, P)) return 0;
-    return jd::layout_of(P, out_channels).total;
+    return jd::layout_of(P, scan_bytes, out_channels).total;
 }
 
 // returns 0, or the DFSFM_E_* code the real entry point would; sweeps_used (may be null) receives, per sweep, the chunks decoded
 extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* f, const uint16_t* lut,
-                              const uint16_t* qt, const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0,
+                              const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg, const uint32_t* seg_end,
+                              const int32_t* seg_chunk0,
                               const int32_t* chunk_seg, uint8_t* out, int64_t out_stride, int out_channels, int sweeps,
                               int resume, int32_t* status, void* workspace, size_t workspace_bytes, int order,
                               int32_t* work_out) {
     jd::Params P{};
     if (!jd::derive(*f, P)) return DFSFM_E_UNSUPPORTED;
     if (out_stride < (int64_t)P.width * out_channels || sweeps < 1 || sweeps > 64) return DFSFM_E_BADARG;
-    const jd::Layout L = jd::layout_of(P, out_channels);
+    const jd::Layout L = jd::layout_of(P, scan_bytes, out_channels);
     if (workspace_bytes < L.total) return DFSFM_E_WORKSPACE;
-    jd::bind(P, L, static_cast<char*>(workspace), scan, lut, qt, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
+    jd::bind(P, L, static_cast<char*>(workspace), scan, scan_bytes, lut, qt, block_base, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
              out_channels, status);
     std::memset(P.work, 0, 64 * 4);
     std::memset(status, 0, 16);
@@ -41,8 +42,22 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
     }
     std::vector<uint16_t> l1(jd::L1_SIZE);                    // the kernels' LDS copy of the tables' first levels
     for (int i = 0; i < jd::L1_SIZE; ++i) l1[i] = jd::l1_entry(P.lut, i);
-    if (!resume)
+    if (!resume) {
+        const int nb = (int)((scan_bytes + jd::UNSTUFF_BLOCK - 1) / jd::UNSTUFF_BLOCK);
+        for (int blk = 0; blk < nb; ++blk) {                  // one workgroup of jd_unstuff_kernel
+            uint32_t cnt[jd::UNSTUFF_T], grp[jd::UNSTUFF_G], keep[jd::UNSTUFF_T];
+            uint64_t w0[jd::UNSTUFF_T], w1[jd::UNSTUFF_T];
+            for (int t = 0; t < jd::UNSTUFF_T; ++t) {
+                keep[t] = jd::unstuff_mask(P, blk, t, w0[t], w1[t]);
+                cnt[t] = (uint32_t)__builtin_popcount(keep[t]);
+            }
+            for (int g = 0; g < jd::UNSTUFF_G; ++g) jd::unstuff_scan_b1(cnt, grp, g);
+            jd::unstuff_scan_b2(grp);
+            for (int t = 0; t < jd::UNSTUFF_T; ++t)
+                jd::unstuff_store(P, blk, keep[t], w0[t], w1[t], cnt[t] + grp[t / (jd::UNSTUFF_T / jd::UNSTUFF_G)]);
+        }
         for (int c = 0; c < P.nchunks; ++c) jd::init_thread(P, c);
+    }
     for (int s = 0; s < sweeps; ++s)
         for (int i = 0; i < P.nchunks; ++i) {
             uint64_t entry = 0;

@@ -24,8 +24,8 @@ def lib():
                                    "-I" + os.path.join(_ROOT, "detectorfreesfm_amd", "csrc"), SRC, "-o", LIB])
         _lib = ctypes.CDLL(LIB)
         _lib.jd_emul_workspace.restype = ctypes.c_size_t
-        _lib.jd_emul_workspace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        _lib.jd_emul_decode.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_void_p] * 6 + \
+        _lib.jd_emul_workspace.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+        _lib.jd_emul_decode.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_void_p] * 7 + \
             [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
              ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     return _lib
@@ -35,7 +35,7 @@ def decode(pl, color: bool, sweeps: int = 64, order: int = 0, max_calls: int = 6
     """Runs the lane model on a ``detectorfreesfm_amd.jpeg.Plan``; returns (image, dict(status, sweeps used, calls))."""
     L = lib()
     ch = 3 if color else 1
-    nbytes = L.jd_emul_workspace(ctypes.byref(pl.frame), ch)
+    nbytes = L.jd_emul_workspace(ctypes.byref(pl.frame), pl.scan.size, ch)
     assert nbytes > 0
     ws = np.zeros(nbytes, dtype=np.uint8)
     out = np.zeros((pl.height, pl.width, 3) if color else (pl.height, pl.width), dtype=np.uint8)
@@ -44,7 +44,7 @@ def decode(pl, color: bool, sweeps: int = 64, order: int = 0, max_calls: int = 6
     p = lambda a: a.ctypes.data
     used, calls = 0, 0
     while True:
-        rc = L.jd_emul_decode(p(pl.scan), pl.scan.size, ctypes.byref(pl.frame), p(pl.lut), p(pl.qt), p(pl.seg_beg), p(pl.seg_end),
+        rc = L.jd_emul_decode(p(pl.scan), pl.scan.size, ctypes.byref(pl.frame), p(pl.lut), p(pl.qt), p(pl.block_base), p(pl.seg_beg), p(pl.seg_end),
                               p(pl.seg_chunk0), p(pl.chunk_seg), p(out), out.strides[0], ch, sweeps, int(calls > 0), p(status),
                               p(ws), nbytes, order, p(work))
         assert rc == 0, rc

@@ -75,8 +75,8 @@ def test_orientation_corrupt_and_unsupported():
         jpeg.decode(encode(img, progressive=True), False, DEV)
     # the C ABI refuses bad arguments before anything is launched
     L = _lib.lib()
-    assert L.dfsfm_jpeg_decode_workspace(None, 1) == 0
-    assert L.dfsfm_jpeg_decode_u8(None, 0, None, None, None, None, None, None, None, None, 0, 1, 1, 0, None, None, 0, None) == -1
+    assert L.dfsfm_jpeg_decode_workspace(None, 0, 1) == 0
+    assert L.dfsfm_jpeg_decode_u8(None, 0, None, None, None, None, None, None, None, None, None, 0, 1, 1, 0, None, None, 0, None) == -1
 
 
 def test_readers_take_file_names(tmp_path):
