@@ -29,7 +29,7 @@ struct Params {
     int32_t scan_bytes;
     const uint32_t* block_base;            // [ceil(scan_bytes / UNSTUFF_BLOCK)] entropy bytes in front of each block of `scan`
     uint8_t* clean;                        // workspace: the scan without stuffed zeros, markers and fill bytes (+ 16 bytes of pad)
-    const uint16_t* lut;                   // [4][65536]: (code length << 8) | symbol for every 16-bit prefix, 0 = no code
+    const uint32_t* tab;                   // [4][TAB_SLOT_WORDS] decoding tables of the (up to) four Huffman codes, see below
     const uint16_t* qt;                    // [3][64] quantisation steps of each component, natural (row-major) order
     const uint32_t* seg_beg;               // [nseg] byte range of each restart segment in `clean`
     const uint32_t* seg_end;
@@ -55,7 +55,7 @@ struct Params {
     int32_t* blk0;                         // [nchunks] exclusive prefix of nblk
     int32_t* work;                         // [64] chunks decoded by sweep i (0 = fixed point reached)
     int32_t* status;                       // [4] work of the last sweep, invalid codes, segments with a wrong block count, sweeps used
-    int16_t* coef;                         // [nblocks][64] natural order; DC differences until the prediction pass
+    int16_t* coef;                         // [nblocks][64] in zig-zag (scan) order; DC differences until the prediction pass
     int32_t* dc_part;                      // [ngroups][4] (sum Y, Cb, Cr since the last reset in the group; has reset)
     int32_t* dc_base;                      // [ngroups][4]
     uint8_t* plane[3];                     // colour output only
@@ -127,26 +127,27 @@ JD_FN void unstuff_scan_b2(uint32_t* grp) {
 // end the reader sees the next segment (or the pad): every loop is bounded by positions, not by what the bits say.
 struct Reader {
     const uint32_t* d;
-    uint32_t i;                            // next word to load
+    uint32_t i;                            // next word to load (the word before it waits in `ahead`)
     uint64_t acc;
     int32_t nbits;
-};
-JD_FN uint32_t load_be32(const uint32_t* p) {
-    const uint32_t w = *p;
-    return (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
-}
+    uint32_t ahead;                        // the next word, loaded one refill early: its latency hides behind a whole refill period
+};                                         //   (a lane refills every ~6 symbols, but SOME lane of the wave does in almost every
+                                           //   iteration, and a load the wave has to wait for on the spot costs every lane ~250 cycles)
+JD_FN uint32_t be32(uint32_t w) { return (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24); }
 JD_FN void reader_init(Reader& r, const uint8_t* clean, uint64_t pos) {
     r.d = reinterpret_cast<const uint32_t*>(clean);
     r.i = (uint32_t)(pos >> 5);
     const uint32_t sh = (uint32_t)(pos & 31);
-    r.acc = (uint64_t)load_be32(r.d + r.i) << (32 + sh);
+    r.acc = (uint64_t)be32(r.d[r.i]) << (32 + sh);
     r.nbits = 32 - (int32_t)sh;
-    r.i += 1;
+    r.ahead = r.d[r.i + 1];                                 // as loaded: the byte swap waits until the word is used
+    r.i += 2;
 }
 JD_FN void reader_fill(Reader& r) {                      // afterwards nbits >= 32
     if (r.nbits < 32) {
-        r.acc |= (uint64_t)load_be32(r.d + r.i) << (32 - r.nbits);
+        r.acc |= (uint64_t)be32(r.ahead) << (32 - r.nbits);
         r.nbits += 32;
+        r.ahead = r.d[r.i];
         r.i += 1;
     }
 }
@@ -155,23 +156,15 @@ JD_FN void reader_skip(Reader& r, uint32_t n) {          // n <= 32 bits that we
     r.acc <<= n;
     r.nbits -= (int32_t)n;
 }
-JD_FN uint64_t reader_pos(const Reader& r) { return (uint64_t)r.i * 32 - (uint64_t)r.nbits; }
+JD_FN uint64_t reader_pos(const Reader& r) { return (uint64_t)(r.i - 1) * 32 - (uint64_t)r.nbits; }
 
 JD_FN int extend(uint32_t v, uint32_t s) { return s && v < (1u << (s - 1)) ? (int)v - (int)(1u << s) + 1 : (int)v; }
 
-__attribute__((unused)) static const uint8_t ZIGZAG_HOST[64] = {
-    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
-    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 #if defined(__HIPCC__)
-__device__ __constant__ uint8_t ZIGZAG_DEV[64] = {
-    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
-    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-#define JD_ZIGZAG ZIGZAG_DEV
 #define JD_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define JD_LOAD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define JD_STORE64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
-#define JD_ZIGZAG ZIGZAG_HOST
 #define JD_ATOMIC_ADD(p, v) (*(p) += (v))
 #define JD_LOAD64(p) (*(p))
 #define JD_STORE64(p, v) (*(p) = (v))
@@ -199,16 +192,35 @@ JD_FN Chunk chunk_of(const Params& P, int c) {
 // the DC coefficient of the MCU's first block
 JD_FN uint64_t default_entry(const Chunk& k) { return pack_state((uint64_t)k.beg * 8, 0, 0); }
 
-// ---- two-level Huffman lookup ----------------------------------------------------------------------------------------
-// The 16-bit-prefix tables (4 x 128 KB) live in L2; a workgroup keeps their first L1_BITS levels in LDS: entry i of a slot is
-// the table's entry for prefix i << (16 - L1_BITS) when that code is no longer than L1_BITS bits (then all 2^(16 - L1_BITS)
-// continuations agree), else 0 = "ask the big table".  Almost every symbol of a photograph is answered from LDS.
+// ---- Huffman lookup: everything in LDS ---------------------------------------------------------------------------------
+// Per code (slot) the host builds (jpeg.py huffman_table), and every workgroup copies into LDS:
+//   l1[1024] u16    (length << 8) | symbol for every 10-bit prefix whose code is at most 10 bits long, else 0
+//   long[6][3] u32  for lengths 11..16: limit (first left-aligned 16-bit value past the codes of that length), base (the
+//                   first code of that length, left aligned), valoff (index of its symbol in vals) -- the canonical code of
+//                   ITU T.81 Annex C: codes of one length are consecutive, longer codes follow numerically
+//   vals[256] u8    HUFFVAL
+// Almost every symbol of a photograph is answered by l1; the few long codes take a six-step search in LDS.  No global memory
+// in the symbol loop: a vector-memory load there would make the loop wait for the scan prefetch as well (one counter).
 constexpr int L1_BITS = 10;
-constexpr int L1_SIZE = 4 << L1_BITS;
-JD_FN uint16_t l1_entry(const uint16_t* lut, int i) {
-    const int slot = i >> L1_BITS, prefix = i & ((1 << L1_BITS) - 1);
-    const uint16_t e = lut[(size_t)slot * 65536 + ((size_t)prefix << (16 - L1_BITS))];
-    return (e >> 8) <= L1_BITS ? e : (uint16_t)0;
+constexpr int TAB_L1_BYTES = 2 << L1_BITS, TAB_LONG_BYTES = 6 * 3 * 4, TAB_VALS_BYTES = 256;
+constexpr int TAB_SLOT_BYTES = (TAB_L1_BYTES + TAB_LONG_BYTES + TAB_VALS_BYTES + 15) / 16 * 16;      // 2384
+constexpr int TAB_SLOT_WORDS = TAB_SLOT_BYTES / 4, TAB_WORDS = 4 * TAB_SLOT_WORDS;
+JD_FN uint32_t huff_lookup(const uint32_t* tab, uint32_t slot, uint32_t pk32) {        // (length << 8) | symbol, 0 = no such code
+    const uint8_t* t = reinterpret_cast<const uint8_t*>(tab) + slot * TAB_SLOT_BYTES;
+    uint32_t e = reinterpret_cast<const uint16_t*>(t)[pk32 >> (32 - L1_BITS)];
+    if (e == 0) {
+        const uint32_t code = pk32 >> 16;
+        const uint32_t* lg = reinterpret_cast<const uint32_t*>(t + TAB_L1_BYTES);
+        const uint8_t* vals = t + TAB_L1_BYTES + TAB_LONG_BYTES;
+        for (uint32_t l = 11; l <= 16; ++l) {
+            const uint32_t* q = lg + 3 * (l - 11);
+            if (code < q[0]) {
+                e = (l << 8) | vals[q[2] + ((code - q[1]) >> (16 - l))];
+                break;
+            }
+        }
+    }
+    return e;
 }
 
 // ---- the Huffman decoder of one chunk ----------------------------------------------------------------------------
@@ -221,7 +233,7 @@ struct ChunkResult {
     int32_t nblk, nbad;
 };
 template <bool WRITE>
-JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint16_t* l1) {
+JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint32_t* tab) {
     Reader r;
     reader_init(r, P.clean, entry >> 16);
     uint32_t b = (uint32_t)(entry >> 8) & 0xFF, z = (uint32_t)entry & 0xFF;
@@ -234,8 +246,7 @@ JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, 
         const uint32_t pk = reader_peek32(r);
         const bool is_dc = z == 0;
         const uint32_t slot = ((is_dc ? P.dc_pack : P.ac_pack) >> (4 * b)) & 15;
-        uint32_t e = l1[(slot << L1_BITS) | (pk >> (32 - L1_BITS))];
-        if (e == 0) e = P.lut[(size_t)slot * 65536 + (pk >> 16)];
+        const uint32_t e = huff_lookup(tab, slot, pk);
         const uint32_t len = e >> 8;
         if (len == 0) {                                        // no code has this prefix
             reader_skip(r, 1);
@@ -251,7 +262,7 @@ JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, 
             z = run == 15 ? z + 16 : 64;                       // ZRL / EOB
         } else {
             z += run;
-            if (WRITE && z < 64) P.coef[(int64_t)blk * 64 + JD_ZIGZAG[z]] = (int16_t)extend(v, s);
+            if (WRITE && z < 64) P.coef[(int64_t)blk * 64 + z] = (int16_t)extend(v, s);      // zig-zag order; the IDCT undoes it
             z += 1;
         }
         if (z >= 64) {
@@ -284,9 +295,9 @@ JD_FN bool sweep_needs(const Params& P, int c, uint64_t& entry) {
     entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : JD_LOAD64(&P.exit_state[c - 1]);
     return entry != P.last_entry[c];
 }
-JD_FN void sweep_thread(const Params& P, int c, int sweep, uint64_t entry, const uint16_t* l1) {
+JD_FN void sweep_thread(const Params& P, int c, int sweep, uint64_t entry, const uint32_t* tab) {
     const Chunk k = chunk_of(P, c);
-    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, l1);
+    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, tab);
     JD_STORE64(&P.exit_state[c], res.exit);
     P.last_entry[c] = entry;
     P.nblk[c] = res.nblk;
@@ -332,7 +343,7 @@ JD_FN void scan_phase_c(const Params& P, int t, const int32_t* part) {
     }
 }
 
-JD_FN void write_thread(const Params& P, int c, const uint16_t* l1) {
+JD_FN void write_thread(const Params& P, int c, const uint32_t* tab) {
     const Chunk k = chunk_of(P, c);
     const uint64_t entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : P.exit_state[c - 1];
     const int32_t per_seg = P.restart ? P.restart * P.nb : P.nblocks;
@@ -341,7 +352,7 @@ JD_FN void write_thread(const Params& P, int c, const uint16_t* l1) {
     if (limit > P.nblocks) limit = P.nblocks;
     const int32_t blk = seg_blk0 + P.blk0[c] - P.blk0[P.seg_chunk0[k.seg]];
     if (blk >= limit && !k.last) return;
-    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit, l1);
+    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit, tab);
     if (res.nbad) JD_ATOMIC_ADD(&P.status[1], res.nbad);
     if (k.last && blk + res.nblk != limit) JD_ATOMIC_ADD(&P.status[2], 1);
 }
@@ -487,11 +498,14 @@ JD_FN void idct_thread(const Params& P, int blk) {
     const int16_t* cf = P.coef + (int64_t)blk * 64;
     const uint16_t* q = P.qt + comp * 64;
     int32_t ws[64], o[8];
+    // coefficient (row r, column c) sits at zig-zag position ZZI[8 r + c] of the block: compile-time indices in the unrolled loop
+    constexpr int ZZI[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                             10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
     JD_UNROLL
     for (int c = 0; c < 8; ++c) {
-        idct_1d((int32_t)cf[c] * q[c], (int32_t)cf[8 + c] * q[8 + c], (int32_t)cf[16 + c] * q[16 + c],
-                (int32_t)cf[24 + c] * q[24 + c], (int32_t)cf[32 + c] * q[32 + c], (int32_t)cf[40 + c] * q[40 + c],
-                (int32_t)cf[48 + c] * q[48 + c], (int32_t)cf[56 + c] * q[56 + c], o);
+        idct_1d((int32_t)cf[ZZI[c]] * q[c], (int32_t)cf[ZZI[8 + c]] * q[8 + c], (int32_t)cf[ZZI[16 + c]] * q[16 + c],
+                (int32_t)cf[ZZI[24 + c]] * q[24 + c], (int32_t)cf[ZZI[32 + c]] * q[32 + c], (int32_t)cf[ZZI[40 + c]] * q[40 + c],
+                (int32_t)cf[ZZI[48 + c]] * q[48 + c], (int32_t)cf[ZZI[56 + c]] * q[56 + c], o);
         JD_UNROLL
         for (int r = 0; r < 8; ++r) ws[r * 8 + c] = (o[r] + (1 << 10)) >> 11;          // DESCALE(CONST_BITS - PASS1_BITS)
     }

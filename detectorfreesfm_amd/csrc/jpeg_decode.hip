@@ -26,10 +26,12 @@
 //   colour    (RGB only) fancy upsampling of Cb / Cr + YCbCr -> RGB per output pixel
 // All integer / byte work, and latency-bound: a thread's next lookup depends on its last.  So the chain is kept short -- one
 // 32-bit window per symbol covers the code AND its value bits (one lookup, one shift), the window refills from aligned words
-// of the compacted scan, DC and AC symbols share one path (no divergence between lanes at different coefficients), the
-// Huffman tables are 16-bit-prefix LUTs in L2 whose first 10 levels every workgroup copies into 8 KB of LDS (where almost
-// every symbol of a photograph is answered).  v1 of this file decoded the stuffed bytes in place: 1.5 us per byte and thread
-// (profiles/r05_jpeg_v1_kernel_stats.csv).
+// of the compacted scan ONE WORD AHEAD of its use (some lane of a wave refills in almost every iteration, and a load the wave
+// waits for on the spot stalls all 64), DC and AC symbols share one path (no divergence between lanes at different
+// coefficients), and the Huffman tables live in 9.5 KB of LDS per workgroup (10-bit direct table + canonical search for
+// the rare long codes): no vector-memory instruction in the symbol loop but that prefetch.  v1 of this file decoded the
+// stuffed bytes in place at 1.5 us per byte and thread, v2 (compaction, one window per symbol) at 0.7
+// (profiles/r05_jpeg_v{1,2}_kernel_stats.csv).
 //
 // The marker segments (tables, frame header, restart positions) are parsed on the host (detectorfreesfm_amd/jpeg.py): a few
 // hundred bytes of control data.  Progressive, arithmetic-coded, 12-bit, CMYK and multi-scan files are refused there
@@ -62,14 +64,14 @@ __global__ __launch_bounds__(256) void jd_init_kernel(Params P) {
     if (c < P.nchunks) jd::init_thread(P, c);
 }
 __global__ __launch_bounds__(256) void jd_sweep_kernel(Params P, int sweep) {
-    __shared__ uint16_t l1[jd::L1_SIZE];
+    __shared__ uint32_t tab[jd::TAB_WORDS];
     const int c = blockIdx.x * 256 + threadIdx.x;
     uint64_t entry = 0;
     const bool need = c < P.nchunks && jd::sweep_needs(P, c, entry);
     if (!__syncthreads_or(need)) return;                     // a settled stretch of the scan: nothing to look up
-    for (int i = threadIdx.x; i < jd::L1_SIZE; i += 256) l1[i] = jd::l1_entry(P.lut, i);
+    for (int i = threadIdx.x; i < jd::TAB_WORDS; i += 256) tab[i] = P.tab[i];
     __syncthreads();
-    if (need) jd::sweep_thread(P, c, sweep, entry, l1);
+    if (need) jd::sweep_thread(P, c, sweep, entry, tab);
 }
 __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
     __shared__ int32_t part[jd::SCAN_T], grp[jd::SCAN_G];
@@ -84,11 +86,11 @@ __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
     jd::scan_phase_c(P, threadIdx.x, part);
 }
 __global__ __launch_bounds__(256) void jd_write_kernel(Params P) {
-    __shared__ uint16_t l1[jd::L1_SIZE];
-    for (int i = threadIdx.x; i < jd::L1_SIZE; i += 256) l1[i] = jd::l1_entry(P.lut, i);
+    __shared__ uint32_t tab[jd::TAB_WORDS];
+    for (int i = threadIdx.x; i < jd::TAB_WORDS; i += 256) tab[i] = P.tab[i];
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < P.nchunks) jd::write_thread(P, c, l1);
+    if (c < P.nchunks) jd::write_thread(P, c, tab);
 }
 __global__ __launch_bounds__(256) void jd_dc_sum_kernel(Params P) {
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -136,11 +138,11 @@ extern "C" size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host
 }
 
 extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* frame_host,
-                                    const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* block_base,
+                                    const uint32_t* huff_tab, const uint16_t* qt, const uint32_t* block_base,
                                     const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg,
                                     uint8_t* out, int64_t out_stride, int out_channels, int sweeps, int resume,
                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!scan || !frame_host || !huff_lut || !qt || !block_base || !seg_beg || !seg_end || !seg_chunk0 || !chunk_seg || !out || !status ||
+    if (!scan || !frame_host || !huff_tab || !qt || !block_base || !seg_beg || !seg_end || !seg_chunk0 || !chunk_seg || !out || !status ||
         !workspace)
         return DFSFM_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(scan) & 15) != 0) return DFSFM_E_BADARG;     // the compaction pass loads aligned 16-byte pieces
@@ -151,7 +153,7 @@ extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, con
     if (out_stride < (int64_t)P.width * out_channels) return DFSFM_E_BADARG;
     const Layout L = layout_of(P, scan_bytes, out_channels);
     if (workspace_bytes < L.total) return DFSFM_E_WORKSPACE;
-    jd::bind(P, L, static_cast<char*>(workspace), scan, scan_bytes, huff_lut, qt, block_base, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
+    jd::bind(P, L, static_cast<char*>(workspace), scan, scan_bytes, huff_tab, qt, block_base, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
              out_channels, status);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 

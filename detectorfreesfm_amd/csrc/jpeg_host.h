@@ -86,14 +86,14 @@ inline Layout layout_of(const Params& P, int64_t scan_bytes, int out_channels) {
 }
 
 
-inline void bind(Params& P, const Layout& L, char* ws, const uint8_t* scan, int64_t scan_bytes, const uint16_t* huff_lut,
+inline void bind(Params& P, const Layout& L, char* ws, const uint8_t* scan, int64_t scan_bytes, const uint32_t* huff_tab,
                  const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg, const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out,
                  int64_t out_stride, int out_channels, int32_t* status) {
     P.scan = scan;
     P.scan_bytes = (int32_t)scan_bytes;
     P.block_base = block_base;
     P.clean = reinterpret_cast<uint8_t*>(ws + L.clean);
-    P.lut = huff_lut;
+    P.tab = huff_tab;
     P.qt = qt;
     P.seg_beg = seg_beg;
     P.seg_end = seg_end;

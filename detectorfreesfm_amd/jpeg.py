@@ -50,8 +50,8 @@ class Plan:
     """Everything ``dfsfm_jpeg_decode_u8`` takes besides the output, as host arrays."""
     frame: Frame
     scan: np.ndarray                 # uint8: the entropy-coded bytes of the scan as in the file
-    lut_key: bytes                   # the DHT payloads the LUT was built from (cache key)
-    lut: np.ndarray                  # uint16 [4, 65536]
+    tab_key: bytes                   # the DHT payloads of the scan's tables, in slot order
+    tab: np.ndarray                  # uint32 [4 * 596]: huff_tab of include/dfsfm_hip.h
     qt: np.ndarray                   # uint16 [3, 64] natural order
     block_base: np.ndarray           # uint32 [ceil(len(scan) / 4096)] entropy bytes in front of each block of the scan
     seg_beg: np.ndarray              # uint32 [nseg] byte range of each restart interval in the compacted scan
@@ -70,33 +70,57 @@ class Plan:
         return int(self.frame.height)
 
 
-def huffman_lut(bits: bytes, vals: bytes) -> np.ndarray:
-    """(code length << 8) | symbol for every 16-bit prefix; codes as ITU T.81 Annex C generates them from BITS / HUFFVAL."""
-    lut = np.zeros(65536, dtype=np.uint16)
+TAB_SLOT_BYTES = 2384        # csrc/jpeg_core.h: uint16 l1[1024] | uint32 long[6][3] | uint8 vals[256], padded to 16
+
+
+def huffman_table(bits: bytes, vals: bytes) -> np.ndarray:
+    """One slot of ``huff_tab`` (include/dfsfm_hip.h) for the code ITU T.81 Annex C generates from BITS / HUFFVAL: the direct
+    table of the 10-bit prefixes and, for the lengths 11..16, (limit, first code, index of its first symbol) in left-aligned
+    16-bit code space -- codes of one length are consecutive and longer codes follow numerically."""
+    slot = np.zeros(TAB_SLOT_BYTES, dtype=np.uint8)
+    l1 = slot[:2048].view(np.uint16)
+    lg = slot[2048:2048 + 72].view(np.uint32)
     code, k = 0, 0
     for length in range(1, 17):
-        for _ in range(bits[length - 1]):
-            if k >= len(vals) or code >= (1 << length):
-                raise CorruptJpeg("bad Huffman table")
-            lo = code << (16 - length)
-            lut[lo:lo + (1 << (16 - length))] = (length << 8) | vals[k]
-            code += 1
-            k += 1
-        code <<= 1
-    return lut
+        n = bits[length - 1]
+        if k + n > len(vals) or code + n > (1 << length):
+            raise CorruptJpeg("bad Huffman table")
+        if length <= 10:
+            for j in range(n):
+                lo = (code + j) << (10 - length)
+                l1[lo:lo + (1 << (10 - length))] = (length << 8) | vals[k + j]
+        else:
+            lg[3 * (length - 11):3 * (length - 11) + 3] = ((code + n) << (16 - length), code << (16 - length), k)
+        code = (code + n) << 1
+        k += n
+    slot[2048 + 72:2048 + 72 + len(vals)] = np.frombuffer(vals, dtype=np.uint8)
+    return slot
+
+
+def huffman_decode_prefix(slot: np.ndarray, prefix16: int) -> int:
+    """The device's lookup (csrc/jpeg_core.h huff_lookup) restated: (length << 8) | symbol of the code that starts the 16 bits, 0
+    if none does."""
+    e = int(slot[:2048].view(np.uint16)[prefix16 >> 6])
+    if e == 0:
+        lg = slot[2048:2048 + 72].view(np.uint32)
+        for length in range(11, 17):
+            limit, base, off = (int(v) for v in lg[3 * (length - 11):3 * (length - 11) + 3])
+            if prefix16 < limit:
+                return (length << 8) | int(slot[2048 + 72 + off + ((prefix16 - base) >> (16 - length))])
+    return e
 
 
 @lru_cache(maxsize=32)
-def _lut_block(key: bytes) -> np.ndarray:
-    """[4, 65536] for up to four (class, bits, vals) tables serialised in ``key``."""
-    out = np.zeros((4, 65536), dtype=np.uint16)
+def _tab_block(key: bytes) -> np.ndarray:
+    """uint32 [4 * 596]: the slots of up to four (bits, vals) tables serialised in ``key``."""
+    out = np.zeros((4, TAB_SLOT_BYTES), dtype=np.uint8)
     o, slot = 0, 0
     while o < len(key):
         n = sum(key[o:o + 16])
-        out[slot] = huffman_lut(key[o:o + 16], key[o + 16:o + 16 + n])
+        out[slot] = huffman_table(key[o:o + 16], key[o + 16:o + 16 + n])
         o += 16 + n
         slot += 1
-    return out
+    return out.reshape(-1).view(np.uint32)
 
 
 def _exif_orientation(seg: bytes) -> int:
@@ -282,7 +306,7 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
     key = b"".join(huff[t][0] + huff[t][1] for t in tables)
     padded = np.zeros((scan_len + 31) // 16 * 16, dtype=np.uint8)    # the compaction pass loads aligned 16-byte pieces
     padded[:scan_len] = d[:scan_len]
-    return Plan(frame=fr, scan=padded[:scan_len], lut_key=key, lut=_lut_block(key), qt=qt, block_base=block_base, seg_beg=seg_beg,
+    return Plan(frame=fr, scan=padded[:scan_len], tab_key=key, tab=_tab_block(key), qt=qt, block_base=block_base, seg_beg=seg_beg,
                 seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling)
 
 
@@ -293,20 +317,6 @@ def is_jpeg(buf) -> bool:
 # ---------------------------------------------------------------------------------------------------------------------
 # device side
 # ---------------------------------------------------------------------------------------------------------------------
-_lut_cache = {}
-
-
-def _device_lut(pl: Plan, device):
-    import torch
-    key = (pl.lut_key, str(device))
-    t = _lut_cache.get(key)
-    if t is None:
-        if len(_lut_cache) > 16:
-            _lut_cache.clear()
-        t = _lut_cache[key] = torch.from_numpy(pl.lut.view(np.int16)).to(device)
-    return t
-
-
 def apply_orientation(img, orientation: int):
     """EXIF orientation the way cv2.imread applies it (loadsave.cpp ExifTransform); ``img`` [H,W] or [H,W,3] tensor."""
     if orientation == 2:
@@ -336,7 +346,7 @@ def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_
     from . import ops
     pl = plan(buf, chunk_bytes)
     device = torch.device(device)
-    out, info = ops.jpeg_decode(pl, _device_lut(pl, device) if device.type == "cuda" else None, 3 if color else 1, device, sweeps)
+    out, info = ops.jpeg_decode(pl, 3 if color else 1, device, sweeps)
     if orient and pl.orientation != 1:
         out = apply_orientation(out, pl.orientation)
     return (out, info) if return_info else out

@@ -754,19 +754,15 @@ def _jpeg_staging(nbytes: int):
     return buf[:nbytes]
 
 
-def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 16, max_calls: int = 8):
+def jpeg_decode(pl, out_channels: int, device, sweeps: int = 16, max_calls: int = 8):
     """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``): uploads the scan and its small tables in ONE copy, runs the
     chunk-parallel entropy decode + IDCT (+ upsampling / colour conversion) and returns (uint8 [H,W] or [H,W,3] device tensor,
-    dict(sweeps, calls)).  ``lut``: the [4,65536] Huffman prefix tables on the device (jpeg._device_lut caches them by DHT
-    content).  Reads the 16-byte status back once per call: a file whose relaxation has not reached its fixed point after
+    dict(sweeps, calls)).  Reads the 16-byte status back once per call: a file whose relaxation has not reached its fixed point after
     ``sweeps`` passes is continued (resume) with twice as many; corrupt streams raise."""
     from . import jpeg as _jpeg
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
-    _require_cuda(lut)
-    if lut.dtype != torch.int16 or tuple(lut.shape) != (4, 65536) or not lut.is_contiguous():
-        raise _lib.DfsfmError("jpeg_decode: lut is the contiguous [4, 65536] 16-bit prefix table")
     if out_channels not in (1, 3):
         raise _lib.DfsfmError("jpeg_decode: out_channels is 1 (luma) or 3 (RGB)")
     with torch.cuda.device(device):
@@ -775,8 +771,8 @@ def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 16, max_calls:
         nbytes = L.dfsfm_jpeg_decode_workspace(ctypes.byref(fr), pl.scan.size, out_channels)
         if nbytes == 0:
             raise _jpeg.UnsupportedJpeg("frame outside the device decoder (dfsfm_jpeg_decode_workspace)")
-        # one host buffer = one H2D copy: [scan | qt | block_base | seg_beg | seg_end | seg_chunk0 | chunk_seg], 16-byte aligned parts
-        parts = [pl.scan, pl.qt.reshape(-1).view(np.uint8), pl.block_base.view(np.uint8), pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8),
+        # one host buffer = one H2D copy: [scan | tab | qt | block_base | seg_beg | seg_end | seg_chunk0 | chunk_seg], 16-byte aligned
+        parts = [pl.scan, pl.tab.view(np.uint8), pl.qt.reshape(-1).view(np.uint8), pl.block_base.view(np.uint8), pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8),
                  pl.seg_chunk0.view(np.uint8), pl.chunk_seg.view(np.uint8)]
         offs, o = [], 0
         for a in parts:
@@ -794,8 +790,8 @@ def jpeg_decode(pl, lut, out_channels: int, device, sweeps: int = 16, max_calls:
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         calls, total, used = 0, 0, 0
         while True:
-            rc = L.dfsfm_jpeg_decode_u8(ptrs[0], pl.scan.size, ctypes.byref(fr), _ptr(lut), ptrs[1], ptrs[2], ptrs[3], ptrs[4],
-                                        ptrs[5], ptrs[6], _ptr(out), out.stride(0), out_channels, sweeps, int(calls > 0), _ptr(status),
+            rc = L.dfsfm_jpeg_decode_u8(ptrs[0], pl.scan.size, ctypes.byref(fr), ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5],
+                                        ptrs[6], ptrs[7], _ptr(out), out.stride(0), out_channels, sweeps, int(calls > 0), _ptr(status),
                                         _ptr(ws), nbytes, _stream())
             _lib.check(rc, "dfsfm_jpeg_decode_u8")
             calls += 1

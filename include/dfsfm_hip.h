@@ -461,8 +461,9 @@ int dfsfm_encoder256_apply_f32(const void* x_hi, const void* x_lo, int64_t ldx, 
  *   block_base  [ceil(scan_bytes / 4096)] uint32: entropy bytes in front of each 4096-byte block of `scan` (a byte counts
  *               unless it is a 00 after FF, an FF not followed by 00, or D0..D7 after FF) -- the first kernel compacts
  *               the scan with them
- *   huff_lut    [4][65536] uint16: (code length << 8) | symbol for every 16-bit prefix, 0 where no code matches;
- *               slots named by dc_slot / ac_slot
+ *   huff_tab    4 slots of 2384 bytes (slots named by dc_slot / ac_slot), per Huffman code: uint16[1024] = (length << 8) |
+ *               symbol for every 10-bit prefix of a code of at most 10 bits, else 0; uint32[6][3] = for lengths 11..16 the
+ *               left-aligned 16-bit (limit, first code, index of its first symbol); uint8[256] = HUFFVAL (T.81 Annex C)
  *   qt          [3][64] uint16 quantisation steps per component, natural (row-major) order
  *   seg_beg / seg_end [nseg] byte range of each restart interval in the COMPACTED scan; seg_chunk0 [nseg] its first
  *               chunk; chunk_seg [nchunks] the segment of a chunk; chunk i of a segment covers chunk_bytes compacted bytes
@@ -483,7 +484,7 @@ typedef struct dfsfm_jpeg_frame {
 } dfsfm_jpeg_frame;
 size_t dfsfm_jpeg_decode_workspace(const dfsfm_jpeg_frame* frame_host, int64_t scan_bytes, int out_channels);   /* 0 = unsupported */
 int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* frame_host,
-                         const uint16_t* huff_lut, const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg,
+                         const uint32_t* huff_tab, const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg,
                          const uint32_t* seg_end, const int32_t* seg_chunk0, const int32_t* chunk_seg, uint8_t* out, int64_t out_stride,
                          int out_channels, int sweeps, int resume, int32_t* status, void* workspace,
                          size_t workspace_bytes, void* stream);

@@ -398,7 +398,7 @@ def _enc256_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=N
     return None
 
 
-def _jpeg_decode(pl, lut, out_channels, device, sweeps=16, max_calls=8):
+def _jpeg_decode(pl, out_channels, device, sweeps=16, max_calls=8):
     """ops.jpeg_decode on the CPU lane model of the decoder (tests/jpeg_emul.cpp: the device thread functions compiled with g++),
     thread order reversed so that every sweep sees only the previous sweep's states, like a launch whose threads all start
     together."""

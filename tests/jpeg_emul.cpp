@@ -16,7 +16,7 @@ extern "C" size_t jd_emul_workspace(const dfsfm_jpeg_frame* f, int64_t scan_byte
 }
 
 // returns 0, or the DFSFM_E_* code the real entry point would; sweeps_used (may be null) receives, per sweep, the chunks decoded
-extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* f, const uint16_t* lut,
+extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jpeg_frame* f, const uint32_t* tab,
                               const uint16_t* qt, const uint32_t* block_base, const uint32_t* seg_beg, const uint32_t* seg_end,
                               const int32_t* seg_chunk0,
                               const int32_t* chunk_seg, uint8_t* out, int64_t out_stride, int out_channels, int sweeps,
@@ -27,7 +27,7 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
     if (out_stride < (int64_t)P.width * out_channels || sweeps < 1 || sweeps > 64) return DFSFM_E_BADARG;
     const jd::Layout L = jd::layout_of(P, scan_bytes, out_channels);
     if (workspace_bytes < L.total) return DFSFM_E_WORKSPACE;
-    jd::bind(P, L, static_cast<char*>(workspace), scan, scan_bytes, lut, qt, block_base, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
+    jd::bind(P, L, static_cast<char*>(workspace), scan, scan_bytes, tab, qt, block_base, seg_beg, seg_end, seg_chunk0, chunk_seg, out, out_stride,
              out_channels, status);
     std::memset(P.work, 0, 64 * 4);
     std::memset(status, 0, 16);
@@ -40,8 +40,7 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
             std::swap(perm[c], perm[(s >> 8) % (uint32_t)(c + 1)]);
         }
     }
-    std::vector<uint16_t> l1(jd::L1_SIZE);                    // the kernels' LDS copy of the tables' first levels
-    for (int i = 0; i < jd::L1_SIZE; ++i) l1[i] = jd::l1_entry(P.lut, i);
+    std::vector<uint32_t> lds(P.tab, P.tab + jd::TAB_WORDS);  // the kernels' LDS copy of the Huffman tables
     if (!resume) {
         const int nb = (int)((scan_bytes + jd::UNSTUFF_BLOCK - 1) / jd::UNSTUFF_BLOCK);
         for (int blk = 0; blk < nb; ++blk) {                  // one workgroup of jd_unstuff_kernel
@@ -61,7 +60,7 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
     for (int s = 0; s < sweeps; ++s)
         for (int i = 0; i < P.nchunks; ++i) {
             uint64_t entry = 0;
-            if (jd::sweep_needs(P, perm[i], entry)) jd::sweep_thread(P, perm[i], s, entry, l1.data());
+            if (jd::sweep_needs(P, perm[i], entry)) jd::sweep_thread(P, perm[i], s, entry, lds.data());
         }
     status[0] = P.work[sweeps - 1];
     for (int i = 0; i < sweeps; ++i)
@@ -76,7 +75,7 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
         for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_c(P, t, part.data());
     }
     std::memset(P.coef, 0, (size_t)P.nblocks * 128);
-    for (int c = 0; c < P.nchunks; ++c) jd::write_thread(P, c, l1.data());
+    for (int c = 0; c < P.nchunks; ++c) jd::write_thread(P, c, lds.data());
     const int ng = jd::dc_ngroups(P);
     for (int g = 0; g < ng; ++g) jd::dc_sum_thread(P, g);
     {

@@ -44,7 +44,7 @@ def decode(pl, color: bool, sweeps: int = 64, order: int = 0, max_calls: int = 6
     p = lambda a: a.ctypes.data
     used, calls = 0, 0
     while True:
-        rc = L.jd_emul_decode(p(pl.scan), pl.scan.size, ctypes.byref(pl.frame), p(pl.lut), p(pl.qt), p(pl.block_base), p(pl.seg_beg), p(pl.seg_end),
+        rc = L.jd_emul_decode(p(pl.scan), pl.scan.size, ctypes.byref(pl.frame), p(pl.tab), p(pl.qt), p(pl.block_base), p(pl.seg_beg), p(pl.seg_end),
                               p(pl.seg_chunk0), p(pl.chunk_seg), p(out), out.strides[0], ch, sweeps, int(calls > 0), p(status),
                               p(ws), nbytes, order, p(work))
         assert rc == 0, rc

@@ -128,29 +128,34 @@ def test_large_frame_multi_entry_scan_spans():
         assert info["status"][:3].tolist() == [0, 0, 0] and np.array_equal(out, rj.decode(buf, True))
 
 
-def test_huffman_lut_is_the_canonical_code():
-    buf = encode(synth(64, 64), quality=75, optimize=True)
-    pl = jpeg.plan(buf)
-    # every code of every table: the prefix range maps to (length, symbol); everything else is 0
-    o = 0
-    for slot in range(4):
-        if o >= len(pl.lut_key):
-            assert not pl.lut[slot].any()
-            continue
-        bits = pl.lut_key[o:o + 16]
-        nv = sum(bits)
-        vals = pl.lut_key[o + 16:o + 16 + nv]
-        o += 16 + nv
-        code, k, covered = 0, 0, 0
-        for length in range(1, 17):
-            for _ in range(bits[length - 1]):
-                lo, hi = code << (16 - length), (code + 1) << (16 - length)
-                assert (pl.lut[slot][lo:hi] == ((length << 8) | vals[k])).all()
-                covered += hi - lo
-                code += 1
-                k += 1
-            code <<= 1
-        assert int((pl.lut[slot] != 0).sum()) == covered
+def test_huffman_tables_are_the_canonical_code():
+    """jpeg.huffman_table (the LDS image of a code) through the device's two-step lookup, restated in
+    jpeg.huffman_decode_prefix: every code of every table of an optimised and of a standard file decodes to its (length, symbol)
+    whatever bits follow it; prefixes no code owns give 0."""
+    for buf in (encode(synth(64, 64), quality=75, optimize=True), encode(synth(64, 64), quality=100)):
+        pl = jpeg.plan(buf)
+        slots = pl.tab.view(np.uint8).reshape(4, jpeg.TAB_SLOT_BYTES)
+        o, slot = 0, 0
+        while o < len(pl.tab_key):
+            bits = pl.tab_key[o:o + 16]
+            nv = sum(bits)
+            vals = pl.tab_key[o + 16:o + 16 + nv]
+            o += 16 + nv
+            code, k, last = 0, 0, 0
+            for length in range(1, 17):
+                for _ in range(bits[length - 1]):
+                    lo, hi = code << (16 - length), ((code + 1) << (16 - length)) - 1
+                    for prefix in (lo, hi, (lo + hi) // 2):
+                        assert jpeg.huffman_decode_prefix(slots[slot], prefix) == ((length << 8) | vals[k]), (slot, length, code)
+                    last = hi
+                    code += 1
+                    k += 1
+                code <<= 1
+            for prefix in {last + 1, 0xFFFF} - {0x10000}:
+                if prefix > last:
+                    assert jpeg.huffman_decode_prefix(slots[slot], prefix) == 0
+            slot += 1
+        assert slot >= 2
 
 
 def test_parser_refuses_what_the_device_path_does_not_take():

@@ -36,12 +36,11 @@ for size in args.sizes.split(","):
             for _ in range(args.reps):
                 pl = jpeg.plan(buf, cb)
             t_plan = (time.perf_counter() - t0) / args.reps
-            lut = jpeg._device_lut(pl, dev)
-            out, info = ops.jpeg_decode(pl, lut, 3 if color else 1, dev)
+            out, info = ops.jpeg_decode(pl, 3 if color else 1, dev)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.reps):
-                out, info = ops.jpeg_decode(pl, lut, 3 if color else 1, dev)
+                out, info = ops.jpeg_decode(pl, 3 if color else 1, dev)
             torch.cuda.synchronize()
             t_dev = (time.perf_counter() - t0) / args.reps
             mpix = h * w / 1e6

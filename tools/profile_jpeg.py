@@ -10,8 +10,7 @@ color = (sys.argv[2] if len(sys.argv) > 2 else "gray") == "rgb"
 buf = encode(synth(1200, 1600, True, seed=1), quality=90, subsampling=2)
 dev = torch.device("cuda:0")
 pl = jpeg.plan(buf)
-lut = jpeg._device_lut(pl, dev)
 for _ in range(n):
-    out, info = ops.jpeg_decode(pl, lut, 3 if color else 1, dev)
+    out, info = ops.jpeg_decode(pl, 3 if color else 1, dev)
 torch.cuda.synchronize()
 print(len(buf), "bytes,", pl.frame.nchunks, "chunks,", info)
