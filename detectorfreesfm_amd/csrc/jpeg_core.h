@@ -22,7 +22,6 @@ constexpr int MAX_BLK = 6;                 // blocks per MCU (4:2:0: Y Y Y Y Cb 
 constexpr int SCAN_T = 1024;               // threads of the single-workgroup scans
 constexpr int DC_GROUP = 4;                // MCUs per thread of the DC prediction passes
 constexpr uint64_t NO_STATE = ~0ull;
-constexpr int CK = 4;                      // a chunk's trajectory is remembered at its quarters
 
 struct Params {
     // ---- the scan and its tables (device) ------------------------------------------------------------------------
@@ -52,8 +51,6 @@ struct Params {
     // ---- workspace (device) --------------------------------------------------------------------------------------
     uint64_t* exit_state;                  // [nchunks] decoder state at the first symbol that starts at / after the chunk's end
     uint64_t* last_entry;                  // [nchunks] entry state the stored exit was computed from
-    uint64_t* ck_state;                    // [nchunks][CK - 1] state at the first symbol at / after each quarter of the chunk
-    int32_t* ck_rem;                       // [nchunks][CK - 1] blocks completed from that symbol to the chunk's exit
     int32_t* nblk;                         // [nchunks] blocks completed by symbols that start inside the chunk
     int32_t* blk0;                         // [nchunks] exclusive prefix of nblk
     int32_t* work;                         // [64] chunks decoded by sweep i (0 = fixed point reached)
@@ -235,15 +232,8 @@ struct ChunkResult {
     uint64_t exit;
     int32_t nblk, nbad;
 };
-// SWEEP (the relaxation passes): the trajectory of the previous decode of this chunk is remembered at the chunk's quarters
-// (state of the first symbol at / after each boundary, blocks completed from there to the exit).  A re-decode from a new entry
-// that arrives at a boundary in the remembered state IS the old trajectory from there on -- same exit, the old remaining block
-// count -- and stops.  That is self-synchronisation cashed in: after the first two sweeps almost every re-decode ends at its
-// first quarter, so a sweep costs a quarter of a chunk instead of a whole one.  c: the chunk (checkpoints), have_old: whether
-// the remembered trajectory exists.
 template <bool WRITE>
-JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint32_t* tab,
-                               int c = 0, bool have_old = false) {
+JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint32_t* tab) {
     Reader r;
     reader_init(r, P.clean, entry >> 16);
     uint32_t b = (uint32_t)(entry >> 8) & 0xFF, z = (uint32_t)entry & 0xFF;
@@ -251,36 +241,7 @@ JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, 
     ChunkResult res;
     res.nblk = 0;
     res.nbad = 0;
-    // checkpoints (SWEEP only)
-    const uint64_t ck_step = (uint64_t)(P.chunk_bytes / CK) * 8;
-    uint64_t next_bound = (uint64_t)k.beg * 8 + ck_step;
-    int j = 0;
-    uint64_t old0 = NO_STATE, old1 = NO_STATE, old2 = NO_STATE;
-    uint64_t* cks = WRITE ? nullptr : P.ck_state + (int64_t)c * (CK - 1);
-    int32_t* ckr = WRITE ? nullptr : P.ck_rem + (int64_t)c * (CK - 1);
-    if (!WRITE && have_old) {
-        old0 = cks[0];
-        old1 = cks[1];
-        old2 = cks[2];
-    }
-    bool rejoined = false;
-    for (;;) {
-        const uint64_t pos = reader_pos(r);
-        if (pos >= end_pos || (WRITE && blk >= blk_limit)) break;
-        if (!WRITE) {
-            while (j < CK - 1 && pos >= next_bound) {          // the first symbol at / after quarter j + 1
-                const uint64_t state = pack_state(pos, b, z);
-                if (state == (j == 0 ? old0 : j == 1 ? old1 : old2)) {
-                    rejoined = true;
-                    break;
-                }
-                cks[j] = state;
-                ckr[j] = res.nblk;                             // blocks BEFORE this symbol for now; turned into "after" below
-                j += 1;
-                next_bound += ck_step;
-            }
-            if (rejoined) break;
-        }
+    while (reader_pos(r) < end_pos && (!WRITE || blk < blk_limit)) {
         reader_fill(r);
         const uint32_t pk = reader_peek32(r);
         const bool is_dc = z == 0;
@@ -311,17 +272,7 @@ JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, 
             blk += 1;
         }
     }
-    if (!WRITE) {
-        if (rejoined) {
-            res.nblk += ckr[j];                                // the remembered rest of the trajectory
-            res.exit = NO_STATE;                               // = the exit already stored
-        } else {
-            res.exit = pack_state(reader_pos(r), b, z);
-        }
-        for (int i = 0; i < j; ++i) ckr[i] = res.nblk - ckr[i];
-    } else {
-        res.exit = pack_state(reader_pos(r), b, z);
-    }
+    res.exit = pack_state(reader_pos(r), b, z);
     return res;
 }
 
@@ -346,8 +297,8 @@ JD_FN bool sweep_needs(const Params& P, int c, uint64_t& entry) {
 }
 JD_FN void sweep_thread(const Params& P, int c, int sweep, uint64_t entry, const uint32_t* tab) {
     const Chunk k = chunk_of(P, c);
-    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, tab, c, P.last_entry[c] != NO_STATE);
-    if (res.exit != NO_STATE) JD_STORE64(&P.exit_state[c], res.exit);
+    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, tab);
+    JD_STORE64(&P.exit_state[c], res.exit);
     P.last_entry[c] = entry;
     P.nblk[c] = res.nblk;
     JD_ATOMIC_ADD(&P.work[sweep], 1);

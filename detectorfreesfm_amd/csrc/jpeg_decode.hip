@@ -16,8 +16,6 @@
 //             publishes its own; chunks whose entry did not change since their last decode do nothing.  The first chunk
 //             of a segment starts from the truth, so this is a fixed-point iteration that is exact when a sweep decodes
 //             nothing, and self-synchronisation makes that happen after a few sweeps instead of nchunks
-//             A re-decode stops as soon as it rejoins the chunk's remembered trajectory at a quarter boundary (same state =>
-//             same continuation), which after the first two sweeps is nearly always the first quarter.
 //             (Weissenberger & Schmidt's scheme for GPU Huffman / JPEG decoding, restated for 64-lane waves: no
 //             intra-block phases, the relaxation runs in place in global memory, 8-byte states are single transactions).
 //             Restart markers (DRI) cut the scan into independent segments: more starting points that are true.

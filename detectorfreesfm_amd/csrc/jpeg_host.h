@@ -9,7 +9,7 @@
 namespace jd {
 
 struct Layout {
-    size_t clean, exit_state, last_entry, ck_state, ck_rem, nblk, blk0, work, coef, dc_part, dc_base, plane[3], total;
+    size_t clean, exit_state, last_entry, nblk, blk0, work, coef, dc_part, dc_base, plane[3], total;
 };
 
 // geometry the frame header implies; false = not a frame this decoder takes
@@ -60,7 +60,7 @@ inline bool derive(const dfsfm_jpeg_frame& f, Params& P) {
     P.nseg = f.nseg;
     P.nchunks = f.nchunks;
     P.chunk_bytes = f.chunk_bytes;
-    if (f.restart < 0 || f.nseg < 1 || f.nchunks < f.nseg || f.chunk_bytes < 16 || f.chunk_bytes % 4) return false;
+    if (f.restart < 0 || f.nseg < 1 || f.nchunks < f.nseg || f.chunk_bytes < 16) return false;
     if (f.restart == 0 ? f.nseg != 1 : f.nseg != (P.nmcu + f.restart - 1) / f.restart) return false;
     return true;
 }
@@ -72,8 +72,6 @@ inline Layout layout_of(const Params& P, int64_t scan_bytes, int out_channels) {
     L.clean = take((size_t)scan_bytes + 64);                   // compacted scan + words the bit reader may touch past its end
     L.exit_state = take((size_t)P.nchunks * 8);
     L.last_entry = take((size_t)P.nchunks * 8);
-    L.ck_state = take((size_t)P.nchunks * (CK - 1) * 8);
-    L.ck_rem = take((size_t)P.nchunks * (CK - 1) * 4);
     L.nblk = take((size_t)P.nchunks * 4);
     L.blk0 = take((size_t)P.nchunks * 4);
     L.work = take(64 * 4 + 4 * 4);                              // work[64] + status scratch
@@ -104,8 +102,6 @@ inline void bind(Params& P, const Layout& L, char* ws, const uint8_t* scan, int6
     P.out_channels = out_channels;
     P.exit_state = reinterpret_cast<uint64_t*>(ws + L.exit_state);
     P.last_entry = reinterpret_cast<uint64_t*>(ws + L.last_entry);
-    P.ck_state = reinterpret_cast<uint64_t*>(ws + L.ck_state);
-    P.ck_rem = reinterpret_cast<int32_t*>(ws + L.ck_rem);
     P.nblk = reinterpret_cast<int32_t*>(ws + L.nblk);
     P.blk0 = reinterpret_cast<int32_t*>(ws + L.blk0);
     P.work = reinterpret_cast<int32_t*>(ws + L.work);
