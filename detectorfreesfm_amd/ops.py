@@ -742,70 +742,97 @@ def resample_u8(src, bounds_x, kk_x, bounds_y, kk_y, out_u8=False, lut=None, pad
     return o8, of, mk
 
 
-_jpeg_stage = [None]
+_jpeg_pool = []              # pinned staging buffers not in use (allocating pinned memory per call costs more than a decode)
 
 
 def _jpeg_staging(nbytes: int):
-    """A grow-only pinned host buffer for the one upload of a decode call (allocating pinned memory per call costs more than the
-    decode).  Safe to reuse: every jpeg_decode call ends with a host read of its status, i.e. after its upload."""
-    buf = _jpeg_stage[0]
-    if buf is None or buf.numel() < nbytes:
-        buf = _jpeg_stage[0] = torch.empty((max(nbytes * 5 // 4, 1 << 20),), dtype=torch.uint8, pin_memory=True)
-    return buf[:nbytes]
+    for i, buf in enumerate(_jpeg_pool):
+        if buf.numel() >= nbytes:
+            return _jpeg_pool.pop(i)
+    if _jpeg_pool:
+        _jpeg_pool.pop()                                     # too small: let it go
+    return torch.empty((max(nbytes * 5 // 4, 1 << 20),), dtype=torch.uint8, pin_memory=True)
 
 
-def jpeg_decode(pl, out_channels: int, device, sweeps: int = 16, max_calls: int = 8):
-    """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``): uploads the scan and its small tables in ONE copy, runs the
-    chunk-parallel entropy decode + IDCT (+ upsampling / colour conversion) and returns (uint8 [H,W] or [H,W,3] device tensor,
-    dict(sweeps, calls)).  Reads the 16-byte status back once per call: a file whose relaxation has not reached its fixed point after
-    ``sweeps`` passes is continued (resume) with twice as many; corrupt streams raise."""
-    from . import jpeg as _jpeg
+class JpegDecodeCall:
+    """One ``dfsfm_jpeg_decode_u8`` in flight: ``jpeg_decode_launch`` uploads the scan and its small tables in ONE copy and
+    queues every kernel on the stream that is current; ``finish()`` reads the 16-byte status back on that stream, continues the
+    relaxation (resume) with twice as many sweeps if its fixed point was not reached, raises on corrupt streams and returns
+    (uint8 [H,W] or [H,W,3] device tensor, dict(sweeps, sweeps_used, calls)).  Several calls may be in flight on different
+    streams (``jpeg.decode_many``): a decode is a chain of small latency-bound launches that leaves most of the chip idle."""
+
+    def __init__(self, pl, out_channels, device, sweeps, max_calls):
+        from . import jpeg as _jpeg
+        self._jpeg, self.pl, self.out_channels, self.device = _jpeg, pl, out_channels, device
+        self.sweeps, self.max_calls = sweeps, max_calls
+        self.stream = torch.cuda.current_stream(device)
+        L = _lib.lib()
+        fr = pl.frame
+        self.nbytes = L.dfsfm_jpeg_decode_workspace(ctypes.byref(fr), pl.scan.size, out_channels)
+        if self.nbytes == 0:
+            raise _jpeg.UnsupportedJpeg("frame outside the device decoder (dfsfm_jpeg_decode_workspace)")
+        # one host buffer = one H2D copy: [scan | tab | qt | block_base | seg_beg | seg_end | seg_chunk0 | chunk_seg], 16-byte aligned
+        parts = [pl.scan, pl.tab.view(np.uint8), pl.qt.reshape(-1).view(np.uint8), pl.block_base.view(np.uint8),
+                 pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8), pl.seg_chunk0.view(np.uint8), pl.chunk_seg.view(np.uint8)]
+        offs, o = [], 0
+        for a in parts:
+            offs.append(o)
+            o = (o + a.size + 15) // 16 * 16
+        self.host = _jpeg_staging(o)                         # pinned; back in the pool when finish() has seen the status
+        hv = self.host.numpy()
+        for a, at in zip(parts, offs):
+            hv[at:at + a.size] = a
+        self.devbuf = self.host[:o].to(device, non_blocking=True)
+        base = self.devbuf.data_ptr()
+        self.ptrs = [ctypes.c_void_p(base + at) for at in offs]
+        self.out = torch.empty((fr.height, fr.width) if out_channels == 1 else (fr.height, fr.width, 3), dtype=torch.uint8, device=device)
+        self.status = torch.empty((4,), dtype=torch.int32, device=device)
+        self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=device)
+        self.calls, self.total, self.used = 0, 0, 0
+        self._launch()
+
+    def _launch(self):
+        p, pl = self.ptrs, self.pl
+        rc = _lib.lib().dfsfm_jpeg_decode_u8(p[0], pl.scan.size, ctypes.byref(pl.frame), p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                                             _ptr(self.out), self.out.stride(0), self.out_channels, self.sweeps, int(self.calls > 0),
+                                             _ptr(self.status), _ptr(self.ws), self.nbytes, ctypes.c_void_p(self.stream.cuda_stream))
+        _lib.check(rc, "dfsfm_jpeg_decode_u8")
+        self.calls += 1
+        self.total += self.sweeps
+
+    def finish(self):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            try:
+                while True:
+                    st = self.status.tolist()
+                    self.used = self.total - self.sweeps + st[3] if st[3] else self.used
+                    if st[0] == 0:
+                        break
+                    if self.calls >= self.max_calls:
+                        raise self._jpeg.CorruptJpeg(f"entropy decode did not reach its fixed point in {self.total} sweeps")
+                    self.sweeps = min(64, 2 * self.sweeps)
+                    self._launch()
+            finally:
+                _jpeg_pool.append(self.host)
+                self.host = None
+        if st[1] or st[2]:
+            raise self._jpeg.CorruptJpeg(f"corrupt scan: {st[1]} invalid codes, {st[2]} restart intervals with a wrong block count")
+        return self.out, dict(sweeps=self.total, sweeps_used=self.used, calls=self.calls)
+
+
+def jpeg_decode_launch(pl, out_channels: int, device, sweeps: int = 16, max_calls: int = 8) -> JpegDecodeCall:
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
     if out_channels not in (1, 3):
         raise _lib.DfsfmError("jpeg_decode: out_channels is 1 (luma) or 3 (RGB)")
     with torch.cuda.device(device):
-        L = _lib.lib()
-        fr = pl.frame
-        nbytes = L.dfsfm_jpeg_decode_workspace(ctypes.byref(fr), pl.scan.size, out_channels)
-        if nbytes == 0:
-            raise _jpeg.UnsupportedJpeg("frame outside the device decoder (dfsfm_jpeg_decode_workspace)")
-        # one host buffer = one H2D copy: [scan | tab | qt | block_base | seg_beg | seg_end | seg_chunk0 | chunk_seg], 16-byte aligned
-        parts = [pl.scan, pl.tab.view(np.uint8), pl.qt.reshape(-1).view(np.uint8), pl.block_base.view(np.uint8), pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8),
-                 pl.seg_chunk0.view(np.uint8), pl.chunk_seg.view(np.uint8)]
-        offs, o = [], 0
-        for a in parts:
-            offs.append(o)
-            o = (o + a.size + 15) // 16 * 16
-        host = _jpeg_staging(o)                             # pinned; free again when this call's status read returns
-        hv = host.numpy()
-        for a, at in zip(parts, offs):
-            hv[at:at + a.size] = a
-        devbuf = host.to(device, non_blocking=True)
-        base = devbuf.data_ptr()
-        ptrs = [ctypes.c_void_p(base + at) for at in offs]
-        out = torch.empty((fr.height, fr.width) if out_channels == 1 else (fr.height, fr.width, 3), dtype=torch.uint8, device=device)
-        status = torch.empty((4,), dtype=torch.int32, device=device)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        calls, total, used = 0, 0, 0
-        while True:
-            rc = L.dfsfm_jpeg_decode_u8(ptrs[0], pl.scan.size, ctypes.byref(fr), ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5],
-                                        ptrs[6], ptrs[7], _ptr(out), out.stride(0), out_channels, sweeps, int(calls > 0), _ptr(status),
-                                        _ptr(ws), nbytes, _stream())
-            _lib.check(rc, "dfsfm_jpeg_decode_u8")
-            calls += 1
-            total += sweeps
-            st = status.tolist()
-            used = total - sweeps + st[3] if st[3] else used
-            if st[0] == 0:
-                break
-            if calls >= max_calls:
-                raise _jpeg.CorruptJpeg(f"entropy decode did not reach its fixed point in {total} sweeps")
-            sweeps = min(64, 2 * sweeps)
-        if st[1] or st[2]:
-            raise _jpeg.CorruptJpeg(f"corrupt scan: {st[1]} invalid codes, {st[2]} restart intervals with a wrong block count")
-        return out, dict(sweeps=total, sweeps_used=used, calls=calls)
+        return JpegDecodeCall(pl, out_channels, device, sweeps, max_calls)
+
+
+def jpeg_decode(pl, out_channels: int, device, sweeps: int = 16, max_calls: int = 8):
+    """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``), synchronously: launch + finish of ``JpegDecodeCall``."""
+    return jpeg_decode_launch(pl, out_channels, device, sweeps, max_calls).finish()
 
 
 @_on_device

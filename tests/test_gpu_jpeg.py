@@ -94,3 +94,13 @@ def test_readers_take_file_names(tmp_path):
     assert torch.equal(a, b)
     with pytest.raises(jpeg.UnsupportedJpeg):
         images.read_grayscale(str(pp), device=DEV, decode="device")
+
+
+def test_decode_many_overlaps_files_on_streams():
+    bufs = [encode(synth(240 + 16 * i, 320 + 8 * i, True, seed=i), quality=70 + 3 * i, subsampling=(0, 1, 2)[i % 3],
+                   **({"restart_marker_rows": 2} if i % 4 == 0 else {})) for i in range(9)]
+    for color in (False, True):
+        outs = jpeg.decode_many(bufs, color, DEV, streams=4)
+        for buf, out in zip(bufs, outs):
+            assert np.array_equal(out.cpu().numpy(), rj.decode(buf, color))
+    assert torch.equal(jpeg.decode_many(bufs[:1], True, DEV, streams=1)[0], jpeg.decode(bufs[0], True, DEV))
