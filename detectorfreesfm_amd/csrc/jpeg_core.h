@@ -125,50 +125,29 @@ JD_FN void unstuff_scan_b2(uint32_t* grp) {
 // 64-bit window, left aligned, refilled 32 bits at a time from aligned big-endian words: at least 32 valid bits at the start
 // of every symbol cover the longest code (16) plus the longest value (15).  Positions are bits of `clean`.  Past a segment's
 // end the reader sees the next segment (or the pad): every loop is bounded by positions, not by what the bits say.
-// The words a thread will read -- its chunk plus the overshoot of the last symbol and the lookahead -- are staged in LDS before
-// the symbol loop (each thread copies its own WIN_WORDS words, all loads in flight at once; word j of thread t at [j * stride + t]:
-// every lane keeps to its own bank).  Why: SOME lane of a wave refills in almost every iteration, the wave's memory counter is
-// shared, so a refill from global memory -- even one word ahead, even from L1 -- made every iteration wait ~260 cycles for the
-// previous iteration's load (profiles/r05_jpeg_pmc_v3.json: 263 of 511 cycles per symbol parked on s_waitcnt); an LDS read
-// returns together with the table lookup the iteration waits for anyway.  Words outside the window (chunks longer than 128
-// bytes) still come from global memory.
-constexpr int WIN_WORDS = 36;              // 128-byte chunk + 3 words of overshoot / lookahead + alignment
 struct Reader {
     const uint32_t* d;
-    const uint32_t* win;                   // this thread's staged words (stride `stride`), first word = word w0 of `d`
-    uint32_t w0, stride;
     uint32_t i;                            // next word to load (the word before it waits in `ahead`)
     uint64_t acc;
     int32_t nbits;
-    uint32_t ahead;                        // the next word, loaded one refill early, byte-swapped at use
-};
+    uint32_t ahead;                        // the next word, loaded one refill early: its latency hides behind a whole refill period
+};                                         //   (a lane refills every ~6 symbols, but SOME lane of the wave does in almost every
+                                           //   iteration, and a load the wave has to wait for on the spot costs every lane ~250 cycles)
 JD_FN uint32_t be32(uint32_t w) { return (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24); }
-JD_FN uint32_t window_first_word(uint64_t entry) { return (uint32_t)((entry >> 16) >> 5); }
-JD_FN void window_stage(const uint8_t* clean, uint64_t entry, uint32_t* win, uint32_t stride) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(clean) + window_first_word(entry);
-    for (int j = 0; j < WIN_WORDS; ++j) win[(uint32_t)j * stride] = src[j];
-}
-JD_FN uint32_t reader_word(const Reader& r, uint32_t i) {
-    const uint32_t j = i - r.w0;
-    return j < (uint32_t)WIN_WORDS ? r.win[j * r.stride] : r.d[i];
-}
-JD_FN void reader_init(Reader& r, const uint8_t* clean, uint64_t pos, const uint32_t* win, uint32_t stride) {
+JD_FN void reader_init(Reader& r, const uint8_t* clean, uint64_t pos) {
     r.d = reinterpret_cast<const uint32_t*>(clean);
-    r.win = win;
-    r.stride = stride;
     r.i = (uint32_t)(pos >> 5);
-    r.w0 = r.i;
     const uint32_t sh = (uint32_t)(pos & 31);
-    r.acc = (uint64_t)be32(reader_word(r, r.i)) << (32 + sh);
+    r.acc = (uint64_t)be32(r.d[r.i]) << (32 + sh);
     r.nbits = 32 - (int32_t)sh;
-    r.ahead = reader_word(r, r.i + 1);
+    r.ahead = r.d[r.i + 1];                                 // as loaded: the byte swap waits until the word is used
     r.i += 2;
 }
 JD_FN void reader_fill(Reader& r) {                      // afterwards nbits >= 32
     if (r.nbits < 32) {
         r.acc |= (uint64_t)be32(r.ahead) << (32 - r.nbits);
         r.nbits += 32;
-        r.ahead = reader_word(r, r.i);
+        r.ahead = r.d[r.i];
         r.i += 1;
     }
 }
@@ -254,10 +233,9 @@ struct ChunkResult {
     int32_t nblk, nbad;
 };
 template <bool WRITE>
-JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint32_t* tab,
-                               const uint32_t* win, uint32_t stride) {
+JD_FN ChunkResult decode_chunk(const Params& P, const Chunk& k, uint64_t entry, int32_t blk, int32_t blk_limit, const uint32_t* tab) {
     Reader r;
-    reader_init(r, P.clean, entry >> 16, win, stride);
+    reader_init(r, P.clean, entry >> 16);
     uint32_t b = (uint32_t)(entry >> 8) & 0xFF, z = (uint32_t)entry & 0xFF;
     const uint64_t end_pos = (uint64_t)k.end * 8;
     ChunkResult res;
@@ -317,9 +295,9 @@ JD_FN bool sweep_needs(const Params& P, int c, uint64_t& entry) {
     entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : JD_LOAD64(&P.exit_state[c - 1]);
     return entry != P.last_entry[c];
 }
-JD_FN void sweep_thread(const Params& P, int c, int sweep, uint64_t entry, const uint32_t* tab, const uint32_t* win, uint32_t stride) {
+JD_FN void sweep_thread(const Params& P, int c, int sweep, uint64_t entry, const uint32_t* tab) {
     const Chunk k = chunk_of(P, c);
-    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, tab, win, stride);
+    const ChunkResult res = decode_chunk<false>(P, k, entry, 0, 0, tab);
     JD_STORE64(&P.exit_state[c], res.exit);
     P.last_entry[c] = entry;
     P.nblk[c] = res.nblk;
@@ -365,19 +343,16 @@ JD_FN void scan_phase_c(const Params& P, int t, const int32_t* part) {
     }
 }
 
-JD_FN uint64_t write_entry(const Params& P, int c) {
+JD_FN void write_thread(const Params& P, int c, const uint32_t* tab) {
     const Chunk k = chunk_of(P, c);
-    return k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : P.exit_state[c - 1];
-}
-JD_FN void write_thread(const Params& P, int c, uint64_t entry, const uint32_t* tab, const uint32_t* win, uint32_t stride) {
-    const Chunk k = chunk_of(P, c);
+    const uint64_t entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : P.exit_state[c - 1];
     const int32_t per_seg = P.restart ? P.restart * P.nb : P.nblocks;
     const int32_t seg_blk0 = k.seg * per_seg;
     int32_t limit = seg_blk0 + per_seg;
     if (limit > P.nblocks) limit = P.nblocks;
     const int32_t blk = seg_blk0 + P.blk0[c] - P.blk0[P.seg_chunk0[k.seg]];
     if (blk >= limit && !k.last) return;
-    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit, tab, win, stride);
+    const ChunkResult res = decode_chunk<true>(P, k, entry, blk, limit, tab);
     if (res.nbad) JD_ATOMIC_ADD(&P.status[1], res.nbad);
     if (k.last && blk + res.nblk != limit) JD_ATOMIC_ADD(&P.status[2], 1);
 }

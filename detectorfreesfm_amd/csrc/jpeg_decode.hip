@@ -28,8 +28,7 @@
 // 32-bit window per symbol covers the code AND its value bits (one lookup, one shift), the window refills from aligned words
 // of the compacted scan ONE WORD AHEAD of its use (some lane of a wave refills in almost every iteration, and a load the wave
 // waits for on the spot stalls all 64), DC and AC symbols share one path (no divergence between lanes at different
-// coefficients), every thread's words are staged in LDS before its loop (a global refill, even from L1, stalled the whole wave
-// in nearly every iteration: one memory counter per wave), and the Huffman tables live in 9.5 KB of LDS per workgroup (10-bit direct table + canonical search for
+// coefficients), and the Huffman tables live in 9.5 KB of LDS per workgroup (10-bit direct table + canonical search for
 // the rare long codes): no vector-memory instruction in the symbol loop but that prefetch.  v1 of this file decoded the
 // stuffed bytes in place at 1.5 us per byte and thread, v2 (compaction, one window per symbol) at 0.7
 // (profiles/r05_jpeg_v{1,2}_kernel_stats.csv).
@@ -70,11 +69,9 @@ __global__ __launch_bounds__(256) void jd_sweep_kernel(Params P, int sweep) {
     uint64_t entry = 0;
     const bool need = c < P.nchunks && jd::sweep_needs(P, c, entry);
     if (!__syncthreads_or(need)) return;                     // a settled stretch of the scan: nothing to look up
-    __shared__ uint32_t win[jd::WIN_WORDS * 256];
     for (int i = threadIdx.x; i < jd::TAB_WORDS; i += 256) tab[i] = P.tab[i];
-    if (need) jd::window_stage(P.clean, entry, win + threadIdx.x, 256);
     __syncthreads();
-    if (need) jd::sweep_thread(P, c, sweep, entry, tab, win + threadIdx.x, 256);
+    if (need) jd::sweep_thread(P, c, sweep, entry, tab);
 }
 __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
     __shared__ int32_t part[jd::SCAN_T], grp[jd::SCAN_G];
@@ -90,16 +87,10 @@ __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
 }
 __global__ __launch_bounds__(256) void jd_write_kernel(Params P) {
     __shared__ uint32_t tab[jd::TAB_WORDS];
-    __shared__ uint32_t win[jd::WIN_WORDS * 256];
     for (int i = threadIdx.x; i < jd::TAB_WORDS; i += 256) tab[i] = P.tab[i];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    uint64_t entry = 0;
-    if (c < P.nchunks) {
-        entry = jd::write_entry(P, c);
-        jd::window_stage(P.clean, entry, win + threadIdx.x, 256);
-    }
     __syncthreads();
-    if (c < P.nchunks) jd::write_thread(P, c, entry, tab, win + threadIdx.x, 256);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < P.nchunks) jd::write_thread(P, c, tab);
 }
 __global__ __launch_bounds__(256) void jd_dc_sum_kernel(Params P) {
     const int g = blockIdx.x * 256 + threadIdx.x;

@@ -69,7 +69,7 @@ inline Layout layout_of(const Params& P, int64_t scan_bytes, int out_channels) {
     Layout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) / 256 * 256; return at; };
-    L.clean = take((size_t)scan_bytes + 256);                  // compacted scan + the words a thread stages / reads past its end
+    L.clean = take((size_t)scan_bytes + 64);                   // compacted scan + words the bit reader may touch past its end
     L.exit_state = take((size_t)P.nchunks * 8);
     L.last_entry = take((size_t)P.nchunks * 8);
     L.nblk = take((size_t)P.nchunks * 4);

@@ -60,11 +60,7 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
     for (int s = 0; s < sweeps; ++s)
         for (int i = 0; i < P.nchunks; ++i) {
             uint64_t entry = 0;
-            if (jd::sweep_needs(P, perm[i], entry)) {
-                uint32_t win[jd::WIN_WORDS];                    // the thread's slice of the workgroup's LDS window
-                jd::window_stage(P.clean, entry, win, 1);
-                jd::sweep_thread(P, perm[i], s, entry, lds.data(), win, 1);
-            }
+            if (jd::sweep_needs(P, perm[i], entry)) jd::sweep_thread(P, perm[i], s, entry, lds.data());
         }
     status[0] = P.work[sweeps - 1];
     for (int i = 0; i < sweeps; ++i)
@@ -79,12 +75,7 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
         for (int t = 0; t < jd::SCAN_T; ++t) jd::scan_phase_c(P, t, part.data());
     }
     std::memset(P.coef, 0, (size_t)P.nblocks * 128);
-    for (int c = 0; c < P.nchunks; ++c) {
-        uint32_t win[jd::WIN_WORDS];
-        const uint64_t entry = jd::write_entry(P, c);
-        jd::window_stage(P.clean, entry, win, 1);
-        jd::write_thread(P, c, entry, lds.data(), win, 1);
-    }
+    for (int c = 0; c < P.nchunks; ++c) jd::write_thread(P, c, lds.data());
     const int ng = jd::dc_ngroups(P);
     for (int g = 0; g < ng; ++g) jd::dc_sum_thread(P, g);
     {
