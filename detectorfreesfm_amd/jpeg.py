@@ -232,6 +232,8 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
         raise UnsupportedJpeg("multi-scan sequential JPEG")
     if sof["width"] == 0 or sof["height"] == 0:
         raise UnsupportedJpeg("frame size given by a DNL marker")
+    if sof["width"] * sof["height"] > (1 << 28):
+        raise UnsupportedJpeg("frame larger than 2^28 pixels")
     fr = Frame()
     fr.width, fr.height, fr.ncomp = sof["width"], sof["height"], ncomp
     qt = np.ones((3, 64), dtype=np.uint16)
@@ -272,9 +274,9 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
     # ---- the scan: up to the first marker that is not RSTn; restart markers cut it into segments -------------------------
     d = data[scan_start:]
     ff = np.flatnonzero(d == 0xFF)
-    nxt = np.where(ff + 1 < d.size, d[np.minimum(ff + 1, d.size - 1)], 0xD9)
-    mark = ff[(nxt != 0) & (nxt != 0xFF)]                       # FF FF is fill, FF 00 a stuffed data byte
-    ends = mark[~((nxt[(nxt != 0) & (nxt != 0xFF)] >= 0xD0) & (nxt[(nxt != 0) & (nxt != 0xFF)] <= 0xD7))]
+    nxt = np.where(ff + 1 < d.size, d[np.minimum(ff + 1, d.size - 1)], 0xD9)        # the byte after each FF (EOI past the end)
+    marker = (nxt != 0) & (nxt != 0xFF)                         # FF 00 is a stuffed data byte, FF FF a fill byte
+    ends = ff[marker & ~((nxt >= 0xD0) & (nxt <= 0xD7))]        # the first marker that is not RSTn ends the scan
     scan_len = int(ends[0]) if ends.size else d.size
     inside = ff < scan_len
     ff, nxt = ff[inside], nxt[inside]
