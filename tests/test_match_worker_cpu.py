@@ -164,3 +164,40 @@ def test_match_worker_empty_tables(which):
     assert list(got) == [PAIRS[0], PAIRS[2]]
     for t in got.values():
         assert t.shape == (0, 5) and t.dtype == np.float32
+
+
+def test_match_worker_from_jpeg_files(tmp_path):
+    """The whole feeding path from FILES (r05): the worker is handed file names (frames=None, the reference's call), every file
+    is decoded by jpeg.decode -- here the CPU lane model of the device decoder --, resized and matched; the tables equal the
+    oracle matcher on the oracle readers fed the ORACLE decode (oracle/jpeg_baseline.c) of the same files."""
+    import io
+    from PIL import Image
+    from oracle import restate_jpeg as rj
+    frames = scene_frames()
+    names, decoded = {}, {}
+    for k, (name, img) in enumerate(frames.items()):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=100, **({"restart_marker_rows": 3} if k == 1 else {}))
+        path = tmp_path / os.path.basename(name)
+        path.write_bytes(b.getvalue())
+        names[name] = str(path)
+        decoded[str(path)] = rj.decode(b.getvalue(), False)
+        assert np.abs(decoded[str(path)].astype(int) - img).max() <= 3             # quality 100: the planted content survives
+    pairs = [" ".join(names[q] for q in p.split(" ")) for p in PAIRS]
+    cfgs, models, oracle = build("loftr_hip")
+    with cpu_ops():
+        got = plugin.match_worker([0, 1, 2], list(names.values()), pairs, cfgs, device="cpu", frames=None, models=models)
+    rule = plugin._DATA_RULES["loftr_hip"]
+    n = 0
+    for p in pairs:
+        p0, p1 = p.split(" ")
+        (i0, s0, _, _), (i1, s1, _, _) = (rr.read_image(decoded[q], resize=(128,), df=rule["df"], pad_to=rule["pad_to"]) for q in (p0, p1))
+        data = {"image0": torch.from_numpy(i0)[None], "image1": torch.from_numpy(i1)[None],
+                "scale0": torch.from_numpy(s0)[None], "scale1": torch.from_numpy(s1)[None]}
+        with torch.no_grad():
+            o = oracle(data)
+        t = got[p]
+        assert np.array_equal(t[:, :2], o["mkpts0_f"].numpy()) and np.array_equal(t[:, 2:4], o["mkpts1_f"].numpy())
+        assert np.abs(t[:, 4] - o["mconf"].numpy()).max(initial=0) < 1e-4
+        n += len(t)
+    assert n > 30
