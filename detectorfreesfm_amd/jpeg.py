@@ -355,29 +355,33 @@ def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_
 
 
 def decode_many(bufs, color: bool, device="cuda", streams: int = 4, sweeps: int = DEFAULT_SWEEPS, orient: bool = True):
-    """``decode`` for a list of files with up to ``streams`` decodes in flight: one decode is a chain of ~25 small,
-    latency-bound launches on a hundred waves, so several of them overlap on the chip almost for free while the host parses
-    the next file.  Returns the list of device tensors (usable on the current stream).  Files the device path does not take
-    raise ``UnsupportedJpeg`` before anything is launched for them."""
+    """``decode`` for a list of files with several decodes in flight: one decode is a chain of ~25 small, latency-bound
+    launches on a hundred waves, so a few of them overlap on the chip almost for free -- and the host parses file i + 1 while
+    the GPU decodes file i (each file is launched as soon as it is parsed; at most 2 x ``streams`` calls are open, which also
+    bounds the workspace held).  Returns the list of device tensors (usable on the current stream).  A file the device path
+    does not take raises ``UnsupportedJpeg`` when its turn comes."""
     import torch
     from . import ops
     device = torch.device(device)
-    plans = [plan(b) for b in bufs]
     cur = torch.cuda.current_stream(device)
-    side = [torch.cuda.Stream(device) for _ in range(max(1, min(streams, len(plans))))]
+    side = [torch.cuda.Stream(device) for _ in range(max(1, min(streams, len(bufs))))]
     for s in side:
         s.wait_stream(cur)
-    calls = []
-    for i, pl in enumerate(plans):
-        with torch.cuda.stream(side[i % len(side)]):
-            calls.append(ops.jpeg_decode_launch(pl, 3 if color else 1, device, sweeps))
-    outs = []
-    for pl, call in zip(plans, calls):
+    outs, open_calls = [], []
+
+    def close_oldest():
+        pl, call = open_calls.pop(0)
         out, _ = call.finish()
         out.record_stream(cur)
-        outs.append(out)
+        outs.append(apply_orientation(out, pl.orientation) if orient and pl.orientation != 1 else out)
+    for i, b in enumerate(bufs):
+        pl = plan(b)
+        if len(open_calls) >= 2 * len(side):
+            close_oldest()
+        with torch.cuda.stream(side[i % len(side)]):
+            open_calls.append((pl, ops.jpeg_decode_launch(pl, 3 if color else 1, device, sweeps)))
+    while open_calls:
+        close_oldest()
     for s in side:
         cur.wait_stream(s)
-    if orient:
-        outs = [apply_orientation(o, pl.orientation) if pl.orientation != 1 else o for o, pl in zip(outs, plans)]
     return outs
