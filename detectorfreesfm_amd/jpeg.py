@@ -143,7 +143,15 @@ def _exif_orientation(seg: bytes) -> int:
 
 
 def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
-    """Parse the marker segments of a JPEG file (bytes / uint8 array) and cut its scan into decoder chunks."""
+    """Parse the marker segments of a JPEG file (bytes / uint8 array) and cut its scan into decoder chunks.  Raises
+    ``UnsupportedJpeg`` / ``CorruptJpeg`` only: a damaged header never surfaces as an IndexError."""
+    try:
+        return _plan(buf, chunk_bytes)
+    except (IndexError, ValueError, OverflowError) as e:
+        raise CorruptJpeg(f"damaged marker segment ({type(e).__name__}: {e})") from None
+
+
+def _plan(buf, chunk_bytes: int) -> Plan:
     data = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray, memoryview)) else np.ascontiguousarray(buf, dtype=np.uint8)
     b = data.tobytes() if not isinstance(buf, bytes) else buf
     n = len(b)

@@ -252,3 +252,34 @@ def test_readers_decode_files_on_the_product_path(tmp_path):
             images.read_grayscale(str(pp), device="cpu", decode="device")
         a = images.read_grayscale(str(p), resize=(96,), df=8, device="cpu", decode="host")
         assert np.array_equal(a.numpy(), images.read_grayscale(pil_gray(p.read_bytes()), resize=(96,), df=8, device="cpu").numpy())
+
+
+def test_damaged_headers_raise_or_decode_within_bounds():
+    """Files cut at random places and files with random bytes changed in the marker segments (frame size, sampling factors, table
+    contents, restart interval, segment lengths): ``plan`` answers with CorruptJpeg / UnsupportedJpeg or a plan; every plan that
+    comes back is run through the lane model of the device decoder, which works under the kernels' own bounds -- it must
+    terminate and stay inside its buffers whatever the header claims (a wrong geometry shows up as status, not as a crash)."""
+    rng = np.random.default_rng(7)
+    good = [encode(synth(97, 131, True, seed=1), quality=80, subsampling=2, restart_marker_blocks=3),
+            encode(synth(64, 64, False, seed=2), quality=60, optimize=True)]
+    planned = refused = 0
+    for trial in range(300):
+        buf = bytearray(good[trial % 2])
+        scan_at = bytes(buf).index(jpeg.plan(bytes(buf)).scan.tobytes()[:12])
+        if trial % 3 == 0:
+            buf = buf[:int(rng.integers(2, len(buf)))]
+        else:
+            for pos in rng.integers(2, scan_at, 1 + trial % 4):
+                buf[pos] = int(rng.integers(0, 256))
+        try:
+            pl = jpeg.plan(bytes(buf), 32)
+        except (jpeg.CorruptJpeg, jpeg.UnsupportedJpeg):
+            refused += 1
+            continue
+        if pl.width * pl.height > 1 << 22:                     # a damaged size field: fine for the device, slow for the model
+            continue
+        planned += 1
+        for color in (False, True):
+            out, info = jpeg_emul.decode(pl, color, sweeps=8, order=1, max_calls=4)
+            assert out.shape[:2] == (pl.height, pl.width)
+    assert planned > 30 and refused > 30
