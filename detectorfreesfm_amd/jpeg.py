@@ -364,30 +364,36 @@ def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_
 
 def decode_many(bufs, color: bool, device="cuda", streams: int = 4, sweeps: int = DEFAULT_SWEEPS, orient: bool = True):
     """``decode`` for a list of files with several decodes in flight: one decode is a chain of ~25 small, latency-bound
-    launches on a hundred waves, so a few of them overlap on the chip almost for free -- and the host parses file i + 1 while
-    the GPU decodes file i (each file is launched as soon as it is parsed; at most 2 x ``streams`` calls are open, which also
-    bounds the workspace held).  Returns the list of device tensors (usable on the current stream).  A file the device path
-    does not take raises ``UnsupportedJpeg`` when its turn comes."""
+    launches on a hundred waves, so a few of them overlap on the chip almost for free -- and the host work overlaps too: two
+    helper threads parse the marker segments of the next files (numpy's passes over a scan release the GIL) while this thread
+    packs and launches, each file as soon as its plan is there.  At most 2 x ``streams`` calls are open and 4 x ``streams`` files
+    parsed ahead, which bounds the memory held.  Returns the list of device tensors (usable on the current stream).  A file the
+    device path does not take raises ``UnsupportedJpeg`` when its turn comes."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from . import ops
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
     side = [torch.cuda.Stream(device) for _ in range(max(1, min(streams, len(bufs))))]
     for s in side:
         s.wait_stream(cur)
-    outs, open_calls = [], []
+    outs, open_calls, parsing, ahead = [], [], [], 0
 
     def close_oldest():
         pl, call = open_calls.pop(0)
         out, _ = call.finish()
         out.record_stream(cur)
         outs.append(apply_orientation(out, pl.orientation) if orient and pl.orientation != 1 else out)
-    for i, b in enumerate(bufs):
-        pl = plan(b)
-        if len(open_calls) >= 2 * len(side):
-            close_oldest()
-        with torch.cuda.stream(side[i % len(side)]):
-            open_calls.append((pl, ops.jpeg_decode_launch(pl, 3 if color else 1, device, sweeps)))
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        for i in range(len(bufs)):
+            while ahead < len(bufs) and len(parsing) < 4 * len(side):
+                parsing.append(pool.submit(plan, bufs[ahead]))
+                ahead += 1
+            pl = parsing.pop(0).result()
+            if len(open_calls) >= 2 * len(side):
+                close_oldest()
+            with torch.cuda.stream(side[i % len(side)]):
+                open_calls.append((pl, ops.jpeg_decode_launch(pl, 3 if color else 1, device, sweeps)))
     while open_calls:
         close_oldest()
     for s in side:
