@@ -133,16 +133,24 @@ def parse_spec(spec, n):
     return out
 
 
-def variant_text(asm_text, scalar_set, nops=None):
-    """`scalar_set`: indices (among the kernel's packed instructions) to rewrite; `nops`: {index: (before, after)} s_nop counts."""
+def variant_text(asm_text, scalar_set, nops=None, swap_after=(), replace=None):
+    """`scalar_set`: indices (among the kernel's packed instructions) to rewrite; `nops`: {index: (before, after)} s_nop counts;
+    `swap_after`: indices k whose two FOLLOWING instructions change places; `replace`: {index: [lines]} literal replacement."""
     lines = asm_text.split("\n")
     pk = packed_lines(lines)
     nops = nops or {}
+    replace = replace or {}
     used_tmp = False
+    for k in swap_after:          # on the untouched text; the ORDER of the packed instructions does not change
+        i = pk[k]
+        lines[i + 1], lines[i + 2] = lines[i + 2], lines[i + 1]
+    pk = packed_lines(lines)
     for k in sorted(range(len(pk)), reverse=True):
         i = pk[k]
         new = [lines[i]]
-        if k in scalar_set:
+        if k in replace:
+            new = list(replace[k])
+        elif k in scalar_set:
             new = scalarize(lines[i])
             used_tmp |= len(new) == 3
         b, a = nops.get(k, (0, 0))
@@ -155,9 +163,9 @@ def variant_text(asm_text, scalar_set, nops=None):
     return text
 
 
-def build_variant(scalar_set, out_so, nops=None, tag="v"):
+def build_variant(scalar_set, out_so, nops=None, tag="v", swap_after=(), replace=None):
     asm, host, capi = prepare()
-    fb = build_fatbin(variant_text(open(asm).read(), scalar_set, nops), tag)
+    fb = build_fatbin(variant_text(open(asm).read(), scalar_set, nops, swap_after, replace), tag)
     obj = os.path.join(WORK, f"{tag}_host.o")
     run([f"{LLVM}/llvm-objcopy", "--update-section", f".hip_fatbin={fb}", host, obj])
     run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", obj, capi, "-o", out_so])
@@ -307,10 +315,59 @@ def auto():
             test({k}, label=f"only #{k} scalarised")
 
 
+def focus():
+    """Second session: the strong culprit of the `auto` run (packed op #25 of the r06 build: v_pk_mul_f32 v[152:153], v[202:203],
+    v[152:153] op_sel:[0,1], followed by a ds_read2_b32 that reloads v[202:203] and then by the consumer of v[152:153]) kept packed
+    with EVERYTHING else scalarised, and what cures it."""
+    asm, _, _ = prepare()
+    lines = open(asm).read().split("\n")
+    pk = packed_lines(lines)
+    n = len(pk)
+    K = int(os.environ.get("FINE_FOCUS", "25"))
+    print(f"# focus on packed op #{K}: {lines[pk[K]].strip()}", flush=True)
+    for j in range(pk[K] - 5, pk[K] + 5):
+        print(("  >> " if j == pk[K] else "     ") + lines[j].rstrip())
+    ck = Checker()
+    allbut = lambda *keep: set(range(n)) - set(keep)
+    m = PK.match(lines[pk[K]])
+    exps = [
+        ("all scalarised but #K", allbut(K), {}, (), None),
+        ("... + s_nop 0 after #K", allbut(K), {K: (0, 1)}, (), None),
+        ("... + s_nop 0 before consumer", allbut(K), {K + 1: (1, 0)}, (), None),
+        ("... + s_nop 0 before #K", allbut(K), {K: (1, 0)}, (), None),
+        ("... + s_nop 3 before #K", allbut(K), {K: (4, 0)}, (), None),
+        ("... + s_nop 3 after #K", allbut(K), {K: (0, 4)}, (), None),
+        ("... + s_nop 3 before consumer", allbut(K), {K + 1: (4, 0)}, (), None),
+        ("... + s_nop 7 x (before, after, consumer)", allbut(K), {K: (8, 8), K + 1: (8, 0)}, (), None),
+        ("... ds_read moved behind the consumer", allbut(K), {}, (K,), None),
+        ("... ds_read behind the consumer, s_nop 0 after #K", allbut(K), {K: (0, 1)}, (K,), None),
+        ("#K and its consumer packed", allbut(K, K + 1), {}, (), None),
+        ("#K-1 and #K packed", allbut(K - 1, K), {}, (), None),
+        ("all packed but #K", {K}, {}, (), None),
+    ]
+    if "op_sel:[0,1]" in lines[pk[K]] and "op_sel_hi" not in lines[pk[K]]:
+        # the same product without the op_sel modifier: broadcast src1.hi into src1.lo first (dst == src1 here, so lo is dead)
+        d = re.search(r"v_pk_mul_f32 v\[(\d+):(\d+)\], (v\[\d+:\d+\]), v\[(\d+):(\d+)\]", lines[pk[K]])
+        if d and d.group(1) == d.group(4):
+            lo, hi, src0 = int(d.group(1)), int(d.group(2)), d.group(3)
+            exps.append(("#K without op_sel (v_mov lo, hi first)", allbut(K), {}, (),
+                         {K: [f"\tv_mov_b32_e32 v{lo}, v{hi}", f"\tv_pk_mul_f32 v[{lo}:{hi}], {src0}, v[{lo}:{hi}]"]}))
+            exps.append(("#K without op_sel + s_nop between", allbut(K), {}, (),
+                         {K: [f"\tv_mov_b32_e32 v{lo}, v{hi}", "\ts_nop 0", f"\tv_pk_mul_f32 v[{lo}:{hi}], {src0}, v[{lo}:{hi}]"]}))
+    runs = int(os.environ.get("FINE_RUNS", "60"))
+    for i, (label, S, nops, swap, repl) in enumerate(exps):
+        so = build_variant(S, os.path.join(WORK, f"lib_f{i}.so"), nops, tag=f"f{i}", swap_after=swap, replace={K: repl[K]} if repl else None)
+        r = ck.check(so, runs=runs)
+        print(f"focus {i:2d} {label:44s}: {'REPRODUCIBLE' if r['bad_runs'] == 0 else 'DEVIATES'} ({r['bad_runs']}/{r['runs']} runs; std "
+              f"{r['std']}, coords {r['coords']}, best {r['best']} entries) {r['ms']:.3f} ms", flush=True)
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "list"
     if mode == "auto":
         auto()
+    elif mode == "focus":
+        focus()
     elif mode == "build":
         asm, _, _ = prepare()
         n = len(packed_lines(open(asm).read().split("\n")))
