@@ -114,6 +114,9 @@ SIGNATURES = [
       c_void_p, c_size_t, c_void_p]),
     ("dfsfm_maxpool3x3s2_nhwc_f32", c_int,
      [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("dfsfm_s2d_front_f32", c_int,
+     [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 ]
 
 _lib = None

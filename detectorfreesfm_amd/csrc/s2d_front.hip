@@ -1,0 +1,390 @@
+// K9 front end -- S2DNet conv1_1 -> ReLU -> conv1_2 -> ReLU -> { centre crop, MaxPool2d(3, 2, 1) } in ONE launch, gfx950 (MI355X).
+//
+// Replaces, for the 35 x 35 RGB patches of the refinement head,
+//   VGG16 features[0..4] with the substituted pooling layer   src/MultiviewMatcher/backbone/S2DNet/s2dnet.py:86-92, 127-160
+//   (conv1_1 3->64, ReLU, conv1_2 64->64, ReLU, MaxPool2d(3, stride 2, padding 1))                 backbone/S2DNet/vggnet.py:12-44
+// and hands out exactly the two things the rest of the network reads of relu1_2: the centre window that adaptation layer 0 is
+// evaluated on (s2dnet.py:164-175; refine.py evaluates it only where the W x W output needs it) and the pooled 18 x 18 map that
+// conv2_1 reads.  As three launches (direct_conv, conv_gemm_sf_same<64,3,8>, maxpool) this front end moved 13 GB per 10 000
+// patches -- conv1_1 wrote the 3.1 GB fp16x2 map that conv1_2 read back, conv1_2 wrote another 3.1 GB of which the pool re-read
+// all and kept a quarter -- and took 5.6 of the 34 ms refinement step (profiles/r05_refine_step_kernel_stats.csv) at a third of
+// the HBM rate and a third of the matrix rate at once.  Here neither map exists in HBM: 14.7 KB of RGB in, 175 KB of split
+// planes out per patch (1.9 GB per 10 000).
+//
+// One workgroup (4 waves) per patch, TWO workgroups per CU (78.9 KB of LDS each), a patch in five bands of seven output rows:
+//   rgb     the band's 11 input rows (zero-padded to 37 columns, 4 floats per pixel) -> LDS
+//   conv1_1 for one 32-channel half: wave w computes channels 8w..8w+7 of the band's 9 relu1_1 rows in exact fp32 (the FMA
+//           order of direct_conv_kernel: bias, then taps (ky, kx, ci)) from LDS with its 216 weights as scalar operands, splits
+//           them (v = hi + lo/2048) and writes the fp16 planes [9 x 37 rows][32 ch] -- zero rows / columns where conv1_2 pads
+//   conv1_2 9 taps x that half = 9 slabs of K = 32 on v_mfma_f32_16x16x32_f16 (three products per slab: hi*hi, hi*lo, lo*hi):
+//           a wave owns 64 of the band's 245 output pixels x 64 channels (4 x 4 blocks); a tap is an LDS ROW OFFSET of the
+//           A fragment (ky * 37 + kx: the zero columns make every tap a plain shift, no masks); the weights stream L2 -> LDS
+//           through a 3-stage ring of 8-KB slabs (buffer_load ... lds, counted vmcnt, one barrier per slab)
+//   ... the other half, same accumulators ...
+//   out     accumulators -> fp32 staging tile (over the dead operand buffers) -> bias, ReLU, fp16x2 split -> the rows of the
+//           crop window and the pooled rows this band completes; a pooled row that straddles two bands is carried as a 4.6-KB
+//           partial maximum (max commutes with + bias, ReLU and the split, all monotone: pooled bytes equal pool-after-split)
+// While one workgroup of a CU runs its VALU phases (conv1_1, epilogue) the other one's MFMA phase owns the matrix pipe.
+// MFMA work per patch: 5 bands x 256 rows x 64 x 576 x 2 x 3 = 283 MFLOP for 271 MFLOP of split product (245 of 256 rows live).
+#include "common.h"
+#include "sf_gemm.h"
+
+namespace {
+
+using namespace dfsfm;
+using dfsfm_sf::half8;
+using dfsfm_sf::tile_off16;
+using dfsfm_sf::wait_vmcnt;
+
+constexpr int P = 35;                             // patch side
+constexpr int PW = P + 2;                         // band row in LDS: one zero column on each side
+constexpr int R = 7;                              // output rows per band
+constexpr int NBAND = P / R;
+constexpr int LR = R + 2;                         // relu1_1 rows of a band
+constexpr int AROWS = 336;                        // LR * PW = 333 rows, rounded
+constexpr int MROWS = R * P;                      // 245 output pixels per band
+constexpr int A_PLANE = AROWS * 64;               // [row][32 channels] fp16
+constexpr int B_PLANE = 64 * 64;                  // [cout][32 k] fp16
+constexpr int B_STAGE = 2 * B_PLANE;
+constexpr int NBST = 3;
+constexpr int OFF_B = 2 * A_PLANE;
+constexpr int RING = OFF_B + NBST * B_STAGE;      // 67 584
+constexpr int TILE_LD = 68;                       // fp32 staging row (floats)
+constexpr int TILE_BYTES = 256 * TILE_LD * 4;     // 69 632: all 256 rows of the MFMA tile, so that staging needs no row test
+constexpr int UNION = RING > TILE_BYTES ? RING : TILE_BYTES;
+constexpr int RGB_ROWS = R + 4;                   // input rows 7 b - 2 .. 7 b + 8
+constexpr int OFF_RGB = UNION;
+constexpr int RGB_BYTES = (RGB_ROWS * PW * 16 + 15) & ~15;
+constexpr int PO = (P + 1) / 2;                   // pooled side: 18
+constexpr int OFF_CARRY = OFF_RGB + RGB_BYTES;
+constexpr int CARRY_BYTES = PO * 64 * 4;
+constexpr int SMEM = OFF_CARRY + CARRY_BYTES;     // 80 752
+constexpr int NSLAB = 18;                         // 2 channel halves x 9 taps
+static_assert(LR * PW <= AROWS && 2 * SMEM <= 160 * 1024 && P % R == 0, "two workgroups per CU");
+
+struct FrontArgs {
+    const float* x;                               // [n][P][P][3] normalised RGB patches (NHWC)
+    const float* w1g;                             // conv1_1 weights [8 channel groups][27 = (ky, kx, ci)][8]
+    const float* b1;                              // [64]
+    const _Float16 *w2h, *w2l;                    // conv1_2 weights, tap-padded split planes [>= 64][kpad], k = tap * 64 + ci
+    const float* b2;                              // [64]
+    _Float16 *crh, *crl;                          // centre window of relu1_2: [n][c1 - c0][c1 - c0][64] split planes
+    _Float16 *poh, *pol;                          // pooled relu1_2: [n][18][18][64] split planes
+    int c0, c1, kpad;
+    unsigned w2bytes;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t patch = blockIdx.x;
+    const float* xp = g.x + patch * (P * P * 3);
+    f32x4* rgb = reinterpret_cast<f32x4*>(smem + OFF_RGB);
+    float* carry = reinterpret_cast<float*>(smem + OFF_CARRY);
+    float* tile = reinterpret_cast<float*>(smem);
+    const int CW = g.c1 - g.c0;
+
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.w2h, 0, g.w2bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.w2l, 0, g.w2bytes, 0x00020000);
+
+    // ---- lane constants of the MFMA loop -------------------------------------------------------------------------------------
+    int arow[4];                                   // LDS row of tap (0, 0) for this lane's pixel of row block i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wave * 64 + i * 16 + (lane & 15);
+        const int mm = m < MROWS ? m : 0;          // the 11 pad rows of the tile multiply pixel 0; nobody reads their results
+        const int y = mm / P;
+        arow[i] = y * PW + (mm - y * P);
+    }
+    const int kslot = lane >> 4;
+    // weight slab DMA: a wave's piece is 16 couts x 64 B of one plane; lane -> (row lane >> 2, physical slot lane & 3)
+    const unsigned bbase = (unsigned)(((wave * 16 + (lane >> 2)) * g.kpad + (((lane & 3) ^ ((lane >> 3) & 3)) * 8)) * 2);
+    auto dma_b = [&](int t) __attribute__((always_inline)) {          // slab t = half * 9 + tap -> stage t % 3
+        const int hf = t >= 9 ? 1 : 0, tap = t - 9 * hf;
+        const unsigned off = t < NSLAB ? bbase + (unsigned)((tap * 64 + hf * 32) * 2) : g.w2bytes;   // past the end: zero fill
+        char* d = smem + OFF_B + (t % NBST) * B_STAGE + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_void*)d, 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d + B_PLANE), 16, off, 0, 0, 0);
+    };
+
+    // ---- conv1_1 lane constants: wave w owns channels 8 w .. 8 w + 7 of a half, lane + 64 it = pixel of the 9 x 35 band ----
+    int rb[5];                                     // rgb index of tap (0, 0); A row written = rb + 1 (same 37-wide rows)
+    bool qok[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int q = lane + 64 * it;
+        qok[it] = q < LR * P;
+        const int qq = qok[it] ? q : 0;
+        const int ly = qq / P;
+        rb[it] = ly * PW + (qq - ly * P);
+    }
+
+    for (int band = 0; band < NBAND; ++band) {
+        const int y0 = band * R;
+        // ---- rgb rows y0 - 2 .. y0 + 8, columns -1 .. 35 ---------------------------------------------------------------------
+        for (int e = tid; e < RGB_ROWS * PW; e += 256) {
+            const int ry = e / PW, cx = e - ry * PW;
+            const int iy = y0 - 2 + ry, ix = cx - 1;
+            const bool ok = iy >= 0 && iy < P && ix >= 0 && ix < P;
+            const float* p = xp + (ok ? (iy * P + ix) * 3 : 0);
+            const float r0 = p[0], r1 = p[1], r2 = p[2];
+            rgb[e] = ok ? f32x4{r0, r1, r2, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        wait_vmcnt<0>();                            // also the previous band's output stores: the counted waits below see only DMA
+        dma_b(0);
+        dma_b(1);
+        lds_barrier();
+
+        f32x4 accm[4][4], accx[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                accm[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            // ---- conv1_1, channels hf * 32 + 8 wave .. + 7 ---------------------------------------------------------------------
+            {
+                const int cg = hf * 4 + wave;
+                // wave-uniform addresses in the CONSTANT address space: scalar loads (the output stores of the previous band would
+                // otherwise make the compiler fetch the 216 weights through vector registers)
+                typedef const __attribute__((address_space(4))) float* cptr;
+                const cptr wg = (cptr)(uintptr_t)(g.w1g + cg * 216);
+                const cptr bg = (cptr)(uintptr_t)(g.b1 + cg * 8);
+                float a1[5][8];
+#pragma unroll
+                for (int it = 0; it < 5; ++it)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a1[it][c] = bg[c];
+#pragma unroll 1                 // a real loop: one tap's 24 weights (scalar registers) live at a time
+                for (int kk = 0; kk < 9; ++kk) {
+                    const int ky = kk / 3, kx = kk - 3 * ky;
+                    f32x4 v[5];
+#pragma unroll
+                    for (int it = 0; it < 5; ++it) v[it] = rgb[rb[it] + ky * PW + kx];
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        float w[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) w[c] = wg[(kk * 3 + ci) * 8 + c];
+#pragma unroll
+                        for (int it = 0; it < 5; ++it)
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) a1[it][c] = __builtin_fmaf(v[it][ci], w[c], a1[it][c]);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int ly = rb[it] / PW;
+                    const int iy = y0 - 1 + ly;
+                    const bool live = iy >= 0 && iy < P;            // rows outside the image are conv1_2's zero padding
+                    half8 h, l;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        _Float16 a, b;
+                        split_f32(live ? fmaxf(a1[it][c], 0.f) : 0.f, a, b);
+                        h[c] = a;
+                        l[c] = b;
+                    }
+                    if (qok[it]) {
+                        const int off = tile_off16(rb[it] + 1, wave);
+                        *reinterpret_cast<half8*>(smem + off) = h;
+                        *reinterpret_cast<half8*>(smem + A_PLANE + off) = l;
+                    }
+                }
+                if (tid < 2 * LR * 4) {                             // the zero columns x' = 0 and x' = 36 of every band row
+                    const int ly = tid >> 3, side = (tid >> 2) & 1;
+                    const int off = tile_off16(ly * PW + side * (PW - 1), tid & 3);
+                    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<half8*>(smem + off) = z;
+                    *reinterpret_cast<half8*>(smem + A_PLANE + off) = z;
+                }
+            }
+            // ---- conv1_2: 9 taps of this half ------------------------------------------------------------------------------------
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int t = hf * 9 + tap;
+                wait_vmcnt<2>();                    // own pieces of slab t landed (slab t + 1 may still fly)
+                lds_barrier();                      // slab t published, every wave is done with slab t - 1; tap 0: the A planes written
+                dma_b(t + 2);
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const char* sb = smem + OFF_B + (t % NBST) * B_STAGE;
+                half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = tile_off16(arow[i] + ky * PW + kx, kslot);
+                    ah[i] = *reinterpret_cast<const half8*>(smem + off);
+                    al[i] = *reinterpret_cast<const half8*>(smem + A_PLANE + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int off = tile_off16(j * 16 + (lane & 15), kslot);
+                    bh[j] = *reinterpret_cast<const half8*>(sb + off);
+                    bl[j] = *reinterpret_cast<const half8*>(sb + B_PLANE + off);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // in place (destination tied to the addend, see sf_gemm.h); consecutive MFMAs never share an accumulator
+#define S2D_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) S2D_MFMA(accm[i][j], ah[i], bh[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) S2D_MFMA(accx[i][j], ah[i], bl[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) S2D_MFMA(accx[i][j], al[i], bh[j]);
+                __builtin_amdgcn_s_setprio(0);
+#undef S2D_MFMA
+            }
+            lds_barrier();                          // every wave has read its last A fragments of this half
+        }
+        wait_vmcnt<0>();                            // the two zero-fill tail slabs, before the ring becomes the staging tile
+        lds_barrier();
+        // the inline-asm MFMAs are invisible to the hazard recogniser: 16 x 16 x 32 results need passes + 3 = 7 wait states before
+        // a VALU read (sf_gemm.h); the accumulators pass through an empty asm so that no read is hoisted above the nop
+        asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                asm volatile("" : "+v"(accm[i][j]));
+                asm volatile("" : "+v"(accx[i][j]));
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wave * 64 + i * 16 + 4 * (lane >> 4) + r;
+                    tile[row * TILE_LD + j * 16 + (lane & 15)] = accm[i][j][r] + accx[i][j][r] * (1.f / 2048.f);
+                }
+        lds_barrier();
+
+        // ---- outputs of the band: 8 channels per thread ------------------------------------------------------------------------
+        auto finish = [&](const float (&v)[8], int c8, _Float16* oh, _Float16* ol, int64_t o) __attribute__((always_inline)) {
+            half8 h, l;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                _Float16 a, b;
+                split_f32(fmaxf(v[q] + g.b2[c8 * 8 + q], 0.f), a, b);
+                h[q] = a;
+                l[q] = b;
+            }
+            *reinterpret_cast<half8*>(oh + o) = h;
+            *reinterpret_cast<half8*>(ol + o) = l;
+        };
+        {   // centre window rows of this band
+            const int ya = y0 > g.c0 ? y0 : g.c0, yb = y0 + R < g.c1 ? y0 + R : g.c1;
+            const int n = yb > ya ? (yb - ya) * CW * 8 : 0;
+            for (int e = tid; e < n; e += 256) {
+                const int c8 = e & 7, px = e >> 3;
+                const int yy = px / CW, xx = px - yy * CW;
+                const int y = ya + yy, x = g.c0 + xx;
+                const float* tp = tile + ((y - y0) * P + x) * TILE_LD + c8 * 8;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+                const float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                finish(v, c8, g.crh, g.crl, ((patch * CW + (y - g.c0)) * CW + xx) * 64 + c8 * 8);
+            }
+        }
+        // pooled rows: j covers rows 2j-1 .. 2j+1 (inside the image); it is finished by the band that holds its last row
+        const int ylast = y0 + R - 1;
+        const int jlo = y0 / 2;                                     // first pooled row with a row in this band (2j + 1 >= y0)
+        const int jhi = (ylast + 1) / 2 < PO - 1 ? (ylast + 1) / 2 : PO - 1;
+        auto pooled = [&](int j, int jx, int c8, bool with_carry, float (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = -INFINITY;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int y = 2 * j + dy;
+                if (y < y0 || y > ylast || y >= P) continue;        // uniform per (j, band) except through j: cheap either way
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int x = 2 * jx + dx;
+                    if (x < 0 || x >= P) continue;
+                    const float* tp = tile + ((y - y0) * P + x) * TILE_LD + c8 * 8;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = fmaxf(v[q], t0[q]);
+                        v[4 + q] = fmaxf(v[4 + q], t1[q]);
+                    }
+                }
+            }
+            if (with_carry) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], carry[jx * 64 + c8 * 8 + q]);
+            }
+        };
+        {
+            const int n = (jhi - jlo + 1) * PO * 8;
+            for (int e = tid; e < n; e += 256) {
+                const int c8 = e & 7, px = e >> 3;
+                const int jj = px / PO, jx = px - jj * PO;
+                const int j = jlo + jj;
+                const int last = 2 * j + 1 < P ? 2 * j + 1 : P - 1;
+                if (last > ylast) continue;                         // finished by the next band (its partial maximum: below)
+                float v[8];
+                pooled(j, jx, c8, 2 * j - 1 < y0 && y0 > 0, v);
+                finish(v, c8, g.poh, g.pol, ((patch * PO + j) * PO + jx) * 64 + c8 * 8);
+            }
+        }
+        lds_barrier();                              // the old partial maxima have been read
+        {
+            const int last = 2 * jhi + 1 < P ? 2 * jhi + 1 : P - 1;
+            if (last > ylast) {                     // uniform: jhi straddles into the next band
+                for (int e = tid; e < PO * 8; e += 256) {
+                    const int c8 = e & 7, jx = e >> 3;
+                    float v[8];
+                    pooled(jhi, jx, c8, false, v);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) carry[jx * 64 + c8 * 8 + q] = v[q];
+                }
+            }
+        }
+        lds_barrier();                              // tile and rgb are free for the next band
+    }
+}
+
+}  // namespace
+
+extern "C" int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int patch, const float* w1g, const float* b1,
+                                   const void* w2_hi, const void* w2_lo, int64_t w2_rows, int64_t kpad, const float* b2, int c0,
+                                   int c1, void* crop_hi, void* crop_lo, void* pool_hi, void* pool_lo, void* stream_) {
+    if (!patches || !w1g || !b1 || !w2_hi || !w2_lo || !b2 || !crop_hi || !crop_lo || !pool_hi || !pool_lo) return DFSFM_E_BADARG;
+    if (n_patches < 0 || c0 < 0 || c1 <= c0 || c1 > patch || w2_rows < 64) return DFSFM_E_BADARG;
+    if (n_patches == 0) return DFSFM_OK;
+    if (patch != P || kpad != 9 * 64 || n_patches > 0x7fffffff) return DFSFM_E_UNSUPPORTED;   // callers keep the three-launch path
+    const uintptr_t al = reinterpret_cast<uintptr_t>(w2_hi) | reinterpret_cast<uintptr_t>(w2_lo) | reinterpret_cast<uintptr_t>(crop_hi) |
+                         reinterpret_cast<uintptr_t>(crop_lo) | reinterpret_cast<uintptr_t>(pool_hi) | reinterpret_cast<uintptr_t>(pool_lo);
+    if ((al & 15) || (reinterpret_cast<uintptr_t>(w1g) & 31) || (reinterpret_cast<uintptr_t>(b1) & 31) ||
+        (reinterpret_cast<uintptr_t>(patches) & 3))
+        return DFSFM_E_UNSUPPORTED;
+    FrontArgs g{};
+    g.x = patches; g.w1g = w1g; g.b1 = b1;
+    g.w2h = static_cast<const _Float16*>(w2_hi); g.w2l = static_cast<const _Float16*>(w2_lo); g.b2 = b2;
+    g.crh = static_cast<_Float16*>(crop_hi); g.crl = static_cast<_Float16*>(crop_lo);
+    g.poh = static_cast<_Float16*>(pool_hi); g.pol = static_cast<_Float16*>(pool_lo);
+    g.c0 = c0; g.c1 = c1; g.kpad = (int)kpad;
+    g.w2bytes = (unsigned)(64 * kpad * 2);
+    static dfsfm::SmemAttr attr;
+    attr.ensure(reinterpret_cast<const void*>(&s2d_front_kernel), SMEM);
+    hipLaunchKernelGGL(s2d_front_kernel, dim3((unsigned)n_patches), dim3(256), SMEM, static_cast<hipStream_t>(stream_), g);
+    return dfsfm::check_launch("dfsfm_s2d_front_f32");
+}

@@ -1442,6 +1442,45 @@ def merge_keypoints(rows, img0, img1, n_images):
 
 
 @_on_device
+class S2dFrontWeights:
+    """Weights of S2DNet's conv1_1 / conv1_2 in the layout dfsfm_s2d_front_f32 reads: conv1_1 as fp32 [8 channel groups][27 taps in
+    (ky, kx, ci) order][8], conv1_2 as the tap-padded split planes of ``PackedDense`` (k = (ky*3 + kx)*64 + ci)."""
+
+    def __init__(self, w1, b1, w2, b2):
+        if tuple(w1.shape) != (64, 3, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3):
+            raise _lib.DfsfmError("S2dFrontWeights: conv1_1 [64,3,3,3] and conv1_2 [64,64,3,3] expected")
+        # [co, ci, ky, kx] -> [group, ky, kx, ci, co in group]
+        self.w1g = w1.detach().float().permute(2, 3, 1, 0).reshape(27, 8, 8).permute(1, 0, 2).contiguous()
+        self.b1 = b1.detach().float().contiguous()
+        self.conv2 = PackedDense(w2, b2, cin_pad=64, tap_padded=True)
+
+
+SUPPORTED_S2D_FRONT_PATCH = 35
+
+
+@_on_device
+def s2d_front(patches, fw: S2dFrontWeights, c0: int, c1: int):
+    """K9 front end in one launch (csrc/s2d_front.hip): patches fp32 [n, 35, 35, 3] (normalised NHWC) ->
+    (relu1_2[:, c0:c1, c0:c1] as SplitAct [n, c1-c0, c1-c0, 64], MaxPool2d(3, 2, 1)(relu1_2) as SplitAct [n, 18, 18, 64])."""
+    _require_cuda(patches)
+    n, P, P2, C = patches.shape
+    if P != P2 or C != 3 or patches.dtype != torch.float32 or not patches.is_contiguous():
+        raise _lib.DfsfmError("s2d_front: dense fp32 [n, P, P, 3] patches expected")
+    dev = patches.device
+    if fw.w1g.device != dev:
+        raise _lib.DfsfmError("s2d_front: weights on another device")
+    crop = SplitAct.empty(n, c1 - c0, c1 - c0, 64, dev)
+    pool = SplitAct.empty(n, (P + 1) // 2, (P + 1) // 2, 64, dev)
+    pw = fw.conv2
+    rc = _lib.lib().dfsfm_s2d_front_f32(_ptr(patches), n, P, _ptr(fw.w1g), _ptr(fw.b1), _ptr(pw.hi), _ptr(pw.lo), pw.hi.shape[0],
+                                        pw.Kpad, _ptr(pw.bias), c0, c1, _ptr(crop.hi), _ptr(crop.lo), _ptr(pool.hi), _ptr(pool.lo),
+                                        _stream())
+    _lib.check(rc, "dfsfm_s2d_front_f32")
+    _range(crop, "s2d_front crop")
+    _range(pool, "s2d_front pool")
+    return crop, pool
+
+
 def maxpool3x3s2_nhwc(x):
     """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor (fp32) or SplitAct."""
     if isinstance(x, SplitAct):

@@ -48,6 +48,9 @@ class HipMultiviewMatcher(ParamModule):
         # tap-reuse ("same") schedule for the stride-1 3x3 / 5x5 convs; False packs them for the flattened-K kernel (set before
         # the first forward; tests/test_gpu_e2e.py::test_flattened_k_conv_schedule_equals_same_schedule)
         self.same_conv = True
+        # conv1_1 -> conv1_2 -> pool / centre window as ONE launch (ops.s2d_front); False: the three separate layers
+        # (tests/test_gpu_kernels.py::test_s2d_front_*, tests/test_gpu_e2e.py::test_refine_fused_front_equals_three_launches)
+        self.fused_front = True
         if not test:
             raise NotImplementedError("training path is out of scope; build with test=True")
         bb = config["backbone"]
@@ -108,6 +111,8 @@ class HipMultiviewMatcher(ParamModule):
             return ops.PackedDense(w, b, cin_pad=(w.shape[1] + 7) // 8 * 8 if split_in else None,
                                    tap_padded=same and split_in and self.same_conv)
         H = {"enc": {i: pk(*P["enc"][i], split_in=(i != 0), same=True) for i in P["enc"]}}   # conv1_1 reads fp32 patches
+        # conv1_1 -> conv1_2 -> {centre window, pool} as one launch (csrc/s2d_front.hip)
+        H["front"] = ops.S2dFrontWeights(*P["enc"][0], *P["enc"][2])
         for i in (0, 1):
             a = P[f"adap{i}"]
             H[f"adap{i}"] = (pk(a[0], a[1]), pk(a[2], a[3], same=(i == 1)))   # adap1's 5x5 is pad 2, adap0's pad 0
@@ -122,10 +127,15 @@ class HipMultiviewMatcher(ParamModule):
         m, crop = x.shape[0], x.shape[1]
         c, r = crop // 2, W // 2
         S = dict(relu=True, out_split=True)             # conv -> ReLU -> split planes for the next conv
-        x = ops.conv2d_nhwc(x, H["enc"][0], 1, 1, **S)
-        x = ops.conv2d_nhwc(x, H["enc"][2], 1, 1, **S)                            # relu1_2 [m,35,35,64]
-        f0 = x.crop(c - r - 2, c + r + 3, c - r - 2, c + r + 3)                     # centre (W+4)^2 view
-        t = ops.maxpool3x3s2_nhwc(x)
+        if self.fused_front and crop == ops.SUPPORTED_S2D_FRONT_PATCH and x.is_contiguous():
+            if ops.range_check_active():                # the fused launch keeps relu1_1 in LDS: show it to the range guard
+                ops.conv2d_nhwc(x, H["enc"][0], 1, 1, **S)
+            f0, t = ops.s2d_front(x, H["front"], c - r - 2, c + r + 3)             # centre (W+4)^2 of relu1_2, pooled relu1_2
+        else:
+            x = ops.conv2d_nhwc(x, H["enc"][0], 1, 1, **S)
+            x = ops.conv2d_nhwc(x, H["enc"][2], 1, 1, **S)                        # relu1_2 [m,35,35,64]
+            f0 = x.crop(c - r - 2, c + r + 3, c - r - 2, c + r + 3)                 # centre (W+4)^2 view
+            t = ops.maxpool3x3s2_nhwc(x)
         t = ops.conv2d_nhwc(ops.conv2d_nhwc(t, H["enc"][5], 1, 1, **S), H["enc"][7], 1, 1, **S)
         t = ops.maxpool3x3s2_nhwc(t)
         for i in (10, 12, 14):

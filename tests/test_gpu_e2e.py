@@ -310,6 +310,30 @@ def test_refine_backbone_patch_chunks_are_invisible(built_lib):
     assert torch.equal(a["std"][-1], b["std"][-1])
 
 
+def test_refine_fused_front_equals_three_launches(built_lib):
+    """``model.fused_front = False`` runs S2DNet's conv1_1 / conv1_2 / max-pool as the three separate launches the fused front
+    end (csrc/s2d_front.hip, the default) replaces: both must meet the oracle, and agree with each other far inside the tolerance
+    (conv1_2 sums the same products in another K order)."""
+    cfg, sd, m = _refiner(1)
+    alt = HipMultiviewMatcher(cfg, test=True)
+    alt.fused_front = False
+    alt.load_state_dict(sd, strict=True)
+    alt = alt.eval().to(DEV)
+    data = synth.refine_bag(T=64, V=5, H=120, W=160, seed=2310, variable_lengths=True)
+    a, b = synth.to_device(data, DEV), synth.to_device(data, DEV)
+    assert m.fused_front
+    m(a)
+    alt(b)
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data)
+    assert len(_strict_refine(a, o, data, 7, "fused S2DNet front end")) <= 2
+    assert len(_strict_refine(b, o, data, 7, "three-launch S2DNet front end")) <= 2
+    same = (a["query_points_refined"] == b["query_points_refined"]).all(-1)[0]
+    assert int(same.sum()) >= same.numel() - 2               # a near-tied candidate may flip between two summation orders
+    d = (a["reference_points_refined"][-1] - b["reference_points_refined"][-1]).abs().amax(-1)[0][:, same]
+    assert float(d.max()) < 1e-3
+
+
 def test_loftr_features_vs_oracle_640x480(built_lib):
     """BASELINE config 2 frame size: transformer output features vs the oracle (1e-4 relative)."""
     for planted in (False, True):

@@ -391,3 +391,26 @@ def test_aspanformer_scene_cached_tokens_equal_pairwise():
                 assert tables[pr].shape == refs[pr].shape and np.array_equal(tables[pr][:, :4], refs[pr][:, :4]), (H, W, pr)
                 assert np.abs(tables[pr][:, 4] - refs[pr][:, 4]).max() <= 1e-4
         assert total > 30
+
+
+def test_s2d_front_weight_layout():
+    """``ops.S2dFrontWeights`` (the operands of dfsfm_s2d_front_f32): conv1_1 as [8 channel groups][27 taps (ky, kx, ci)][8],
+    conv1_2 as tap-padded split planes with k = (ky*3 + kx)*64 + ci."""
+    import torch
+    from detectorfreesfm_amd import ops
+    g = torch.Generator().manual_seed(5)
+    w1, b1 = torch.randn((64, 3, 3, 3), generator=g), torch.randn((64,), generator=g)
+    w2, b2 = torch.randn((64, 64, 3, 3), generator=g), torch.randn((64,), generator=g)
+    fw = ops.S2dFrontWeights(w1, b1, w2, b2)
+    assert fw.w1g.shape == (8, 27, 8) and fw.w1g.is_contiguous()
+    for grp, ky, kx, ci, c in [(0, 0, 0, 0, 0), (3, 1, 2, 1, 5), (7, 2, 2, 2, 7), (4, 0, 1, 2, 3)]:
+        assert fw.w1g[grp, (ky * 3 + kx) * 3 + ci, c] == w1[grp * 8 + c, ci, ky, kx]
+    pw = fw.conv2
+    assert pw.tap_padded and pw.Kpad == 576 and pw.hi.shape == (128, 576)
+    full = pw.hi.double() + pw.lo.double() / 2048.0
+    for co, ci, ky, kx in [(0, 0, 0, 0), (63, 63, 2, 2), (17, 40, 1, 0)]:
+        assert abs(float(full[co, (ky * 3 + kx) * 64 + ci]) - float(w2[co, ci, ky, kx])) < 1e-6 * max(1.0, abs(float(w2[co, ci, ky, kx])))
+    assert torch.equal(pw.bias, b2)
+    import pytest
+    with pytest.raises(Exception):
+        ops.S2dFrontWeights(w1[:32], b1, w2, b2)
