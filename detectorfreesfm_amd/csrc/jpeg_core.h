@@ -285,11 +285,18 @@ JD_FN void init_thread(const Params& P, int c) {
     P.nblk[c] = 0;
 }
 
-// One relaxation sweep: chunk c decodes from the exit state its predecessor currently reports (in the same launch that may
+// One relaxation ROUND: chunk c decodes from the exit state its predecessor currently reports (in the same launch that may
 // be the old or the new one: both are proposals) unless that is the entry its stored result was computed from.  Chunk 0 of a
-// segment starts from the truth, so after sweep i the first i + 1 chunks of every segment are final; because Huffman
+// segment starts from the truth, so after round i the first i + 1 chunks of every segment are final; because Huffman
 // streams self-synchronise, a wrong entry usually leads to the right exit within the chunk and the fixed point arrives
-// after a handful of sweeps.  A sweep that decodes nothing IS the fixed point (every stored result matches its entry).
+// after a handful of rounds.  A round that decodes nothing IS the fixed point (every stored result matches its entry).
+// r06: a sweep LAUNCH runs rounds inside each workgroup (SWEEP_WG consecutive chunks) until none of its chunks changes (at most
+// SWEEP_ROUNDS): where the stream does NOT self-synchronise -- a flat area is one short code repeated, a decoder that enters it
+// out of phase stays out of phase -- the truth still advances one chunk per round, and r05 paid one 54-us launch per round for
+// that (a 12-megapixel frame with a blown-out sky: > 400 launches, then CorruptJpeg).  Now a launch settles every workgroup whose
+// first entry is true, so the number of launches is bounded by the workgroups a segment spans, + 1 (flat_launch_bound).
+constexpr int SWEEP_WG = 256;              // chunks per workgroup of the sweep kernel
+constexpr int SWEEP_ROUNDS = 256;          // rounds per launch: enough to carry a true entry through the whole workgroup
 JD_FN bool sweep_needs(const Params& P, int c, uint64_t& entry) {
     const Chunk k = chunk_of(P, c);
     entry = k.first ? pack_state((uint64_t)k.beg * 8, 0, 0) : JD_LOAD64(&P.exit_state[c - 1]);

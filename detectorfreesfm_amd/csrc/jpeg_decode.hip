@@ -12,7 +12,8 @@
 //   unstuff   the scan is compacted once (stuffed zeros, restart markers and fill bytes out), so that bit positions are plain
 //             offsets and the decoder's inner loop has no byte-level special cases
 //   init      every chunk's exit state := "next chunk starts on its first byte, at the DC of block 0"
-//   sweep x n chunk c decodes from its predecessor's current exit state (position, block-in-MCU, coefficient index) and
+//   sweep x n (each launch: rounds inside every workgroup of 256 chunks until none of them changes, csrc/jpeg_core.h)
+//             chunk c decodes from its predecessor's current exit state (position, block-in-MCU, coefficient index) and
 //             publishes its own; chunks whose entry did not change since their last decode do nothing.  The first chunk
 //             of a segment starts from the truth, so this is a fixed-point iteration that is exact when a sweep decodes
 //             nothing, and self-synchronisation makes that happen after a few sweeps instead of nchunks
@@ -63,15 +64,23 @@ __global__ __launch_bounds__(256) void jd_init_kernel(Params P) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < P.nchunks) jd::init_thread(P, c);
 }
-__global__ __launch_bounds__(256) void jd_sweep_kernel(Params P, int sweep) {
+__global__ __launch_bounds__(jd::SWEEP_WG) void jd_sweep_kernel(Params P, int sweep) {
     __shared__ uint32_t tab[jd::TAB_WORDS];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    uint64_t entry = 0;
-    const bool need = c < P.nchunks && jd::sweep_needs(P, c, entry);
-    if (!__syncthreads_or(need)) return;                     // a settled stretch of the scan: nothing to look up
-    for (int i = threadIdx.x; i < jd::TAB_WORDS; i += 256) tab[i] = P.tab[i];
-    __syncthreads();
-    if (need) jd::sweep_thread(P, c, sweep, entry, tab);
+    if (sweep > 0 && P.work[sweep - 1] == 0) return;         // the launch before this one decoded nothing: the fixed point is reached
+    const int c = blockIdx.x * jd::SWEEP_WG + threadIdx.x;
+    bool loaded = false;
+    for (int round = 0; round < jd::SWEEP_ROUNDS; ++round) {
+        uint64_t entry = 0;
+        const bool need = c < P.nchunks && jd::sweep_needs(P, c, entry);
+        if (!__syncthreads_or(need)) return;                 // a settled stretch of the scan: nothing (more) to look up
+        if (!loaded) {
+            for (int i = threadIdx.x; i < jd::TAB_WORDS; i += jd::SWEEP_WG) tab[i] = P.tab[i];
+            loaded = true;
+        }
+        __syncthreads();
+        if (need) jd::sweep_thread(P, c, sweep, entry, tab);
+        __syncthreads();                                     // exit states are agent-scope stores / loads: the neighbours see them
+    }
 }
 __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
     __shared__ int32_t part[jd::SCAN_T], grp[jd::SCAN_G];
@@ -157,7 +166,7 @@ extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, con
              out_channels, status);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
-    const unsigned gc = (unsigned)((P.nchunks + 255) / 256);
+    const unsigned gc = (unsigned)((P.nchunks + jd::SWEEP_WG - 1) / jd::SWEEP_WG);
     (void)hipMemsetAsync(P.work, 0, 64 * 4, stream);
     (void)hipMemsetAsync(status, 0, 4 * 4, stream);
     if (!resume) {
@@ -165,7 +174,7 @@ extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, con
         hipLaunchKernelGGL(jd_unstuff_kernel, dim3(gu), dim3(jd::UNSTUFF_T), 0, stream, P);
         hipLaunchKernelGGL(jd_init_kernel, dim3(gc), dim3(256), 0, stream, P);
     }
-    for (int s = 0; s < sweeps; ++s) hipLaunchKernelGGL(jd_sweep_kernel, dim3(gc), dim3(256), 0, stream, P, s);
+    for (int s = 0; s < sweeps; ++s) hipLaunchKernelGGL(jd_sweep_kernel, dim3(gc), dim3(jd::SWEEP_WG), 0, stream, P, s);
     hipLaunchKernelGGL(jd_status_kernel, dim3(1), dim3(1), 0, stream, P, sweeps);
     hipLaunchKernelGGL(jd_scan_kernel, dim3(1), dim3(jd::SCAN_T), 0, stream, P);
     (void)hipMemsetAsync(P.coef, 0, (size_t)P.nblocks * 128, stream);

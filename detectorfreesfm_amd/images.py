@@ -13,6 +13,7 @@ files keep the reference's host decode (``decode="auto"``).
 decoded uint8 array / tensor ([H,W] or [H,W,3] RGB), which is what a maintainer passes after ``cv2.imread``.
 """
 import math
+import warnings
 from functools import lru_cache
 
 import numpy as np
@@ -114,6 +115,7 @@ def resize_lanczos(image_u8, size, device=None):
 
 
 _warned_pil_decode = False
+_warned_device_fallback = False
 
 
 def _decode_host(path, color: bool):
@@ -166,11 +168,19 @@ def _decode(path, color: bool, device=None, decode: str = "auto"):
         if decode == "device" and not jpeg.is_jpeg(buf):
             raise jpeg.UnsupportedJpeg("not a JPEG file")
         if jpeg.is_jpeg(buf):
+            from ._lib import DfsfmError
             try:
                 return jpeg.decode(buf, color, device if device is not None else "cuda")
-            except jpeg.UnsupportedJpeg:
+            except (jpeg.UnsupportedJpeg, jpeg.CorruptJpeg, DfsfmError) as e:
+                # "auto" returns what the reference's reader returns: libjpeg (cv2.imread) takes progressive / multi-scan files and
+                # decodes slightly damaged ones with a warning (a wrong restart count, a truncated scan); the device path raises
                 if decode == "device":
                     raise
+                global _warned_device_fallback
+                if not isinstance(e, jpeg.UnsupportedJpeg) and not _warned_device_fallback:
+                    warnings.warn(f"{path}: device JPEG decode failed ({type(e).__name__}: {e}); decoding on the host like the "
+                                  "reference (further files: silently)", RuntimeWarning)
+                    _warned_device_fallback = True
     return _decode_host(path, color)
 
 

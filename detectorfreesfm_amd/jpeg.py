@@ -20,7 +20,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 CHUNK_BYTES = 128            # bytes of the compacted scan per decoder thread
-DEFAULT_SWEEPS = 16          # relaxation sweeps per call before the first status check
+DEFAULT_SWEEPS = 4           # sweep launches per call before the first status check (each runs rounds inside its workgroups)
+SWEEP_WG = 256               # csrc/jpeg_core.h: chunks per workgroup of the sweep kernel
 UNSTUFF_BLOCK = 4096         # csrc/jpeg_core.h
 
 ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
@@ -60,6 +61,7 @@ class Plan:
     chunk_seg: np.ndarray            # int32 [nchunks]
     orientation: int = 1
     sampling: List[Tuple[int, int]] = field(default_factory=list)
+    launch_bound: int = 0            # sweep launches that guarantee the fixed point (flat_launch_bound)
 
     @property
     def width(self):
@@ -188,8 +190,9 @@ def _plan(buf, chunk_bytes: int) -> Plan:
                 pq, tq = seg[i] >> 4, seg[i] & 15
                 i += 1
                 if pq:
-                    q = np.frombuffer(seg[i:i + 128], dtype=">u2").astype(np.uint16)
-                    i += 128
+                    # 16-bit steps: coefficient x step can leave the int32 range of the device's dequantisation / IDCT (libjpeg's
+                    # JLONG is 64 bits wide) -- a file for the host decoder
+                    raise UnsupportedJpeg("16-bit quantisation table")
                 else:
                     q = np.frombuffer(seg[i:i + 64], dtype=np.uint8).astype(np.uint16)
                     i += 64
@@ -317,7 +320,17 @@ def _plan(buf, chunk_bytes: int) -> Plan:
     padded = np.zeros((scan_len + 31) // 16 * 16, dtype=np.uint8)    # the compaction pass loads aligned 16-byte pieces
     padded[:scan_len] = d[:scan_len]
     return Plan(frame=fr, scan=padded[:scan_len], tab_key=key, tab=_tab_block(key), qt=qt, block_base=block_base, seg_beg=seg_beg,
-                seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling)
+                seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling,
+                launch_bound=flat_launch_bound(seg_chunk0, per))
+
+
+def flat_launch_bound(seg_chunk0, per) -> int:
+    """Sweep launches after which the relaxation HAS reached its fixed point whatever the scan looks like: a launch settles every
+    workgroup (SWEEP_WG consecutive chunks) whose first entry is final, a segment's first chunk is final from the start, so the
+    truth crosses one workgroup boundary per launch at worst; + 1 for the launch that finds nothing to do."""
+    first = np.asarray(seg_chunk0, dtype=np.int64)
+    last = first + np.asarray(per, dtype=np.int64) - 1
+    return int((last // SWEEP_WG - first // SWEEP_WG).max()) + 2
 
 
 def is_jpeg(buf) -> bool:
@@ -350,8 +363,9 @@ def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_
            return_info: bool = False):
     """The bytes of ``cv2.imread(IMREAD_GRAYSCALE)`` ([H,W] uint8, ``color=False``) / of ``cv2.imread(IMREAD_COLOR)`` after
     BGR2RGB ([H,W,3], ``color=True``) as a device tensor.  Raises ``UnsupportedJpeg`` for files outside the device path and
-    ``CorruptJpeg`` for streams that do not decode; reads 16 bytes of status back once per call (more sweeps follow only if the
-    fixed point was not reached, which the default covers for every file seen so far)."""
+    ``CorruptJpeg`` for streams that do not decode; reads 16 bytes of status back once per call (more sweep launches follow only if
+    the fixed point was not reached: photographs settle in two or three, a frame that is one flat colour needs one launch per 256
+    chunks of its longest restart interval -- ``Plan.launch_bound`` -- and gets them)."""
     import torch
     from . import ops
     pl = plan(buf, chunk_bytes)

@@ -808,9 +808,13 @@ class JpegDecodeCall:
                     self.used = self.total - self.sweeps + st[3] if st[3] else self.used
                     if st[0] == 0:
                         break
-                    if self.calls >= self.max_calls:
-                        raise self._jpeg.CorruptJpeg(f"entropy decode did not reach its fixed point in {self.total} sweeps")
-                    self.sweeps = min(64, 2 * self.sweeps)
+                    # the relaxation provably settles within pl.launch_bound launches (jpeg.flat_launch_bound); a stream that is
+                    # still moving after that many is not one a consistent decoder state sequence explains
+                    bound = int(getattr(self.pl, "launch_bound", 0)) or 64 * self.max_calls
+                    if self.total >= bound:
+                        raise self._jpeg.CorruptJpeg(f"entropy decode did not reach its fixed point in {self.total} sweep launches "
+                                                     f"(bound {bound})")
+                    self.sweeps = max(1, min(64, 2 * self.sweeps, bound - self.total))
                     self._launch()
             finally:
                 _jpeg_pool.append(self.host)
@@ -820,7 +824,7 @@ class JpegDecodeCall:
         return self.out, dict(sweeps=self.total, sweeps_used=self.used, calls=self.calls)
 
 
-def jpeg_decode_launch(pl, out_channels: int, device, sweeps: int = 16, max_calls: int = 8) -> JpegDecodeCall:
+def jpeg_decode_launch(pl, out_channels: int, device, sweeps: int = 4, max_calls: int = 8) -> JpegDecodeCall:
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
@@ -830,7 +834,7 @@ def jpeg_decode_launch(pl, out_channels: int, device, sweeps: int = 16, max_call
         return JpegDecodeCall(pl, out_channels, device, sweeps, max_calls)
 
 
-def jpeg_decode(pl, out_channels: int, device, sweeps: int = 16, max_calls: int = 8):
+def jpeg_decode(pl, out_channels: int, device, sweeps: int = 4, max_calls: int = 8):
     """``dfsfm_jpeg_decode_u8`` on a parsed file (``jpeg.Plan``), synchronously: launch + finish of ``JpegDecodeCall``."""
     return jpeg_decode_launch(pl, out_channels, device, sweeps, max_calls).finish()
 

@@ -200,6 +200,15 @@ def _maxpool(x):
     return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
 
 
+def _s2d_front(patches, fw, c0, c1):
+    """ops.s2d_front: conv1_1 in fp32, conv1_2 with the split algebra of ``_conv``, then the centre window and the max-pool."""
+    import torch.nn.functional as F
+    w1 = fw.w1g.permute(1, 0, 2).reshape(3, 3, 3, 64).permute(3, 2, 0, 1).contiguous()          # [27 (ky,kx,ci), 64] -> [co, ci, ky, kx]
+    r1 = torch.relu(F.conv2d(patches.permute(0, 3, 1, 2), w1, fw.b1, 1, 1)).permute(0, 2, 3, 1)
+    y = _conv(_to_split(r1), fw.conv2, 1, 1, relu=True, out_split=True)
+    return y.crop(c0, c1, c0, c1), _maxpool(y)
+
+
 def _resample(y, By, Bx, out=None):
     r = torch.einsum("ab,cd,mbdk->mack", By, Bx, y).reshape(y.shape[0], By.shape[0] * Bx.shape[0], y.shape[-1])
     if out is None:
@@ -398,7 +407,7 @@ def _enc256_apply(x, fw, state, S, q_mask=None, q_group=1, out_split=None, out=N
     return None
 
 
-def _jpeg_decode(pl, out_channels, device, sweeps=16, max_calls=8):
+def _jpeg_decode(pl, out_channels, device, sweeps=4, max_calls=8):
     """ops.jpeg_decode on the CPU lane model of the decoder (tests/jpeg_emul.cpp: the device thread functions compiled with g++),
     thread order reversed so that every sweep sees only the previous sweep's states, like a launch whose threads all start
     together."""
@@ -422,8 +431,9 @@ def cpu_ops():
                                           "bilinear_up", "resample_u8", "avgpool", "full_attention",
                                           "span_attention", "layernorm2d", "upsample", "flow_decode", "resize_bilinear",
                                           "encoder_kv", "encoder_apply", "encoder256_state", "encoder256_apply", "encoder256_kv",
-                                          "jpeg_decode")}
+                                          "jpeg_decode", "s2d_front")}
     ops.jpeg_decode = _jpeg_decode
+    ops.s2d_front = _s2d_front
     ops.linear_attention, ops.coarse_match, ops.roi_align, ops.fine_match = _la, _cm, _roi, _fm
     ops.layernorm, ops.add_scatter_tokens = _ln, _scatter
     ops.conv2d_nhwc, ops.linear, ops.maxpool3x3s2_nhwc = _conv, _linear, _maxpool

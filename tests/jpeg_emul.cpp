@@ -1,7 +1,7 @@
 // CPU lane model of the device JPEG decoder: the SAME thread functions as csrc/jpeg_decode.hip (csrc/jpeg_core.h) and the same
 // host geometry (csrc/jpeg_host.h), compiled with g++; every kernel launch becomes a loop over its threads, in the launch
-// order of dfsfm_jpeg_decode_u8.  `order` permutes the thread order of the sweeps (0 ascending, 1 descending, 2 a fixed
-// shuffle): the relaxation must reach the same fixed point whatever the hardware's scheduling does.
+// order of dfsfm_jpeg_decode_u8.  `order` permutes the workgroup order of a sweep launch and the thread order inside a round (0 ascending, 1 descending, 2 a fixed
+// shuffle of the workgroups): the relaxation must reach the same fixed point whatever the hardware's scheduling does.
 // Test infrastructure (tests/test_jpeg_cpu.py builds it into tests/_build/); not part of the product library.
 #include <cstdlib>
 #include <cstring>
@@ -31,15 +31,6 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
              out_channels, status);
     std::memset(P.work, 0, 64 * 4);
     std::memset(status, 0, 16);
-    std::vector<int> perm(P.nchunks);
-    for (int c = 0; c < P.nchunks; ++c) perm[c] = order == 1 ? P.nchunks - 1 - c : c;
-    if (order == 2) {
-        uint32_t s = 12345;
-        for (int c = P.nchunks - 1; c > 0; --c) {
-            s = s * 1664525u + 1013904223u;
-            std::swap(perm[c], perm[(s >> 8) % (uint32_t)(c + 1)]);
-        }
-    }
     std::vector<uint32_t> lds(P.tab, P.tab + jd::TAB_WORDS);  // the kernels' LDS copy of the Huffman tables
     if (!resume) {
         const int nb = (int)((scan_bytes + jd::UNSTUFF_BLOCK - 1) / jd::UNSTUFF_BLOCK);
@@ -57,11 +48,38 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
         }
         for (int c = 0; c < P.nchunks; ++c) jd::init_thread(P, c);
     }
-    for (int s = 0; s < sweeps; ++s)
-        for (int i = 0; i < P.nchunks; ++i) {
-            uint64_t entry = 0;
-            if (jd::sweep_needs(P, perm[i], entry)) jd::sweep_thread(P, perm[i], s, entry, lds.data());
+    // a sweep launch = every workgroup of SWEEP_WG chunks runs rounds until none of its chunks changes; within a round every thread
+    // looks at its entry BEFORE any thread of the workgroup decodes (the kernel's __syncthreads_or).  The workgroups of a launch run
+    // in the order `order` gives (ascending = each sees the final result of the one before it: the best case, descending = the worst)
+    const int nwg = (P.nchunks + jd::SWEEP_WG - 1) / jd::SWEEP_WG;
+    std::vector<int> wperm(nwg);
+    for (int w = 0; w < nwg; ++w) wperm[w] = order == 1 ? nwg - 1 - w : w;
+    if (order == 2) {
+        uint32_t s2 = 54321;
+        for (int w = nwg - 1; w > 0; --w) {
+            s2 = s2 * 1664525u + 1013904223u;
+            std::swap(wperm[w], wperm[(s2 >> 8) % (uint32_t)(w + 1)]);
         }
+    }
+    for (int s = 0; s < sweeps; ++s) {
+        if (s > 0 && P.work[s - 1] == 0) break;
+        for (int wi = 0; wi < nwg; ++wi) {
+            const int c0 = wperm[wi] * jd::SWEEP_WG, c1 = c0 + jd::SWEEP_WG < P.nchunks ? c0 + jd::SWEEP_WG : P.nchunks;
+            for (int round = 0; round < jd::SWEEP_ROUNDS; ++round) {
+                std::vector<int> todo;
+                std::vector<uint64_t> ent;
+                for (int c = c0; c < c1; ++c) {
+                    uint64_t entry = 0;
+                    if (jd::sweep_needs(P, c, entry)) { todo.push_back(c); ent.push_back(entry); }
+                }
+                if (todo.empty()) break;
+                for (size_t k = 0; k < todo.size(); ++k) {
+                    const size_t kk = order == 1 ? todo.size() - 1 - k : k;
+                    jd::sweep_thread(P, todo[kk], s, ent[kk], lds.data());
+                }
+            }
+        }
+    }
     status[0] = P.work[sweeps - 1];
     for (int i = 0; i < sweeps; ++i)
         if (P.work[i]) status[3] = i + 1;

@@ -104,3 +104,48 @@ def test_decode_many_overlaps_files_on_streams():
         for buf, out in zip(bufs, outs):
             assert np.array_equal(out.cpu().numpy(), rj.decode(buf, color))
     assert torch.equal(jpeg.decode_many(bufs[:1], True, DEV, streams=1)[0], jpeg.decode(bufs[0], True, DEV))
+
+
+def test_reference_example_scene_on_the_device():
+    """The reference's own eight camera JPEGs (tests/golden/example_scene, copied by oracle/make_jpeg_golden.py together with the
+    hashes of what libjpeg-turbo decodes them to): the device decode returns exactly those bytes, luma plane and RGB, and the
+    sequential oracle agrees."""
+    import hashlib
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_scene")
+    man = json.load(open(os.path.join(root, "manifest.json")))["files"]
+    assert len(man) == 8
+    for name, m in man.items():
+        buf = open(os.path.join(root, name), "rb").read()
+        assert hashlib.sha256(buf).hexdigest() == m["file_sha256"]
+        for color, key in ((False, "gray_sha256"), (True, "rgb_sha256")):
+            out, info = jpeg.decode(buf, color, DEV, return_info=True)
+            assert out.shape[:2] == (m["height"], m["width"])
+            assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == m[key], (name, color, info)
+            assert info["calls"] == 1, (name, info)                              # photographs settle within the default launches
+        assert hashlib.sha256(rj.decode(buf, False).tobytes()).hexdigest() == m["gray_sha256"]
+    outs = jpeg.decode_many([open(os.path.join(root, n), "rb").read() for n in man], False, DEV)
+    for out, m in zip(outs, man.values()):
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == m["gray_sha256"]
+
+
+def test_flat_and_saturated_frames_on_the_device():
+    """valid files with large exactly-flat areas (no Huffman self-synchronisation there) decode on the device --
+    the relaxation rounds run inside the sweep launches -- within ``Plan.launch_bound`` launches, to libjpeg-turbo's bytes."""
+    flat_l = np.full((1024, 1024), 128, np.uint8)
+    flat_c = np.full((1024, 1536, 3), 77, np.uint8)
+    sky = synth(3000, 4000, True, seed=3)
+    sky[:1400] = 255
+    big_flat = np.full((3000, 4000, 3), 200, np.uint8)
+    for name, img, kw in [("flat L", flat_l, dict(quality=90)), ("flat 4:2:0", flat_c, dict(quality=90, subsampling=2)),
+                          ("saturated sky", sky, dict(quality=92, subsampling=2)), ("12 MP flat", big_flat, dict(quality=95, subsampling=2)),
+                          ("flat + restarts", flat_c, dict(quality=90, subsampling=0, restart_marker_rows=4))]:
+        buf = encode(img, **kw)
+        color = img.ndim == 3
+        pl = jpeg.plan(buf)
+        want = pil_rgb(buf) if color else pil_gray(buf)
+        for c in ((False, True) if color else (False,)):
+            out, info = jpeg.decode(buf, c, DEV, return_info=True)
+            ref = want if c == color else pil_gray(buf)
+            assert np.array_equal(out.cpu().numpy(), ref), (name, c, info)
+            assert info["sweeps_used"] <= pl.launch_bound, (name, info, pl.launch_bound)

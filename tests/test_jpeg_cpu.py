@@ -283,3 +283,63 @@ def test_damaged_headers_raise_or_decode_within_bounds():
             out, info = jpeg_emul.decode(pl, color, sweeps=8, order=1, max_calls=4)
             assert out.shape[:2] == (pl.height, pl.width)
     assert planned > 30 and refused > 30
+
+
+def test_flat_and_saturated_frames_settle_in_a_few_launches():
+    """an exactly flat area is one short code repeated, a decoder that enters it out of phase never
+    re-synchronises, and the truth advances one chunk per relaxation round.  With the rounds INSIDE the sweep launch (256 chunks per
+    workgroup) a flat frame settles in one launch per workgroup boundary of its longest restart interval -- ``Plan.launch_bound`` --
+    in every workgroup order, and the bytes are libjpeg-turbo's."""
+    flat_l = np.full((1024, 1024), 128, np.uint8)
+    flat_c = np.full((1024, 1536, 3), 77, np.uint8)
+    sky = synth(1500, 2000, True, seed=3)
+    sky[:700] = 255                                                 # a blown-out sky above a textured ground
+    big_flat = np.full((3000, 4000, 3), 200, np.uint8)              # 12 megapixels of one colour: ~1400 chunks, 6 workgroups
+    for name, img, kw in [("flat L", flat_l, dict(quality=90)), ("flat 4:2:0", flat_c, dict(quality=90, subsampling=2)),
+                          ("saturated sky", sky, dict(quality=92, subsampling=2)), ("12 MP flat", big_flat, dict(quality=95, subsampling=2)),
+                          ("flat + restarts", flat_c, dict(quality=90, subsampling=0, restart_marker_rows=4))]:
+        buf = encode(img, **kw)
+        color = img.ndim == 3
+        pl = jpeg.plan(buf)
+        want = pil_rgb(buf) if color else pil_gray(buf)
+        for order in (0, 1, 2):
+            out, info = jpeg_emul.decode(pl, color, sweeps=4, order=order, max_calls=64)
+            assert info["status"][0] == 0 and np.array_equal(out, want), (name, order, info)
+            assert info["sweeps"] <= pl.launch_bound, (name, order, info, pl.launch_bound)
+        assert name == "saturated sky" or pl.launch_bound <= 8, (name, pl.launch_bound)     # flat frames: a handful of workgroups
+
+
+def test_auto_decode_falls_back_to_the_host_like_the_reference(tmp_path):
+    """decode='auto' returns what the reference's reader returns for files libjpeg takes and the device path refuses: a wrong
+    restart-marker count (CorruptJpeg from the parser), a 16-bit quantisation table (UnsupportedJpeg); decode='device' raises."""
+    img = synth(96, 128)
+    good = encode(img, quality=85, subsampling=2, restart_marker_rows=1)
+    pl = jpeg.plan(good)
+    k = good.rindex(b"\xff\xd3") if b"\xff\xd3" in good else None
+    assert k is not None
+    damaged = good[:k] + good[k + 2:]                               # one RSTn marker removed: libjpeg resynchronises with a warning
+    p = tmp_path / "damaged.jpg"
+    p.write_bytes(damaged)
+    with pytest.raises(jpeg.CorruptJpeg):
+        jpeg.plan(damaged)
+    with cpu_ops():
+        import warnings
+        images._warned_device_fallback = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            a = images.read_grayscale(str(p), resize=(64,), df=8, device="cpu")
+        assert any("device JPEG decode failed" in str(x.message) for x in w)
+        b = images.read_grayscale(images._decode_host(str(p), False), resize=(64,), df=8, device="cpu")
+        assert np.array_equal(a.numpy(), b.numpy())
+        with pytest.raises(jpeg.CorruptJpeg):
+            images.read_grayscale(str(p), device="cpu", decode="device")
+    # a 16-bit DQT entry (pq = 1): refused by the parser, the host decodes it
+    dqt = good.index(b"\xff\xdb")
+    ln = (good[dqt + 2] << 8) | good[dqt + 3]
+    seg = good[dqt + 4:dqt + 2 + ln]
+    assert seg[0] >> 4 == 0
+    wide = bytes([0x10 | (seg[0] & 15)]) + b"".join(bytes([0, v]) for v in seg[1:65]) + seg[65:]
+    b16 = good[:dqt + 2] + (len(wide) + 2).to_bytes(2, "big") + wide + good[dqt + 2 + ln:]
+    with pytest.raises(jpeg.UnsupportedJpeg, match="16-bit"):
+        jpeg.plan(b16)
+    assert np.array_equal(pil_gray(b16), pil_gray(good))            # the same image for libjpeg
