@@ -28,6 +28,7 @@
 // MFMA work per patch: 5 bands x 256 rows x 64 x 576 x 2 x 3 = 283 MFLOP for 271 MFLOP of split product (245 of 256 rows live).
 #include "common.h"
 #include "sf_gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -72,6 +73,8 @@ struct FrontArgs {
     _Float16 *poh, *pol;                          // pooled relu1_2: [n][18][18][64] split planes
     int c0, c1, kpad;
     unsigned w2bytes;
+    unsigned first_gen;                           // workgroups of the first dispatch generation (2 per CU)
+    int skew;                                     // start delay of the second workgroup of a CU, in s_sleep 127 units (~8 K cycles)
 };
 
 __device__ __forceinline__ void lds_barrier() {
@@ -127,6 +130,14 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
         rb[it] = ly * PW + (qq - ly * P);
     }
 
+    // Two workgroups share a CU and every workgroup runs the same VALU / MFMA phase sequence: started together they stay in step --
+    // both in conv1_1, then both in the MFMA loop -- and the kernel takes the SUM of its phases (measured: timing-only ablations,
+    // profiles/r06_s2d_front_ablation.txt).  The second workgroup of a CU (its LDS allocation does not start at 0) of the FIRST
+    // generation of workgroups therefore starts late by about one VALU phase; workgroups dispatched later inherit the offset from the
+    // slot they replace.  Purely a schedule hint: wrong guesses cost the delay, never a result.
+    if (blockIdx.x < g.first_gen && (__builtin_amdgcn_s_getreg((6) | (0 << 6) | (11 << 11)) != 0)) {
+        for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (int band = 0; band < NBAND; ++band) {
         const int y0 = band * R;
         // ---- rgb rows y0 - 2 .. y0 + 8, columns -1 .. 35 ---------------------------------------------------------------------
@@ -155,18 +166,24 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             // ---- conv1_1, channels hf * 32 + 8 wave .. + 7 ---------------------------------------------------------------------
+#ifndef S2D_ABL_NO_CONV1
             {
                 const int cg = hf * 4 + wave;
                 // wave-uniform addresses in the CONSTANT address space: scalar loads (the output stores of the previous band would
                 // otherwise make the compiler fetch the 216 weights through vector registers)
                 typedef const __attribute__((address_space(4))) float* cptr;
-                const cptr wg = (cptr)(uintptr_t)(g.w1g + cg * 216);
                 const cptr bg = (cptr)(uintptr_t)(g.b1 + cg * 8);
-                float a1[5][8];
+                // two channels per instruction (v_pk_fma_f32: plain vector code, the full fp32 rate; a scalar v_fma_f32 runs at half
+                // of it).  Forms: pixel value broadcast into both lanes (op_sel_hi), weights as a scalar register pair -- none of
+                // them the op_sel form that misreads beside in-flight MFMAs (csrc/Makefile, tools/ubench/pk_opsel_inplace.hip).
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef const __attribute__((address_space(4))) f32x2* cptr2;
+                const cptr2 wg2 = (cptr2)(uintptr_t)(g.w1g + cg * 216);
+                f32x2 a1[5][4];
 #pragma unroll
                 for (int it = 0; it < 5; ++it)
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) a1[it][c] = bg[c];
+                    for (int c = 0; c < 4; ++c) a1[it][c] = f32x2{bg[2 * c], bg[2 * c + 1]};
 #pragma unroll 1                 // a real loop: one tap's 24 weights (scalar registers) live at a time
                 for (int kk = 0; kk < 9; ++kk) {
                     const int ky = kk / 3, kx = kk - 3 * ky;
@@ -175,13 +192,15 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                     for (int it = 0; it < 5; ++it) v[it] = rgb[rb[it] + ky * PW + kx];
 #pragma unroll
                     for (int ci = 0; ci < 3; ++ci) {
-                        float w[8];
+                        f32x2 w[4];
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) w[c] = wg[(kk * 3 + ci) * 8 + c];
+                        for (int c = 0; c < 4; ++c) w[c] = wg2[(kk * 3 + ci) * 4 + c];
 #pragma unroll
-                        for (int it = 0; it < 5; ++it)
+                        for (int it = 0; it < 5; ++it) {
+                            const f32x2 xv = {v[it][ci], v[it][ci]};
 #pragma unroll
-                            for (int c = 0; c < 8; ++c) a1[it][c] = __builtin_fmaf(v[it][ci], w[c], a1[it][c]);
+                            for (int c = 0; c < 4; ++c) a1[it][c] += xv * w[c];      // one expression: an FMA (-ffp-contract=on)
+                        }
                     }
                 }
 #pragma unroll
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         _Float16 a, b;
-                        split_f32(live ? fmaxf(a1[it][c], 0.f) : 0.f, a, b);
+                        split_f32(live ? fmaxf(a1[it][c >> 1][c & 1], 0.f) : 0.f, a, b);
                         h[c] = a;
                         l[c] = b;
                     }
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                     *reinterpret_cast<half8*>(smem + A_PLANE + off) = z;
                 }
             }
+#endif
             // ---- conv1_2: 9 taps of this half ------------------------------------------------------------------------------------
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
@@ -234,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                     bl[j] = *reinterpret_cast<const half8*>(sb + B_PLANE + off);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef S2D_ABL_NO_MFMA
                 // in place (destination tied to the addend, see sf_gemm.h); consecutive MFMAs never share an accumulator
 #define S2D_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
                 __builtin_amdgcn_s_setprio(1);
@@ -251,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                     for (int j = 0; j < 4; ++j) S2D_MFMA(accx[i][j], al[i], bh[j]);
                 __builtin_amdgcn_s_setprio(0);
 #undef S2D_MFMA
+#endif
             }
             lds_barrier();                          // every wave has read its last A fragments of this half
         }
@@ -277,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 }
         lds_barrier();
 
+#ifndef S2D_ABL_NO_EPI
         // ---- outputs of the band: 8 channels per thread ------------------------------------------------------------------------
         auto finish = [&](const float (&v)[8], int c8, _Float16* oh, _Float16* ol, int64_t o) __attribute__((always_inline)) {
             half8 h, l;
@@ -358,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 }
             }
         }
+#endif
         lds_barrier();                              // tile and rgb are free for the next band
     }
 }
@@ -383,6 +407,21 @@ extern "C" int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int 
     g.poh = static_cast<_Float16*>(pool_hi); g.pol = static_cast<_Float16*>(pool_lo);
     g.c0 = c0; g.c1 = c1; g.kpad = (int)kpad;
     g.w2bytes = (unsigned)(64 * kpad * 2);
+    {
+        static int cus = 0, skew = -1;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            (void)hipGetDevice(&dev);
+            cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        }
+        if (skew < 0) {
+            const char* e = getenv("DFSFM_S2D_SKEW");             // tuning knob of tools/bench_s2d_front.py
+            skew = e ? atoi(e) : 1;
+        }
+        g.first_gen = (unsigned)(2 * cus);
+        g.skew = skew;
+    }
     static dfsfm::SmemAttr attr;
     attr.ensure(reinterpret_cast<const void*>(&s2d_front_kernel), SMEM);
     hipLaunchKernelGGL(s2d_front_kernel, dim3((unsigned)n_patches), dim3(256), SMEM, static_cast<hipStream_t>(stream_), g);

@@ -362,10 +362,36 @@ def focus():
               f"{r['std']}, coords {r['coords']}, best {r['best']} entries) {r['ms']:.3f} ms", flush=True)
 
 
+def hazardous(line):
+    """A packed fp32 instruction whose LOW lane takes the HIGH half of src1 / src2 (op_sel bit set behind position 0): the form the
+    reproducer (tools/ubench/pk_opsel_inplace.hip) shows reading 0 while an MFMA of the same wave is in flight."""
+    m = re.search(r"op_sel:\[([0-9,]+)\]", line)
+    return bool(PK.match(line) and m and any(int(x) for x in m.group(1).split(",")[1:]))
+
+
+def opsel():
+    """Third session: the SLP build with ONLY the hazardous form rewritten (everything else stays packed) must be bit-reproducible."""
+    asm, _, _ = prepare()
+    lines = open(asm).read().split("\n")
+    pk = packed_lines(lines)
+    haz = {k for k, i in enumerate(pk) if hazardous(lines[i])}
+    print(f"# {len(pk)} packed-fp32 instructions, {len(haz)} with op_sel on src1/src2: " + "; ".join(f"#{k} {lines[pk[k]].strip()}" for k in sorted(haz)), flush=True)
+    ck = Checker()
+    runs = int(os.environ.get("FINE_RUNS", "300"))
+    for label, S in (("as compiled", set()), ("only the op_sel (src1/src2) forms scalarised", haz),
+                     ("everything BUT those forms scalarised", set(range(len(pk))) - haz)):
+        so = build_variant(S, os.path.join(WORK, f"lib_o{len(S)}.so"), tag=f"o{len(S)}")
+        r = ck.check(so, runs=runs)
+        print(f"opsel: {label:46s}: {'REPRODUCIBLE' if r['bad_runs'] == 0 else 'DEVIATES'} ({r['bad_runs']}/{r['runs']} runs; std {r['std']}, "
+              f"coords {r['coords']}, best {r['best']} entries) {r['ms']:.3f} ms", flush=True)
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "list"
     if mode == "auto":
         auto()
+    elif mode == "opsel":
+        opsel()
     elif mode == "focus":
         focus()
     elif mode == "build":

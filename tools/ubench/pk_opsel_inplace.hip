@@ -25,7 +25,7 @@ struct Sample {
 };
 
 enum Form { A_MUL_SRC1HI_TO_LO, A_INPLACE, B_MUL_SRC0HI_TO_LO, C_MUL_SRC1LO_TO_HI, D_ADD_SRC1HI_TO_LO, E_FMA_SRC1HI_TO_LO, F_NOSEL_AFTER_MOV,
-            G_TWO_SCALAR };
+            G_TWO_SCALAR, H_FMA_BROADCAST_SRC0, P_PLAIN_FMA };
 enum Env { OWN, NONE, PARTNER };
 
 template <int FORM>
@@ -40,6 +40,10 @@ __device__ __forceinline__ void apply(f2& D, const f2 S, float& exp_lo, float& e
         asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(exp_lo), "=&v"(exp_hi) : "v"(sl), "v"(sh), "v"(dl));
     } else if (FORM == D_ADD_SRC1HI_TO_LO) {
         asm volatile("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %4" : "=&v"(exp_lo), "=&v"(exp_hi) : "v"(sl), "v"(sh), "v"(dh));
+    } else if (FORM == H_FMA_BROADCAST_SRC0) {      // fma(D.lo (both lanes), S, D): direct_conv's / SLP code's broadcast form
+        asm volatile("v_fma_f32 %0, %4, %2, %4\n\tv_fma_f32 %1, %4, %3, %5" : "=&v"(exp_lo), "=&v"(exp_hi) : "v"(sl), "v"(sh), "v"(dl), "v"(dh));
+    } else if (FORM == P_PLAIN_FMA) {               // fma(S, D, S), no modifier
+        asm volatile("v_fma_f32 %0, %2, %4, %2\n\tv_fma_f32 %1, %3, %5, %3" : "=&v"(exp_lo), "=&v"(exp_hi) : "v"(sl), "v"(sh), "v"(dl), "v"(dh));
     } else {      // E: fma(S, D.hi-crossed, S)
         asm volatile("v_fma_f32 %0, %2, %4, %2\n\tv_fma_f32 %1, %3, %4, %3" : "=&v"(exp_lo), "=&v"(exp_hi) : "v"(sl), "v"(sh), "v"(dh));
     }
@@ -60,6 +64,12 @@ __device__ __forceinline__ void apply(f2& D, const f2 S, float& exp_lo, float& e
         D = T;
     } else if (FORM == E_FMA_SRC1HI_TO_LO) {
         asm volatile("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,1,0]\n\ts_nop 0" : "=&v"(T) : "v"(S), "v"(D));
+        D = T;
+    } else if (FORM == H_FMA_BROADCAST_SRC0) {
+        asm volatile("s_nop 0\n\tv_pk_fma_f32 %0, %2, %1, %2 op_sel_hi:[0,1,1]\n\ts_nop 0" : "=&v"(T) : "v"(S), "v"(D));
+        D = T;
+    } else if (FORM == P_PLAIN_FMA) {
+        asm volatile("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %1\n\ts_nop 0" : "=&v"(T) : "v"(S), "v"(D));
         D = T;
     } else if (FORM == F_NOSEL_AFTER_MOV) {
         D.x = D.y;
@@ -179,5 +189,12 @@ int main(int argc, char** argv) {
     run<F_NOSEL_AFTER_MOV, OWN, false>("F  v_mov_b32 D.lo, D.hi ; v_pk_mul_f32 D, S, D   (no modifier)", iters);
     run<F_NOSEL_AFTER_MOV, OWN, true>("F  v_mov_b32 D.lo, D.hi ; v_pk_mul_f32 D, S, D", iters);
     run<G_TWO_SCALAR, OWN, false>("G  v_mul_f32 x 2", iters);
+    // the forms the library's kernels DO contain beside MFMAs (encoder_fused / encoder256: plain and broadcast), 25 x as long
+    run<P_PLAIN_FMA, OWN, false>("P  v_pk_fma_f32 T, S, D, S                 (no modifier), long run", iters * 25);
+    run<P_PLAIN_FMA, OWN, true>("P  v_pk_fma_f32 T, S, D, S, long run", iters * 25);
+    run<H_FMA_BROADCAST_SRC0, OWN, false>("H  v_pk_fma_f32 T, D, S, D op_sel_hi:[0,1,1] (D.lo in both lanes), long run", iters * 25);
+    run<H_FMA_BROADCAST_SRC0, OWN, true>("H  v_pk_fma_f32 T, D, S, D op_sel_hi:[0,1,1], long run", iters * 25);
+    run<C_MUL_SRC1LO_TO_HI, OWN, false>("C  v_pk_mul_f32 T, S, D op_sel_hi:[1,0], long run", iters * 25);
+    run<B_MUL_SRC0HI_TO_LO, OWN, false>("B  v_pk_mul_f32 T, S, D op_sel:[1,0], long run", iters * 25);
     return 0;
 }
