@@ -75,6 +75,9 @@ struct FrontArgs {
     unsigned w2bytes;
     unsigned first_gen;                           // workgroups of the first dispatch generation (2 per CU)
     int skew;                                     // start delay of the second workgroup of a CU, in s_sleep 127 units (~8 K cycles)
+#ifdef S2D_CENSUS
+    unsigned long long* census;                   // [n][4]: HW_ID, LDS_ALLOC, start, end (tools/ubench/s2d_census.hip)
+#endif
 };
 
 __device__ __forceinline__ void lds_barrier() {
@@ -94,6 +97,9 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
     float* carry = reinterpret_cast<float*>(smem + OFF_CARRY);
     float* tile = reinterpret_cast<float*>(smem);
     const int CW = g.c1 - g.c0;
+#ifdef S2D_CENSUS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
 
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.w2h, 0, g.w2bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.w2l, 0, g.w2bytes, 0x00020000);
@@ -138,6 +144,9 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
     if (blockIdx.x < g.first_gen && (__builtin_amdgcn_s_getreg((6) | (0 << 6) | (11 << 11)) != 0)) {
         for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    float bias2[8];                                // every output item of this thread has c8 = tid & 7 (items are strided by 256)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bias2[q] = g.b2[(tid & 7) * 8 + q];
     for (int band = 0; band < NBAND; ++band) {
         const int y0 = band * R;
         // ---- rgb rows y0 - 2 .. y0 + 8, columns -1 .. 35 ---------------------------------------------------------------------
@@ -184,24 +193,43 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 for (int it = 0; it < 5; ++it)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a1[it][c] = f32x2{bg[2 * c], bg[2 * c + 1]};
-#pragma unroll 1                 // a real loop: one tap's 24 weights (scalar registers) live at a time
+                // The 9 taps, software-pipelined: tap kk + 1's 24 weights (scalar loads) are requested
+                // behind the first third of tap kk's arithmetic and land under the rest of it -- scalar-memory and LDS returns share one
+                // counter, so a request placed in FRONT of a use makes that use wait for it (measured: as a rolled loop this phase was
+                // nine exposed scalar-load latencies long, 1.1 of the kernel's 3.2 ms).  sched_barrier pins the positions.
+                f32x4 v[5];
+                f32x2 w[3][4], wn[3][4];
+                auto fetch_w = [&](int kk, f32x2 (&dst)[3][4]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dst[ci][c] = wg2[(kk * 3 + ci) * 4 + c];
+                };
+                auto mac = [&](int ci) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int it = 0; it < 5; ++it) {
+                        const f32x2 xv = {v[it][ci], v[it][ci]};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a1[it][c] += xv * w[ci][c];      // one expression: an FMA (-ffp-contract=on)
+                    }
+                };
+                fetch_w(0, w);
+#pragma unroll 1
                 for (int kk = 0; kk < 9; ++kk) {
                     const int ky = kk / 3, kx = kk - 3 * ky;
-                    f32x4 v[5];
 #pragma unroll
-                    for (int it = 0; it < 5; ++it) v[it] = rgb[rb[it] + ky * PW + kx];
+                    for (int it = 0; it < 5; ++it) v[it] = rgb[rb[it] + ky * PW + kx];    // LDS: short wait (and tap kk's weights with it)
+                    mac(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch_w(kk < 8 ? kk + 1 : 8, wn);                                     // scalar loads: land under the other two thirds
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(1);
+                    mac(2);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int ci = 0; ci < 3; ++ci) {
-                        f32x2 w[4];
+                    for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) w[c] = wg2[(kk * 3 + ci) * 4 + c];
-#pragma unroll
-                        for (int it = 0; it < 5; ++it) {
-                            const f32x2 xv = {v[it][ci], v[it][ci]};
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) a1[it][c] += xv * w[c];      // one expression: an FMA (-ffp-contract=on)
-                        }
-                    }
+                        for (int c = 0; c < 4; ++c) w[ci][c] = wn[ci][c];
                 }
 #pragma unroll
                 for (int it = 0; it < 5; ++it) {
@@ -240,20 +268,23 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 dma_b(t + 2);
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const char* sb = smem + OFF_B + (t % NBST) * B_STAGE;
+                // fragment reads in the order the MFMA groups need them (A hi, B hi | B lo | A lo): the compiler's counted lgkmcnt waits
+                // let the first 16 MFMAs start when half of the reads have landed
                 half8 ah[4], al[4], bh[4], bl[4];
+                int aoff[4], boff[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int off = tile_off16(arow[i] + ky * PW + kx, kslot);
-                    ah[i] = *reinterpret_cast<const half8*>(smem + off);
-                    al[i] = *reinterpret_cast<const half8*>(smem + A_PLANE + off);
-                }
+                for (int i = 0; i < 4; ++i) aoff[i] = tile_off16(arow[i] + ky * PW + kx, kslot);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int off = tile_off16(j * 16 + (lane & 15), kslot);
-                    bh[j] = *reinterpret_cast<const half8*>(sb + off);
-                    bl[j] = *reinterpret_cast<const half8*>(sb + B_PLANE + off);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int j = 0; j < 4; ++j) boff[j] = tile_off16(j * 16 + (lane & 15), kslot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ah[i] = *reinterpret_cast<const half8*>(smem + aoff[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bh[j] = *reinterpret_cast<const half8*>(sb + boff[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const half8*>(sb + B_PLANE + boff[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) al[i] = *reinterpret_cast<const half8*>(smem + A_PLANE + aoff[i]);
+                __builtin_amdgcn_sched_barrier(0);
 #ifndef S2D_ABL_NO_MFMA
                 // in place (destination tied to the addend, see sf_gemm.h); consecutive MFMAs never share an accumulator
 #define S2D_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
@@ -306,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 _Float16 a, b;
-                split_f32(fmaxf(v[q] + g.b2[c8 * 8 + q], 0.f), a, b);
+                split_f32(fmaxf(v[q] + bias2[q], 0.f), a, b);
                 h[q] = a;
                 l[q] = b;
             }
@@ -384,6 +415,14 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 #endif
         lds_barrier();                              // tile and rgb are free for the next band
     }
+#ifdef S2D_CENSUS
+    if (tid == 0) {
+        g.census[patch * 4 + 0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        g.census[patch * 4 + 1] = __builtin_amdgcn_s_getreg((6) | (0 << 6) | (31 << 11));
+        g.census[patch * 4 + 2] = t_start;
+        g.census[patch * 4 + 3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 }  // namespace
@@ -423,7 +462,9 @@ extern "C" int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int 
         g.skew = skew;
     }
     static dfsfm::SmemAttr attr;
-    attr.ensure(reinterpret_cast<const void*>(&s2d_front_kernel), SMEM);
-    hipLaunchKernelGGL(s2d_front_kernel, dim3((unsigned)n_patches), dim3(256), SMEM, static_cast<hipStream_t>(stream_), g);
+    attr.ensure(reinterpret_cast<const void*>(&s2d_front_kernel), 160 * 1024);
+    static int lds_pad = -1;                                    // experiment: DFSFM_S2D_LDS_PAD=4096 leaves room for ONE workgroup per CU
+    if (lds_pad < 0) { const char* e = getenv("DFSFM_S2D_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(s2d_front_kernel, dim3((unsigned)n_patches), dim3(256), SMEM + lds_pad, static_cast<hipStream_t>(stream_), g);
     return dfsfm::check_launch("dfsfm_s2d_front_f32");
 }

@@ -299,6 +299,32 @@ def planted_aspanformer_state_dict(spec: Spec, seed: int = 0, alpha: float = 3.0
         sd[k] = v
     return sd
 
+def planted_multiview_state_dict(spec: Spec, seed: int = 1, alpha: float = 32.0) -> Dict[str, torch.Tensor]:
+    """``random_state_dict`` of the refinement head with PEAKED fine heat-maps.
+
+    With seeded weights the two adaptation layers of S2DNet emit a large per-channel constant plus a small content term (mean /
+    std ~ 6), every window feature correlates equally with every other, the 15 x 15 heat-maps are flat and the 49 candidate
+    scores of a track differ by ~1e-5 -- the argmin of fine_matching.py:129-179 is then decided by rounding, which exercises the
+    tie rule, not the expectation arithmetic.  Here the BatchNorm affine that ends each adaptation layer becomes
+    ``alpha * (BN(x) - mu)``: mu = that layer's per-channel output mean for the seeded weights (committed, [2, 128] doubles,
+    data/planted_mu_refine_seed<seed>.npy, measured once by ``python -m oracle.make_planted refine``), so the constant is removed
+    and the content amplified.  On ``synth.refine_bag`` bags the candidate scores then spread over (0.36, 1.29) with the best and
+    the second-best candidate of every track >= 1.7e-3 apart.  Everything else stays the seeded tensor."""
+    import os
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"planted_mu_refine_seed{seed}.npy")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: run `python -m oracle.make_planted refine` for this seed")
+    sd = random_state_dict(spec, seed)
+    mu = torch.from_numpy(np.load(path)).double()
+    for i in (0, 1):
+        q = f"backbone.adaptation_layers.adap_layer_{i}.3."
+        w, b = sd[q + "weight"].double(), sd[q + "bias"].double()
+        sd[q + "weight"] = (alpha * w).float()
+        sd[q + "bias"] = (alpha * (b - mu[i])).float()
+    return sd
+
+
 class ParamModule(nn.Module):
     """nn.Module whose parameters/buffers carry the reference's dotted names.
 

@@ -64,8 +64,42 @@ def main_matchformer(seed=0):
     print(out, mu.shape, float(mu.mean()))
 
 
+def main_refine(seed=1):
+    """mu of ``params.planted_multiview_state_dict``: per-channel means of the two adaptation-layer outputs of S2DNet (after their
+    BatchNorm, s2dnet.py:24-52) for the seeded refinement weights, over the patches of a 24-track x 5-view config-3 bag through the
+    oracle's arithmetic (restate.s2dnet_forward's layers).  [2, 128] doubles."""
+    import torch.nn.functional as F
+    from detectorfreesfm_amd.config import multiview_refinement_config
+    from detectorfreesfm_amd.params import multiview_param_spec
+    cfg = multiview_refinement_config()
+    sd = random_state_dict(multiview_param_spec(cfg), seed)
+    data = synth.refine_bag(24, 5, 480, 640, seed=2000)
+    p = "backbone."
+    pts = torch.cat([data["query_points"][:, None], data["reference_points_coarse"]], 1)[0]            # [V, T, 2]
+    with torch.no_grad():
+        patches = torch.cat([restate.extract_local_patches(data["images"][v], pts[v], 35) for v in range(5)], 0)
+        mean = patches.new_tensor(restate.IMAGENET_MEAN)[:, None, None]
+        std = patches.new_tensor(restate.IMAGENET_STD)[:, None, None]
+        x = (patches - mean) / std
+        conv = lambda i, t: F.relu(F.conv2d(t, sd[f"{p}encoder.{i}.weight"], sd[f"{p}encoder.{i}.bias"], 1, 1))
+        f0 = conv(2, conv(0, x))
+        x = conv(7, conv(5, F.max_pool2d(f0, 3, 2, 1)))
+        f1 = conv(14, conv(12, conv(10, F.max_pool2d(x, 3, 2, 1))))
+        mus = []
+        for i, t in ((0, f0), (1, f1)):
+            q = f"{p}adaptation_layers.adap_layer_{i}."
+            t = F.relu(F.conv2d(t, sd[q + "0.weight"], sd[q + "0.bias"]))
+            t = restate._bn(sd, q + "3.", F.conv2d(t, sd[q + "2.weight"], sd[q + "2.bias"], 1, 2))
+            mus.append(t.double().mean((0, 2, 3)))
+    out = os.path.join(ROOT, "detectorfreesfm_amd", "data", f"planted_mu_refine_seed{seed}.npy")
+    np.save(out, torch.stack(mus).numpy())
+    print(out, torch.stack(mus).shape, float(torch.stack(mus).abs().mean()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "matchformer":
         main_matchformer()
+    elif len(sys.argv) > 1 and sys.argv[1] == "refine":
+        main_refine()
     else:
         main()

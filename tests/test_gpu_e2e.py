@@ -509,27 +509,62 @@ def test_multiview_config3_T2000_ragged(built_lib):
     assert torch.equal(d["query_points_refined"][0].cpu()[imm], data["query_points"][0][imm])     # unmovable => centre
 
 
-def test_multiview_benched_bag_vs_oracle(built_lib):
-    """The refinement bag ``bench.py`` steps (configs[2]: ``synth.refine_bag(2000, 5, 480, 640, seed=2000)``, every view valid, seeded
-    weights 1 -- `secondary` of the bench line) held to the oracle: tracks are independent units (attention batch dimension = track,
-    src/MultiviewMatcher/matcher_module/transformer.py:132-178), so a seeded sample of 128 tracks of the full launch is compared with
-    the oracle run on those tracks alone; the whole bag is checked for finiteness and the +-7.5 px search window."""
-    cfg, sd, m = _refiner(1)
-    data = synth.refine_bag(2000, 5, 480, 640, seed=2000)
+def _whole_bag_vs_oracle(cfg, sd, m, data, label, chunk=250):
+    """Every track of ``data`` against the oracle: tracks are independent units (attention batch dimension = track,
+    src/MultiviewMatcher/matcher_module/transformer.py:132-178), so the oracle runs the bag in chunks of 250 tracks (its S2DNet pass
+    holds ~1.5 GB per 1000 patches) while the HIP model ran it as ONE launch sequence."""
     d = synth.to_device(data, DEV)
     m(d)
-    q, r = d["query_points_refined"], d["reference_points_refined"][-1]
-    assert q.shape == (1, 2000, 2) and r.shape == (1, 4, 2000, 2) and torch.isfinite(q).all() and torch.isfinite(r).all()
-    assert (r.cpu() - data["reference_points_coarse"]).abs().max().item() <= 7.5
-    g = torch.Generator().manual_seed(11)
-    idx = torch.sort(torch.randperm(2000, generator=g)[:128])[0]
-    sub = _subset_bag(data, idx)
+    T = data["query_points"].shape[1]
+    q, r, sdv = d["query_points_refined"], d["reference_points_refined"][-1], d["std"][-1]
+    assert q.shape == (1, T, 2) and torch.isfinite(q).all() and torch.isfinite(r).all()
+    flips = []
+    for lo in range(0, T, chunk):
+        idx = torch.arange(lo, min(T, lo + chunk))
+        sub = _subset_bag(data, idx)
+        with torch.no_grad():
+            o = restate.multiview_matcher_forward(sd, cfg, sub)
+        dsub = {"query_points_refined": q[:, idx.to(DEV)], "reference_points_refined": [r[:, :, idx.to(DEV)]],
+                "std": [sdv[:, :, idx.to(DEV)]]}
+        flips += [(lo + f[0],) + tuple(f[1:]) for f in _strict_refine(dsub, o, sub, 7, f"{label}, tracks {lo}..{lo + len(idx) - 1}")]
+    return d, flips
+
+
+def test_multiview_benched_bag_vs_oracle(built_lib):
+    """The refinement bag ``bench.py`` steps (configs[2]: ``synth.refine_bag(2000, 5, 480, 640, seed=2000)``, every view valid, seeded
+    weights 1 -- `secondary` of the bench line) held to the oracle, ALL 2000 tracks (r06; r05 checked a 128-track sample).  With the
+    seeded weights the fine heat-maps are flat and a track's 49 candidate scores differ by ~1e-5: a handful of tracks may pick the
+    other of two candidates whose ORACLE scores are within 1e-5 (listed; tests/parity.py); every other track agrees within 1e-4 px
+    on all three outputs, and the whole bag stays inside the +-7.5 px search window."""
+    cfg, sd, m = _refiner(1)
+    data = synth.refine_bag(2000, 5, 480, 640, seed=2000)
+    d, flips = _whole_bag_vs_oracle(cfg, sd, m, data, "bench bag 2000 x 5 (whole)")
+    assert (d["reference_points_refined"][-1].cpu() - data["reference_points_coarse"]).abs().max().item() <= 7.5
+    print(f"[bench bag, whole] {len(flips)} near-tied argmin flips of 2000 tracks: {flips}")
+    assert len(flips) <= 20
+
+
+def test_multiview_planted_weights_no_flips(built_lib):
+    """``params.planted_multiview_state_dict``: peaked heat-maps, candidate scores spread over (0.05, 1.6) with the best two of a
+    track >= 1e-3 apart, so the argmin over candidates is decided by margins far above rounding and the expectation / std
+    arithmetic (fine_matching.py:195-219, 258-285) carries the comparison: NO track may pick another candidate, on the whole
+    2000-track bag with ragged track lengths and on the benched all-valid bag's first 500 tracks."""
+    from detectorfreesfm_amd.params import planted_multiview_state_dict
+    cfg = multiview_refinement_config()
+    sd = planted_multiview_state_dict(multiview_param_spec(cfg), 1)
+    m = HipMultiviewMatcher(cfg, test=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    data = synth.refine_bag(2000, 5, 480, 640, seed=2001, variable_lengths=True)
+    d, flips = _whole_bag_vs_oracle(cfg, sd, m, data, "planted weights, 2000 ragged tracks")
+    assert flips == []
     with torch.no_grad():
-        o = restate.multiview_matcher_forward(sd, cfg, sub)
-    dsub = {"query_points_refined": q[:, idx.to(DEV)], "reference_points_refined": [r[:, :, idx.to(DEV)]],
-            "std": [d["std"][-1][:, :, idx.to(DEV)]]}
-    flips = _strict_refine(dsub, o, sub, 7, "bench bag 2000 x 5 (128-track sample)")
-    assert len(flips) <= 2
+        o = restate.multiview_matcher_forward(sd, cfg, _subset_bag(data, torch.arange(0, 250)))
+    s2 = torch.sort(o["cand_score"], 1)[0]
+    assert float((s2[:, 1] - s2[:, 0]).min()) > 1e-4 and float(s2[:, -1].max() - s2[:, 0].min()) > 0.5     # peaked, decidable
+    data = _subset_bag(synth.refine_bag(2000, 5, 480, 640, seed=2000), torch.arange(0, 500))
+    d, flips = _whole_bag_vs_oracle(cfg, sd, m, data, "planted weights, bench bag tracks 0..499")
+    assert flips == []
 
 
 def test_multiview_chunk16000_equals_two_chunks(built_lib):

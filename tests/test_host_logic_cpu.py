@@ -414,3 +414,30 @@ def test_s2d_front_weight_layout():
     import pytest
     with pytest.raises(Exception):
         ops.S2dFrontWeights(w1[:32], b1, w2, b2)
+
+
+def test_planted_multiview_weights_give_decidable_candidates():
+    """``params.planted_multiview_state_dict``: the adaptation layers' BatchNorm affine becomes alpha * (BN(x) - mu); with it the
+    oracle's 49 candidate scores of a track are spread out (peaked heat-maps) and the best two are far more than 1e-5 apart, so the
+    host logic on the CPU stand-ins must pick exactly the oracle's candidate for every track (no tie rule involved)."""
+    from detectorfreesfm_amd.params import planted_multiview_state_dict
+    cfg = multiview_refinement_config()
+    spec = multiview_param_spec(cfg)
+    sd, plain = planted_multiview_state_dict(spec, 1), random_state_dict(spec, 1)
+    changed = sorted(k for k in sd if not torch.equal(sd[k], plain[k]))
+    assert changed == [f"backbone.adaptation_layers.adap_layer_{i}.3.{n}" for i in (0, 1) for n in ("bias", "weight")]
+    data = synth.refine_bag(T=16, V=4, H=120, W=160, seed=2000, variable_lengths=True)
+    o = restate.multiview_matcher_forward(sd, cfg, data)
+    s2 = torch.sort(o["cand_score"], 1)[0]
+    assert float((s2[:, 1] - s2[:, 0]).min()) > 1e-4 and float(s2[:, -1].max() - s2[:, 0].min()) > 0.5
+    flat = torch.sort(restate.multiview_matcher_forward(plain, cfg, data)["cand_score"], 1)[0]
+    assert float(flat[:, -1].max() - flat[:, 0].min()) < 0.05            # the seeded weights: flat heat-maps
+    m = HipMultiviewMatcher(cfg, test=True).eval()
+    m.load_state_dict(sd, strict=True)
+    with cpu_ops():
+        d = dict(data)
+        m(d)
+    mask = data["track_valid_mask"]
+    assert torch.allclose(d["query_points_refined"], o["query_points_refined"], atol=1e-4)
+    assert torch.allclose(d["reference_points_refined"][-1][mask], o["reference_points_refined"][mask], atol=1e-4)
+    assert torch.allclose(d["std"][-1][mask], o["std"][mask], atol=1e-4)
