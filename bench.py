@@ -45,6 +45,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s 
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
 MFMA_F16_PEAK_TF = 2500.0    # fp16/bf16 dense MFMA peak (spec; 2178-2382 TF measured micro-benchmarks)
 N_RESIDENT = 4               # distinct resident input batches rotated through the steps
+# DFSFM_BENCH_DRYRUN=cpu: the SAME step loops (shards, barriers, table gather, max-reduce over ranks, the JSON line) over gloo on the CPU
+# stand-ins of tests/cpu_standins.py with toy frame sizes -- a plumbing rehearsal of the multi-GPU launch for machines without GPUs
+# (tests/test_dist_gloo.py runs it at world 8).  Its line says "dry-run" in `data` and is never a measurement.
+DRYRUN = os.environ.get("DFSFM_BENCH_DRYRUN") == "cpu"
+FRAME_HW = (96, 128) if DRYRUN else (480, 640)
+
+
+def _sync():
+    if not DRYRUN:
+        torch.cuda.synchronize()
 
 # algorithmic flops (hook-counted on the reference): per 640x480 image / pair / 5-view track
 BACKBONE_FLOP_PER_IMAGE = 163.4e9      # ResNetFPN_8_2 without the dead FPN top-down branch (327 G per pair)
@@ -82,7 +92,7 @@ def timed_steps(step, steps, warmup, distributed, drain=None):
         drain()
     if distributed:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
@@ -90,10 +100,10 @@ def timed_steps(step, steps, warmup, distributed, drain=None):
         drain()
     if distributed:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    _sync()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if DRYRUN else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -274,6 +284,21 @@ def kernel_rooflines(dev, batch):
     return out
 
 
+def real_module_ratio():
+    """Time of the oracle port divided by the time of the REAL reference modules on the same inputs, from the committed record of
+    tools/time_reference_vs_restate.py (the reference tree is not on the GPU box): how far ``cpu_baseline`` (kind "port") is from
+    what the reference itself would score on these cores."""
+    import re
+    for name in ("r06_reference_vs_restate_cpu.txt", "r05_reference_vs_restate_cpu.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            r = re.findall(r"port / reference time ratio\s+([0-9.]+)", open(path).read())
+            if len(r) >= 2:
+                return {"coarse": float(r[0]), "refinement": float(r[1]), "source": f"profiles/{name}",
+                        "meaning": "oracle-port time / real-module time on the build container's 8 cores (< 1: the port is faster)"}
+    return None
+
+
 def cpu_baseline():
     """The oracle (CPU port of the reference PyTorch path, same weights / inputs) on the host cores, BASELINE.md section 2
     protocol: 1 warm-up + >= 5 timed 640x480 pairs one at a time (the reference runs batch 1) and one bag of 200 tracks x 5
@@ -321,6 +346,7 @@ def cpu_baseline():
             "sample": f"{n} single 640x480 pairs through oracle.restate.loftr_coarse_forward (incl. the FPN branch the "
                       f"reference computes and discards) at the fastest of {cand} threads; 1 warm-up",
             "thread_sweep_s_per_pair": {str(k): round(v, 3) for k, v in sweep_c.items()}, "host_threads": all_threads,
+            "real_module_ratio": real_module_ratio(),
             "secondary": {"value": tracks_per_s, "unit": "tracks/s", "cores": best_r,
                           "sample": "1 bag of 200 tracks x 5 views through oracle.restate.multiview_matcher_forward "
                                     f"at the fastest of {cand} threads (swept on a 24-track bag)",
@@ -391,23 +417,26 @@ def load_pmc(result):
               "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",),
               "enc256_apply_kernel": ("enc256_apply_kernel",), "enc256_kv_kernel": ("enc256_kv_kernel", "enc256_image_kernel"),
               "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_rgb_kernel", "roi_align_kernel"),
-              "fine_match": ("fine_match_kernel",),
+              # the two input forms are two template instances: one roofline entry each (r05 summed both under one key)
+              "fine_match W=15 (fp32 input)": ("fine_match_kernel<128, false>", "fine_match_kernelILi128ELb0E"),
+              "fine_match W=15": ("fine_match_kernel<128, true>", "fine_match_kernelILi128ELb1E"),
               "coarse_match_split": ("cm_gemm_sf", "cm_reduce_stats", "cm_select", "cm_compact", "cm_top", "cm_eval"),
               "coarse_match_f32": ("cm_gemm<",)}
     for r in result["rooflines"]:
-        for key, subs in groups.items():
+        for key, subs in groups.items():            # first match wins: longer keys of one family come first
             if r["kernel"].startswith(key):
                 sel = [k for k in rows if any(s_ in k["kernel"] for s_ in subs)]
                 if sel:
                     r["traffic"] = sum(k["fetch_MB_x2"] + k["write_MB"] for k in sel) * 1024 * 1024
                     r["traffic_unit"] = f"bytes per call (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/{name})"
                     r["traffic_source"] = "committed PMC pass (not measured by this run)"
+                break
 
 
 def run_pairs(args, dev, rank, world, distributed, out_fd):
     """configs[1] (+ configs[2] as ``secondary``)."""
     matcher = build_coarse(dev)
-    batches = [synth.to_device(synth.coarse_pair_batch(args.batch, 480, 640, seed=1000 + 1000 * rank + 10 * k), dev)
+    batches = [synth.to_device(synth.coarse_pair_batch(args.batch, *FRAME_HW, seed=1000 + 1000 * rank + 10 * k), dev)
                for k in range(N_RESIDENT)]
     n_matches = [0]
 
@@ -449,7 +478,7 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
 
     # stage breakdown of one coarse step (events, rank 0 only, outside the timed region)
     breakdown = {}
-    if rank == 0:
+    if rank == 0 and not DRYRUN:
         data = batches[0]
         P = matcher._packed or matcher._pack()
         imgs = torch.cat([data["image0"], data["image1"]], 0)
@@ -467,7 +496,7 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
 
     # ---- refinement head: configs[2] --------------------------------------------------------------
     refiner = build_refiner(dev)
-    bags = [synth.to_device(synth.refine_bag(args.tracks, 5, 480, 640, seed=2000 + 1000 * rank + 10 * k), dev)
+    bags = [synth.to_device(synth.refine_bag(args.tracks, 5, *FRAME_HW, seed=2000 + 1000 * rank + 10 * k), dev)
             for k in range(N_RESIDENT)]
 
     def refine_step(i):
@@ -486,7 +515,8 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
         "metric": "coarse_image_pairs_per_sec", "value": pairs_per_s, "unit": "image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (fp16x2-split operands, fp32 accumulate)",
+        "data": "dry-run (CPU stand-ins over gloo, toy frames: plumbing only, not a measurement)" if DRYRUN else "synthetic",
         "config": {"workload": f"configs[1]: LoFTR coarse_only, 640x480, batch {args.batch} pairs per GPU per step, "
                                f"{N_RESIDENT} distinct resident batches rotating, seeded planted weights (real match tables "
                                "at thr 0.2), inputs resident in HBM; match-table gather to rank 0 per step when N>1",
@@ -503,6 +533,8 @@ def run_pairs(args, dev, rank, world, distributed, out_fd):
                                         "frac_of_fp16_mfma_peak": args.tracks * REFINE_FLOP_PER_TRACK_EXECUTED * r_steps / rdt / 1e12 / MFMA_F16_PEAK_TF,
                                         "reference_flops_per_step": args.tracks * REFINE_FLOP_PER_TRACK,
                                         "frac_if_priced_with_reference_flops": args.tracks * REFINE_FLOP_PER_TRACK * r_steps / rdt / 1e12 / MFMA_F16_PEAK_TF}},
+        # BASELINE's metric has two halves; the second one also at the top level of the line (the full record stays in `secondary`)
+        "refinement_tracks_per_sec": tracks_per_s, "refinement_ms_per_step": 1000.0 * rdt / r_steps,
         "matches_last_step": n_matches[0],
         "pipelined": {"value": args.batch * world * args.steps / dt_p, "unit": "image-pairs/s", "ms_per_step": 1000.0 * dt_p / args.steps,
                       "matches_last_step": piped_rows[0],
@@ -673,7 +705,7 @@ def run_hires(args, dev, rank, world, distributed, out_fd):
         n_matches[0] = int(d["mconf"].shape[0])
     dt = timed_steps(coarse_step, args.steps, args.warmup, distributed)
     breakdown = {}
-    if rank == 0:
+    if rank == 0 and not DRYRUN:
         data = batches[0]
         P = matcher._packed or matcher._pack()
         imgs = torch.cat([data["image0"], data["image1"]], 0)
@@ -784,8 +816,30 @@ def main():
     # DFSFM_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barriers, max-reduce, table all-gather) with a
     # single rank; multi-GPU runs have WORLD_SIZE > 1
     distributed = world > 1 or os.environ.get("DFSFM_BENCH_FORCE_DIST") == "1"
+    if world != args.gpus:
+        # the driver computes scaling from `value` per N: a line labelled N that N ranks did not produce must not exist
+        raise SystemExit(f"bench.py --gpus {args.gpus} but {world} rank(s) were launched (WORLD_SIZE): refusing to report")
+    if DRYRUN:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from cpu_standins import cpu_ops
+        dev = torch.device("cpu")
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        args.no_rooflines = args.no_cpu_baseline = True
+        with cpu_ops(), torch.no_grad():
+            if args.workload != "pairs":
+                raise SystemExit("the dry run rehearses --workload pairs")
+            run_pairs(args, dev, rank, world, distributed, out_fd)
+        if distributed:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks on a node with {torch.cuda.device_count()} GPU(s): one process per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -794,7 +848,14 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         probe = torch.ones(1, device=dev)
         torch.distributed.all_reduce(probe)                 # RCCL really is up: the sum must equal the world size
-        assert int(probe.item()) == world, (int(probe.item()), world)
+        if int(probe.item()) != world:
+            raise SystemExit(f"RCCL all-reduce over {world} rank(s) returned {int(probe.item())}: refusing to report")
+        # one process per GPU: the ranks must sit on distinct devices
+        ids = [None] * world
+        torch.distributed.all_gather_object(ids, (local_rank, str(torch.cuda.get_device_properties(dev).uuid) if hasattr(
+            torch.cuda.get_device_properties(dev), "uuid") else str(local_rank)))
+        if len({i[1] for i in ids}) != world:
+            raise SystemExit(f"ranks share a GPU: {ids}")
 
     if args.kernels_only:
         _emit(out_fd, {"rooflines": kernel_rooflines(dev, args.batch)})

@@ -66,20 +66,17 @@ struct Moments {
 // stages of its first view before the workgroup stages the candidate rows, so that latency runs under the prologue.
 // (d) r04: 4-KB stages (KC = 32) and 52 stored candidate rows = 79 KB of LDS per workgroup (Vq <= 5): TWO workgroups per CU, two
 // waves per SIMD -- one wave's DMA issue, LDS reads and softmax VALU work run under the other's MFMAs: 0.305 -> 0.218 ms per 2000
-// tracks (4.5 TB/s).  r03 had measured that schedule and dropped it because 1-14 of 2000 tracks changed from run to run.  ROOT CAUSE
-// (r04: a 13-variant matrix of temporary build switches, tools/fine_determinism.py + tools/fine_which_fail.py, log in
-// profiles/r04_fine_match_root_cause.txt; the switches have left this file again):
-// not the DMA ring -- the deviations survive draining every DMA before every read, a workgroup barrier or a sleep behind the
-// wait, never issuing the out-of-range tail stages, 1 KB of slack behind the allocation, and even replacing the LDS-DMA by
-// ordinary loads + ds_write; two co-resident workgroups get disjoint LDS (tools/ubench/lds_alloc.hip).  What deviates is only the
-// `std` output (the second moments sxx, syy), by 1e-4 .. 1e-3 relative, in ~18 of 8000 (track, view) entries per run, and only when
-// two workgroups share a CU.  The compiler's SLP vectoriser had packed the moment updates into v_pk_mul_f32 / v_pk_add_f32 /
-// v_pk_fma_f32 (757 packed-fp32 instructions in this kernel); with those instructions gone -- -fno-slp-vectorize, or the target
-// feature -packed-fp32-ops -- the two-workgroup build is bit-identical over 200 runs x 2000 tracks, equals the one-workgroup
-// results bit for bit, and is 7 % faster still (the guide prices packed f32 beside MFMAs as an anti-lever).  Packed-fp32 VALU
-// results are unreliable on this part while another wave of the SIMD has MFMAs in flight; with one wave per SIMD (every other
-// MFMA kernel of this library that mixes the two: scanned) it never shows.  Hence the rule for THIS file: built
-// with -fno-slp-vectorize, and the Makefile fails the build if a packed-fp32 instruction appears in its ISA.
+// tracks (4.5 TB/s).  r03 had measured that schedule and dropped it because 1-14 of 2000 tracks changed from run to run; r04 found that
+// the deviations vanish when the file is built without the SLP vectoriser (and called packed fp32 unreliable beside MFMAs), r05 showed
+// that plain packed fp32 is reliable there.  THE CAUSE (r06, profiles/r06_fine_match_bisect.txt): the vectoriser had turned the moment
+// update of candidate block 0 into packed instructions, one of them `v_pk_mul_f32 v[152:153], v[202:203], v[152:153] op_sel:[0,1]` --
+// the LOW lane reads the HIGH register of src1.  On gfx950 that form reads the operand as 0 in ~3e-3 of its executions while an MFMA the
+// same wave issued earlier is still in flight (tools/ubench/pk_opsel_inplace.hip; no other packed form does, and not without own
+// MFMAs).  Block 0's update runs while the last MFMA of block 1 can still be queued behind the OTHER workgroup's MFMAs -- hence only
+// with two workgroups per CU, only in the second moments (one e * g^2 term of 225 lost), and not in block 1's twin of the instruction.
+// Rewriting only the four op_sel instructions of the SLP build's assembly in place makes it bit-reproducible; rewriting the other
+// 175 does not.  Rule (csrc/Makefile): this file is built without the vectoriser (also 7 % faster: packed fp32 is an anti-lever beside
+// MFMAs), and the build fails if a packed-fp32 instruction with op_sel on src1 / src2 appears in any translation unit with MFMAs.
 template <int C, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void fine_match_kernel(FineArgs g) {
     constexpr int KC = 32;                   // channels per stage: 4-KB stages, 79 KB of LDS per workgroup (Vq <= 5), two per CU
@@ -90,10 +87,8 @@ __global__ __launch_bounds__(256, 2) void fine_match_kernel(FineArgs g) {
     constexpr int STAGE = 32 * KC * 4;       // one A stage: 32 rows x KC channels (fp32, or fp16 hi plane + fp16 lo plane)
     constexpr int PIECES = STAGE / 1024;     // DMA instructions per stage
     constexpr int NSTG = 3;                  // ring depth per wave: two stages in flight while one is multiplied
-    // (d) below: the schedule is only known to be reproducible with ONE workgroup per CU.  __launch_bounds__ does not cap
-    // residency; the LDS footprint does -- the ring alone must exceed half of the CU's 160 KB, whatever C, Vq or MAXL are.
-    // (d) below: with two workgroups per CU this translation unit must be built WITHOUT packed-fp32 VALU instructions
-    // (-fno-slp-vectorize; the Makefile checks the ISA).
+    // (d) above: two workgroups per CU; this translation unit is built without the SLP vectoriser and the Makefile checks its ISA
+    // for the packed op_sel form that misreads beside in-flight MFMAs.
     constexpr int RB = SPLIT ? KC * 2 : KC * 4;          // bytes of a row inside a stage (per plane)
     constexpr int NS = RB / 16;                          // its 16-byte slots: 16, 8 or 4
     constexpr int PLANE = 32 * RB;                       // split input: bytes of one plane of a stage

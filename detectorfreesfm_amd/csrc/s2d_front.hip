@@ -24,11 +24,16 @@
 //   out     accumulators -> fp32 staging tile (over the dead operand buffers) -> bias, ReLU, fp16x2 split -> the rows of the
 //           crop window and the pooled rows this band completes; a pooled row that straddles two bands is carried as a 4.6-KB
 //           partial maximum (max commutes with + bias, ReLU and the split, all monotone: pooled bytes equal pool-after-split)
-// While one workgroup of a CU runs its VALU phases (conv1_1, epilogue) the other one's MFMA phase owns the matrix pipe.
+// Two workgroups per CU: 3.24 ms per 10 000 patches against 4.6 - 4.9 ms with one (and 4.8 - 5.0 ms for the three launches).  What
+// bounds it (profiles/r06_s2d_front.txt: timing-only ablations at one / two workgroups per CU, SQ counters, a residency census): the
+// matrix pipe is busy 38 % of the kernel and VALU instructions issue 50 % of it, and the two barely overlap -- fp32 VALU work of a
+// wave runs at HALF rate while its SIMD partner issues back-to-back MFMAs (tools/ubench/mfma_valu_overlap.hip: x2.0 - 2.2 for
+// v_fma / v_pk_fma, x1.15 - 1.3 for integer work, the MFMAs unaffected), so a second workgroup hides latency, not VALU time; wave
+// priority and a start skew between the two workgroups of a CU measured +-1 %.  786 M VALU instructions per launch for 173 M MFMAs:
+// half of them are conv1_1 (the next lever: conv1_1 as one more MFMA k-step on an im2col operand built in LDS).
 // MFMA work per patch: 5 bands x 256 rows x 64 x 576 x 2 x 3 = 283 MFLOP for 271 MFLOP of split product (245 of 256 rows live).
 #include "common.h"
 #include "sf_gemm.h"
-#include <cstdlib>
 
 namespace {
 
@@ -73,11 +78,6 @@ struct FrontArgs {
     _Float16 *poh, *pol;                          // pooled relu1_2: [n][18][18][64] split planes
     int c0, c1, kpad;
     unsigned w2bytes;
-    unsigned first_gen;                           // workgroups of the first dispatch generation (2 per CU)
-    int skew;                                     // start delay of the second workgroup of a CU, in s_sleep 127 units (~8 K cycles)
-#ifdef S2D_CENSUS
-    unsigned long long* census;                   // [n][4]: HW_ID, LDS_ALLOC, start, end (tools/ubench/s2d_census.hip)
-#endif
 };
 
 __device__ __forceinline__ void lds_barrier() {
@@ -97,9 +97,6 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
     float* carry = reinterpret_cast<float*>(smem + OFF_CARRY);
     float* tile = reinterpret_cast<float*>(smem);
     const int CW = g.c1 - g.c0;
-#ifdef S2D_CENSUS
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-#endif
 
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void*)g.w2h, 0, g.w2bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)g.w2l, 0, g.w2bytes, 0x00020000);
@@ -136,14 +133,6 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
         rb[it] = ly * PW + (qq - ly * P);
     }
 
-    // Two workgroups share a CU and every workgroup runs the same VALU / MFMA phase sequence: started together they stay in step --
-    // both in conv1_1, then both in the MFMA loop -- and the kernel takes the SUM of its phases (measured: timing-only ablations,
-    // profiles/r06_s2d_front_ablation.txt).  The second workgroup of a CU (its LDS allocation does not start at 0) of the FIRST
-    // generation of workgroups therefore starts late by about one VALU phase; workgroups dispatched later inherit the offset from the
-    // slot they replace.  Purely a schedule hint: wrong guesses cost the delay, never a result.
-    if (blockIdx.x < g.first_gen && (__builtin_amdgcn_s_getreg((6) | (0 << 6) | (11 << 11)) != 0)) {
-        for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     float bias2[8];                                // every output item of this thread has c8 = tid & 7 (items are strided by 256)
 #pragma unroll
     for (int q = 0; q < 8; ++q) bias2[q] = g.b2[(tid & 7) * 8 + q];
@@ -175,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             // ---- conv1_1, channels hf * 32 + 8 wave .. + 7 ---------------------------------------------------------------------
-#ifndef S2D_ABL_NO_CONV1
             {
                 const int cg = hf * 4 + wave;
                 // wave-uniform addresses in the CONSTANT address space: scalar loads (the output stores of the previous band would
@@ -258,7 +246,6 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                     *reinterpret_cast<half8*>(smem + A_PLANE + off) = z;
                 }
             }
-#endif
             // ---- conv1_2: 9 taps of this half ------------------------------------------------------------------------------------
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
@@ -285,10 +272,8 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) al[i] = *reinterpret_cast<const half8*>(smem + A_PLANE + aoff[i]);
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef S2D_ABL_NO_MFMA
                 // in place (destination tied to the addend, see sf_gemm.h); consecutive MFMAs never share an accumulator
 #define S2D_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
-                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -301,9 +286,7 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) S2D_MFMA(accx[i][j], al[i], bh[j]);
-                __builtin_amdgcn_s_setprio(0);
 #undef S2D_MFMA
-#endif
             }
             lds_barrier();                          // every wave has read its last A fragments of this half
         }
@@ -330,7 +313,6 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 }
         lds_barrier();
 
-#ifndef S2D_ABL_NO_EPI
         // ---- outputs of the band: 8 channels per thread ------------------------------------------------------------------------
         auto finish = [&](const float (&v)[8], int c8, _Float16* oh, _Float16* ol, int64_t o) __attribute__((always_inline)) {
             half8 h, l;
@@ -412,17 +394,8 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
                 }
             }
         }
-#endif
         lds_barrier();                              // tile and rgb are free for the next band
     }
-#ifdef S2D_CENSUS
-    if (tid == 0) {
-        g.census[patch * 4 + 0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
-        g.census[patch * 4 + 1] = __builtin_amdgcn_s_getreg((6) | (0 << 6) | (31 << 11));
-        g.census[patch * 4 + 2] = t_start;
-        g.census[patch * 4 + 3] = __builtin_amdgcn_s_memtime();
-    }
-#endif
 }
 
 }  // namespace
@@ -446,25 +419,8 @@ extern "C" int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int 
     g.poh = static_cast<_Float16*>(pool_hi); g.pol = static_cast<_Float16*>(pool_lo);
     g.c0 = c0; g.c1 = c1; g.kpad = (int)kpad;
     g.w2bytes = (unsigned)(64 * kpad * 2);
-    {
-        static int cus = 0, skew = -1;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            (void)hipGetDevice(&dev);
-            cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-        }
-        if (skew < 0) {
-            const char* e = getenv("DFSFM_S2D_SKEW");             // tuning knob of tools/bench_s2d_front.py
-            skew = e ? atoi(e) : 1;
-        }
-        g.first_gen = (unsigned)(2 * cus);
-        g.skew = skew;
-    }
     static dfsfm::SmemAttr attr;
-    attr.ensure(reinterpret_cast<const void*>(&s2d_front_kernel), 160 * 1024);
-    static int lds_pad = -1;                                    // experiment: DFSFM_S2D_LDS_PAD=4096 leaves room for ONE workgroup per CU
-    if (lds_pad < 0) { const char* e = getenv("DFSFM_S2D_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(s2d_front_kernel, dim3((unsigned)n_patches), dim3(256), SMEM + lds_pad, static_cast<hipStream_t>(stream_), g);
+    attr.ensure(reinterpret_cast<const void*>(&s2d_front_kernel), SMEM);
+    hipLaunchKernelGGL(s2d_front_kernel, dim3((unsigned)n_patches), dim3(256), SMEM, static_cast<hipStream_t>(stream_), g);
     return dfsfm::check_launch("dfsfm_s2d_front_f32");
 }

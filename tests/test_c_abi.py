@@ -72,3 +72,44 @@ def test_ops_refuse_cpu_tensors(built_lib):
         ops.linear_attention(q, q, q)
     with pytest.raises(_lib.DfsfmError):
         ops.coarse_match(torch.zeros(1, 16, 256), torch.zeros(1, 16, 256), (4, 4), (4, 4), 0.2, 2, 0.1)
+
+
+def test_isa_gate_pattern_and_stamps():
+    """csrc/Makefile's ISA gate (the packed-fp32 op_sel hazard, profiles/r06_fine_match_bisect.txt): its pattern flags the forms the
+    reproducer shows misreading beside in-flight MFMAs -- op_sel set for src1 / src2 -- and none of the clean ones, and every
+    translation unit with MFMAs went through it in this build (the .isa_ok stamp sits next to its ISA listing)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "detectorfreesfm_amd", "csrc")
+    mk = open(os.path.join(root, "Makefile")).read()
+    m = re.search(r'grep -E "([^"]+)" \$\(ROOT\)/build/\$\*\.s > /dev/null', mk)
+    assert m, "the gate's grep is gone from csrc/Makefile"
+    pat = re.compile(m.group(1))
+    bad = ["v_pk_mul_f32 v[152:153], v[202:203], v[152:153] op_sel:[0,1]",
+           "v_pk_add_f32 v[78:79], v[78:79], v[78:79] op_sel:[0,1] op_sel_hi:[1,0]",
+           "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]",
+           "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]",
+           "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,1,0] op_sel_hi:[0,1,1]"]
+    good = ["v_pk_mul_f32 v[138:139], v[84:85], v[86:87] op_sel_hi:[1,0]",
+            "v_pk_fma_f32 v[82:83], v[80:81], s[90:91], v[82:83] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]",
+            "v_pk_fma_f32 v[0:1], v[2:3], s[4:5], v[0:1] op_sel:[1,0,0]",
+            "v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]",
+            "v_pk_add_f32 v[154:155], v[154:155], v[202:203]",
+            "v_pk_add_f16 v1, v2, v3 op_sel:[0,1]"]
+    for line in bad:
+        assert pat.search(line), line
+    for line in good:
+        assert not pat.search(line), line
+    srcs = re.search(r"^MFMA_SRCS\s*:=\s*(.+)$", mk, re.M).group(1)
+    nos = re.search(r"^NOSLP_SRCS\s*:=\s*(.+)$", mk, re.M).group(1).split()
+    units = [u for u in srcs.replace("$(NOSLP_SRCS)", " ".join(nos)).split()]
+    assert set(units) >= {"fine_match", "coarse_match", "conv_gemm", "linear_attention", "s2d_front", "encoder_fused", "encoder256"}
+    for u in units:
+        isa = os.path.join(root, "build", u + ".s")
+        assert os.path.exists(os.path.join(root, "build", u + ".isa_ok")) and os.path.exists(isa), u
+        text = open(isa).read()
+        assert "v_mfma" in text and not pat.search(text), u
+    # every translation unit that holds MFMAs is on the list
+    with_mfma = {f[:-4] for f in os.listdir(root) if f.endswith(".hip") and re.search(r"__builtin_amdgcn_mfma|v_mfma_f32", open(os.path.join(root, f)).read())}
+    with_mfma |= {"conv_gemm", "coarse_match"} if re.search(r"__builtin_amdgcn_mfma|v_mfma_f32", open(os.path.join(root, "sf_gemm.h")).read()) else set()
+    assert with_mfma <= set(units), with_mfma - set(units)

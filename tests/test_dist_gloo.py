@@ -320,3 +320,33 @@ def test_tiled_pair_shards_level_sparse_lists():
 def test_single_process_passthrough():
     t = [torch.ones(3, 5), torch.zeros(0, 5)]
     assert ddist.all_gather_tables(t)[0] is t[0]
+
+
+def test_bench_step_loop_dry_run_world8():
+    """no 8-GPU node has run ``bench.py`` yet, so the exact step loops of ``bench.py --gpus 8`` (rank / world from the
+    launcher's environment, shards, barriers, the per-step gather of match tables to rank 0, the max over ranks, ONE JSON line from rank
+    0) are rehearsed here as 8 processes over gloo on the CPU stand-ins (DFSFM_BENCH_DRYRUN=cpu, toy frames), launched the way the
+    driver launches it.  And ``--gpus N`` with another number of ranks refuses to report."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFSFM_BENCH_DRYRUN="cpu", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "1",
+           "--tracks", "6"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["data"].startswith("dry-run") and d["value"] > 0 and d["refinement_tracks_per_sec"] > 0
+    assert abs(d["value"] - 8 * 1 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job rate: 8 ranks x batch 1 per step
+    assert d["matches_last_step"] > 0                                # rank 0 received the gathered tables of all ranks
+    # a line labelled N that N ranks did not produce must not exist
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert bad.returncode != 0 and "refusing to report" in (bad.stderr + bad.stdout)
+    assert not any(l.strip().startswith("{") for l in bad.stdout.splitlines())

@@ -1,6 +1,7 @@
 """S2DNet front end (conv1_1 -> conv1_2 -> centre window + max-pool): the fused launch (ops.s2d_front, csrc/s2d_front.hip) beside the
 three launches it replaces, 10 000 patches of 35 x 35 (BASELINE configs[2]: 2000 tracks x 5 views).  DFSFM_LIB_PATH selects an
-experiment build of the library (timing-only ablations)."""
+experiment build of the library (the timing-only ablation / priority / skew / one-workgroup-per-CU switches it was written for were
+temporary and have left csrc/s2d_front.hip; their numbers are in profiles/r06_s2d_front.txt)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

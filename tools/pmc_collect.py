@@ -24,7 +24,7 @@ import time
 from collections import defaultdict
 
 OURS = ("conv_gemm", "cm_", "la_", "roi_align", "fine_match", "layernorm", "split_rows", "direct_conv", "maxpool",
-        "add_scatter", "mk_", "mlp_", "bag_", "dfsfm", "enc_", "enc256", "jd_")
+        "add_scatter", "mk_", "mlp_", "bag_", "dfsfm", "enc_", "enc256", "jd_", "s2d_front")
 
 
 def source_sha256():
