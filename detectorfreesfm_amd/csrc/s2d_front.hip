@@ -12,10 +12,13 @@
 // planes out per patch (1.9 GB per 10 000).
 //
 // One workgroup (4 waves) per patch, TWO workgroups per CU (78.9 KB of LDS each), a patch in five bands of seven output rows:
-//   rgb     the band's 11 input rows (zero-padded to 37 columns, 4 floats per pixel) -> LDS
-//   conv1_1 for one 32-channel half: wave w computes channels 8w..8w+7 of the band's 9 relu1_1 rows in exact fp32 (the FMA
-//           order of direct_conv_kernel: bias, then taps (ky, kx, ci)) from LDS with its 216 weights as scalar operands, splits
-//           them (v = hi + lo/2048) and writes the fp16 planes [9 x 37 rows][32 ch] -- zero rows / columns where conv1_2 pads
+//   rgb     the band's 11 input rows (zero-padded to 37 columns, (r, g, b, 0) per pixel) -> LDS as fp16 hi / lo planes
+//   conv1_1 for one 32-channel half of the band's 9 relu1_1 rows, as ONE more MFMA k-step (K = 27 taps padded to 32) of the same
+//           fp16x2-split product: the weights are the A operand (host-built fragments), a pixel's im2col row is gathered from the
+//           rgb planes in LDS two bytes at a time; bias, ReLU, split
+//           (v = hi + lo/2048) and an 8-byte store per plane into [9 x 37 rows][32 ch] -- zero rows / columns where conv1_2 pads
+//           (r06 first version: 27-tap FMA chains in fp32 on the VALU -- half of the kernel's VALU instructions, which do not hide
+//           under the other workgroup's MFMAs)
 //   conv1_2 9 taps x that half = 9 slabs of K = 32 on v_mfma_f32_16x16x32_f16 (three products per slab: hi*hi, hi*lo, lo*hi):
 //           a wave owns 64 of the band's 245 output pixels x 64 channels (4 x 4 blocks); a tap is an LDS ROW OFFSET of the
 //           A fragment (ky * 37 + kx: the zero columns make every tap a plain shift, no masks); the weights stream L2 -> LDS
@@ -30,7 +33,7 @@
 // wave runs at HALF rate while its SIMD partner issues back-to-back MFMAs (tools/ubench/mfma_valu_overlap.hip: x2.0 - 2.2 for
 // v_fma / v_pk_fma, x1.15 - 1.3 for integer work, the MFMAs unaffected), so a second workgroup hides latency, not VALU time; wave
 // priority and a start skew between the two workgroups of a CU measured +-1 %.  786 M VALU instructions per launch for 173 M MFMAs:
-// half of them are conv1_1 (the next lever: conv1_1 as one more MFMA k-step on an im2col operand built in LDS).
+// half of them were conv1_1's FMA chains -- now an MFMA k-step (above).
 // MFMA work per patch: 5 bands x 256 rows x 64 x 576 x 2 x 3 = 283 MFLOP for 271 MFLOP of split product (245 of 256 rows live).
 #include "common.h"
 #include "sf_gemm.h"
@@ -60,7 +63,8 @@ constexpr int TILE_BYTES = 256 * TILE_LD * 4;     // 69 632: all 256 rows of the
 constexpr int UNION = RING > TILE_BYTES ? RING : TILE_BYTES;
 constexpr int RGB_ROWS = R + 4;                   // input rows 7 b - 2 .. 7 b + 8
 constexpr int OFF_RGB = UNION;
-constexpr int RGB_BYTES = (RGB_ROWS * PW * 16 + 15) & ~15;
+constexpr int RGB_PLANE = RGB_ROWS * PW * 8;      // fp16 (r, g, b, 0) per pixel
+constexpr int RGB_BYTES = (2 * RGB_PLANE + 15) & ~15;
 constexpr int PO = (P + 1) / 2;                   // pooled side: 18
 constexpr int OFF_CARRY = OFF_RGB + RGB_BYTES;
 constexpr int CARRY_BYTES = PO * 64 * 4;
@@ -70,7 +74,7 @@ static_assert(LR * PW <= AROWS && 2 * SMEM <= 160 * 1024 && P % R == 0, "two wor
 
 struct FrontArgs {
     const float* x;                               // [n][P][P][3] normalised RGB patches (NHWC)
-    const float* w1g;                             // conv1_1 weights [8 channel groups][27 = (ky, kx, ci)][8]
+    const _Float16* w1f;                          // conv1_1 weights as MFMA A fragments [2 halves][2 x 16 channels][hi, lo][64 lanes][8]
     const float* b1;                              // [64]
     const _Float16 *w2h, *w2l;                    // conv1_2 weights, tap-padded split planes [>= 64][kpad], k = tap * 64 + ci
     const float* b2;                              // [64]
@@ -93,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t patch = blockIdx.x;
     const float* xp = g.x + patch * (P * P * 3);
-    f32x4* rgb = reinterpret_cast<f32x4*>(smem + OFF_RGB);
+    dfsfm_half4* rgb_h = reinterpret_cast<dfsfm_half4*>(smem + OFF_RGB);                 // [RGB_ROWS * PW] pixels x (r, g, b, 0) fp16, hi plane
+    dfsfm_half4* rgb_l = rgb_h + RGB_ROWS * PW;                                          // lo plane
     float* carry = reinterpret_cast<float*>(smem + OFF_CARRY);
     float* tile = reinterpret_cast<float*>(smem);
     const int CW = g.c1 - g.c0;
@@ -121,18 +126,20 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void*)(d + B_PLANE), 16, off, 0, 0, 0);
     };
 
-    // ---- conv1_1 lane constants: wave w owns channels 8 w .. 8 w + 7 of a half, lane + 64 it = pixel of the 9 x 35 band ----
-    int rb[5];                                     // rgb index of tap (0, 0); A row written = rb + 1 (same 37-wide rows)
-    bool qok[5];
+    // ---- conv1_1 as ONE MFMA k-step per product (K = 27 taps -> 32), transposed: relu1_1^T[channel][pixel] = W1[channel][k] X^T[k][pixel].
+    // A operand = the weights of 16 channels (host-built fragments, lane = channel + 16 kslot), B operand = the im2col row of a pixel
+    // (lane = pixel + 16 kslot: k = 8 kslot .. + 7, k = 3 tap + ci), gathered from the band's rgb planes in LDS two bytes at a time and
+    // packed in pairs.  A result block has
+    // lane = pixel, registers = 4 consecutive channels -> one 8-byte store per plane into the A planes of conv1_2.
+    // Wave w takes the 16-pixel blocks w, w + 4, ... of the band's 9 x 35 = 315 pixels (20 blocks).
+    unsigned koff[8];                              // byte offset of k = 8 kslot + j inside an rgb plane, relative to the pixel's tap (0, 0)
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        const int q = lane + 64 * it;
-        qok[it] = q < LR * P;
-        const int qq = qok[it] ? q : 0;
-        const int ly = qq / P;
-        rb[it] = ly * PW + (qq - ly * P);
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * kslot + j;
+        const int tap = k < 27 ? k / 3 : 0, ci = k < 27 ? k - 3 * tap : 3;          // k >= 27: the zero fourth element of a pixel
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        koff[j] = (unsigned)(((ky * PW + kx) * 4 + ci) * 2);
     }
-
     float bias2[8];                                // every output item of this thread has c8 = tid & 7 (items are strided by 256)
 #pragma unroll
     for (int q = 0; q < 8; ++q) bias2[q] = g.b2[(tid & 7) * 8 + q];
@@ -144,8 +151,14 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
             const int iy = y0 - 2 + ry, ix = cx - 1;
             const bool ok = iy >= 0 && iy < P && ix >= 0 && ix < P;
             const float* p = xp + (ok ? (iy * P + ix) * 3 : 0);
-            const float r0 = p[0], r1 = p[1], r2 = p[2];
-            rgb[e] = ok ? f32x4{r0, r1, r2, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float r0 = ok ? p[0] : 0.f, r1 = ok ? p[1] : 0.f, r2 = ok ? p[2] : 0.f;
+            dfsfm_half4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
+            _Float16 a, b;
+            split_f32(r0, a, b); h[0] = a; l[0] = b;
+            split_f32(r1, a, b); h[1] = a; l[1] = b;
+            split_f32(r2, a, b); h[2] = a; l[2] = b;
+            rgb_h[e] = h;
+            rgb_l[e] = l;
         }
         wait_vmcnt<0>();                            // also the previous band's output stores: the counted waits below see only DMA
         dma_b(0);
@@ -163,79 +176,67 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
-            // ---- conv1_1, channels hf * 32 + 8 wave .. + 7 ---------------------------------------------------------------------
+            // ---- conv1_1, channels hf * 32 .. + 31 of the band's 9 rows (three MFMAs per 16 channels x 16 pixels) -------------------------
             {
-                const int cg = hf * 4 + wave;
-                // wave-uniform addresses in the CONSTANT address space: scalar loads (the output stores of the previous band would
-                // otherwise make the compiler fetch the 216 weights through vector registers)
-                typedef const __attribute__((address_space(4))) float* cptr;
-                const cptr bg = (cptr)(uintptr_t)(g.b1 + cg * 8);
-                // two channels per instruction (v_pk_fma_f32: plain vector code, the full fp32 rate; a scalar v_fma_f32 runs at half
-                // of it).  Forms: pixel value broadcast into both lanes (op_sel_hi), weights as a scalar register pair -- none of
-                // them the op_sel form that misreads beside in-flight MFMAs (csrc/Makefile, tools/ubench/pk_opsel_inplace.hip).
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                typedef const __attribute__((address_space(4))) f32x2* cptr2;
-                const cptr2 wg2 = (cptr2)(uintptr_t)(g.w1g + cg * 216);
-                f32x2 a1[5][4];
-#pragma unroll
-                for (int it = 0; it < 5; ++it)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) a1[it][c] = f32x2{bg[2 * c], bg[2 * c + 1]};
-                // The 9 taps, software-pipelined: tap kk + 1's 24 weights (scalar loads) are requested
-                // behind the first third of tap kk's arithmetic and land under the rest of it -- scalar-memory and LDS returns share one
-                // counter, so a request placed in FRONT of a use makes that use wait for it (measured: as a rolled loop this phase was
-                // nine exposed scalar-load latencies long, 1.1 of the kernel's 3.2 ms).  sched_barrier pins the positions.
-                f32x4 v[5];
-                f32x2 w[3][4], wn[3][4];
-                auto fetch_w = [&](int kk, f32x2 (&dst)[3][4]) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) dst[ci][c] = wg2[(kk * 3 + ci) * 4 + c];
-                };
-                auto mac = [&](int ci) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int it = 0; it < 5; ++it) {
-                        const f32x2 xv = {v[it][ci], v[it][ci]};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) a1[it][c] += xv * w[ci][c];      // one expression: an FMA (-ffp-contract=on)
-                    }
-                };
-                fetch_w(0, w);
-#pragma unroll 1
-                for (int kk = 0; kk < 9; ++kk) {
-                    const int ky = kk / 3, kx = kk - 3 * ky;
-#pragma unroll
-                    for (int it = 0; it < 5; ++it) v[it] = rgb[rb[it] + ky * PW + kx];    // LDS: short wait (and tap kk's weights with it)
-                    mac(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    fetch_w(kk < 8 ? kk + 1 : 8, wn);                                     // scalar loads: land under the other two thirds
-                    __builtin_amdgcn_sched_barrier(0);
-                    mac(1);
-                    mac(2);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) w[ci][c] = wn[ci][c];
-                }
-#pragma unroll
+                const half8* wf = reinterpret_cast<const half8*>(g.w1f) + hf * 4 * 64 + lane;       // [half][cb][plane][lane] fragments
+                const half8 wh0 = wf[0], wl0 = wf[64], wh1 = wf[128], wl1 = wf[192];
+                const f32x4 bv0 = *reinterpret_cast<const f32x4*>(g.b1 + hf * 32 + 4 * kslot);
+                const f32x4 bv1 = *reinterpret_cast<const f32x4*>(g.b1 + hf * 32 + 16 + 4 * kslot);
+                const unsigned rgb_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + OFF_RGB);   // LDS byte address of the hi plane
+#pragma unroll 1                 // a rolled loop: one block's fragments and accumulators live at a time
                 for (int it = 0; it < 5; ++it) {
-                    const int ly = rb[it] / PW;
+                    const int q = (wave + 4 * it) * 16 + (lane & 15);          // this lane's pixel of the 9 x 35 band
+                    const bool pix_ok = q < LR * P;
+                    const int qq = pix_ok ? q : 0;
+                    const int ly = qq / P;
+                    const int pix_rb = ly * PW + (qq - ly * P);                // rgb pixel index of tap (0, 0); A row = pix_rb + 1
+                    // im2col fragment of this lane's pixel: 8 fp16 of each plane, two bytes per LDS read, into register halves
+                    // (ds_read_u16_d16 / _d16_hi into register halves would save the packing, but with SRAM ECC on -- this part -- a d16 load
+                    // clears the other half of its destination: measured, the low halves came back 0)
+                    unsigned th[8], tl[8];
+                    const unsigned pa = rgb_base + (unsigned)pix_rb * 8u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned ad = pa + koff[j];
+                        asm volatile("ds_read_u16 %0, %1" : "=v"(th[j]) : "v"(ad));
+                        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(tl[j]) : "v"(ad), "n"(RGB_PLANE));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(th[0]), "+v"(th[1]), "+v"(th[2]), "+v"(th[3]), "+v"(th[4]), "+v"(th[5]), "+v"(th[6]),
+                                 "+v"(th[7]), "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7])::"memory");
+                    unsigned xh[4], xl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xh[i] = th[2 * i] | (th[2 * i + 1] << 16);
+                        xl[i] = tl[2 * i] | (tl[2 * i + 1] << 16);
+                    }
+                    half8 bh, bl;
+                    __builtin_memcpy(&bh, xh, 16);
+                    __builtin_memcpy(&bl, xl, 16);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, bh, z, 0, 0, 0);
+                    const f32x4 m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, bh, z, 0, 0, 0);
+                    f32x4 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, bl, z, 0, 0, 0);
+                    f32x4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, bl, z, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, bh, x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, bh, x1, 0, 0, 0);
                     const int iy = y0 - 1 + ly;
                     const bool live = iy >= 0 && iy < P;            // rows outside the image are conv1_2's zero padding
-                    half8 h, l;
+                    dfsfm_half4 h0, l0, h1, l1;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
+                    for (int r = 0; r < 4; ++r) {
                         _Float16 a, b;
-                        split_f32(live ? fmaxf(a1[it][c >> 1][c & 1], 0.f) : 0.f, a, b);
-                        h[c] = a;
-                        l[c] = b;
+                        split_f32(live ? fmaxf(m0[r] + x0[r] * (1.f / 2048.f) + bv0[r], 0.f) : 0.f, a, b);
+                        h0[r] = a; l0[r] = b;
+                        split_f32(live ? fmaxf(m1[r] + x1[r] * (1.f / 2048.f) + bv1[r], 0.f) : 0.f, a, b);
+                        h1[r] = a; l1[r] = b;
                     }
-                    if (qok[it]) {
-                        const int off = tile_off16(rb[it] + 1, wave);
-                        *reinterpret_cast<half8*>(smem + off) = h;
-                        *reinterpret_cast<half8*>(smem + A_PLANE + off) = l;
+                    if (pix_ok) {                  // channels 4 kslot .. + 3 of block cb: logical slot 2 cb + (kslot >> 1), half (kslot & 1)
+                        const int row = pix_rb + 1;
+                        const int o0 = tile_off16(row, kslot >> 1) + (kslot & 1) * 8, o1 = tile_off16(row, 2 + (kslot >> 1)) + (kslot & 1) * 8;
+                        *reinterpret_cast<dfsfm_half4*>(smem + o0) = h0;
+                        *reinterpret_cast<dfsfm_half4*>(smem + A_PLANE + o0) = l0;
+                        *reinterpret_cast<dfsfm_half4*>(smem + o1) = h1;
+                        *reinterpret_cast<dfsfm_half4*>(smem + A_PLANE + o1) = l1;
                     }
                 }
                 if (tid < 2 * LR * 4) {                             // the zero columns x' = 0 and x' = 36 of every band row
@@ -400,20 +401,20 @@ __global__ __launch_bounds__(256, 2) void s2d_front_kernel(FrontArgs g) {
 
 }  // namespace
 
-extern "C" int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int patch, const float* w1g, const float* b1,
+extern "C" int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int patch, const void* w1_frag, const float* b1,
                                    const void* w2_hi, const void* w2_lo, int64_t w2_rows, int64_t kpad, const float* b2, int c0,
                                    int c1, void* crop_hi, void* crop_lo, void* pool_hi, void* pool_lo, void* stream_) {
-    if (!patches || !w1g || !b1 || !w2_hi || !w2_lo || !b2 || !crop_hi || !crop_lo || !pool_hi || !pool_lo) return DFSFM_E_BADARG;
+    if (!patches || !w1_frag || !b1 || !w2_hi || !w2_lo || !b2 || !crop_hi || !crop_lo || !pool_hi || !pool_lo) return DFSFM_E_BADARG;
     if (n_patches < 0 || c0 < 0 || c1 <= c0 || c1 > patch || w2_rows < 64) return DFSFM_E_BADARG;
     if (n_patches == 0) return DFSFM_OK;
     if (patch != P || kpad != 9 * 64 || n_patches > 0x7fffffff) return DFSFM_E_UNSUPPORTED;   // callers keep the three-launch path
     const uintptr_t al = reinterpret_cast<uintptr_t>(w2_hi) | reinterpret_cast<uintptr_t>(w2_lo) | reinterpret_cast<uintptr_t>(crop_hi) |
                          reinterpret_cast<uintptr_t>(crop_lo) | reinterpret_cast<uintptr_t>(pool_hi) | reinterpret_cast<uintptr_t>(pool_lo);
-    if ((al & 15) || (reinterpret_cast<uintptr_t>(w1g) & 31) || (reinterpret_cast<uintptr_t>(b1) & 31) ||
+    if ((al & 15) || (reinterpret_cast<uintptr_t>(w1_frag) & 15) || (reinterpret_cast<uintptr_t>(b1) & 15) ||
         (reinterpret_cast<uintptr_t>(patches) & 3))
         return DFSFM_E_UNSUPPORTED;
     FrontArgs g{};
-    g.x = patches; g.w1g = w1g; g.b1 = b1;
+    g.x = patches; g.w1f = static_cast<const _Float16*>(w1_frag); g.b1 = b1;
     g.w2h = static_cast<const _Float16*>(w2_hi); g.w2l = static_cast<const _Float16*>(w2_lo); g.b2 = b2;
     g.crh = static_cast<_Float16*>(crop_hi); g.crl = static_cast<_Float16*>(crop_lo);
     g.poh = static_cast<_Float16*>(pool_hi); g.pol = static_cast<_Float16*>(pool_lo);

@@ -1447,14 +1447,22 @@ def merge_keypoints(rows, img0, img1, n_images):
 
 @_on_device
 class S2dFrontWeights:
-    """Weights of S2DNet's conv1_1 / conv1_2 in the layout dfsfm_s2d_front_f32 reads: conv1_1 as fp32 [8 channel groups][27 taps in
-    (ky, kx, ci) order][8], conv1_2 as the tap-padded split planes of ``PackedDense`` (k = (ky*3 + kx)*64 + ci)."""
+    """Weights of S2DNet's conv1_1 / conv1_2 in the layout dfsfm_s2d_front_f32 reads: conv1_1 as MFMA A fragments of its split
+    planes -- fp16 [2 halves of 32 channels][2 blocks of 16][hi, lo][64 lanes][8], element j of lane l = w1[32 half + 16 block +
+    (l & 15)][k = 8 (l >> 4) + j], k = 3 (3 ky + kx) + ci, zero for k >= 27 -- conv1_2 as the tap-padded split planes of
+    ``PackedDense`` (k = (ky*3 + kx)*64 + ci)."""
 
     def __init__(self, w1, b1, w2, b2):
         if tuple(w1.shape) != (64, 3, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3):
             raise _lib.DfsfmError("S2dFrontWeights: conv1_1 [64,3,3,3] and conv1_2 [64,64,3,3] expected")
-        # [co, ci, ky, kx] -> [group, ky, kx, ci, co in group]
-        self.w1g = w1.detach().float().permute(2, 3, 1, 0).reshape(27, 8, 8).permute(1, 0, 2).contiguous()
+        wk = torch.zeros((64, 32), dtype=torch.float32, device=w1.device)
+        wk[:, :27] = w1.detach().float().permute(0, 2, 3, 1).reshape(64, 27)                 # [co][k = (ky, kx, ci)]
+        if not bool(torch.isfinite(wk).all()) or float(wk.abs().max()) >= FP16_MAX:
+            raise _lib.DfsfmError(f"S2dFrontWeights: weights must be finite with |w| < {FP16_MAX:.0f} (split-plane range)")
+        hi = wk.half()
+        lo = ((wk - hi.float()) * 2048.0).half()
+        planes = torch.stack([hi, lo], 0).reshape(2, 2, 2, 16, 4, 8)                        # [plane][half][block][channel][kslot][j]
+        self.w1f = planes.permute(1, 2, 0, 4, 3, 5).reshape(2, 2, 2, 64, 8).contiguous()    # lane = channel + 16 kslot
         self.b1 = b1.detach().float().contiguous()
         self.conv2 = PackedDense(w2, b2, cin_pad=64, tap_padded=True)
 
@@ -1471,12 +1479,12 @@ def s2d_front(patches, fw: S2dFrontWeights, c0: int, c1: int):
     if P != P2 or C != 3 or patches.dtype != torch.float32 or not patches.is_contiguous():
         raise _lib.DfsfmError("s2d_front: dense fp32 [n, P, P, 3] patches expected")
     dev = patches.device
-    if fw.w1g.device != dev:
+    if fw.w1f.device != dev:
         raise _lib.DfsfmError("s2d_front: weights on another device")
     crop = SplitAct.empty(n, c1 - c0, c1 - c0, 64, dev)
     pool = SplitAct.empty(n, (P + 1) // 2, (P + 1) // 2, 64, dev)
     pw = fw.conv2
-    rc = _lib.lib().dfsfm_s2d_front_f32(_ptr(patches), n, P, _ptr(fw.w1g), _ptr(fw.b1), _ptr(pw.hi), _ptr(pw.lo), pw.hi.shape[0],
+    rc = _lib.lib().dfsfm_s2d_front_f32(_ptr(patches), n, P, _ptr(fw.w1f), _ptr(fw.b1), _ptr(pw.hi), _ptr(pw.lo), pw.hi.shape[0],
                                         pw.Kpad, _ptr(pw.bias), c0, c1, _ptr(crop.hi), _ptr(crop.lo), _ptr(pool.hi), _ptr(pool.lo),
                                         _stream())
     _lib.check(rc, "dfsfm_s2d_front_f32")

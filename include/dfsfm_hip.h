@@ -360,15 +360,16 @@ int dfsfm_conv2d_nhwc_f32(const float* x, const void* x_hi, const void* x_lo, in
  * { centre window, MaxPool2d(3, stride 2, padding 1) } of S2DNet's VGG encoder on `patch` x `patch` RGB patches
  *   src/MultiviewMatcher/backbone/S2DNet/s2dnet.py:86-92,127-175 (features[0..4] with the substituted pooling layer),
  *   backbone/S2DNet/vggnet.py:12-44
- * Neither relu1_1 nor relu1_2 is written to memory (csrc/s2d_front.hip).  conv1_1 is exact fp32 (the arithmetic of
- * dfsfm_conv2d_direct_f32), conv1_2 the fp16x2-split MFMA product of dfsfm_conv2d_nhwc_f32.
- * patches [n][patch][patch][3] fp32 NHWC (normalised); w1g [8][27][8] fp32: conv1_1 weights by 8-channel group,
- * tap (ky,kx,ci), channel in group; b1 [64]; w2_hi / w2_lo [w2_rows >= 64][kpad] fp16 tap-padded split planes of conv1_2
+ * Neither relu1_1 nor relu1_2 is written to memory (csrc/s2d_front.hip).  Both layers are the fp16x2-split MFMA product of
+ * dfsfm_conv2d_nhwc_f32 (fp32-class: operands hi + lo/2048, fp32 accumulation).
+ * patches [n][patch][patch][3] fp32 NHWC (normalised); w1_frag: conv1_1 weights as MFMA A fragments, fp16
+ * [2 halves of 32 channels][2 blocks of 16][hi, lo][64 lanes][8]: element j of lane l = plane(w1[c][k]) with
+ * c = 32 half + 16 block + (l & 15), k = 8 (l >> 4) + j = 3 (3 ky + kx) + ci (k >= 27: 0); b1 [64]; w2_hi / w2_lo [w2_rows >= 64][kpad] fp16 tap-padded split planes of conv1_2
  * (k = (ky*3 + kx)*64 + ci, kpad = 576); b2 [64].  Outputs, split planes (value = hi + lo/2048), 64 channels:
  * crop_* [n][c1-c0][c1-c0][64] = relu1_2[:, c0:c1, c0:c1, :], pool_* [n][(patch+1)/2][(patch+1)/2][64].
  * patch must be 35 (else DFSFM_E_UNSUPPORTED: callers run the three separate layers).
  * ---------------------------------------------------------------------------------------- */
-int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int patch, const float* w1g, const float* b1,
+int dfsfm_s2d_front_f32(const float* patches, int64_t n_patches, int patch, const void* w1_frag, const float* b1,
                         const void* w2_hi, const void* w2_lo, int64_t w2_rows, int64_t kpad, const float* b2, int c0, int c1,
                         void* crop_hi, void* crop_lo, void* pool_hi, void* pool_lo, void* stream);
 

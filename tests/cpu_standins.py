@@ -201,10 +201,14 @@ def _maxpool(x):
 
 
 def _s2d_front(patches, fw, c0, c1):
-    """ops.s2d_front: conv1_1 in fp32, conv1_2 with the split algebra of ``_conv``, then the centre window and the max-pool."""
+    """ops.s2d_front: both layers with the split algebra of ``_conv`` (conv1_1's weights unpacked from its MFMA fragments), then
+    the centre window and the max-pool."""
     import torch.nn.functional as F
-    w1 = fw.w1g.permute(1, 0, 2).reshape(3, 3, 3, 64).permute(3, 2, 0, 1).contiguous()          # [27 (ky,kx,ci), 64] -> [co, ci, ky, kx]
-    r1 = torch.relu(F.conv2d(patches.permute(0, 3, 1, 2), w1, fw.b1, 1, 1)).permute(0, 2, 3, 1)
+    pl = fw.w1f.reshape(2, 2, 2, 4, 16, 8).permute(2, 0, 1, 4, 3, 5).reshape(2, 64, 32).float()     # [plane][co][k]
+    wh, wl = (pl[i][:, :27].reshape(64, 3, 3, 3).permute(0, 3, 1, 2).contiguous() for i in (0, 1))   # [co, ci, ky, kx]
+    xh, xl = _split(patches.permute(0, 3, 1, 2))
+    r1 = F.conv2d(xh, wh, None, 1, 1) + (F.conv2d(xh, wl, None, 1, 1) + F.conv2d(xl, wh, None, 1, 1)) / 2048.0
+    r1 = torch.relu(r1 + fw.b1[None, :, None, None]).permute(0, 2, 3, 1)
     y = _conv(_to_split(r1), fw.conv2, 1, 1, relu=True, out_split=True)
     return y.crop(c0, c1, c0, c1), _maxpool(y)
 

@@ -394,17 +394,22 @@ def test_aspanformer_scene_cached_tokens_equal_pairwise():
 
 
 def test_s2d_front_weight_layout():
-    """``ops.S2dFrontWeights`` (the operands of dfsfm_s2d_front_f32): conv1_1 as [8 channel groups][27 taps (ky, kx, ci)][8],
-    conv1_2 as tap-padded split planes with k = (ky*3 + kx)*64 + ci."""
+    """``ops.S2dFrontWeights`` (the operands of dfsfm_s2d_front_f32): conv1_1 as MFMA A fragments of its split planes
+    [half][block][hi, lo][lane = channel + 16 kslot][8] with k = 8 kslot + j = 3 (3 ky + kx) + ci, conv1_2 as tap-padded split planes
+    with k = (ky*3 + kx)*64 + ci."""
     import torch
     from detectorfreesfm_amd import ops
     g = torch.Generator().manual_seed(5)
     w1, b1 = torch.randn((64, 3, 3, 3), generator=g), torch.randn((64,), generator=g)
     w2, b2 = torch.randn((64, 64, 3, 3), generator=g), torch.randn((64,), generator=g)
     fw = ops.S2dFrontWeights(w1, b1, w2, b2)
-    assert fw.w1g.shape == (8, 27, 8) and fw.w1g.is_contiguous()
-    for grp, ky, kx, ci, c in [(0, 0, 0, 0, 0), (3, 1, 2, 1, 5), (7, 2, 2, 2, 7), (4, 0, 1, 2, 3)]:
-        assert fw.w1g[grp, (ky * 3 + kx) * 3 + ci, c] == w1[grp * 8 + c, ci, ky, kx]
+    assert fw.w1f.shape == (2, 2, 2, 64, 8) and fw.w1f.dtype == torch.float16 and fw.w1f.is_contiguous()
+    for co, ci, ky, kx in [(0, 0, 0, 0), (37, 1, 1, 2), (63, 2, 2, 2), (20, 2, 0, 1), (48, 0, 2, 0)]:
+        k = 3 * (3 * ky + kx) + ci
+        hf, blk, ch, ks, j = co // 32, (co % 32) // 16, co % 16, k // 8, k % 8
+        v = float(fw.w1f[hf, blk, 0, ch + 16 * ks, j]) + float(fw.w1f[hf, blk, 1, ch + 16 * ks, j]) / 2048.0
+        assert abs(v - float(w1[co, ci, ky, kx])) < 1e-6 * max(1.0, abs(float(w1[co, ci, ky, kx])))
+    assert float(fw.w1f[:, :, :, 48:, 3:].abs().max()) == 0.0           # k = 27 .. 31: padding
     pw = fw.conv2
     assert pw.tap_padded and pw.Kpad == 576 and pw.hi.shape == (128, 576)
     full = pw.hi.double() + pw.lo.double() / 2048.0
@@ -414,6 +419,15 @@ def test_s2d_front_weight_layout():
     import pytest
     with pytest.raises(Exception):
         ops.S2dFrontWeights(w1[:32], b1, w2, b2)
+    # the CPU stand-in unpacks the same fragments: its relu1_2 equals a float64 evaluation of the two layers
+    import torch.nn.functional as F
+    from cpu_standins import _s2d_front
+    x = torch.randn((2, 35, 35, 3), generator=g)
+    crop, pool = _s2d_front(x, fw, 8, 27)
+    r1 = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w1.double(), b1.double(), 1, 1))
+    r2 = torch.relu(F.conv2d(r1, w2.double(), b2.double(), 1, 1)).permute(0, 2, 3, 1)
+    assert float((crop.float().double() - r2[:, 8:27, 8:27]).abs().max()) < 2e-6 * float(r2.abs().max())
+    assert pool.hi.shape == (2, 18, 18, 64)
 
 
 def test_planted_multiview_weights_give_decidable_candidates():
