@@ -40,6 +40,7 @@
 #include "common.h"
 #include "jpeg_core.h"
 #include "jpeg_host.h"
+#include <mutex>
 
 namespace {
 
@@ -48,26 +49,37 @@ using jd::Layout;
 using jd::derive;
 using jd::layout_of;
 
-__global__ __launch_bounds__(jd::UNSTUFF_T) void jd_unstuff_kernel(Params P) {
-    __shared__ uint32_t cnt[jd::UNSTUFF_T], grp[jd::UNSTUFF_G];
+// Every stage is written once as a body over (parameter block, block index) and launched in two forms: for one file (the
+// parameter block is the kernel argument) and for a BATCH of files (r06: grid.y -- grid.z for the colour stage -- = file; the
+// parameter blocks of up to JD_BATCH files travel as one kernel argument, indexed with the block id: scalar loads with a computed
+// offset, pointers still known to be global).  A scene's files then cost one set of launches per JD_BATCH files instead of one
+// per file; blocks past a file's own extent leave at once.
+constexpr int JD_BATCH = 7;
+struct Batch {
+    Params p[JD_BATCH];
+};
+static_assert(sizeof(Batch) + 16 <= 4096, "kernel argument segment");
+
+__device__ __forceinline__ void unstuff_body(const Params& P, int bx, uint32_t* cnt, uint32_t* grp) {
+    if ((int64_t)bx * jd::UNSTUFF_BLOCK >= P.scan_bytes) return;          // uniform per workgroup
     uint64_t w0, w1;
-    const uint32_t keep = jd::unstuff_mask(P, blockIdx.x, threadIdx.x, w0, w1);
+    const uint32_t keep = jd::unstuff_mask(P, bx, threadIdx.x, w0, w1);
     cnt[threadIdx.x] = __popc(keep);
     __syncthreads();
     if (threadIdx.x < jd::UNSTUFF_G) jd::unstuff_scan_b1(cnt, grp, threadIdx.x);
     __syncthreads();
     if (threadIdx.x == 0) jd::unstuff_scan_b2(grp);
     __syncthreads();
-    jd::unstuff_store(P, blockIdx.x, keep, w0, w1, cnt[threadIdx.x] + grp[threadIdx.x / (jd::UNSTUFF_T / jd::UNSTUFF_G)]);
+    jd::unstuff_store(P, bx, keep, w0, w1, cnt[threadIdx.x] + grp[threadIdx.x / (jd::UNSTUFF_T / jd::UNSTUFF_G)]);
 }
-__global__ __launch_bounds__(256) void jd_init_kernel(Params P) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void init_body(const Params& P, int bx) {
+    const int c = bx * 256 + threadIdx.x;
     if (c < P.nchunks) jd::init_thread(P, c);
 }
-__global__ __launch_bounds__(jd::SWEEP_WG) void jd_sweep_kernel(Params P, int sweep) {
-    __shared__ uint32_t tab[jd::TAB_WORDS];
+__device__ __forceinline__ void sweep_body(const Params& P, int bx, int sweep, uint32_t* tab) {
+    if (bx * jd::SWEEP_WG >= P.nchunks) return;
     if (sweep > 0 && P.work[sweep - 1] == 0) return;         // the launch before this one decoded nothing: the fixed point is reached
-    const int c = blockIdx.x * jd::SWEEP_WG + threadIdx.x;
+    const int c = bx * jd::SWEEP_WG + threadIdx.x;
     bool loaded = false;
     for (int round = 0; round < jd::SWEEP_ROUNDS; ++round) {
         uint64_t entry = 0;
@@ -82,8 +94,7 @@ __global__ __launch_bounds__(jd::SWEEP_WG) void jd_sweep_kernel(Params P, int sw
         __syncthreads();                                     // exit states are agent-scope stores / loads: the neighbours see them
     }
 }
-__global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
-    __shared__ int32_t part[jd::SCAN_T], grp[jd::SCAN_G];
+__device__ __forceinline__ void scan_body(const Params& P, int32_t* part, int32_t* grp) {
     jd::scan_phase_a(P, threadIdx.x, part);
     __syncthreads();
     if (threadIdx.x < jd::SCAN_G) jd::scan_phase_b1(part, grp, threadIdx.x);
@@ -94,19 +105,14 @@ __global__ __launch_bounds__(jd::SCAN_T) void jd_scan_kernel(Params P) {
     __syncthreads();
     jd::scan_phase_c(P, threadIdx.x, part);
 }
-__global__ __launch_bounds__(256) void jd_write_kernel(Params P) {
-    __shared__ uint32_t tab[jd::TAB_WORDS];
+__device__ __forceinline__ void write_body(const Params& P, int bx, uint32_t* tab) {
+    if (bx * 256 >= P.nchunks) return;
     for (int i = threadIdx.x; i < jd::TAB_WORDS; i += 256) tab[i] = P.tab[i];
     __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = bx * 256 + threadIdx.x;
     if (c < P.nchunks) jd::write_thread(P, c, tab);
 }
-__global__ __launch_bounds__(256) void jd_dc_sum_kernel(Params P) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g < jd::dc_ngroups(P)) jd::dc_sum_thread(P, g);
-}
-__global__ __launch_bounds__(jd::SCAN_T) void jd_dc_scan_kernel(Params P) {
-    __shared__ int32_t part[4 * jd::SCAN_T], grp[4 * jd::SCAN_G];
+__device__ __forceinline__ void dc_scan_body(const Params& P, int32_t* part, int32_t* grp) {
     jd::dc_scan_phase_a(P, threadIdx.x, part);
     __syncthreads();
     if (threadIdx.x < jd::SCAN_G) jd::dc_scan_phase_b1(part, grp, threadIdx.x);
@@ -117,7 +123,60 @@ __global__ __launch_bounds__(jd::SCAN_T) void jd_dc_scan_kernel(Params P) {
     __syncthreads();
     jd::dc_scan_phase_c(P, threadIdx.x, part);
 }
+__device__ __forceinline__ void status_body(const Params& P, int sweeps) {
+    P.status[0] = P.work[sweeps - 1];
+    int used = 0;
+    for (int i = 0; i < sweeps; ++i)
+        if (P.work[i]) used = i + 1;
+    P.status[3] = used;                                          // sweeps of this call that still decoded something
+}
+// batch form of the three memsets: work[64] + status[4] (first launch of a call) and the coefficient array (before the write stage)
+__device__ __forceinline__ void zero_body(const Params& P, int bx, int nbx, int what) {
+    if (what == 0) {
+        if (bx == 0 && threadIdx.x < 64) P.work[threadIdx.x] = 0;
+        if (bx == 0 && threadIdx.x < 4) P.status[threadIdx.x] = 0;
+        return;
+    }
+    uint4* c = reinterpret_cast<uint4*>(P.coef);
+    const int64_t n = (int64_t)P.nblocks * 8;                    // 128 bytes per block
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n; i += (int64_t)nbx * 256) c[i] = uint4{0, 0, 0, 0};
+}
+
+#define JD_FORMS(NAME, BOUNDS, SHARED, CALL1, CALLB)                                                                     \
+    __global__ __launch_bounds__(BOUNDS) void NAME(Params P) { SHARED CALL1; }                                            \
+    __global__ __launch_bounds__(BOUNDS) void NAME##_b(Batch B) { SHARED const Params& P = B.p[blockIdx.y]; CALLB; }
+
+JD_FORMS(jd_unstuff_kernel, jd::UNSTUFF_T, __shared__ uint32_t cnt[jd::UNSTUFF_T]; __shared__ uint32_t grp[jd::UNSTUFF_G];,
+         unstuff_body(P, blockIdx.x, cnt, grp), unstuff_body(P, blockIdx.x, cnt, grp))
+JD_FORMS(jd_init_kernel, 256, , init_body(P, blockIdx.x), init_body(P, blockIdx.x))
+JD_FORMS(jd_scan_kernel, jd::SCAN_T, __shared__ int32_t part[jd::SCAN_T]; __shared__ int32_t grp[jd::SCAN_G];, scan_body(P, part, grp),
+         scan_body(P, part, grp))
+JD_FORMS(jd_write_kernel, 256, __shared__ uint32_t tab[jd::TAB_WORDS];, write_body(P, blockIdx.x, tab), write_body(P, blockIdx.x, tab))
+JD_FORMS(jd_dc_scan_kernel, jd::SCAN_T, __shared__ int32_t part[4 * jd::SCAN_T]; __shared__ int32_t grp[4 * jd::SCAN_G];,
+         dc_scan_body(P, part, grp), dc_scan_body(P, part, grp))
+__global__ __launch_bounds__(jd::SWEEP_WG) void jd_sweep_kernel(Params P, int sweep) {
+    __shared__ uint32_t tab[jd::TAB_WORDS];
+    sweep_body(P, blockIdx.x, sweep, tab);
+}
+__global__ __launch_bounds__(jd::SWEEP_WG) void jd_sweep_kernel_b(Batch B, int sweep) {
+    __shared__ uint32_t tab[jd::TAB_WORDS];
+    sweep_body(B.p[blockIdx.y], blockIdx.x, sweep, tab);
+}
+__global__ __launch_bounds__(256) void jd_dc_sum_kernel(Params P) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < jd::dc_ngroups(P)) jd::dc_sum_thread(P, g);
+}
+__global__ __launch_bounds__(256) void jd_dc_sum_kernel_b(Batch B) {
+    const Params& P = B.p[blockIdx.y];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < jd::dc_ngroups(P)) jd::dc_sum_thread(P, g);
+}
 __global__ __launch_bounds__(256) void jd_dc_apply_kernel(Params P) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < jd::dc_ngroups(P)) jd::dc_apply_thread(P, g);
+}
+__global__ __launch_bounds__(256) void jd_dc_apply_kernel_b(Batch B) {
+    const Params& P = B.p[blockIdx.y];
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < jd::dc_ngroups(P)) jd::dc_apply_thread(P, g);
 }
@@ -125,17 +184,23 @@ __global__ __launch_bounds__(64) void jd_idct_kernel(Params P) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b < P.nblocks) jd::idct_thread(P, b);
 }
+__global__ __launch_bounds__(64) void jd_idct_kernel_b(Batch B) {
+    const Params& P = B.p[blockIdx.y];
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < P.nblocks) jd::idct_thread(P, b);
+}
 __global__ __launch_bounds__(256) void jd_color_kernel(Params P) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < P.width && y < P.height) jd::color_thread(P, x, y);
 }
-__global__ void jd_status_kernel(Params P, int sweeps) {
-    P.status[0] = P.work[sweeps - 1];
-    int used = 0;
-    for (int i = 0; i < sweeps; ++i)
-        if (P.work[i]) used = i + 1;
-    P.status[3] = used;                                          // sweeps of this call that still decoded something
+__global__ __launch_bounds__(256) void jd_color_kernel_b(Batch B) {
+    const Params& P = B.p[blockIdx.z];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < P.width && y < P.height) jd::color_thread(P, x, y);
 }
+__global__ void jd_status_kernel(Params P, int sweeps) { status_body(P, sweeps); }
+__global__ void jd_status_kernel_b(Batch B, int sweeps) { status_body(B.p[blockIdx.y], sweeps); }
+__global__ __launch_bounds__(256) void jd_zero_kernel_b(Batch B, int what) { zero_body(B.p[blockIdx.y], blockIdx.x, gridDim.x, what); }
 
 }  // namespace
 
@@ -189,3 +254,106 @@ extern "C" int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, con
                            stream, P);
     return dfsfm::check_launch("dfsfm_jpeg_decode_u8");
 }
+
+namespace {
+constexpr int JD_SIDE = 4;
+struct SideStreams {
+    hipStream_t s[JD_SIDE];
+    hipEvent_t fork, join[JD_SIDE];
+};
+// one pool per device, created on first use and kept for the life of the process (a handful of handles)
+SideStreams* side_streams() {
+    static SideStreams pool[64];
+    static bool made[64] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!made[dev]) {
+        SideStreams& p = pool[dev];
+        for (int k = 0; k < JD_SIDE; ++k) {
+            if (hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&p.join[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return &pool[dev];
+}
+}  // namespace
+
+extern "C" int dfsfm_jpeg_decode_batch_u8(const dfsfm_jpeg_job* jobs_host, int n_jobs, int out_channels, int sweeps, int resume,
+                                          void* stream_) {
+    if (!jobs_host || n_jobs < 0) return DFSFM_E_BADARG;
+    if ((out_channels != 1 && out_channels != 3) || sweeps < 1 || sweeps > 64) return DFSFM_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // every job is checked before anything is launched
+    for (int i = 0; i < n_jobs; ++i) {
+        const dfsfm_jpeg_job& j = jobs_host[i];
+        if (!j.scan || !j.frame_host || !j.huff_tab || !j.qt || !j.block_base || !j.seg_beg || !j.seg_end || !j.seg_chunk0 || !j.chunk_seg ||
+            !j.out || !j.status || !j.workspace)
+            return DFSFM_E_BADARG;
+        if ((reinterpret_cast<uintptr_t>(j.scan) & 15) != 0 || j.scan_bytes <= 0 || j.scan_bytes >= (1ll << 31)) return DFSFM_E_BADARG;
+        Params P{};
+        if (!derive(*j.frame_host, P)) return DFSFM_E_UNSUPPORTED;
+        if (j.out_stride < (int64_t)P.width * out_channels) return DFSFM_E_BADARG;
+        if (j.workspace_bytes < layout_of(P, j.scan_bytes, out_channels).total) return DFSFM_E_WORKSPACE;
+    }
+    // Groups of JD_BATCH files are independent chains of small, latency-bound launches (a group's sweep launch is ~180 workgroups on
+    // 256 CUs): they run on up to JD_SIDE internal streams that fork from `stream` and join it again, so that several groups share
+    // the chip (measured: one group at a time 0.19 ms per 1600 x 1200 file on the device, profiles/r06_jpeg_batch.txt).
+    const int ngroups = (n_jobs + JD_BATCH - 1) / JD_BATCH;
+    SideStreams* side = ngroups > 1 ? side_streams() : nullptr;
+    if (side) {
+        (void)hipEventRecord(side->fork, stream);
+        for (int k = 0; k < JD_SIDE && k < ngroups; ++k) (void)hipStreamWaitEvent(side->s[k], side->fork, 0);
+    }
+    for (int i0 = 0, grp = 0; i0 < n_jobs; i0 += JD_BATCH, ++grp) {
+        const int nb = n_jobs - i0 < JD_BATCH ? n_jobs - i0 : JD_BATCH;
+        hipStream_t gs = side ? side->s[grp % JD_SIDE] : stream;
+        Batch B{};
+        unsigned gu = 1, gc = 1, gg = 1, gi = 1, gz = 1, gcx = 1, gcy = 1;        // grid extents: the largest of the group
+        for (int k = 0; k < nb; ++k) {
+            const dfsfm_jpeg_job& j = jobs_host[i0 + k];
+            Params& P = B.p[k];
+            derive(*j.frame_host, P);
+            const Layout L = layout_of(P, j.scan_bytes, out_channels);
+            jd::bind(P, L, static_cast<char*>(j.workspace), j.scan, j.scan_bytes, j.huff_tab, j.qt, j.block_base, j.seg_beg, j.seg_end, j.seg_chunk0,
+                     j.chunk_seg, j.out, j.out_stride, out_channels, j.status);
+            auto up = [](unsigned& g, int64_t v) { if (v > (int64_t)g) g = (unsigned)v; };
+            up(gu, (j.scan_bytes + jd::UNSTUFF_BLOCK - 1) / jd::UNSTUFF_BLOCK);
+            up(gc, (P.nchunks + jd::SWEEP_WG - 1) / jd::SWEEP_WG);
+            up(gg, (jd::dc_ngroups(P) + 255) / 256);
+            up(gi, (P.nblocks + 63) / 64);
+            up(gz, ((int64_t)P.nblocks * 8 + 256 * 8 - 1) / (256 * 8));
+            up(gcx, (P.width + 63) / 64);
+            up(gcy, (P.height + 3) / 4);
+        }
+        for (int k = nb; k < JD_BATCH; ++k) B.p[k] = B.p[0];                       // never indexed: grid.y = nb
+        const unsigned ny = (unsigned)nb;
+        hipLaunchKernelGGL(jd_zero_kernel_b, dim3(1, ny), dim3(256), 0, gs, B, 0);
+        if (!resume) {
+            hipLaunchKernelGGL(jd_unstuff_kernel_b, dim3(gu, ny), dim3(jd::UNSTUFF_T), 0, gs, B);
+            hipLaunchKernelGGL(jd_init_kernel_b, dim3(gc, ny), dim3(256), 0, gs, B);
+        }
+        for (int s = 0; s < sweeps; ++s) hipLaunchKernelGGL(jd_sweep_kernel_b, dim3(gc, ny), dim3(jd::SWEEP_WG), 0, gs, B, s);
+        hipLaunchKernelGGL(jd_status_kernel_b, dim3(1, ny), dim3(1), 0, gs, B, sweeps);
+        hipLaunchKernelGGL(jd_scan_kernel_b, dim3(1, ny), dim3(jd::SCAN_T), 0, gs, B);
+        hipLaunchKernelGGL(jd_zero_kernel_b, dim3(gz, ny), dim3(256), 0, gs, B, 1);
+        hipLaunchKernelGGL(jd_write_kernel_b, dim3(gc, ny), dim3(256), 0, gs, B);
+        hipLaunchKernelGGL(jd_dc_sum_kernel_b, dim3(gg, ny), dim3(256), 0, gs, B);
+        hipLaunchKernelGGL(jd_dc_scan_kernel_b, dim3(1, ny), dim3(jd::SCAN_T), 0, gs, B);
+        hipLaunchKernelGGL(jd_dc_apply_kernel_b, dim3(gg, ny), dim3(256), 0, gs, B);
+        hipLaunchKernelGGL(jd_idct_kernel_b, dim3(gi, ny), dim3(64), 0, gs, B);
+        if (out_channels == 3) hipLaunchKernelGGL(jd_color_kernel_b, dim3(gcx, gcy, ny), dim3(256), 0, gs, B);
+    }
+    if (side) {
+        for (int k = 0; k < JD_SIDE && k < ngroups; ++k) {
+            (void)hipEventRecord(side->join[k], side->s[k]);
+            (void)hipStreamWaitEvent(stream, side->join[k], 0);
+        }
+    }
+    return dfsfm::check_launch("dfsfm_jpeg_decode_batch_u8");
+}
+

@@ -376,38 +376,56 @@ def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_
     return (out, info) if return_info else out
 
 
-def decode_many(bufs, color: bool, device="cuda", streams: int = 4, sweeps: int = DEFAULT_SWEEPS, orient: bool = True):
-    """``decode`` for a list of files with several decodes in flight: one decode is a chain of ~25 small, latency-bound
-    launches on a hundred waves, so a few of them overlap on the chip almost for free -- and the host work overlaps too: two
-    helper threads parse the marker segments of the next files (numpy's passes over a scan release the GIL) while this thread
-    packs and launches, each file as soon as its plan is there.  At most 2 x ``streams`` calls are open and 4 x ``streams`` files
-    parsed ahead, which bounds the memory held.  Returns the list of device tensors (usable on the current stream).  A file the
-    device path does not take raises ``UnsupportedJpeg`` when its turn comes."""
+def decode_batch(bufs, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, orient: bool = True, plans=None):
+    """``decode`` for a list of files as ONE batched call (``dfsfm_jpeg_decode_batch_u8``: grid.y = file, one set of launches per seven
+    files, one upload, one status read).  Returns the list of device tensors; a file that does not decode raises its error after
+    the others are done (``UnsupportedJpeg`` is raised by ``plan`` before anything is uploaded)."""
+    import torch
+    from . import ops
+    plans = [plan(b) for b in bufs] if plans is None else plans
+    if not plans:
+        return []
+    res = ops.jpeg_decode_batch_launch(plans, 3 if color else 1, torch.device(device), sweeps).finish()
+    for r in res:
+        if isinstance(r, Exception):
+            raise r
+    return [apply_orientation(r, pl.orientation) if orient and pl.orientation != 1 else r for r, pl in zip(res, plans)]
+
+
+def decode_many(bufs, color: bool, device="cuda", streams: int = 2, sweeps: int = DEFAULT_SWEEPS, orient: bool = True, batch: int = 14,
+                workers: int = 2):
+    """``decode`` for a list of files: batches of ``batch`` files (``decode_batch``: one set of launches per seven files) on
+    ``streams`` side streams, while ``workers`` helper threads parse the marker segments of the next files (numpy's passes over a scan
+    release the GIL).  r05 launched every file by itself (~27 launches each, four in flight) and was bound by the launching thread
+    at 0.44 ms per file; a batch costs the launching thread ~15 launches per seven files.  At most ``streams`` batches are open,
+    which bounds the memory held.  Returns the list of device tensors (usable on the current stream).  A file the device path
+    does not take raises ``UnsupportedJpeg`` when its turn comes."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from . import ops
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
-    side = [torch.cuda.Stream(device) for _ in range(max(1, min(streams, len(bufs))))]
+    groups = [list(range(i, min(len(bufs), i + max(1, batch)))) for i in range(0, len(bufs), max(1, batch))]
+    side = [torch.cuda.Stream(device) for _ in range(max(1, min(streams, len(groups))))]
     for s in side:
         s.wait_stream(cur)
-    outs, open_calls, parsing, ahead = [], [], [], 0
+    outs, open_calls = [None] * len(bufs), []
 
     def close_oldest():
-        pl, call = open_calls.pop(0)
-        out, _ = call.finish()
-        out.record_stream(cur)
-        outs.append(apply_orientation(out, pl.orientation) if orient and pl.orientation != 1 else out)
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        for i in range(len(bufs)):
-            while ahead < len(bufs) and len(parsing) < 4 * len(side):
-                parsing.append(pool.submit(plan, bufs[ahead]))
-                ahead += 1
-            pl = parsing.pop(0).result()
-            if len(open_calls) >= 2 * len(side):
+        idx, plans, call = open_calls.pop(0)
+        for i, pl, r in zip(idx, plans, call.finish()):
+            if isinstance(r, Exception):
+                raise r
+            r.record_stream(cur)
+            outs[i] = apply_orientation(r, pl.orientation) if orient and pl.orientation != 1 else r
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+        parsed = [pool.submit(plan, b) for b in bufs]
+        for gi, idx in enumerate(groups):
+            plans = [parsed[i].result() for i in idx]
+            if len(open_calls) >= len(side):
                 close_oldest()
-            with torch.cuda.stream(side[i % len(side)]):
-                open_calls.append((pl, ops.jpeg_decode_launch(pl, 3 if color else 1, device, sweeps)))
+            with torch.cuda.stream(side[gi % len(side)]):
+                open_calls.append((idx, plans, ops.jpeg_decode_batch_launch(plans, 3 if color else 1, device, sweeps)))
     while open_calls:
         close_oldest()
     for s in side:

@@ -839,6 +839,112 @@ def jpeg_decode(pl, out_channels: int, device, sweeps: int = 4, max_calls: int =
     return jpeg_decode_launch(pl, out_channels, device, sweeps, max_calls).finish()
 
 
+class JpegJob(ctypes.Structure):
+    """``dfsfm_jpeg_job`` of include/dfsfm_hip.h."""
+    _fields_ = [("scan", ctypes.c_void_p), ("scan_bytes", ctypes.c_int64), ("frame_host", ctypes.c_void_p),
+                ("huff_tab", ctypes.c_void_p), ("qt", ctypes.c_void_p), ("block_base", ctypes.c_void_p), ("seg_beg", ctypes.c_void_p),
+                ("seg_end", ctypes.c_void_p), ("seg_chunk0", ctypes.c_void_p), ("chunk_seg", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("out_stride", ctypes.c_int64), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class JpegBatchCall:
+    """``dfsfm_jpeg_decode_batch_u8`` in flight for a list of parsed files (``jpeg.Plan``): ONE pinned staging buffer and one H2D copy
+    for all scans and tables, one workspace allocation, one [n, 4] status tensor, one set of launches per seven files.
+    ``finish()`` reads the statuses back once; files whose relaxation has not settled (rare: flat frames beyond the default launches)
+    continue as a smaller batch with ``resume``; returns the list of (uint8 tensor or the exception of that file)."""
+
+    def __init__(self, plans, out_channels, device, sweeps):
+        from . import jpeg as _jpeg
+        self._jpeg, self.plans, self.out_channels, self.device, self.sweeps = _jpeg, list(plans), out_channels, device, sweeps
+        self.stream = torch.cuda.current_stream(device)
+        L = _lib.lib()
+        n = len(self.plans)
+        self.ws_bytes, parts_of, offs_of, o = [], [], [], 0
+        for pl in self.plans:
+            nb = L.dfsfm_jpeg_decode_workspace(ctypes.byref(pl.frame), pl.scan.size, out_channels)
+            if nb == 0:
+                raise _jpeg.UnsupportedJpeg("frame outside the device decoder (dfsfm_jpeg_decode_workspace)")
+            self.ws_bytes.append((nb + 255) // 256 * 256)
+            parts = [pl.scan, pl.tab.view(np.uint8), pl.qt.reshape(-1).view(np.uint8), pl.block_base.view(np.uint8),
+                     pl.seg_beg.view(np.uint8), pl.seg_end.view(np.uint8), pl.seg_chunk0.view(np.uint8), pl.chunk_seg.view(np.uint8)]
+            offs = []
+            for a in parts:
+                offs.append(o)
+                o = (o + a.size + 15) // 16 * 16
+            parts_of.append(parts)
+            offs_of.append(offs)
+        self.host = _jpeg_staging(max(o, 16))
+        hv = self.host.numpy()
+        for parts, offs in zip(parts_of, offs_of):
+            for a, at in zip(parts, offs):
+                hv[at:at + a.size] = a
+        self.devbuf = self.host[:max(o, 16)].to(device, non_blocking=True)
+        self.ws = torch.empty((sum(self.ws_bytes),), dtype=torch.uint8, device=device)
+        self.status = torch.empty((n, 4), dtype=torch.int32, device=device)
+        self.outs = [torch.empty((pl.frame.height, pl.frame.width) if out_channels == 1 else (pl.frame.height, pl.frame.width, 3),
+                                 dtype=torch.uint8, device=device) for pl in self.plans]
+        base, wbase = self.devbuf.data_ptr(), self.ws.data_ptr()
+        self.jobs = (JpegJob * max(n, 1))()
+        w = 0
+        for i, (pl, offs) in enumerate(zip(self.plans, offs_of)):
+            j = self.jobs[i]
+            j.scan, j.scan_bytes, j.frame_host = base + offs[0], pl.scan.size, ctypes.addressof(pl.frame)
+            j.huff_tab, j.qt, j.block_base, j.seg_beg, j.seg_end, j.seg_chunk0, j.chunk_seg = (base + offs[k] for k in range(1, 8))
+            j.out, j.out_stride = self.outs[i].data_ptr(), self.outs[i].stride(0)
+            j.status, j.workspace, j.workspace_bytes = self.status.data_ptr() + 16 * i, wbase + w, self.ws_bytes[i]
+            w += self.ws_bytes[i]
+        self.total = [0] * n
+        self._launch(list(range(n)), resume=False)
+
+    def _launch(self, idx, resume):
+        if not idx:
+            return
+        jobs = (JpegJob * len(idx))(*[self.jobs[i] for i in idx])
+        rc = _lib.lib().dfsfm_jpeg_decode_batch_u8(ctypes.byref(jobs), len(idx), self.out_channels, self.sweeps, int(resume),
+                                                   ctypes.c_void_p(self.stream.cuda_stream))
+        _lib.check(rc, "dfsfm_jpeg_decode_batch_u8")
+        for i in idx:
+            self.total[i] += self.sweeps
+
+    def finish(self):
+        results = [None] * len(self.plans)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            try:
+                pending = list(range(len(self.plans)))
+                while pending:
+                    st = self.status.tolist()
+                    again = []
+                    for i in pending:
+                        bound = int(getattr(self.plans[i], "launch_bound", 0)) or 512
+                        if st[i][0] != 0 and self.total[i] < bound:
+                            again.append(i)
+                        elif st[i][0] != 0:
+                            results[i] = self._jpeg.CorruptJpeg(f"entropy decode did not reach its fixed point in {self.total[i]} sweep launches")
+                        elif st[i][1] or st[i][2]:
+                            results[i] = self._jpeg.CorruptJpeg(f"corrupt scan: {st[i][1]} invalid codes, {st[i][2]} restart intervals with a "
+                                                                "wrong block count")
+                        else:
+                            results[i] = self.outs[i]
+                    if again:
+                        self.sweeps = min(64, 2 * self.sweeps)
+                        self._launch(again, resume=True)
+                    pending = again
+            finally:
+                _jpeg_pool.append(self.host)
+                self.host = None
+        return results
+
+
+def jpeg_decode_batch_launch(plans, out_channels: int, device, sweeps: int = 4) -> JpegBatchCall:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.DfsfmError("HIP ops need device tensors (there is no CPU path)")
+    if out_channels not in (1, 3):
+        raise _lib.DfsfmError("jpeg_decode_batch: out_channels is 1 (luma) or 3 (RGB)")
+    with torch.cuda.device(device):
+        return JpegBatchCall(plans, out_channels, device, sweeps)
+
+
 @_on_device
 def resample_separable(y, By, Bx, out=None):
     """out[m, oy*wout+ox, c] = sum By[oy,qy] Bx[ox,qx] y[m,qy,qx,c];  y [M,hin,win,C] fp32 contiguous (NHWC patches),

@@ -507,6 +507,30 @@ int dfsfm_jpeg_decode_u8(const uint8_t* scan, int64_t scan_bytes, const dfsfm_jp
                          int out_channels, int sweeps, int resume, int32_t* status, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* The same decode for a BATCH of files with one set of launches per 7 files (grid.y = file): a scene's frames
+ * (src/dataset/coarse_matching_dataset.py:41-88 reads them one by one through cv2.imread) cost ~15 launches per seven files
+ * instead of per file.  jobs_host: host array of n_jobs argument sets of dfsfm_jpeg_decode_u8 (device pointers inside; each
+ * job has its own output, status[4] and workspace of dfsfm_jpeg_decode_workspace bytes).  Every job is validated before
+ * anything is launched; results per job are those of dfsfm_jpeg_decode_u8 with the same sweeps / resume. */
+typedef struct dfsfm_jpeg_job {
+    const uint8_t* scan;
+    int64_t scan_bytes;
+    const dfsfm_jpeg_frame* frame_host;
+    const uint32_t* huff_tab;
+    const uint16_t* qt;
+    const uint32_t* block_base;
+    const uint32_t* seg_beg;
+    const uint32_t* seg_end;
+    const int32_t* seg_chunk0;
+    const int32_t* chunk_seg;
+    uint8_t* out;
+    int64_t out_stride;
+    int32_t* status;
+    void* workspace;
+    size_t workspace_bytes;
+} dfsfm_jpeg_job;
+int dfsfm_jpeg_decode_batch_u8(const dfsfm_jpeg_job* jobs_host, int n_jobs, int out_channels, int sweeps, int resume, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

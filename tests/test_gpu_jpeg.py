@@ -149,3 +149,46 @@ def test_flat_and_saturated_frames_on_the_device():
             ref = want if c == color else pil_gray(buf)
             assert np.array_equal(out.cpu().numpy(), ref), (name, c, info)
             assert info["sweeps_used"] <= pl.launch_bound, (name, info, pl.launch_bound)
+
+
+def test_decode_batch_equals_single_decodes():
+    """``dfsfm_jpeg_decode_batch_u8`` (grid.y = file, one set of launches per seven files): a mixed list -- sizes from 1 x 1 to
+    1600 x 1200, grey / 4:4:4 / 4:2:2 / 4:2:0, with and without restart markers, a flat frame that needs extra launches, EXIF
+    orientations, 17 files = two full groups and a ragged one -- gives exactly the bytes of the one-file entry point; a corrupt
+    member raises after the batch, an unsupported one before anything is uploaded."""
+    from PIL import Image
+    bufs = []
+    for i, (h, w) in enumerate([(1, 1), (8, 8), (17, 33), (100, 75), (241, 319), (480, 640), (1200, 1600), (64, 64), (333, 77),
+                                (480, 640), (96, 128), (7, 5), (600, 800), (50, 1000), (1000, 50), (256, 256), (480, 640)]):
+        kw = dict(quality=(35, 60, 85, 95)[i % 4])
+        if i % 5 != 4:
+            kw["subsampling"] = i % 3
+        if i % 4 == 1:
+            kw["restart_marker_rows"] = 1 + i % 3
+        bufs.append(encode(synth(h, w, i % 5 != 4, seed=100 + i), **kw))
+    bufs[7] = encode(np.full((1024, 1536, 3), 77, np.uint8), quality=90, subsampling=2)        # flat: extra sweep launches for one member
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    b = io.BytesIO()
+    Image.fromarray(synth(40, 56)).save(b, "JPEG", quality=90, exif=exif)
+    bufs[3] = b.getvalue()
+    for color in (False, True):
+        outs = jpeg.decode_batch(bufs, color, DEV)
+        assert len(outs) == len(bufs)
+        for buf, out in zip(bufs, outs):
+            one = jpeg.decode(buf, color, DEV)
+            assert out.shape == one.shape and torch.equal(out, one)
+        many = jpeg.decode_many(bufs, color, DEV, streams=2, batch=5)
+        for a, o in zip(many, outs):
+            assert torch.equal(a, o)
+    assert jpeg.decode_batch([], True, DEV) == []
+    good = bufs[5]
+    pl = jpeg.plan(good)
+    start = good.index(pl.scan.tobytes()[:16])
+    cut = good[:start + pl.scan.size // 2] + b"\xff\xd9"
+    with pytest.raises(jpeg.CorruptJpeg):
+        jpeg.decode_batch([bufs[4], cut, bufs[6]], False, DEV)
+    with pytest.raises(jpeg.UnsupportedJpeg):
+        jpeg.decode_batch([bufs[4], encode(synth(40, 56), progressive=True)], False, DEV)
+    # the C ABI refuses bad arguments before anything is launched
+    assert _lib.lib().dfsfm_jpeg_decode_batch_u8(None, 1, 1, 4, 0, None) == -1

@@ -54,12 +54,30 @@ for size in args.sizes.split(","):
 # ---- several decodes in flight: a scene's worth of frames -------------------------------------------------------------------
 h, w = 1200, 1600
 bufs = [encode(synth(h, w, True, seed=100 + i), quality=90, subsampling=2) for i in range(8)] * 4          # 32 files, 8 distinct
-for k in (1, 2, 4, 8):
-    jpeg.decode_many(bufs[:8], False, dev, streams=k)
+bufs = bufs * 2                                                                                            # 64 files
+plans = [jpeg.plan(b) for b in bufs]
+for color in (False, True):
+    jpeg.decode_batch(bufs, color, dev, plans=plans)          # warm: staging buffer, workspace, side streams
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = jpeg.decode_many(bufs, False, dev, streams=k)
+    outs = jpeg.decode_batch(bufs, color, dev, plans=plans)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"decode_many: {len(bufs)} x {h}x{w} gray, {k} stream(s): {1e3 * dt / len(bufs):.3f} ms per frame = {len(bufs) / dt:.0f} frames/s "
-          f"(host parse + launches included; Pillow on one core: {1 / pil_gray_2mp:.0f} frames/s)")
+    scan = sum(p.scan.size for p in plans)
+    px = h * w * len(bufs)
+    coef = sum(int(p.frame.nchunks) for p in plans)       # placeholder for the line below (chunks)
+    print(f"decode_batch (plans given): {len(bufs)} x {h}x{w} {'rgb' if color else 'gray'}: {1e3 * dt / len(bufs):.3f} ms per frame = "
+          f"{len(bufs) / dt:.0f} frames/s from ONE launching thread; {px / dt / 1e9:.2f} GPix/s, scan {scan / dt / 1e9:.2f} GB/s, "
+          f"{coef} chunks")
+t0 = time.perf_counter()
+plans = [jpeg.plan(b) for b in bufs]
+print(f"host parse alone (one thread): {1e3 * (time.perf_counter() - t0) / len(bufs):.3f} ms per file")
+for k, bsz, nw in ((1, 14, 2), (2, 14, 2), (2, 14, 4), (2, 21, 4), (2, 14, 8), (3, 14, 8)):
+    jpeg.decode_many(bufs, False, dev, streams=k, batch=bsz, workers=nw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = jpeg.decode_many(bufs, False, dev, streams=k, batch=bsz, workers=nw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"decode_many: {len(bufs)} x {h}x{w} gray, {k} stream(s) x batches of {bsz}: {1e3 * dt / len(bufs):.3f} ms per frame = {len(bufs) / dt:.0f} frames/s "
+          f"(host parse on {nw} helper threads + launches included; Pillow on one core: {1 / pil_gray_2mp:.0f} frames/s)")

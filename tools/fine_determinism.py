@@ -1,6 +1,7 @@
 """Run-to-run reproducibility of fine_match at BASELINE configs[2] (2000 tracks x 4 views): N runs, tracks whose outputs differ
 from run 0 (any bit of coords / std / best_index), and the timing.  With DFSFM_LIB_PATH = an experiment build
-(temporary build switches of round 4, since removed from csrc/fine_match.hip; -DFINE_1WG remains) this is the root-cause experiment of DESIGN.md section 3 (K11-K12)."""
+(the temporary build switches of round 4 have all left csrc/fine_match.hip) this was the experiment matrix of profiles/r04_fine_match_root_cause.txt;
+the cause was found in r06 by tools/studies/fine_bisect.py, which builds its variants from the assembly (profiles/r06_fine_match_bisect.txt)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
