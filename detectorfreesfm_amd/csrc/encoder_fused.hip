@@ -114,6 +114,10 @@ __device__ __forceinline__ void slab_mma(const char* slab, int lane, f32x16 (&am
 // The same with the ring refill inside: right after the barrier the four DMA requests of the refill (address arithmetic, M0,
 // ~100 issue cycles each with one wave per SIMD) stood in front of the slab's first MFMA; here each one follows a group of MFMAs
 // that is already executing.  sched_barriers pin the places (the compiler hoists the requests to the top otherwise).
+// (r06, measured and not kept: requesting k-step ks + 1's fragments inside k-step ks -- lo fragments behind the group that reads
+// this k-step's lo fragments, hi fragments behind the last group -- to expose one LDS latency per slab instead of one per k-step:
+// enc_apply 1.845 -> 1.867 ms, MLP stage 360 -> 367 us per tile, same box, gpurun_out/r6n: the compiler's counted waits already let a
+// k-step's MFMAs start as its fragments land, and the extra live fragments cost more than the latency they hide.)
 template <int NB, int KPS>
 __device__ __forceinline__ void slab_mma(SlabRing& ring, int lane, f32x16 (&am)[NB], f32x16 (&ax)[NB], f32x16 (&ay)[NB],
                                          const half8* bh, const half8* bl) {
@@ -121,46 +125,23 @@ __device__ __forceinline__ void slab_mma(SlabRing& ring, int lane, f32x16 (&am)[
     const char* slab = ring.acquire_wait();
     const unsigned gn = ring.next + NSTG - 1;
     int piece = 0;
-    // r06: the fragments of k-step ks + 1 are requested INSIDE k-step ks -- the lo fragments as soon as the group that reads this
-    // k-step's lo fragments has been issued (their registers are free), the hi fragments behind the last group -- and k-step
-    // ks + 1 starts with the group whose operands were requested first.  One exposed LDS latency per SLAB instead of one per k-step
-    // (one wave per SIMD: nothing else hides it).  Every accumulator still receives its products in the same order: same bits.
-    half8 wh[NB], wl[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        wh[b] = *reinterpret_cast<const half8*>(slab + (b * 2 + 0) * 1024 + lane * 16);
-        wl[b] = *reinterpret_cast<const half8*>(slab + (b * 2 + 1) * 1024 + lane * 16);
-    }
 #pragma unroll
     for (int ks = 0; ks < KPS; ++ks) {
-        half8 nh[NB], nl[NB];
-        if (ks == 0) {
+        half8 wh[NB], wl[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) am[b] = mfma(wh[b], bh[ks], am[b]);
-        } else {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) ax[b] = mfma(wl[b], bh[ks], ax[b]);
+        for (int b = 0; b < NB; ++b) {
+            wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 0) * 1024 + lane * 16);
+            wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * NB + b) * 2 + 1) * 1024 + lane * 16);
         }
-        if (ks > 0 && ks + 1 < KPS) {              // this k-step's lo fragments have been read
 #pragma unroll
-            for (int b = 0; b < NB; ++b) nl[b] = *reinterpret_cast<const half8*>(slab + (((ks + 1) * NB + b) * 2 + 1) * 1024 + lane * 16);
-        }
+        for (int b = 0; b < NB; ++b) am[b] = mfma(wh[b], bh[ks], am[b]);
         if (KPS == 2 || (ks & 1) == 0) {           // KPS = 2: after both first groups of a k-step; KPS = 4: once per k-step
             __builtin_amdgcn_sched_barrier(0);
             ring.issue_piece(gn, piece++);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ks == 0) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) ax[b] = mfma(wl[b], bh[ks], ax[b]);
-            if (ks + 1 < KPS) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) nl[b] = *reinterpret_cast<const half8*>(slab + (((ks + 1) * NB + b) * 2 + 1) * 1024 + lane * 16);
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) am[b] = mfma(wh[b], bh[ks], am[b]);
-        }
+        for (int b = 0; b < NB; ++b) ax[b] = mfma(wl[b], bh[ks], ax[b]);
         if (KPS == 2 || (ks & 1) == 1) {
             __builtin_amdgcn_sched_barrier(0);
             ring.issue_piece(gn, piece++);
@@ -168,14 +149,6 @@ __device__ __forceinline__ void slab_mma(SlabRing& ring, int lane, f32x16 (&am)[
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) ay[b] = mfma(wh[b], bl[ks], ay[b]);
-        if (ks + 1 < KPS) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                nh[b] = *reinterpret_cast<const half8*>(slab + (((ks + 1) * NB + b) * 2 + 0) * 1024 + lane * 16);
-                wh[b] = nh[b];
-                wl[b] = nl[b];
-            }
-        }
     }
     ring.advance();
 }
