@@ -167,6 +167,20 @@ def kernel_rooflines(dev, batch):
     out.append(_rl("enc_kv_kernel (fused k|v projection + phi(K)^T V per track)", "mfma", rows * 69632.0, ms, f"{rows} token rows",
                    hbm_GBps_of_rows=rows * 512.0 / ms / 1e6))
     del qs, qo, st, lw
+    # K9 front end (r06): conv1_1 -> conv1_2 -> centre window + max-pool of S2DNet in one launch, 10 000 patches of 35 x 35
+    # (2000 tracks x 5 views).  Algorithmic work per patch: 1225 pixels x 2 x (27 x 64 + 576 x 64) flop; 14.7 KB read, 175 KB written.
+    gp = torch.Generator().manual_seed(5)
+    npatch = 2000 * 5
+    px = (torch.randn((npatch, 35, 35, 3), generator=gp) * 1.3).to(dev)
+    fw = ops.S2dFrontWeights((torch.randn((64, 3, 3, 3), generator=gp) * 0.27).to(dev), (torch.randn((64,), generator=gp) * 0.1).to(dev),
+                             (torch.randn((64, 64, 3, 3), generator=gp) * 0.06).to(dev), (torch.randn((64,), generator=gp) * 0.1).to(dev))
+    ms = event_time_ms(lambda: ops.s2d_front(px, fw, 8, 27))
+    fl = npatch * 1225 * 2.0 * (27 * 64 + 576 * 64)
+    out.append(_rl("s2d_front_kernel (S2DNet conv1_1 -> conv1_2 -> centre window + max-pool, one launch)", "mfma", fl, ms,
+                   f"{npatch} patches of 35 x 35", mfma_flops_executed_frac=3.0 * fl / ms / 1e9 / MFMA_F16_PEAK_TF,
+                   hbm_GBps_of_outputs=npatch * (19 * 19 + 18 * 18) * 64 * 4.0 / ms / 1e6,
+                   step_share="~9% of the refinement step (the three launches it replaces: 16%)"))
+    del px, fw
     # K2 + K1 of the COARSE transformer (d_model 256): one cross-layer application on batch x 4800 query tokens =
     # k|v projection (linear_gemm_sf_kernel, N = 512) + attention state (la_kv_partial_staged + enc256_image_kernel) +
     # enc256_apply_kernel.  Algorithmic work per query row: 2 * (256*256 q + 256*32 attention + 256*256 merge + 512*512 mlp.0
@@ -397,7 +411,7 @@ def load_pmc(result):
     """Attach the HBM traffic measured by the committed rocprofv3 --pmc passes (tools/pmc_collect.py writes
     profiles/r02_pmc_traffic.json; traffic cannot be counted from inside this process).  Corrected as the MI355X
     guide prescribes: 2*FETCH_SIZE (16-byte/lane streaming reads) + WRITE_SIZE, per launch."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
                  "r01_pmc_kernels_only_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -414,7 +428,7 @@ def load_pmc(result):
     result["traffic_build_matches"] = bool(pmc.get("library_source_sha256")) and pmc.get("library_source_sha256") == _lib.source_sha256()
     result["traffic_file"] = f"profiles/{name}"
     groups = {"conv_gemm_sf_same_kernel<128,3>": ("conv_gemm_sf_same_kernel<128, 3", "conv_gemm_sf_same_kernel<128,3"),
-              "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",),
+              "enc_apply_kernel": ("enc_apply_kernel",), "enc_kv_kernel": ("enc_kv_kernel",), "s2d_front_kernel": ("s2d_front_kernel",),
               "enc256_apply_kernel": ("enc256_apply_kernel",), "enc256_kv_kernel": ("enc256_kv_kernel", "enc256_image_kernel"),
               "linear_attention": ("la_kv_partial", "la_kv_finalize", "la_apply"), "roi_align": ("roi_align_rgb_kernel", "roi_align_kernel"),
               # the two input forms are two template instances: one roofline entry each (r05 summed both under one key)
