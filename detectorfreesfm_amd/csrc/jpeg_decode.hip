@@ -41,6 +41,9 @@
 #include "jpeg_core.h"
 #include "jpeg_host.h"
 #include <mutex>
+#include <vector>
+#include <algorithm>
+#include <cstring>
 
 namespace {
 
@@ -355,5 +358,66 @@ extern "C" int dfsfm_jpeg_decode_batch_u8(const dfsfm_jpeg_job* jobs_host, int n
         }
     }
     return dfsfm::check_launch("dfsfm_jpeg_decode_batch_u8");
+}
+
+// ---- host side: the index of a scan (r06) -------------------------------------------------------------------------------
+// What jpeg.plan needs to know about the entropy-coded bytes before anything is uploaded: where the scan ends (the first marker that
+// is not RSTn), where the restart markers are, and how many bytes the device's compaction pass keeps in front of every 4096-byte
+// block / restart interval (kept = not a stuffed zero, not the FF of a marker or fill byte, not a restart marker's code).  The
+// numpy formulation of the same rules (jpeg._scan_index_numpy, the specification the tests hold this to) costs 0.33 ms per 0.84-MB
+// file and holds the interpreter lock for part of it; this is one memchr walk over the ~1/256 of the bytes that are 0xFF, outside
+// the lock (ctypes), so that helper threads really parse in parallel.  Plain host code: no device is touched.
+extern "C" int64_t dfsfm_jpeg_scan_index(const uint8_t* scan, int64_t n_avail, uint32_t* block_base, int64_t block_cap, uint32_t* seg_beg,
+                                         uint32_t* seg_end, int64_t seg_cap, int64_t* n_rst_out) {
+    if (!scan || n_avail < 0 || !block_base || !seg_beg || !seg_end || !n_rst_out || block_cap < 0 || seg_cap < 1) return DFSFM_E_BADARG;
+    if (n_avail >= (1ll << 31)) return DFSFM_E_UNSUPPORTED;
+    std::vector<int64_t> drops, rst;
+    int64_t scan_len = n_avail;
+    for (int64_t p = 0; p < n_avail;) {
+        const void* hit = memchr(scan + p, 0xFF, (size_t)(n_avail - p));
+        if (!hit) break;
+        p = static_cast<const uint8_t*>(hit) - scan;
+        const unsigned c = p + 1 < n_avail ? scan[p + 1] : 0xD9u;        // what follows the data is a marker
+        if (c == 0) {
+            drops.push_back(p + 1);                                        // the stuffed zero behind a data FF
+            p += 2;
+        } else if (c == 0xFF) {
+            drops.push_back(p);                                            // a fill byte; the next FF is looked at on its own
+            p += 1;
+        } else if (c >= 0xD0 && c <= 0xD7) {
+            drops.push_back(p);
+            drops.push_back(p + 1);                                        // RSTn: both bytes
+            rst.push_back(p);
+            p += 2;
+        } else {
+            scan_len = p;                                                  // any other marker ends the scan
+            break;
+        }
+    }
+    // an FF in the last byte of the scan is followed by the end marker: dropped as a marker byte, never a restart marker (the
+    // walk above classified it from the byte that follows, which IS that marker's FF or nothing: same result)
+    while (!rst.empty() && rst.back() + 1 >= scan_len) {                   // (cannot happen: an RSTn pair lies inside the scan)
+        rst.pop_back();
+    }
+    *n_rst_out = (int64_t)rst.size();
+    const int64_t nblocks = (scan_len + jd::UNSTUFF_BLOCK - 1) / jd::UNSTUFF_BLOCK;
+    if (nblocks > block_cap || (int64_t)rst.size() + 1 > seg_cap) return scan_len;      // the caller sees the counts and raises
+    size_t k = 0;
+    for (int64_t b = 0; b < nblocks; ++b) {                                // kept bytes in front of block b = start - #drops before it
+        const int64_t x = b * jd::UNSTUFF_BLOCK;
+        while (k < drops.size() && drops[k] < x) ++k;
+        block_base[b] = (uint32_t)(x - (int64_t)k);
+    }
+    auto clean = [&](int64_t x) {                                          // x is increasing over the calls below per array
+        const size_t lo = std::lower_bound(drops.begin(), drops.end(), x) - drops.begin();
+        return (uint32_t)(x - (int64_t)lo);
+    };
+    seg_beg[0] = clean(0);
+    for (size_t i = 0; i < rst.size(); ++i) {
+        seg_end[i] = clean(rst[i]);
+        seg_beg[i + 1] = clean(rst[i] + 2);
+    }
+    seg_end[rst.size()] = clean(scan_len);
+    return scan_len;
 }
 

@@ -284,32 +284,13 @@ def _plan(buf, chunk_bytes: int) -> Plan:
 
     # ---- the scan: up to the first marker that is not RSTn; restart markers cut it into segments -------------------------
     d = data[scan_start:]
-    ff = np.flatnonzero(d == 0xFF)
-    nxt = np.where(ff + 1 < d.size, d[np.minimum(ff + 1, d.size - 1)], 0xD9)        # the byte after each FF (EOI past the end)
-    marker = (nxt != 0) & (nxt != 0xFF)                         # FF 00 is a stuffed data byte, FF FF a fill byte
-    ends = ff[marker & ~((nxt >= 0xD0) & (nxt <= 0xD7))]        # the first marker that is not RSTn ends the scan
-    scan_len = int(ends[0]) if ends.size else d.size
-    inside = ff < scan_len
-    ff, nxt = ff[inside], nxt[inside]
-    nxt = np.where(ff + 1 < scan_len, nxt, 0xD9)                # what follows the scan is a marker
-    is_rst = (nxt >= 0xD0) & (nxt <= 0xD7)
-    rst = ff[is_rst]
+    nseg = -(-nmcu // restart) if restart else 1
+    scan_len, n_rst, block_base, seg_beg, seg_end = SCAN_INDEX(d, nseg)
     if restart:
-        nseg = -(-nmcu // restart)
-        if rst.size != nseg - 1:
-            raise CorruptJpeg(f"{rst.size} restart markers for {nseg} intervals")
-    else:
-        if rst.size:
-            raise CorruptJpeg("restart markers without DRI")
-        nseg = 1
-    # bytes the device's compaction pass drops (csrc/jpeg_core.h unstuff_mask, the same three rules): the stuffed zero after a
-    # data FF, the FF of a marker / fill byte (an FF not followed by 00), the code byte of a restart marker
-    drops = np.sort(np.concatenate([ff[nxt == 0] + 1, ff[nxt != 0], rst + 1]))
-    clean = lambda x: np.asarray(x, dtype=np.int64) - np.searchsorted(drops, x, side="left")
-    nblocks = -(-scan_len // UNSTUFF_BLOCK)
-    block_base = clean(np.arange(nblocks, dtype=np.int64) * UNSTUFF_BLOCK).astype(np.uint32)
-    seg_beg = clean(np.concatenate([[0], rst + 2])).astype(np.uint32)
-    seg_end = clean(np.concatenate([rst, [scan_len]])).astype(np.uint32)
+        if n_rst != nseg - 1:
+            raise CorruptJpeg(f"{n_rst} restart markers for {nseg} intervals")
+    elif n_rst:
+        raise CorruptJpeg("restart markers without DRI")
     if np.any(seg_end <= seg_beg):
         raise CorruptJpeg("empty restart interval")
     per = -(-(seg_end - seg_beg).astype(np.int64) // chunk_bytes)
@@ -331,6 +312,52 @@ def flat_launch_bound(seg_chunk0, per) -> int:
     first = np.asarray(seg_chunk0, dtype=np.int64)
     last = first + np.asarray(per, dtype=np.int64) - 1
     return int((last // SWEEP_WG - first // SWEEP_WG).max()) + 2
+
+
+def _scan_index_numpy(d: np.ndarray, nseg_expected: int):
+    """The index of an entropy-coded scan, as array passes -- the SPECIFICATION of ``dfsfm_jpeg_scan_index`` (tests hold the library
+    function to it; nothing on the product path calls it): (scan_len, restart markers found, block_base, seg_beg, seg_end)."""
+    ff = np.flatnonzero(d == 0xFF)
+    nxt = np.where(ff + 1 < d.size, d[np.minimum(ff + 1, max(d.size - 1, 0))], 0xD9) if d.size else ff   # the byte after each FF (EOI past the end)
+    marker = (nxt != 0) & (nxt != 0xFF)                         # FF 00 is a stuffed data byte, FF FF a fill byte
+    ends = ff[marker & ~((nxt >= 0xD0) & (nxt <= 0xD7))]        # the first marker that is not RSTn ends the scan
+    scan_len = int(ends[0]) if ends.size else d.size
+    inside = ff < scan_len
+    ff, nxt = ff[inside], nxt[inside]
+    nxt = np.where(ff + 1 < scan_len, nxt, 0xD9)                # what follows the scan is a marker
+    rst = ff[(nxt >= 0xD0) & (nxt <= 0xD7)]
+    # bytes the device's compaction pass drops (csrc/jpeg_core.h unstuff_mask, the same three rules): the stuffed zero after a
+    # data FF, the FF of a marker / fill byte (an FF not followed by 00), the code byte of a restart marker
+    drops = np.sort(np.concatenate([ff[nxt == 0] + 1, ff[nxt != 0], rst + 1]))
+    clean = lambda x: np.asarray(x, dtype=np.int64) - np.searchsorted(drops, x, side="left")
+    nblocks = -(-scan_len // UNSTUFF_BLOCK)
+    block_base = clean(np.arange(nblocks, dtype=np.int64) * UNSTUFF_BLOCK).astype(np.uint32)
+    seg_beg = clean(np.concatenate([[0], rst + 2])).astype(np.uint32)
+    seg_end = clean(np.concatenate([rst, [scan_len]])).astype(np.uint32)
+    return scan_len, int(rst.size), block_base, seg_beg, seg_end
+
+
+def _scan_index_lib(d: np.ndarray, nseg_expected: int):
+    """The same through ``dfsfm_jpeg_scan_index`` (host code of the library, csrc/jpeg_decode.hip): one memchr walk outside the
+    interpreter lock instead of ten array passes inside it."""
+    from . import _lib
+    d = np.ascontiguousarray(d)
+    nblk = -(-d.size // UNSTUFF_BLOCK)
+    block_base = np.empty(max(nblk, 1), dtype=np.uint32)
+    seg_beg = np.empty(max(nseg_expected, 1), dtype=np.uint32)
+    seg_end = np.empty(max(nseg_expected, 1), dtype=np.uint32)
+    n_rst = ctypes.c_int64(0)
+    scan_len = _lib.lib().dfsfm_jpeg_scan_index(d.ctypes.data, d.size, block_base.ctypes.data, block_base.size, seg_beg.ctypes.data,
+                                                seg_end.ctypes.data, seg_beg.size, ctypes.byref(n_rst))
+    if scan_len < 0:
+        raise CorruptJpeg(f"dfsfm_jpeg_scan_index -> {scan_len}")
+    n = int(n_rst.value)
+    if n + 1 > seg_beg.size:             # more restart markers than intervals: the caller reports the counts
+        return int(scan_len), n, block_base[:0], seg_beg[:0], seg_end[:0]
+    return int(scan_len), n, block_base[:-(-int(scan_len) // UNSTUFF_BLOCK)], seg_beg[:n + 1], seg_end[:n + 1]
+
+
+SCAN_INDEX = _scan_index_lib             # tests swap in _scan_index_numpy to hold the two to each other
 
 
 def is_jpeg(buf) -> bool:

@@ -531,6 +531,15 @@ typedef struct dfsfm_jpeg_job {
 } dfsfm_jpeg_job;
 int dfsfm_jpeg_decode_batch_u8(const dfsfm_jpeg_job* jobs_host, int n_jobs, int out_channels, int sweeps, int resume, void* stream);
 
+/* HOST function (no device is touched): the index of an entropy-coded scan that the decode calls above take as arguments --
+ * what libjpeg's jdmarker.c / jdhuff.c learn byte by byte while cv2.imread decodes.  scan = the bytes behind the SOS header,
+ * n_avail of them.  Returns scan_len = offset of the first marker that is not RSTn (n_avail if there is none) or a negative
+ * DFSFM_E_*; *n_rst = restart markers inside the scan; block_base[ceil(scan_len / 4096)] = entropy bytes in front of each
+ * 4096-byte block of the scan (stuffed zeros, marker / fill FFs and restart codes not counted); seg_beg / seg_end [n_rst + 1] =
+ * byte range of each restart interval in that compacted numbering.  If an array is too small only the counts are returned. */
+int64_t dfsfm_jpeg_scan_index(const uint8_t* scan, int64_t n_avail, uint32_t* block_base, int64_t block_cap, uint32_t* seg_beg,
+                              uint32_t* seg_end, int64_t seg_cap, int64_t* n_rst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,3 +343,45 @@ def test_auto_decode_falls_back_to_the_host_like_the_reference(tmp_path):
     with pytest.raises(jpeg.UnsupportedJpeg, match="16-bit"):
         jpeg.plan(b16)
     assert np.array_equal(pil_gray(b16), pil_gray(good))            # the same image for libjpeg
+
+
+def test_native_scan_index_equals_the_array_specification():
+    """``dfsfm_jpeg_scan_index`` (host code of the product library: one memchr walk) against ``jpeg._scan_index_numpy`` (the rules as
+    array passes) on encoder output of every layout -- restart markers, stuffed FFs, optimised tables -- and on adversarial byte
+    strings: fill bytes (FF FF ...), an FF as the last byte, RST pairs back to back, an RST right before the end marker, no end
+    marker at all, empty input; and whole plans built either way are identical."""
+    import ctypes
+    rng = np.random.default_rng(7)
+    strings = [bytes(), b"\xff", b"\xff\xff", b"\x01\xff", b"\xff\x00", b"\xff\xd9", b"ab\xff\x00cd\xff\xd0\xff\xd1ef\xff\xff\xff\xd9zz",
+               b"\xff\xd0" * 5 + b"\xff\xd9", b"x" * 5000 + b"\xff\x00" * 3000 + b"\xff\xd3" + b"y" * 9000 + b"\xff\xff\xd9", b"q" * 4096,
+               b"q" * 4095 + b"\xff", b"q" * 4095 + b"\xff\x00" + b"r" * 10, b"\xff\xd7\xff\xd9", b"abc\xff\xc4zzz"]
+    for _ in range(40):                                                   # random soups rich in FF / 00 / D0..D9
+        n = int(rng.integers(1, 20000))
+        a = rng.choice(np.array([0xFF, 0x00, 0xD0, 0xD5, 0xD9, 0x12, 0x80, 0xFF, 0x00], dtype=np.uint8), size=n,
+                       p=[0.2, 0.2, 0.05, 0.05, 0.002, 0.2, 0.198, 0.05, 0.05])
+        strings.append(a.tobytes())
+    for sbytes in strings:
+        d = np.frombuffer(sbytes, dtype=np.uint8)
+        want = jpeg._scan_index_numpy(d, 1)
+        nseg = want[1] + 1
+        got = jpeg._scan_index_lib(d, nseg)
+        assert got[0] == want[0] and got[1] == want[1], (sbytes[:40], got[:2], want[:2])
+        for g, w in zip(got[2:], want[2:]):
+            assert np.array_equal(g, w), (sbytes[:40], g[:8], w[:8])
+        short = jpeg._scan_index_lib(d, max(1, nseg - 1))                # too few intervals expected: the counts still come back
+        assert short[0] == want[0] and short[1] == want[1]
+    n = 0
+    for key, buf in cases([(17, 33), (100, 75), (241, 319)], qualities=(5, 92), restarts=(0, 1, 5)):
+        try:
+            jpeg.SCAN_INDEX = jpeg._scan_index_numpy
+            a = jpeg.plan(buf)
+        finally:
+            jpeg.SCAN_INDEX = jpeg._scan_index_lib
+        b = jpeg.plan(buf)
+        for f in ("scan", "block_base", "seg_beg", "seg_end", "seg_chunk0", "chunk_seg"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (key, f)
+        assert a.launch_bound == b.launch_bound and bytes(a.frame) == bytes(b.frame)
+        n += 1
+    assert n > 20
+    from detectorfreesfm_amd import _lib
+    assert _lib.lib().dfsfm_jpeg_scan_index(None, 0, None, 0, None, None, 1, None) == -1
