@@ -46,15 +46,16 @@ constexpr int NBLK = EC / 32;            // 32-channel blocks
 constexpr int NKS = EC / 16;             // k-steps over d_model
 constexpr int STG = 16384;               // per-wave staging tile: 32 tokens x 128 channels, hi + lo planes
 constexpr int SMEM_BYTES = RING + 4 * STG;
-constexpr int KV_MASK_MAX = 4096;         // mask entries of a sequence kept in LDS by enc_kv_kernel
-constexpr int SMEM_KV = SMEM_BYTES + KV_MASK_MAX;
+constexpr int KV_W_BYTES = 8 * SLAB;       // enc_kv_kernel: the whole k|v weight stream, resident (128 KB)
+constexpr int KV_RED = 16384;             // cross-wave partial sums of one head pair
+constexpr int KV_KSP = 4096;              // Ksum partials [wave][pair][lane]
+constexpr int SMEM_KV = KV_W_BYTES + KV_RED + KV_KSP;
 constexpr int SMEM_APPLY = SMEM_BYTES + 4 * EC * 4 + 4 * 1024;   // + the LayerNorms' gamma / beta (2 KB) + Ksum of a tile's two sequences per wave
 // This file keeps the SLP vectoriser (packed-fp32 VALU instructions) that csrc/Makefile bans from kernels whose MFMA waves can share a
 // SIMD: its kernels must therefore never be co-resident on a CU.  Registers already cap them at one wave per SIMD; the LDS footprint
 // must as well, whatever a future register diet does.
 static_assert(SMEM_APPLY > 80 * 1024 && SMEM_KV > 80 * 1024, "one workgroup per CU is a correctness premise here (packed fp32 beside MFMAs)");
 constexpr int NSLAB_APPLY = 32;          // q 4, merge 4, 4 x (mlp.0 chunk 4 + mlp.2 chunk 2)
-constexpr int NSLAB_KV = 8;              // 4 head pairs x 2
 constexpr int KVIMG = 16 * 1024 + 512;   // bytes per sequence: 16 KV^T fragments + Ksum[128]
 
 __device__ __forceinline__ f32x16 mfma(const half8 a, const half8 b, const f32x16 c) {
@@ -549,176 +550,224 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
 }
 
 // =====================================================================================================================
-// enc_kv_kernel: one workgroup per sequence; wave w takes token blocks w, w+4, ... of the sequence.
+// enc_kv_kernel: persistent, one workgroup per CU walks the sequences; wave w takes token blocks w, w+4, ... of a sequence.
 // Classic orientation: D[token][channel] = x[token][k] W[channel][k]: lane = channel, registers = 16 tokens, so that
 // KV[d][d'] = sum_tokens phi(k)[token][d] v[token][d'] is an MFMA whose A and B fragments are the k / v accumulators.
-// Weight stream: 8 slabs; slab 2 p + u = rows [k channels of head pair p | v channels of head pair p] (2 blocks) x k-steps 4u..4u+3.
+// Weights: 8 slabs; slab 2 p + u = rows [k channels of head pair p | v channels of head pair p] (2 blocks) x k-steps 4u..4u+3.
+// r06: the 128 KB of k|v weight fragments are RESIDENT in LDS for the whole launch (loaded once per workgroup) and the x
+// fragments of a token block go global -> registers (lane = token, 16 bytes per k-step and plane), requested one block ahead.
+// Before, the slabs cycled through the 4-deep ring of enc_common.h -- per token block eight barriers that kept the four waves in
+// lock step, 32 LDS-DMA requests per wave, and a vmcnt(0) on the block's own x rows staged through LDS with nothing to overlap:
+// a token block took ~28 K cycles for 6.9 K cycles of MFMA issue.  The arithmetic, the block -> wave assignment and the order of
+// the cross-wave sums are unchanged: the apply image is bit-identical to the ring version's.
 // =====================================================================================================================
 struct KvArgs {
     const _Float16 *xh, *xl;     // source rows as split planes
     int64_t ldx;
     unsigned xbytes;
-    const char* wstream;         // NSLAB_KV slabs
+    const char* wstream;         // 8 slabs
     const uint8_t* kvmask;       // [N][km_per_seq] or null
     int kv_group, km_per_seq;
     char* kvimg;                 // [N][KVIMG] out
     int S, N;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KV_AHEAD = 2, KV_NBUF = 4;       // k-steps a fragment pair is requested ahead; register ring (divides the 64-step stream)
+static_assert(64 % KV_NBUF == 0 && KV_NBUF > KV_AHEAD && 2 * KV_AHEAD <= 15, "");
+// LDS byte offset of the hi fragment of k-step q = 16 p + 8 b + k of a token block (p head pair, b 0 = k channels / 1 = v channels):
+// slab 2 p + (k >> 2), fragment ((k & 3) * 2 + b) * 2; the lo fragment follows 1 KB later
+constexpr int kv_frag_off(int q) { return (2 * (q >> 4) + ((q & 7) >> 2)) * SLAB + ((((q & 7) & 3) * 2 + ((q >> 3) & 1)) * 2) * 1024; }
+// one k-step's fragment pair, requested by hand (ds_read's offset field is 16 bits: two base registers 64 KB apart)
+#define KV_READ(Q)                                                                                                                      \
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                                       \
+                 : "=&v"(wfh[(Q) % KV_NBUF]), "=&v"(wfl[(Q) % KV_NBUF])                                                                  \
+                 : "v"(kv_frag_off((Q) % 64) < 65536 ? wb0 : wb1), "n"(kv_frag_off((Q) % 64) & 65535), "n"((kv_frag_off((Q) % 64) & 65535) + 1024))
+#define KV_WAIT(N, Q) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wfh[(Q) % KV_NBUF]), "+v"(wfl[(Q) % KV_NBUF]) : "n"(N))
+
+// end of block b of head pair p: k block -> phi(k) with the token mask (+ Ksum); v block -> v / S with the mask, then the pair's KV update
+template <int P, int B>
+__device__ __forceinline__ void kv_block_end(const f32x16& dm, const f32x16& dx, const f32x16& dy, const float (&tm)[16], float inv_S,
+                                             float (&kf)[16], float (&vf)[16], float& ksum, f32x16& kvm, f32x16& kvx) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = dm[r] + (dx[r] + dy[r]) * (1.f / 2048.f);
+        if (B == 0) {
+            kf[r] = phi_fast(v) * tm[r];
+            ksum += kf[r];
+        } else {
+            vf[r] = (v * tm[r]) * inv_S;
+        }
+    }
+    if (B == 1) {
+        half8 kh0, kl0, kh1, kl1, vh0, vl0, vh1, vl1;
+        to_frags(kf, kh0, kl0, kh1, kl1);
+        to_frags(vf, vh0, vl0, vh1, vl1);
+        // KV[d][d'] += sum over the 16 + 16 tokens: A = phi(k) (lane = d), B = v (lane = d'); same token order on both
+        kvm = mfma(kh0, vh0, kvm);
+        kvx = mfma(kl0, vh0, kvx);
+        kvm = mfma(kh1, vh1, kvm);
+        kvx = mfma(kh0, vl0, kvx);
+        kvx = mfma(kl1, vh1, kvx);
+        kvx = mfma(kh1, vl1, kvx);
+    }
+}
+
 __global__ __launch_bounds__(256) void enc_kv_kernel(KvArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
-    char* stg = smem + RING + wave * STG;
-    const int n = blockIdx.x;
+    float* red = reinterpret_cast<float*>(smem + KV_W_BYTES);                 // [wave][r][lane]: one head pair's partial sums
+    float* ksp = reinterpret_cast<float*>(smem + KV_W_BYTES + KV_RED);        // [wave][p][lane]
+    const unsigned wb0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u, wb1 = wb0 + 65536u;
 
-    SlabRing ring;
-    ring.ring = smem;
-    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.wstream, 0, NSLAB_KV * SLAB, 0x00020000);
-    ring.lane_off = (unsigned)(wave * 4096 + lane * 16);
-    ring.wave = wave;
-    ring.nslab = NSLAB_KV;
-    ring.prologue();
-
+    {   // the weight fragments, once: 32 rounds of 4 KB (a wave moves 1 KB per request)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)g.wstream, 0, KV_W_BYTES, 0x00020000);
+#pragma unroll 4
+        for (int i = 0; i < KV_W_BYTES / 4096; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(smem + i * 4096 + wave * 1024), 16,
+                                                     (unsigned)(i * 4096 + wave * 1024 + lane * 16), 0, 0, 0);
+    }
     const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)g.xh, 0, g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)g.xl, 0, g.xbytes, 0x00020000);
-    const float Sf = (float)g.S;
+    // v / S as one multiplication by 1 / S (as encoder256.hip since r05: the IEEE division was ten VALU instructions per element of an
+    // epilogue that runs beside nothing; the quotient differs by at most one rounding, inside the 2^-22 of the split it feeds)
+    const float inv_S = 1.f / (float)g.S;
     const int nblocks = (g.S + 31) / 32;
-    const int niter = (nblocks + 3) / 4;            // every wave runs the same number of rounds (shared weight stream)
-    // the sequence's mask entries once into LDS: as byte loads inside the block loop each of a lane's 16 entries was its own
-    // global load + s_waitcnt vmcnt(0) -- sixteen serial L2 round trips per block, each also draining the x block's DMA
-    uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + SMEM_BYTES);
-    const bool lds_mask = g.kvmask && g.km_per_seq <= KV_MASK_MAX;
-    if (lds_mask) {
-        for (int i = tid; i < g.km_per_seq; i += 256) s_mask[i] = g.kvmask[(int64_t)n * g.km_per_seq + i];
-        __syncthreads();
-    }
+    const __amdgpu_buffer_rsrc_t rmk = __builtin_amdgcn_make_buffer_rsrc((void*)g.kvmask, 0, g.kvmask ? (unsigned)g.N * (unsigned)g.km_per_seq : 0u, 0x00020000);
 
-    f32x16 kvm[NBLK], kvx[NBLK];                    // KV of head pair p: rows = k channel, cols = v channel (lane)
-    float ksum[NBLK];
+    // A fragments of x for token block blk of sequence n: lane = token, natural k order (16 bytes = channels 16 s + 8 half ..);
+    // tokens past the sequence read zeros (out-of-range buffer offset), and so does "no next block"
+    auto block_off = [&](int n, int blk) __attribute__((always_inline)) -> unsigned {
+        const int s = blk * 32 + col;
+        return (n < g.N && s < g.S) ? (unsigned)((((int64_t)n * g.S + s) * g.ldx + 8 * half) * 2) : g.xbytes;
+    };
+    // validity of token blk * 32 + (lane & 31) of sequence n: one byte load per lane and block, requested with the block's x rows (as byte
+    // loads inside the block loop each of a lane's 16 entries was its own global load + wait); a ballot turns it into the block's bit mask
+    auto block_mask = [&](int n, int blk) __attribute__((always_inline)) -> int {
+        const int s = blk * 32 + col;
+        if (!(n < g.N && s < g.S)) return 0;
+        return g.kvmask ? (int)__builtin_amdgcn_raw_buffer_load_b8(rmk, (unsigned)n * (unsigned)g.km_per_seq + (unsigned)(s / g.kv_group), 0, 0) : 1;
+    };
+    // (every sequence has the same number of blocks: a wave without one never reads its x registers)
+    u32x4 xrh[NKS], xrl[NKS];
+    int mk = block_mask(blockIdx.x, wave);
+    {
+        const unsigned off = block_off(blockIdx.x, wave);
 #pragma unroll
-    for (int p = 0; p < NBLK; ++p) {
-        kvm[p] = kvx[p] = f32x16{0};
-        ksum[p] = 0.f;
+        for (int k = 0; k < NKS; ++k) {
+            xrh[k] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, k * 32, 0);
+            xrl[k] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, k * 32, 0);
+        }
     }
+    wait_vmcnt<2 * NKS>();                          // the weights were requested first and loads complete in order
+    __syncthreads();
 
-    for (int it = 0; it < niter; ++it) {
-        const int blk = it * 4 + wave;
-        const int s0 = blk * 32;                    // first token of this wave's block (may be past the sequence: all masked)
-        {
-            const int trow = lane >> 4, pp = lane & 15;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t = 4 * i + trow;
-                const int s = s0 + t;
-                const unsigned off = s < g.S ? (unsigned)((((int64_t)n * g.S + s) * g.ldx + ((pp ^ (t & 15)) << 3)) * 2) : g.xbytes;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_void*)(stg + i * 1024), 16, off, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_void*)(stg + 8192 + i * 1024), 16, off, 0, 0, 0);
-            }
-        }
-        // mask of the 16 tokens this lane's accumulator registers hold: token s0 + dch(r, half)
-        float tm[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s = s0 + dch(r, half);
-            float m = s < g.S ? 1.f : 0.f;
-            if (lds_mask) { if (s < g.S) m = (float)s_mask[s / g.kv_group]; }
-            else if (g.kvmask && s < g.S) m = (float)g.kvmask[(int64_t)n * g.km_per_seq + s / g.kv_group];
-            tm[r] = m;
-        }
-        wait_vmcnt<0>();
-        // A fragments of x: lane = token, natural k order (16 bytes = channels 16 s + 8 half ..)
-        half8 xh[NKS], xl[NKS];
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            xh[s] = *reinterpret_cast<const half8*>(stg + stg_off(col, 2 * s + half));
-            xl[s] = *reinterpret_cast<const half8*>(stg + 8192 + stg_off(col, 2 * s + half));
-        }
+    for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
+        f32x16 kvm[NBLK], kvx[NBLK];                // KV of head pair p: rows = k channel, cols = v channel (lane)
+        float ksum[NBLK];
 #pragma unroll
         for (int p = 0; p < NBLK; ++p) {
-            f32x16 dm[2], dx[2], dy[2];             // block 0 = k channels of head pair p, block 1 = v channels
+            kvm[p] = kvx[p] = f32x16{0};
+            ksum[p] = 0.f;
+        }
+
+        // (the first KV_AHEAD k-steps of a wave's first block of the sequence; later blocks find theirs requested by the block before)
+        u32x4 wfh[KV_NBUF], wfl[KV_NBUF];
+        if (wave < nblocks) {
+            KV_READ(0);
+            KV_READ(1);
+        }
+        for (int blk = wave; blk < nblocks; blk += 4) {
+            // this wave's next block -- of this sequence, or its first one of the workgroup's next sequence: requested k-step by
+            // k-step inside the LAST head pair, each into the registers whose fragment has just been used for the last time
+            const bool more = blk + 4 < nblocks;
+            const int nn = more ? n : n + (int)gridDim.x, nb = more ? blk + 4 : wave;
+            const unsigned noff = block_off(nn, nb);
+            // mask of the 16 tokens this lane's accumulator registers hold: token s0 + dch(r, half) (0 / 1 factors)
+            const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(mk != 0) >> (4 * half);
+            mk = block_mask(nn, nb);
+            float tm[16];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) dm[b] = dx[b] = dy[b] = f32x16{0};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const char* slab = ring.acquire();
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    half8 wh[2], wl[2];
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        wh[b] = *reinterpret_cast<const half8*>(slab + ((ks * 2 + b) * 2 + 0) * 1024 + lane * 16);
-                        wl[b] = *reinterpret_cast<const half8*>(slab + ((ks * 2 + b) * 2 + 1) * 1024 + lane * 16);
-                    }
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) dm[b] = mfma(xh[4 * u + ks], wh[b], dm[b]);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) dx[b] = mfma(xh[4 * u + ks], wl[b], dx[b]);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) dy[b] = mfma(xl[4 * u + ks], wh[b], dy[b]);
-                }
-            }
+            for (int r = 0; r < 16; ++r) tm[r] = (float)((bits >> dch(r, 0)) & 1u);
+            // The block's 64 k-steps as ONE stream q = 16 p + 8 b + k: head pair p, block b (0 = its k channels, 1 = its v channels; one
+            // after the other on one accumulator triple -- both at once held 96 accumulator registers and left the epilogue of one
+            // nothing to run beside), k-step k.  Its weight fragments are read KV_AHEAD k-steps ahead by hand: left to the compiler every
+            // k-step was "two ds_read_b128, s_waitcnt lgkmcnt(0), three MFMAs" -- one exposed LDS latency per 96 cycles of MFMA issue.
+            // (An inline-asm read is invisible to the compiler's own wait counting: every one is retired by a KV_WAIT that carries its
+            // registers before they are used or die.)
             float kf[16], vf[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                kf[r] = phi_fast(dm[0][r] + (dx[0][r] + dy[0][r]) * (1.f / 2048.f)) * tm[r];
-                vf[r] = ((dm[1][r] + (dx[1][r] + dy[1][r]) * (1.f / 2048.f)) * tm[r]) / Sf;
-                ksum[p] += kf[r];
+            f32x16 dm, dx, dy;
+            const bool again = blk + 4 < nblocks;      // this wave has another block of this sequence: keep the fragment stream running
+#define KV_STEP(Q)                                                                                                                      \
+            {                                                                                                                           \
+                constexpr int pq = (Q) >> 4, bq = ((Q) >> 3) & 1, kq = (Q) & 7;                                                         \
+                if ((Q) + KV_AHEAD < 64) {                                                                                              \
+                    KV_READ((Q) + KV_AHEAD);                                                                                            \
+                    KV_WAIT(2 * KV_AHEAD, Q);                                                                                           \
+                } else if (again) {                                                                                                     \
+                    KV_READ((Q) + KV_AHEAD);                                                                                            \
+                    KV_WAIT(2 * KV_AHEAD, Q);                                                                                           \
+                } else {                                                                                                                \
+                    KV_WAIT(2 * (63 - (Q)), Q);                                                                                         \
+                }                                                                                                                       \
+                const half8 wh = __builtin_bit_cast(half8, wfh[(Q) % KV_NBUF]), wl = __builtin_bit_cast(half8, wfl[(Q) % KV_NBUF]);     \
+                const half8 xh = __builtin_bit_cast(half8, xrh[kq]), xl = __builtin_bit_cast(half8, xrl[kq]);                           \
+                if (kq == 0) dm = dx = dy = f32x16{0};                                                                                  \
+                dm = mfma(xh, wh, dm);                                                                                                  \
+                dx = mfma(xh, wl, dx);                                                                                                  \
+                dy = mfma(xl, wh, dy);                                                                                                  \
+                if (pq == NBLK - 1 && bq == 1) {   /* last use of this x fragment: the next block's into the same registers */          \
+                    xrh[kq] = __builtin_amdgcn_raw_buffer_load_b128(rxh, noff, kq * 32, 0);                                             \
+                    xrl[kq] = __builtin_amdgcn_raw_buffer_load_b128(rxl, noff, kq * 32, 0);                                             \
+                }                                                                                                                       \
+                if (kq == 7) kv_block_end<pq, bq>(dm, dx, dy, tm, inv_S, kf, vf, ksum[pq], kvm[pq], kvx[pq]);                           \
             }
-            half8 kh0, kl0, kh1, kl1, vh0, vl0, vh1, vl1;
-            to_frags(kf, kh0, kl0, kh1, kl1);
-            to_frags(vf, vh0, vl0, vh1, vl1);
-            // KV[d][d'] += sum over the 16 + 16 tokens: A = phi(k) (lane = d), B = v (lane = d'); same token order on both
-            kvm[p] = mfma(kh0, vh0, kvm[p]);
-            kvx[p] = mfma(kl0, vh0, kvx[p]);
-            kvm[p] = mfma(kh1, vh1, kvm[p]);
-            kvx[p] = mfma(kh0, vl0, kvx[p]);
-            kvx[p] = mfma(kl1, vh1, kvx[p]);
-            kvx[p] = mfma(kh1, vl1, kvx[p]);
+#define KV_STEP8(Q) KV_STEP(Q) KV_STEP((Q) + 1) KV_STEP((Q) + 2) KV_STEP((Q) + 3) KV_STEP((Q) + 4) KV_STEP((Q) + 5) KV_STEP((Q) + 6) KV_STEP((Q) + 7)
+            KV_STEP8(0) KV_STEP8(8) KV_STEP8(16) KV_STEP8(24) KV_STEP8(32) KV_STEP8(40) KV_STEP8(48) KV_STEP8(56)
+#undef KV_STEP8
+#undef KV_STEP
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    wait_vmcnt<0>();
-    __syncthreads();                                // ring and staging are free: reuse them for the cross-wave sums
-    // every wave parks its partial KV (fp32) in its staging tile: [p][r][lane], and its Ksum in the ring area
-    float* part = reinterpret_cast<float*>(stg);
-    float* ksp = reinterpret_cast<float*>(smem);    // [wave][p][lane]
+        // cross-wave sums, one head pair at a time through 16 KB: every wave parks its partial KV of pair p, wave p adds the four
+        // in a fixed order (deterministic, independent of the batch) and writes the pair's part of the apply image
 #pragma unroll
-    for (int p = 0; p < NBLK; ++p) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[(p * 16 + r) * 64 + lane] = kvm[p][r] + kvx[p][r] * (1.f / 2048.f);
-        ksp[(wave * NBLK + p) * 64 + lane] = ksum[p];
-    }
-    __syncthreads();
-    // wave w finishes head pair w: fixed summation order over the waves (deterministic)
-    {
-        const int p = wave;
-        float kv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) a += reinterpret_cast<const float*>(smem + RING + w * STG)[(p * 16 + r) * 64 + lane];
-            kv[r] = a;
-        }
-        float ks = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) ks += ksp[(w * NBLK + p) * 64 + lane];
-        ks = add_xor32(ks);                         // the two lane halves hold the two token halves of every block
+        for (int p = 0; p < NBLK; ++p) ksp[(wave * NBLK + p) * 64 + lane] = ksum[p];
         char* img = g.kvimg + (int64_t)n * KVIMG;
-        // apply image: fragment (b = p, t) of KV^T for enc_apply_kernel = this lane's registers 8t..8t+7, rows of the other
-        // head zeroed (block-diagonal): lane = v channel d' (row of KV^T), slot j = k channel 16 t + dch(j, half)
-        half8 h0, l0, h1, l1;
-        to_frags(kv, h0, l0, h1, l1);
-        if ((col >> 4) == 0) {                      // rows of head 2p: fragment t = 0; the other lanes' slots stay unwritten
-            *reinterpret_cast<half8*>(img + ((p * 2 + 0) * 2 + 0) * 1024 + lane * 16) = h0;      // (the consumer never loads them)
-            *reinterpret_cast<half8*>(img + ((p * 2 + 0) * 2 + 1) * 1024 + lane * 16) = l0;
-        } else {                                    // rows of head 2p + 1: fragment t = 1
-            *reinterpret_cast<half8*>(img + ((p * 2 + 1) * 2 + 0) * 1024 + lane * 16) = h1;
-            *reinterpret_cast<half8*>(img + ((p * 2 + 1) * 2 + 1) * 1024 + lane * 16) = l1;
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = kvm[p][r] + kvx[p][r] * (1.f / 2048.f);
+            __syncthreads();
+            if (wave == p) {
+                float kv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) a += red[(w * 16 + r) * 64 + lane];
+                    kv[r] = a;
+                }
+                float ks = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ks += ksp[(w * NBLK + p) * 64 + lane];
+                ks = add_xor32(ks);                     // the two lane halves hold the two token halves of every block
+                // apply image: fragment (b = p, t) of KV^T for enc_apply_kernel = this lane's registers 8t..8t+7, rows of the
+                // other head zeroed (block-diagonal): lane = v channel d' (row of KV^T), slot j = k channel 16 t + dch(j, half)
+                half8 h0, l0, h1, l1;
+                to_frags(kv, h0, l0, h1, l1);
+                if ((col >> 4) == 0) {                  // rows of head 2p: fragment t = 0; the other lanes' slots stay unwritten
+                    *reinterpret_cast<half8*>(img + ((p * 2 + 0) * 2 + 0) * 1024 + lane * 16) = h0;  // (the consumer never loads them)
+                    *reinterpret_cast<half8*>(img + ((p * 2 + 0) * 2 + 1) * 1024 + lane * 16) = l0;
+                } else {                                // rows of head 2p + 1: fragment t = 1
+                    *reinterpret_cast<half8*>(img + ((p * 2 + 1) * 2 + 0) * 1024 + lane * 16) = h1;
+                    *reinterpret_cast<half8*>(img + ((p * 2 + 1) * 2 + 1) * 1024 + lane * 16) = l1;
+                }
+                if (half == 0) reinterpret_cast<float*>(img + 16384)[32 * p + col] = ks;
+            }
+            __syncthreads();
         }
-        if (half == 0) reinterpret_cast<float*>(img + 16384)[32 * p + col] = ks;
     }
 }
 
@@ -749,8 +798,12 @@ extern "C" int dfsfm_encoder_kv_f32(const void* src_hi, const void* src_lo, int6
     g.kvimg = static_cast<char*>(kv_image);
     g.S = S;
     g.N = N;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = N < cus ? N : cus;              // persistent: the weights are loaded into LDS once per workgroup
     attr_kv.ensure(reinterpret_cast<const void*>(&enc_kv_kernel), SMEM_KV);
-    hipLaunchKernelGGL(enc_kv_kernel, dim3((unsigned)N), dim3(256), SMEM_KV, static_cast<hipStream_t>(stream_), g);
+    hipLaunchKernelGGL(enc_kv_kernel, dim3((unsigned)grid), dim3(256), SMEM_KV, static_cast<hipStream_t>(stream_), g);
     return dfsfm::check_launch("dfsfm_encoder_kv_f32");
 }
 
