@@ -559,7 +559,15 @@ __global__ __launch_bounds__(256) void enc_apply_kernel(ApplyArgs g) {
 // Before, the slabs cycled through the 4-deep ring of enc_common.h -- per token block eight barriers that kept the four waves in
 // lock step, 32 LDS-DMA requests per wave, and a vmcnt(0) on the block's own x rows staged through LDS with nothing to overlap:
 // a token block took ~28 K cycles for 6.9 K cycles of MFMA issue.  The arithmetic, the block -> wave assignment and the order of
-// the cross-wave sums are unchanged: the apply image is bit-identical to the ring version's.
+// the cross-wave sums are unchanged (the image is bit-identical to the ring version's up to the 1 / S below).
+// Measured on the same boxes and not kept (gpurun_out/r6q - r6w): (a) sched_group_barrier patterns "1 MFMA : 8 / 11 VALU" over the
+// stream, +2 - 4 %; (b) the projection MFMAs in place by inline asm on two accumulators (main; both cross products), v unmasked, 1 / S
+// on the finished sums: 1274 instead of 2302 VALU instructions per token block (900 of the 2302 are v_accvgpr moves of accumulators the
+// allocator chains through copies) and NOT faster, 0.57 vs 0.55 ms -- and a trap on the way: an asm MFMA whose operand the compiler
+// has just produced with a VALU instruction (v_accvgpr_read) needs two wait states the hazard recogniser cannot see (NaNs until every
+// asm MFMA carried an s_nop 1); (c) fragment reads three k-steps ahead, equal; (d) diagnostic: x rows always re-read from a cache-hot
+// address, -6 %: the block loop does not wait for its x rows.  s_memtime: a token block takes 16.3 K cycles (6.9 K of MFMA issue), the
+// cross-wave reduction 6.6 K per sequence; wave 0's eighth block of a 900-token sequence (4 valid tokens) is 10 % of the launch.
 // =====================================================================================================================
 struct KvArgs {
     const _Float16 *xh, *xl;     // source rows as split planes
