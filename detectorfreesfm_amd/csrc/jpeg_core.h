@@ -18,7 +18,7 @@
 
 namespace jd {
 
-constexpr int MAX_BLK = 6;                 // blocks per MCU (4:2:0: Y Y Y Y Cb Cr)
+constexpr int MAX_BLK = 6;                 // blocks per MCU (4:2:0: Y Y Y Y Cb Cr; 4:1:1 the same count, 4:4:0 four)
 constexpr int SCAN_T = 1024;               // threads of the single-workgroup scans
 constexpr int DC_GROUP = 4;                // MCUs per thread of the DC prediction passes
 constexpr uint64_t NO_STATE = ~0ull;
@@ -554,6 +554,15 @@ JD_FN int chroma_at(const Params& P, int comp, int x, int y) {
     const int pw = P.plane_w[comp], rw = P.real_w[comp], rh = P.real_h[comp];
     const int hr = P.hmax / P.comp_h[comp], vr = P.vmax / P.comp_v[comp];
     if (hr == 1 && vr == 1) return pl[(int64_t)y * pw + x];
+    // jinit_upsampler: 4:1:1 goes through int_upsample (replication); the 2h fancy filters only for components more than two samples
+    // wide, else h2v1_upsample / h2v2_upsample (replication)
+    if (hr == 4) return pl[(int64_t)y * pw + (x >> 2)];
+    if (hr == 2 && rw <= 2) return pl[(int64_t)(vr == 2 ? y >> 1 : y) * pw + (x >> 1)];
+    if (hr == 1) {                                          // h1v2_fancy_upsample (4:4:0): 3/4 nearer row + 1/4 further, bias 1 / 2
+        const int cy = y >> 1;
+        const int fy = clampi((y & 1) ? cy + 1 : cy - 1, 0, rh - 1);
+        return (3 * pl[(int64_t)cy * pw + x] + pl[(int64_t)fy * pw + x] + ((y & 1) ? 2 : 1)) >> 2;
+    }
     const int cx = x >> 1;
     if (vr == 1) {                                          // h2v1_fancy_upsample: 3/4 nearer + 1/4 further, edges replicated
         const uint8_t* row = pl + (int64_t)y * pw;

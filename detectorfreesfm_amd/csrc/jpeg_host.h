@@ -25,7 +25,9 @@ inline bool derive(const dfsfm_jpeg_frame& f, Params& P) {
     } else {
         for (int c = 0; c < 3; ++c) { P.comp_h[c] = f.h[c]; P.comp_v[c] = f.v[c]; }
         if (f.h[1] != 1 || f.v[1] != 1 || f.h[2] != 1 || f.v[2] != 1) return false;
-        if (!((f.h[0] == 1 && f.v[0] == 1) || (f.h[0] == 2 && f.v[0] == 1) || (f.h[0] == 2 && f.v[0] == 2))) return false;
+        if (!((f.h[0] == 1 && f.v[0] == 1) || (f.h[0] == 2 && f.v[0] == 1) || (f.h[0] == 2 && f.v[0] == 2) ||
+              (f.h[0] == 1 && f.v[0] == 2) || (f.h[0] == 4 && f.v[0] == 1)))       // 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1
+            return false;
         hmax = f.h[0];
         vmax = f.v[0];
     }

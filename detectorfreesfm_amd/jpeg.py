@@ -7,10 +7,11 @@ header, restart positions: ``plan``), the entropy decode, the inverse DCT, the c
 run on the GPU.  EXIF orientation is applied as cv2.imread does (index bookkeeping on the decoded bytes).
 
 What the device path takes: baseline / extended-sequential Huffman files (SOF0, SOF1), 8 bit, one interleaved scan, grey or
-YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling, with or without restart markers -- what cameras and ``cv2.imwrite`` / Pillow write
-by default, and all eight frames of the reference's example scene.  Everything else (progressive, arithmetic, 12 bit, CMYK / RGB
-colour spaces, 4:4:0 / 4:1:1, multi-scan) raises ``UnsupportedJpeg``; ``images._decode`` then falls back to the host decoder the
-reference itself uses.
+YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling -- what cameras and ``cv2.imwrite`` / Pillow write by default, and all eight frames of
+the reference's example scene -- and (r06) 4:4:0 / 4:1:1 (what a lossless 90-degree rotation of a 4:2:2 file and DV-derived
+material carry; libjpeg-turbo's h1v2 fancy filter / plain replication), with or without restart markers.  Everything else
+(progressive, arithmetic, 12 bit, CMYK / RGB colour spaces, other sampling ratios, multi-scan) raises ``UnsupportedJpeg``;
+``images._decode`` then falls back to the host decoder the reference itself uses.
 """
 import ctypes
 from dataclasses import dataclass, field
@@ -275,7 +276,7 @@ def _plan(buf, chunk_bytes: int) -> Plan:
             ycc = False
         if not ycc:
             raise UnsupportedJpeg("RGB-coded JPEG")
-        if sampling[1] != (1, 1) or sampling[2] != (1, 1) or sampling[0] not in ((1, 1), (2, 1), (2, 2)):
+        if sampling[1] != (1, 1) or sampling[2] != (1, 1) or sampling[0] not in ((1, 1), (2, 1), (2, 2), (1, 2), (4, 1)):
             raise UnsupportedJpeg(f"sampling {sampling}")
     hmax, vmax = fr.h[0], fr.v[0]
     mcux = -(-fr.width // (8 * hmax))

@@ -178,10 +178,21 @@ static void idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-/* one chroma sample at full resolution (jdsample.c): fancy h2v1 / h2v2, plain copy for h1v1 */
+/* one chroma sample at full resolution (jdsample.c): fancy h2v1 / h2v2 / h1v2, replication for h4v1, plain copy for h1v1 */
 static int upsampled(const Comp* c, int hmax, int vmax, int x, int y) {
     const int hr = hmax / c->h, vr = vmax / c->v;
     if (hr == 1 && vr == 1) return c->plane[y * c->pw + x];
+    /* jinit_upsampler: 4:1:1 (and every other integral ratio without a special case) goes through int_upsample = replication;
+       the 2h fancy filters are only chosen when the component is more than two samples wide, else h2v1_upsample / h2v2_upsample
+       (replication again) */
+    if (hr == 4 && vr == 1) return c->plane[y * c->pw + (x >> 2)];
+    if (hr == 2 && c->rw <= 2) return c->plane[(vr == 2 ? y >> 1 : y) * c->pw + (x >> 1)];
+    if (hr == 1 && vr == 2) {
+        /* h1v2_fancy_upsample (4:4:0): 3/4 nearer row + 1/4 further row, bias 1 for the upper output row, 2 for the lower */
+        const int cy = y >> 1;
+        const int fy = clampi((y & 1) ? cy + 1 : cy - 1, 0, c->rh - 1);
+        return (3 * c->plane[cy * c->pw + x] + c->plane[fy * c->pw + x] + ((y & 1) ? 2 : 1)) >> 2;
+    }
     if (hr == 2 && vr == 1) {
         const int cx = x >> 1;
         const uint8_t* row = c->plane + y * c->pw;
@@ -327,7 +338,8 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
     if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }      /* a single-component scan is never interleaved */
     else {
         if (comp[1].h != 1 || comp[1].v != 1 || comp[2].h != 1 || comp[2].v != 1) return E_UNSUPPORTED;
-        if (!((comp[0].h == 1 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 2)))
+        if (!((comp[0].h == 1 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 2) ||
+              (comp[0].h == 1 && comp[0].v == 2) || (comp[0].h == 4 && comp[0].v == 1)))     /* 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1 */
             return E_UNSUPPORTED;
     }
     const int mw = 8 * hmax, mh = 8 * vmax;

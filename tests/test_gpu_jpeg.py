@@ -10,7 +10,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from test_jpeg_cpu import cases, encode, pil_gray, pil_rgb, synth   # noqa: E402
+from test_jpeg_cpu import cases, cases_440_411, encode, pil_gray, pil_rgb, synth   # noqa: E402
 from detectorfreesfm_amd import _lib, images, jpeg                   # noqa: E402
 from oracle import restate_jpeg as rj                                # noqa: E402
 
@@ -29,6 +29,25 @@ def test_device_decode_matches_oracle_and_libjpeg_turbo():
             assert np.array_equal(out.cpu().numpy(), ref), (key, color, info)
         n += 1
     assert n > 200
+
+
+def test_440_and_411_sampling_on_the_device():
+    """4:4:0 (h1v2 fancy upsampling) and 4:1:1 (replication) files from the tests' encoder, narrow frames included: the device's bytes
+    are libjpeg-turbo's; a camera-sized 4:4:0 frame settles within the default sweep budget."""
+    n = 0
+    for key, buf in cases_440_411():
+        for color in (False, True):
+            ref = pil_rgb(buf) if color else pil_gray(buf)
+            out, info = jpeg.decode(buf, color, DEV, chunk_bytes=32 if n % 2 else 128, return_info=True)
+            assert np.array_equal(out.cpu().numpy(), ref), (key, color, info)
+        n += 1
+    assert n == 48
+    import jpeg_testenc
+    for luma in ((1, 2), (4, 1)):
+        buf = jpeg_testenc.encode(synth(480, 640, True, seed=11), luma, quality=88, restart=0)
+        out, info = jpeg.decode(buf, True, DEV, return_info=True)
+        assert np.array_equal(out.cpu().numpy(), pil_rgb(buf)) and info["calls"] <= 2, (luma, info)
+        assert np.array_equal(jpeg.decode_batch([buf, buf], True, DEV)[1].cpu().numpy(), pil_rgb(buf))
 
 
 def test_camera_sized_frames_and_sweep_counts():

@@ -14,6 +14,7 @@ from PIL import Image
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import jpeg_emul                                                     # noqa: E402
+import jpeg_testenc                                                  # noqa: E402
 from cpu_standins import cpu_ops                                     # noqa: E402
 from detectorfreesfm_amd import images, jpeg                         # noqa: E402
 from oracle import restate_jpeg as rj                                # noqa: E402
@@ -101,6 +102,42 @@ def test_lane_model_matches_oracle_on_every_supported_layout():
             assert np.array_equal(out, ref), (key, color, info)
         n += 1
     assert n > 200
+
+
+def cases_440_411(sizes=((40, 56), (17, 33), (3, 3), (4, 2), (100, 75), (241, 319)), lumas=((1, 2), (4, 1))):
+    """Files Pillow's encoder cannot write (4:4:0 = Y 1x2, 4:1:1 = Y 4x1) from the tests' own encoder (tests/jpeg_testenc.py;
+    lumas (2, 1) / (2, 2) check that encoder against the Pillow-encoded cases)."""
+    k = 0
+    for luma in lumas:
+        for (h, w) in sizes:
+            for rst in (0, 3):
+                for q in (30, 92):
+                    k += 1
+                    yield (luma, h, w, rst, q), jpeg_testenc.encode(synth(h, w, True, seed=k), luma, quality=q, restart=rst)
+
+
+def test_440_and_411_sampling_oracle_pinned_and_lane_model():
+    """cv2.imread takes 4:4:0 and 4:1:1 files (src/dataset/utils.py:86-92,127,183); r06: so does the device path.  libjpeg-turbo's
+    jinit_upsampler picks h1v2_fancy_upsample for 4:4:0, int_upsample (replication) for 4:1:1, and the NON-fancy 2h routines when a
+    chroma plane is at most two samples wide (frames up to four pixels wide): oracle == libjpeg-turbo, lane model == oracle."""
+    n = 0
+    for key, buf in cases_440_411(lumas=((1, 2), (4, 1), (2, 1), (2, 2))):
+        g, c = rj.decode(buf, False), rj.decode(buf, True)
+        assert np.array_equal(g, pil_gray(buf)) and np.array_equal(c, pil_rgb(buf)), key
+        pl = jpeg.plan(buf, 64 if n % 2 else 16)
+        assert pl.sampling[0] == key[0]
+        for color in (False, True):
+            out, info = jpeg_emul.decode(pl, color, sweeps=3, order=n % 3)
+            assert info["status"][:3].tolist() == [0, 0, 0], (key, info)
+            assert np.array_equal(out, c if color else g), (key, color)
+        n += 1
+    assert n == 96
+    for sub in (1, 2):                                   # the narrow-frame rule on Pillow-written files as well
+        for (h, w) in ((3, 3), (5, 4), (2, 2), (9, 1)):
+            buf = encode(synth(h, w, True, seed=h * w), quality=90, subsampling=sub)
+            assert np.array_equal(rj.decode(buf, True), pil_rgb(buf)), (sub, h, w)
+            out, info = jpeg_emul.decode(jpeg.plan(buf, 16), True, sweeps=3, order=1)
+            assert np.array_equal(out, rj.decode(buf, True)), (sub, h, w)
 
 
 def test_thread_order_does_not_change_the_fixed_point():
