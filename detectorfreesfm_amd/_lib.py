@@ -99,6 +99,7 @@ SIGNATURES = [
      [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
       c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("dfsfm_jpeg_decode_batch_u8", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("dfsfm_jpeg_ycc_planes_to_rgb_u8", c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     ("dfsfm_jpeg_scan_index", c_int64, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     ("dfsfm_resample_separable_f32", c_int,
      [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -360,6 +360,20 @@ extern "C" int dfsfm_jpeg_decode_batch_u8(const dfsfm_jpeg_job* jobs_host, int n
     return dfsfm::check_launch("dfsfm_jpeg_decode_batch_u8");
 }
 
+// ---- the colour stage alone (r06): multi-scan sequential files ---------------------------------------------------------------
+// A sequential file may carry each component in a scan of its own (T.81 A.2.2; one block per MCU over the component's own block
+// grid).  jpeg.plan_components turns such a file into three grey frames of the components' real samples, each decoded by
+// dfsfm_jpeg_decode_u8; this is what is left: libjpeg-turbo's upsampling (jdsample.c) + ycc_rgb_convert (jdcolor.c) per output pixel.
+extern "C" int dfsfm_jpeg_ycc_planes_to_rgb_u8(const uint8_t* y, int64_t y_stride, const uint8_t* cb, const uint8_t* cr, int64_t c_stride,
+                                               int width, int height, int h0, int v0, uint8_t* out, int64_t out_stride, void* stream_) {
+    if (!y || !cb || !cr || !out || out_stride < 3 * (int64_t)width) return DFSFM_E_BADARG;
+    jd::Params P;
+    if (!jd::planes_params(P, y, y_stride, cb, cr, c_stride, width, height, h0, v0, out, out_stride)) return DFSFM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(jd_color_kernel, dim3((unsigned)((P.width + 63) / 64), (unsigned)((P.height + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), P);
+    return dfsfm::check_launch("dfsfm_jpeg_ycc_planes_to_rgb_u8");
+}
+
 // ---- host side: the index of a scan (r06) -------------------------------------------------------------------------------
 // What jpeg.plan needs to know about the entropy-coded bytes before anything is uploaded: where the scan ends (the first marker that
 // is not RSTn), where the restart markers are, and how many bytes the device's compaction pass keeps in front of every 4096-byte

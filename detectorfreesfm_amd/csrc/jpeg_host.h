@@ -67,6 +67,37 @@ inline bool derive(const dfsfm_jpeg_frame& f, Params& P) {
     return true;
 }
 
+// the colour stage alone, on three component planes that calls of their own decoded (multi-scan sequential files): the fields
+// color_thread / chroma_at read.  false = a sampling the decoder does not take
+inline bool planes_params(Params& P, const uint8_t* y, int64_t y_stride, const uint8_t* cb, const uint8_t* cr, int64_t c_stride, int width,
+                          int height, int h0, int v0, uint8_t* out, int64_t out_stride) {
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535) return false;
+    if (!((h0 == 1 && v0 == 1) || (h0 == 2 && v0 == 1) || (h0 == 2 && v0 == 2) || (h0 == 1 && v0 == 2) || (h0 == 4 && v0 == 1))) return false;
+    if (y_stride < width || c_stride < (width + h0 - 1) / h0 || y_stride > 0x7fffffff || c_stride > 0x7fffffff) return false;
+    P = Params{};
+    P.ncomp = 3;
+    P.width = width;
+    P.height = height;
+    P.hmax = h0;
+    P.vmax = v0;
+    P.comp_h[0] = h0; P.comp_v[0] = v0;
+    P.comp_h[1] = P.comp_h[2] = P.comp_v[1] = P.comp_v[2] = 1;
+    P.plane[0] = const_cast<uint8_t*>(y);
+    P.plane[1] = const_cast<uint8_t*>(cb);
+    P.plane[2] = const_cast<uint8_t*>(cr);
+    P.plane_w[0] = (int32_t)y_stride;
+    P.plane_w[1] = P.plane_w[2] = (int32_t)c_stride;
+    for (int c = 0; c < 3; ++c) {
+        P.real_w[c] = (width * P.comp_h[c] + h0 - 1) / h0;
+        P.real_h[c] = (height * P.comp_v[c] + v0 - 1) / v0;
+        P.plane_h[c] = P.real_h[c];
+    }
+    P.out_channels = 3;
+    P.out = out;
+    P.out_stride = out_stride;
+    return true;
+}
+
 inline Layout layout_of(const Params& P, int64_t scan_bytes, int out_channels) {
     Layout L;
     size_t o = 0;

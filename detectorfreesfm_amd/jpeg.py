@@ -6,11 +6,12 @@ returns the same bytes from ``dfsfm_jpeg_decode_u8`` (csrc/jpeg_decode.hip): the
 header, restart positions: ``plan``), the entropy decode, the inverse DCT, the chroma upsampling and the colour conversion
 run on the GPU.  EXIF orientation is applied as cv2.imread does (index bookkeeping on the decoded bytes).
 
-What the device path takes: baseline / extended-sequential Huffman files (SOF0, SOF1), 8 bit, one interleaved scan, grey or
-YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling -- what cameras and ``cv2.imwrite`` / Pillow write by default, and all eight frames of
+What the device path takes: baseline / extended-sequential Huffman files (SOF0, SOF1), 8 bit, one interleaved scan (or, r06, one
+scan per component: ``plan_components``), grey or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling -- what cameras and ``cv2.imwrite`` / Pillow write by default, and all eight frames of
 the reference's example scene -- and (r06) 4:4:0 / 4:1:1 (what a lossless 90-degree rotation of a 4:2:2 file and DV-derived
 material carry; libjpeg-turbo's h1v2 fancy filter / plain replication), with or without restart markers.  Everything else
-(progressive, arithmetic, 12 bit, CMYK / RGB colour spaces, other sampling ratios, multi-scan) raises ``UnsupportedJpeg``;
+(progressive, arithmetic, 12 bit, CMYK / RGB colour spaces, other sampling ratios, partly interleaved multi-scan files) raises
+``UnsupportedJpeg``;
 ``images._decode`` then falls back to the host decoder the reference itself uses.
 """
 import ctypes
@@ -145,6 +146,10 @@ def _exif_orientation(seg: bytes) -> int:
     return 1
 
 
+class MultiScanJpeg(UnsupportedJpeg):
+    """A sequential file whose components come in separate scans: not one ``Plan`` -- ``plan_components`` takes it."""
+
+
 def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
     """Parse the marker segments of a JPEG file (bytes / uint8 array) and cut its scan into decoder chunks.  Raises
     ``UnsupportedJpeg`` / ``CorruptJpeg`` only: a damaged header never surfaces as an IndexError."""
@@ -154,22 +159,43 @@ def plan(buf, chunk_bytes: int = CHUNK_BYTES) -> Plan:
         raise CorruptJpeg(f"damaged marker segment ({type(e).__name__}: {e})") from None
 
 
-def _plan(buf, chunk_bytes: int) -> Plan:
+@dataclass
+class ComponentPlans:
+    """A multi-scan sequential file (T.81 A.2.2: each component in a scan of its own, one block per MCU): one grey-frame ``Plan`` per
+    component, ``plans[c].width x .height`` = the component's real samples, + what the colour stage needs."""
+    width: int
+    height: int
+    sampling: List[Tuple[int, int]]
+    orientation: int
+    plans: List[Plan]
+
+
+def plan_components(buf, chunk_bytes: int = CHUNK_BYTES) -> ComponentPlans:
+    try:
+        return _plan_components(buf, chunk_bytes)
+    except (IndexError, ValueError, OverflowError) as e:
+        raise CorruptJpeg(f"damaged marker segment ({type(e).__name__}: {e})") from None
+
+
+class _Header:
+    """What the marker segments in front of a scan have said so far."""
+
+    def __init__(self):
+        self.qts, self.huff = {}, {}             # id -> natural-order steps; (class, id) -> (bits, vals)
+        self.sof, self.restart, self.orientation, self.jfif, self.adobe = None, 0, 1, False, None
+
+
+def _as_bytes(buf):
     data = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray, memoryview)) else np.ascontiguousarray(buf, dtype=np.uint8)
     b = data.tobytes() if not isinstance(buf, bytes) else buf
-    n = len(b)
-    if n < 4 or b[0] != 0xFF or b[1] != 0xD8:
+    if len(b) < 4 or b[0] != 0xFF or b[1] != 0xD8:
         raise CorruptJpeg("no SOI marker")
-    qts = {}
-    huff = {}                        # (class, id) -> (bits, vals)
-    sof = None
-    restart = 0
-    orientation = 1
-    jfif = False
-    adobe = None
-    p = 2
-    scan_start = None
-    sos = None
+    return data, b
+
+
+def _walk(b, p, st):
+    """Marker segments from offset p up to and including the next SOS header: (SOS payload, offset of the entropy-coded data)."""
+    n = len(b)
     while p + 4 <= n:
         if b[p] != 0xFF:
             raise CorruptJpeg("marker expected")
@@ -201,7 +227,7 @@ def _plan(buf, chunk_bytes: int) -> Plan:
                     raise CorruptJpeg("bad DQT")
                 nat = np.zeros(64, dtype=np.uint16)
                 nat[ZIGZAG] = q
-                qts[tq] = nat
+                st.qts[tq] = nat
         elif m == 0xC4:
             i = 0
             while i < len(seg):
@@ -211,79 +237,63 @@ def _plan(buf, chunk_bytes: int) -> Plan:
                 vals = seg[i + 17:i + 17 + cnt]
                 if len(bits) != 16 or len(vals) != cnt or tc > 1 or th > 3:
                     raise CorruptJpeg("bad DHT")
-                huff[(tc, th)] = (bytes(bits), bytes(vals))
+                st.huff[(tc, th)] = (bytes(bits), bytes(vals))
                 i += 17 + cnt
         elif m in (0xC0, 0xC1, 0xC2):
             if seg[0] != 8:
                 raise UnsupportedJpeg(f"{seg[0]}-bit samples")
-            sof = dict(progressive=m == 0xC2, height=(seg[1] << 8) | seg[2], width=(seg[3] << 8) | seg[4], ncomp=seg[5],
-                       comps=[(seg[6 + 3 * c], seg[7 + 3 * c] >> 4, seg[7 + 3 * c] & 15, seg[8 + 3 * c]) for c in range(seg[5])])
+            st.sof = dict(progressive=m == 0xC2, height=(seg[1] << 8) | seg[2], width=(seg[3] << 8) | seg[4], ncomp=seg[5],
+                          comps=[(seg[6 + 3 * c], seg[7 + 3 * c] >> 4, seg[7 + 3 * c] & 15, seg[8 + 3 * c]) for c in range(seg[5])])
         elif 0xC3 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
             raise UnsupportedJpeg("lossless / differential / arithmetic-coded JPEG")
         elif m == 0xDD:
-            restart = (seg[0] << 8) | seg[1]
+            st.restart = (seg[0] << 8) | seg[1]
         elif m == 0xE0 and seg[:5] == b"JFIF\0":
-            jfif = True
+            st.jfif = True
         elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
-            adobe = seg[11]
+            st.adobe = seg[11]
         elif m == 0xE1 and seg[:6] == b"Exif\0\0":
-            orientation = _exif_orientation(seg)
+            st.orientation = _exif_orientation(seg)
         elif m == 0xDA:
-            sos = seg
-            scan_start = p + ln
-            break
+            return seg, p + ln
         p += ln
-    if sof is None or sos is None:
+    raise CorruptJpeg("no frame / scan header")
+
+
+def _check_frame(st, sos):
+    sof = st.sof
+    if sof is None:
         raise CorruptJpeg("no frame / scan header")
     if sof["progressive"]:
         raise UnsupportedJpeg("progressive JPEG")
     ncomp = sof["ncomp"]
     if ncomp not in (1, 3):
         raise UnsupportedJpeg(f"{ncomp} components")
-    if sos[0] != ncomp:
-        raise UnsupportedJpeg("multi-scan sequential JPEG")
     if sof["width"] == 0 or sof["height"] == 0:
         raise UnsupportedJpeg("frame size given by a DNL marker")
     if sof["width"] * sof["height"] > (1 << 28):
         raise UnsupportedJpeg("frame larger than 2^28 pixels")
-    fr = Frame()
-    fr.width, fr.height, fr.ncomp = sof["width"], sof["height"], ncomp
-    qt = np.ones((3, 64), dtype=np.uint16)
-    tables = []                      # distinct (class, id) in slot order
-    sampling = []
-    for c in range(ncomp):
-        cid, h, v, tq = sof["comps"][c]
-        if sos[1 + 2 * c] != cid:
-            raise UnsupportedJpeg("scan components out of frame order")
-        td, ta = sos[2 + 2 * c] >> 4, sos[2 + 2 * c] & 15
-        if tq not in qts or (0, td) not in huff or (1, ta) not in huff:
-            raise CorruptJpeg("missing table")
-        qt[c] = qts[tq]
-        for key in ((0, td), (1, ta)):
-            if key not in tables:
-                tables.append(key)
-        fr.dc_slot[c], fr.ac_slot[c] = tables.index((0, td)), tables.index((1, ta))
-        fr.h[c], fr.v[c] = (1, 1) if ncomp == 1 else (h, v)
-        sampling.append((h, v))
-    if len(tables) > 4:
-        raise UnsupportedJpeg("more than four Huffman tables in one scan")
+    sampling = [(h, v) for (_, h, v, _) in sof["comps"]]
     if ncomp == 3:
         ids = [c[0] for c in sof["comps"]]
         ycc = True                   # jdapimin.c default_decompress_parms
-        if not jfif and adobe == 0:
+        if not st.jfif and st.adobe == 0:
             ycc = False
-        if not jfif and adobe is None and ids == [ord("R"), ord("G"), ord("B")]:
+        if not st.jfif and st.adobe is None and ids == [ord("R"), ord("G"), ord("B")]:
             ycc = False
         if not ycc:
             raise UnsupportedJpeg("RGB-coded JPEG")
         if sampling[1] != (1, 1) or sampling[2] != (1, 1) or sampling[0] not in ((1, 1), (2, 1), (2, 2), (1, 2), (4, 1)):
             raise UnsupportedJpeg(f"sampling {sampling}")
-    hmax, vmax = fr.h[0], fr.v[0]
-    mcux = -(-fr.width // (8 * hmax))
-    mcuy = -(-fr.height // (8 * vmax))
-    nmcu = mcux * mcuy
+    if sos[1 + 2 * sos[0]] != 0 or sos[2 + 2 * sos[0]] != 63:
+        raise UnsupportedJpeg("spectral selection in a sequential frame")
+    return sampling
 
-    # ---- the scan: up to the first marker that is not RSTn; restart markers cut it into segments -------------------------
+
+def _scan_plan(st, data, scan_start, fr, qt, tables, nmcu, chunk_bytes, sampling) -> Plan:
+    """The scan that starts at scan_start, as decoder chunks: up to the first marker that is not RSTn; restart markers cut it into
+    segments."""
+    restart = st.restart
     d = data[scan_start:]
     nseg = -(-nmcu // restart) if restart else 1
     scan_len, n_rst, block_base, seg_beg, seg_end = SCAN_INDEX(d, nseg)
@@ -298,12 +308,80 @@ def _plan(buf, chunk_bytes: int) -> Plan:
     seg_chunk0 = np.concatenate([[0], np.cumsum(per)[:-1]]).astype(np.int32)
     chunk_seg = np.repeat(np.arange(nseg, dtype=np.int32), per)
     fr.restart, fr.nseg, fr.nchunks, fr.chunk_bytes = restart, nseg, int(chunk_seg.size), chunk_bytes
-    key = b"".join(huff[t][0] + huff[t][1] for t in tables)
+    key = b"".join(st.huff[t][0] + st.huff[t][1] for t in tables)
     padded = np.zeros((scan_len + 31) // 16 * 16, dtype=np.uint8)    # the compaction pass loads aligned 16-byte pieces
     padded[:scan_len] = d[:scan_len]
     return Plan(frame=fr, scan=padded[:scan_len], tab_key=key, tab=_tab_block(key), qt=qt, block_base=block_base, seg_beg=seg_beg,
-                seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=orientation, sampling=sampling,
+                seg_end=seg_end, seg_chunk0=seg_chunk0, chunk_seg=chunk_seg, orientation=st.orientation, sampling=sampling,
                 launch_bound=flat_launch_bound(seg_chunk0, per))
+
+
+def _plan(buf, chunk_bytes: int) -> Plan:
+    data, b = _as_bytes(buf)
+    st = _Header()
+    sos, scan_start = _walk(b, 2, st)
+    sampling = _check_frame(st, sos)
+    sof = st.sof
+    ncomp = sof["ncomp"]
+    if sos[0] != ncomp:
+        if sos[0] == 1 and ncomp == 3:
+            raise MultiScanJpeg("multi-scan sequential JPEG (one component per scan): plan_components")
+        raise UnsupportedJpeg("multi-scan sequential JPEG with partly interleaved scans")
+    fr = Frame()
+    fr.width, fr.height, fr.ncomp = sof["width"], sof["height"], ncomp
+    qt = np.ones((3, 64), dtype=np.uint16)
+    tables = []                      # distinct (class, id) in slot order
+    for c in range(ncomp):
+        cid, h, v, tq = sof["comps"][c]
+        if sos[1 + 2 * c] != cid:
+            raise UnsupportedJpeg("scan components out of frame order")
+        td, ta = sos[2 + 2 * c] >> 4, sos[2 + 2 * c] & 15
+        if tq not in st.qts or (0, td) not in st.huff or (1, ta) not in st.huff:
+            raise CorruptJpeg("missing table")
+        qt[c] = st.qts[tq]
+        for key in ((0, td), (1, ta)):
+            if key not in tables:
+                tables.append(key)
+        fr.dc_slot[c], fr.ac_slot[c] = tables.index((0, td)), tables.index((1, ta))
+        fr.h[c], fr.v[c] = (1, 1) if ncomp == 1 else (h, v)
+    if len(tables) > 4:
+        raise UnsupportedJpeg("more than four Huffman tables in one scan")
+    hmax, vmax = fr.h[0], fr.v[0]
+    nmcu = (-(-fr.width // (8 * hmax))) * (-(-fr.height // (8 * vmax)))
+    return _scan_plan(st, data, scan_start, fr, qt, tables, nmcu, chunk_bytes, sampling)
+
+
+def _plan_components(buf, chunk_bytes: int) -> ComponentPlans:
+    data, b = _as_bytes(buf)
+    st = _Header()
+    p, plans, sampling = 2, [None, None, None], None
+    while any(pl is None for pl in plans):
+        sos, scan_start = _walk(b, p, st)
+        sampling = _check_frame(st, sos)
+        sof = st.sof
+        if sof["ncomp"] != 3 or sos[0] != 1:
+            raise UnsupportedJpeg("not a one-component-per-scan sequential JPEG")
+        ids = [c[0] for c in sof["comps"]]
+        if sos[1] not in ids:
+            raise CorruptJpeg("scan of an unknown component")
+        c = ids.index(sos[1])
+        if plans[c] is not None:
+            raise CorruptJpeg("a component in two scans")
+        _, h, v, tq = sof["comps"][c]
+        td, ta = sos[2] >> 4, sos[2] & 15
+        if tq not in st.qts or (0, td) not in st.huff or (1, ta) not in st.huff:
+            raise CorruptJpeg("missing table")
+        hmax, vmax = sampling[0]
+        fr = Frame()                 # the component as a grey frame of its real samples: ceil(W h / hmax) x ceil(H v / vmax)
+        fr.width, fr.height, fr.ncomp = -(-sof["width"] * h // hmax), -(-sof["height"] * v // vmax), 1
+        fr.h[0] = fr.v[0] = 1
+        fr.dc_slot[0], fr.ac_slot[0] = 0, 1
+        qt = np.ones((3, 64), dtype=np.uint16)
+        qt[0] = st.qts[tq]
+        nmcu = (-(-fr.width // 8)) * (-(-fr.height // 8))
+        plans[c] = _scan_plan(st, data, scan_start, fr, qt, [(0, td), (1, ta)], nmcu, chunk_bytes, [(1, 1)])
+        p = scan_start + int(plans[c].scan.size)
+    return ComponentPlans(width=st.sof["width"], height=st.sof["height"], sampling=sampling, orientation=st.orientation, plans=plans)
 
 
 def flat_launch_bound(seg_chunk0, per) -> int:
@@ -396,12 +474,38 @@ def decode(buf, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, chunk_
     chunks of its longest restart interval -- ``Plan.launch_bound`` -- and gets them)."""
     import torch
     from . import ops
-    pl = plan(buf, chunk_bytes)
     device = torch.device(device)
-    out, info = ops.jpeg_decode(pl, 3 if color else 1, device, sweeps)
+    try:
+        pl = plan(buf, chunk_bytes)
+    except MultiScanJpeg:
+        pl = plan_components(buf, chunk_bytes)
+        out, info = _decode_components(pl, color, device, sweeps)
+    else:
+        out, info = ops.jpeg_decode(pl, 3 if color else 1, device, sweeps)
     if orient and pl.orientation != 1:
         out = apply_orientation(out, pl.orientation)
     return (out, info) if return_info else out
+
+
+def _decode_components(cp: ComponentPlans, color: bool, device, sweeps: int):
+    """A multi-scan sequential file: the luma scan alone for grey output; else the three component scans as ONE batched call of grey
+    frames, then the colour stage on the planes (``dfsfm_jpeg_ycc_planes_to_rgb_u8``)."""
+    from . import ops
+    if not color:
+        return ops.jpeg_decode(cp.plans[0], 1, device, sweeps)
+    planes = ops.jpeg_decode_batch_launch(cp.plans, 1, device, sweeps).finish()
+    for r in planes:
+        if isinstance(r, Exception):
+            raise r
+    return ops.jpeg_planes_to_rgb(planes[0], planes[1], planes[2], cp.width, cp.height, cp.sampling[0]), dict(calls=1, components=3)
+
+
+def _plan_any(buf):
+    """``plan``, or ``plan_components`` for a multi-scan sequential file."""
+    try:
+        return plan(buf)
+    except MultiScanJpeg:
+        return plan_components(buf)
 
 
 def decode_batch(bufs, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS, orient: bool = True, plans=None):
@@ -410,10 +514,18 @@ def decode_batch(bufs, color: bool, device="cuda", sweeps: int = DEFAULT_SWEEPS,
     the others are done (``UnsupportedJpeg`` is raised by ``plan`` before anything is uploaded)."""
     import torch
     from . import ops
-    plans = [plan(b) for b in bufs] if plans is None else plans
+    plans = [_plan_any(b) for b in bufs] if plans is None else plans
     if not plans:
         return []
-    res = ops.jpeg_decode_batch_launch(plans, 3 if color else 1, torch.device(device), sweeps).finish()
+    device = torch.device(device)
+    one = [i for i, pl in enumerate(plans) if isinstance(pl, Plan)]
+    res = [None] * len(plans)
+    if one:
+        for i, r in zip(one, ops.jpeg_decode_batch_launch([plans[i] for i in one], 3 if color else 1, device, sweeps).finish()):
+            res[i] = r
+    for i, pl in enumerate(plans):                   # multi-scan sequential files: a batched call of their own each
+        if not isinstance(pl, Plan):
+            res[i] = _decode_components(pl, color, device, sweeps)[0]
     for r in res:
         if isinstance(r, Exception):
             raise r
@@ -447,9 +559,14 @@ def decode_many(bufs, color: bool, device="cuda", streams: int = 2, sweeps: int 
             r.record_stream(cur)
             outs[i] = apply_orientation(r, pl.orientation) if orient and pl.orientation != 1 else r
     with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
-        parsed = [pool.submit(plan, b) for b in bufs]
+        parsed = [pool.submit(_plan_any, b) for b in bufs]
+        multi = []
         for gi, idx in enumerate(groups):
-            plans = [parsed[i].result() for i in idx]
+            got = [(i, parsed[i].result()) for i in idx]
+            multi += [(i, pl) for i, pl in got if not isinstance(pl, Plan)]
+            idx, plans = [i for i, pl in got if isinstance(pl, Plan)], [pl for _, pl in got if isinstance(pl, Plan)]
+            if not plans:
+                continue
             if len(open_calls) >= len(side):
                 close_oldest()
             with torch.cuda.stream(side[gi % len(side)]):
@@ -458,4 +575,7 @@ def decode_many(bufs, color: bool, device="cuda", streams: int = 2, sweeps: int 
         close_oldest()
     for s in side:
         cur.wait_stream(s)
+    for i, cp in multi:                              # multi-scan sequential files (rare): one by one on the caller's stream
+        r = _decode_components(cp, color, device, sweeps)[0]
+        outs[i] = apply_orientation(r, cp.orientation) if orient and cp.orientation != 1 else r
     return outs

@@ -839,6 +839,24 @@ def jpeg_decode(pl, out_channels: int, device, sweeps: int = 4, max_calls: int =
     return jpeg_decode_launch(pl, out_channels, device, sweeps, max_calls).finish()
 
 
+def jpeg_planes_to_rgb(y, cb, cr, width: int, height: int, luma_sampling):
+    """``dfsfm_jpeg_ycc_planes_to_rgb_u8``: the colour stage of the JPEG decode on three component planes (uint8 device tensors of the
+    components' real samples) -> RGB [height, width, 3]."""
+    _require_cuda(y, cb, cr)
+    h0, v0 = int(luma_sampling[0]), int(luma_sampling[1])
+    cw, chh = -(-width // h0), -(-height // v0)
+    for t, shp in ((y, (height, width)), (cb, (chh, cw)), (cr, (chh, cw))):
+        if t.dtype != torch.uint8 or tuple(t.shape) != shp or t.stride(1) != 1:
+            raise _lib.DfsfmError("jpeg_planes_to_rgb: planes must be uint8 [rows, cols] of the components' real samples")
+    if cb.stride(0) != cr.stride(0):
+        raise _lib.DfsfmError("jpeg_planes_to_rgb: cb / cr strides differ")
+    out = torch.empty((height, width, 3), dtype=torch.uint8, device=y.device)
+    rc = _lib.lib().dfsfm_jpeg_ycc_planes_to_rgb_u8(_ptr(y), y.stride(0), _ptr(cb), _ptr(cr), cb.stride(0), width, height, h0, v0,
+                                                    _ptr(out), out.stride(0), _stream())
+    _lib.check(rc, "dfsfm_jpeg_ycc_planes_to_rgb_u8")
+    return out
+
+
 class JpegJob(ctypes.Structure):
     """``dfsfm_jpeg_job`` of include/dfsfm_hip.h."""
     _fields_ = [("scan", ctypes.c_void_p), ("scan_bytes", ctypes.c_int64), ("frame_host", ctypes.c_void_p),

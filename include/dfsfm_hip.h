@@ -531,6 +531,14 @@ typedef struct dfsfm_jpeg_job {
 } dfsfm_jpeg_job;
 int dfsfm_jpeg_decode_batch_u8(const dfsfm_jpeg_job* jobs_host, int n_jobs, int out_channels, int sweeps, int resume, void* stream);
 
+/* The colour stage alone, for multi-scan sequential files (each component in a scan of its own -- cv2.imread takes them,
+ * /root/reference/src/dataset/utils.py:86-92): y / cb / cr are device planes of the components' REAL samples (width x height for y,
+ * ceil(width / h0) x ceil(height / v0) for cb and cr; row strides in bytes) as three dfsfm_jpeg_decode_u8 calls on the grey frames of
+ * jpeg.plan_components leave them; out = RGB [height][width][3], libjpeg-turbo's fancy upsampling + YCbCr -> RGB.  (h0, v0) = luma
+ * sampling factors: 1x1, 2x1, 2x2, 1x2, 4x1. */
+int dfsfm_jpeg_ycc_planes_to_rgb_u8(const uint8_t* y, int64_t y_stride, const uint8_t* cb, const uint8_t* cr, int64_t c_stride,
+                                    int width, int height, int h0, int v0, uint8_t* out, int64_t out_stride, void* stream);
+
 /* HOST function (no device is touched): the index of an entropy-coded scan that the decode calls above take as arguments --
  * what libjpeg's jdmarker.c / jdhuff.c learn byte by byte while cv2.imread decodes.  scan = the bytes behind the SOS header,
  * n_avail of them.  Returns scan_len = offset of the first marker that is not RSTn (n_avail if there is none) or a negative

@@ -225,7 +225,13 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
     memset(ac, 0, sizeof ac);
     memset(comp, 0, sizeof comp);
     int W = 0, H = 0, ncomp = 0, progressive = 0, restart = 0, have_sof = 0, orientation = 0, adobe_transform = -1, jfif = 0;
+    int scan_comp = -1;            /* -1: the scan interleaves every component; c: a non-interleaved scan of component c */
+    int geometry_done = 0, decoded[3] = {0, 0, 0}, hmax = 1, vmax = 1, rc = 0;
     long p = 2;
+  next_scan:                       /* r06: a sequential file may carry its components in separate scans (T.81 A.2.2) */
+    scan_comp = -1;
+    {
+    int saw_sos = 0;
     while (p + 4 <= n) {
         if (buf[p] != 0xFF) return E_FORMAT;
         while (p < n && buf[p] == 0xFF) ++p;                      /* fill bytes */
@@ -312,12 +318,22 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
                 info[11] = orientation;
             }
             if (progressive) return E_UNSUPPORTED;
-            if (s[0] != ncomp) return E_UNSUPPORTED;              /* one interleaved scan only */
-            for (int c = 0; c < ncomp; ++c) {
-                if (s[1 + 2 * c] != comp[c].id) return E_UNSUPPORTED;
-                comp[c].td = s[2 + 2 * c] >> 4;
-                comp[c].ta = s[2 + 2 * c] & 15;
+            if (s[0] == ncomp) {                                  /* one scan that interleaves every component */
+                for (int c = 0; c < ncomp; ++c) {
+                    if (s[1 + 2 * c] != comp[c].id) return E_UNSUPPORTED;
+                    comp[c].td = s[2 + 2 * c] >> 4;
+                    comp[c].ta = s[2 + 2 * c] & 15;
+                }
+            } else if (s[0] == 1 && ncomp == 3) {                 /* a non-interleaved scan of one component */
+                for (int c = 0; c < 3; ++c)
+                    if (s[1] == comp[c].id) scan_comp = c;
+                if (scan_comp < 0) return E_FORMAT;
+                comp[scan_comp].td = s[2] >> 4;
+                comp[scan_comp].ta = s[2] & 15;
+            } else {
+                return E_UNSUPPORTED;                             /* partial interleaves (Y, then Cb + Cr together) */
             }
+            if (s[1 + 2 * s[0]] != 0 || s[2 + 2 * s[0]] != 63) return E_UNSUPPORTED;     /* spectral selection = a progressive scan */
             if (ncomp == 3) {
                 /* colour space as jdapimin.c default_decompress_parms decides it: YCbCr only here */
                 int ycc = 1;
@@ -327,13 +343,15 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
             }
             if (!out) return 0;
             p += len;
+            saw_sos = 1;
             break;
         }
         p += len;
     }
-    if (!have_sof || p >= n) return E_FORMAT;
+    if (!have_sof || !saw_sos || p >= n) { rc = E_FORMAT; goto done; }
+    }
 
-    int hmax = 1, vmax = 1;
+    if (!geometry_done) {
     for (int c = 0; c < ncomp; ++c) { if (comp[c].h > hmax) hmax = comp[c].h; if (comp[c].v > vmax) vmax = comp[c].v; }
     if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }      /* a single-component scan is never interleaved */
     else {
@@ -342,21 +360,31 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
               (comp[0].h == 1 && comp[0].v == 2) || (comp[0].h == 4 && comp[0].v == 1)))     /* 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1 */
             return E_UNSUPPORTED;
     }
-    const int mw = 8 * hmax, mh = 8 * vmax;
-    const int mx = (W + mw - 1) / mw, my = (H + mh - 1) / mh;
+    const int fmx = (W + 8 * hmax - 1) / (8 * hmax), fmy = (H + 8 * vmax - 1) / (8 * vmax);
     for (int c = 0; c < ncomp; ++c) {
-        comp[c].bw = mx * comp[c].h;
-        comp[c].bh = my * comp[c].v;
+        comp[c].bw = fmx * comp[c].h;
+        comp[c].bh = fmy * comp[c].v;
         comp[c].pw = comp[c].bw * 8;
         comp[c].ph = comp[c].bh * 8;
         comp[c].rw = (W * comp[c].h + hmax - 1) / hmax;
         comp[c].rh = (H * comp[c].v + vmax - 1) / vmax;
-        if (!dc[comp[c].td].present || !ac[comp[c].ta].present) return E_FORMAT;
     }
-    for (int c = 0; c < ncomp; ++c) comp[c].plane = (uint8_t*)malloc((size_t)comp[c].pw * comp[c].ph);
+    for (int c = 0; c < ncomp; ++c) comp[c].plane = (uint8_t*)calloc((size_t)comp[c].pw, comp[c].ph);
+    geometry_done = 1;
+    }
+    for (int c = 0; c < ncomp; ++c)
+        if ((scan_comp < 0 || scan_comp == c) && (!dc[comp[c].td].present || !ac[comp[c].ta].present)) { rc = E_FORMAT; goto done; }
+    if (scan_comp >= 0 ? decoded[scan_comp] : (decoded[0] || decoded[1] || decoded[2])) { rc = E_FORMAT; goto done; }   /* a component twice */
 
+    /* MCU grid of this scan: the frame's for an interleaved scan; the component's own blocks, ceil(samples / 8) each way and ONE
+       block per MCU, for a non-interleaved one (its restart interval counts those) */
+    const int mw = 8 * hmax, mh = 8 * vmax;
+    const int mx = scan_comp < 0 ? (W + mw - 1) / mw : (comp[scan_comp].rw + 7) / 8;
+    const int my = scan_comp < 0 ? (H + mh - 1) / mh : (comp[scan_comp].rh + 7) / 8;
+    const int c_lo = scan_comp < 0 ? 0 : scan_comp, c_hi = scan_comp < 0 ? ncomp : scan_comp + 1;
+    for (int c = c_lo; c < c_hi; ++c) comp[c].pred = 0;
     Bits b = {buf + p, buf + n, 0, 0, 0};
-    int rc = 0, todo = restart;
+    int todo = restart;
     for (int m = 0; m < mx * my && rc == 0; ++m) {
         if (restart && todo == 0) {                               /* RSTn: byte align, skip the marker, reset predictions */
             const uint8_t* q = b.p;
@@ -364,13 +392,14 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
             if (q + 1 >= b.end) { rc = E_FORMAT; break; }
             b.p = q + 2;
             b.acc = 0; b.n = 0; b.marker = 0;
-            for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+            for (int c = c_lo; c < c_hi; ++c) comp[c].pred = 0;
             todo = restart;
         }
         const int mcx = m % mx, mcy = m / mx;
-        for (int c = 0; c < ncomp && rc == 0; ++c)
-            for (int by = 0; by < comp[c].v && rc == 0; ++by)
-                for (int bx = 0; bx < comp[c].h; ++bx) {
+        for (int c = c_lo; c < c_hi && rc == 0; ++c) {
+            const int bh_ = scan_comp < 0 ? comp[c].h : 1, bv_ = scan_comp < 0 ? comp[c].v : 1;
+            for (int by = 0; by < bv_ && rc == 0; ++by)
+                for (int bx = 0; bx < bh_; ++bx) {
                     int16_t coef[64];
                     memset(coef, 0, sizeof coef);
                     int s = decode_sym(&b, &dc[comp[c].td]);
@@ -393,10 +422,24 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
                         ++k;
                     }
                     if (rc) break;
-                    const int row = (mcy * comp[c].v + by) * 8, col = (mcx * comp[c].h + bx) * 8;
+                    const int row = (mcy * bv_ + by) * 8, col = (mcx * bh_ + bx) * 8;
                     idct_islow(coef, qt[comp[c].tq], comp[c].plane + (size_t)row * comp[c].pw + col, comp[c].pw);
                 }
+        }
         if (restart) --todo;
+    }
+    if (rc == 0) {
+        for (int c = c_lo; c < c_hi; ++c) decoded[c] = 1;
+        int all = 1;
+        for (int c = 0; c < ncomp; ++c) all = all && decoded[c];
+        if (!all) {
+            /* the next marker that is not RSTn ends this scan's entropy-coded data: more tables / the next scan follow */
+            long q = p;
+            while (q + 1 < n && !(buf[q] == 0xFF && buf[q + 1] != 0 && buf[q + 1] != 0xFF && !(buf[q + 1] >= 0xD0 && buf[q + 1] <= 0xD7))) ++q;
+            if (q + 1 >= n || buf[q + 1] == 0xD9) { rc = E_FORMAT; goto done; }          /* EOI before every component came */
+            p = q;
+            goto next_scan;
+        }
     }
     if (rc == 0) {
         if (!want_color) {
@@ -425,6 +468,7 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
                 }
         }
     }
+  done:
     for (int c = 0; c < ncomp; ++c) free(comp[c].plane);
     return rc;
 }

@@ -111,3 +111,13 @@ extern "C" int jd_emul_decode(const uint8_t* scan, int64_t scan_bytes, const dfs
             for (int x = 0; x < P.width; ++x) jd::color_thread(P, x, y);
     return 0;
 }
+
+// the colour stage alone on three host planes (dfsfm_jpeg_ycc_planes_to_rgb_u8's kernel as a loop)
+extern "C" int jd_emul_planes_to_rgb(const uint8_t* y, int64_t y_stride, const uint8_t* cb, const uint8_t* cr, int64_t c_stride, int width,
+                                     int height, int h0, int v0, uint8_t* out, int64_t out_stride) {
+    jd::Params P;
+    if (!jd::planes_params(P, y, y_stride, cb, cr, c_stride, width, height, h0, v0, out, out_stride)) return -3;
+    for (int yy = 0; yy < P.height; ++yy)
+        for (int x = 0; x < P.width; ++x) jd::color_thread(P, x, yy);
+    return 0;
+}

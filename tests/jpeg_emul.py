@@ -55,3 +55,21 @@ def decode(pl, color: bool, sweeps: int = 64, order: int = 0, max_calls: int = 6
         if status[0] == 0 or calls >= max_calls:
             break
     return out, dict(status=status.copy(), sweeps=used, calls=calls)
+
+
+def decode_components(cp, color: bool, sweeps: int = 64, order: int = 0):
+    """A ``jpeg.ComponentPlans`` (multi-scan sequential file) through the lane model: one grey decode per component, then the colour
+    stage on the three planes; grey output = the luma plane."""
+    planes = [decode(pl, False, sweeps, order)[0] for pl in (cp.plans if color else cp.plans[:1])]
+    if not color:
+        return planes[0]
+    y, cb, cr = [np.ascontiguousarray(a) for a in planes]
+    assert cb.shape == cr.shape and y.shape == (cp.height, cp.width)
+    out = np.zeros((cp.height, cp.width, 3), dtype=np.uint8)
+    L = lib()
+    L.jd_emul_planes_to_rgb.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_int] * 4 + \
+        [ctypes.c_void_p, ctypes.c_int64]
+    rc = L.jd_emul_planes_to_rgb(y.ctypes.data, y.strides[0], cb.ctypes.data, cr.ctypes.data, cb.strides[0], cp.width, cp.height,
+                                 cp.sampling[0][0], cp.sampling[0][1], out.ctypes.data, out.strides[0])
+    assert rc == 0, rc
+    return out

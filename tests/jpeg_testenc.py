@@ -84,8 +84,9 @@ def _magnitude(v):
     return s, (v if v >= 0 else v + (1 << s) - 1)
 
 
-def encode(rgb, luma=(1, 2), quality=85, restart=0):
-    """rgb [H, W, 3] uint8 -> bytes of a baseline JFIF file, Y sampled luma = (h, v), Cb / Cr 1x1."""
+def encode(rgb, luma=(1, 2), quality=85, restart=0, per_component=False):
+    """rgb [H, W, 3] uint8 -> bytes of a baseline JFIF file, Y sampled luma = (h, v), Cb / Cr 1x1; one interleaved scan, or
+    (per_component) three non-interleaved scans -- a multi-scan SEQUENTIAL file."""
     H, W = rgb.shape[:2]
     h, v = luma
     dqt, dht, q, huff = _tables_like_pillow(quality)
@@ -110,40 +111,58 @@ def encode(rgb, luma=(1, 2), quality=85, restart=0):
     out += dht
     if restart:
         out += b"\xFF\xDD\x00\x04" + restart.to_bytes(2, "big")
-    out += b"\xFF\xDA\x00\x0C\x03\x01\x00\x02\x11\x03\x11\x00\x3F\x00"
-    bits, pred, rst = _Bits(), [0, 0, 0], 0
-    for m in range(mx * my):
-        if restart and m and m % restart == 0:
-            bits.flush()
-            out += bits.out + bytes([0xFF, 0xD0 + (rst & 7)])
-            bits, pred, rst = _Bits(), [0, 0, 0], rst + 1
-        r, cm = divmod(m, mx)
+    def block(bits, c, z, pred):
+        dc_t, ac_t = huff[(0, 0 if c == 0 else 1)], huff[(1, 0 if c == 0 else 1)]
+        s_, extra = _magnitude(int(z[0]) - pred[c])
+        pred[c] = int(z[0])
+        bits.put(*dc_t[s_])
+        if s_:
+            bits.put(extra, s_)
+        run = 0
+        last = int(np.flatnonzero(z).max(initial=0))
+        for k in range(1, last + 1):
+            if z[k] == 0:
+                run += 1
+                continue
+            while run > 15:
+                bits.put(*ac_t[0xF0])
+                run -= 16
+            s_, extra = _magnitude(int(z[k]))
+            bits.put(*ac_t[(run << 4) | s_])
+            bits.put(extra, s_)
+            run = 0
+        if last < 63:
+            bits.put(*ac_t[0])
+
+    def scan(header, units):
+        """units: per MCU the list of (component, zig-zag block); restart markers every `restart` MCUs"""
+        nonlocal out
+        out += header
+        bits, pred, rst = _Bits(), [0, 0, 0], 0
+        for m, unit in enumerate(units):
+            if restart and m and m % restart == 0:
+                bits.flush()
+                out += bits.out + bytes([0xFF, 0xD0 + (rst & 7)])
+                bits, pred, rst = _Bits(), [0, 0, 0], rst + 1
+            for c, z in unit:
+                block(bits, c, z, pred)
+        bits.flush()
+        out += bits.out
+
+    if not per_component:
+        units = []
+        for m in range(mx * my):
+            r, cm = divmod(m, mx)
+            units.append([(c, coefs[c][r * cv + by, cm * ch + bx]) for c in range(3) for (ch, cv) in (((h, v) if c == 0 else (1, 1)),)
+                          for by in range(cv) for bx in range(ch)])
+        scan(b"\xFF\xDA\x00\x0C\x03\x01\x00\x02\x11\x03\x11\x00\x3F\x00", units)
+    else:
+        # three non-interleaved scans (T.81 A.2.2): a component's own block grid, ceil(samples / 8) each way, one block per MCU
         for c in range(3):
             ch, cv = (h, v) if c == 0 else (1, 1)
-            dc_t, ac_t = huff[(0, 0 if c == 0 else 1)], huff[(1, 0 if c == 0 else 1)]
-            for by in range(cv):
-                for bx in range(ch):
-                    z = coefs[c][r * cv + by, cm * ch + bx]
-                    s, extra = _magnitude(int(z[0]) - pred[c])
-                    pred[c] = int(z[0])
-                    bits.put(*dc_t[s])
-                    if s:
-                        bits.put(extra, s)
-                    run = 0
-                    last = int(np.flatnonzero(z).max(initial=0))
-                    for k in range(1, last + 1):
-                        if z[k] == 0:
-                            run += 1
-                            continue
-                        while run > 15:
-                            bits.put(*ac_t[0xF0])
-                            run -= 16
-                        s, extra = _magnitude(int(z[k]))
-                        bits.put(*ac_t[(run << 4) | s])
-                        bits.put(extra, s)
-                        run = 0
-                    if last < 63:
-                        bits.put(*ac_t[0])
-    bits.flush()
-    out += bits.out + b"\xFF\xD9"
+            rw, rh = -(-W * ch // h), -(-H * cv // v)
+            nbx, nby = -(-rw // 8), -(-rh // 8)
+            units = [[(c, coefs[c][by, bx])] for by in range(nby) for bx in range(nbx)]
+            scan(b"\xFF\xDA\x00\x08\x01" + bytes([c + 1, 0x00 if c == 0 else 0x11]) + b"\x00\x3F\x00", units)
+    out += b"\xFF\xD9"
     return bytes(out)

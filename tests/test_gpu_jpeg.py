@@ -10,7 +10,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from test_jpeg_cpu import cases, cases_440_411, encode, pil_gray, pil_rgb, synth   # noqa: E402
+from test_jpeg_cpu import cases, cases_440_411, cases_multiscan, encode, pil_gray, pil_rgb, synth   # noqa: E402
 from detectorfreesfm_amd import _lib, images, jpeg                   # noqa: E402
 from oracle import restate_jpeg as rj                                # noqa: E402
 
@@ -48,6 +48,25 @@ def test_440_and_411_sampling_on_the_device():
         out, info = jpeg.decode(buf, True, DEV, return_info=True)
         assert np.array_equal(out.cpu().numpy(), pil_rgb(buf)) and info["calls"] <= 2, (luma, info)
         assert np.array_equal(jpeg.decode_batch([buf, buf], True, DEV)[1].cpu().numpy(), pil_rgb(buf))
+
+
+def test_multiscan_sequential_files_on_the_device():
+    """One component per scan (what jpeg.plan alone refuses): three grey frames in one batched call + the colour stage on the planes
+    (dfsfm_jpeg_ycc_planes_to_rgb_u8) = libjpeg-turbo's bytes; mixed into decode_batch / decode_many lists as well."""
+    import jpeg_testenc
+    n = 0
+    for key, buf in cases_multiscan():
+        for color in (False, True):
+            out = jpeg.decode(buf, color, DEV, chunk_bytes=32 if n % 2 else 128)
+            assert np.array_equal(out.cpu().numpy(), pil_rgb(buf) if color else pil_gray(buf)), (key, color)
+        n += 1
+    assert n == 60
+    big = jpeg_testenc.encode(synth(480, 640, True, seed=21), (2, 2), quality=88, per_component=True)
+    plain = encode(synth(240, 320, True, seed=22), quality=85, subsampling=2)
+    for outs in (jpeg.decode_batch([plain, big, plain], True, DEV), jpeg.decode_many([plain, big, plain, big], True, DEV, batch=2)):
+        for o, b in zip(outs, [plain, big, plain, big]):
+            assert np.array_equal(o.cpu().numpy(), pil_rgb(b))
+    assert np.array_equal(jpeg.decode(big, False, DEV).cpu().numpy(), pil_gray(big))
 
 
 def test_camera_sized_frames_and_sweep_counts():

@@ -140,6 +140,43 @@ def test_440_and_411_sampling_oracle_pinned_and_lane_model():
             assert np.array_equal(out, rj.decode(buf, True)), (sub, h, w)
 
 
+def cases_multiscan(sizes=((40, 56), (17, 33), (3, 3), (100, 75), (8, 8), (1, 1)), lumas=((1, 1), (2, 2), (2, 1), (1, 2), (4, 1))):
+    """Sequential files with one component per scan (T.81 A.2.2; one block per MCU over the component's own block grid) from the tests'
+    encoder -- Pillow's writes only interleaved scans."""
+    k = 0
+    for luma in lumas:
+        for (h, w) in sizes:
+            for rst in (0, 3):
+                k += 1
+                yield (luma, h, w, rst), jpeg_testenc.encode(synth(h, w, True, seed=k), luma, quality=80, restart=rst, per_component=True)
+
+
+def test_multiscan_sequential_files():
+    """cv2.imread reads sequential files whose components come in separate scans; r06: oracle == libjpeg-turbo on them, ``jpeg.plan``
+    says MultiScanJpeg, ``plan_components`` turns the file into three grey frames, and the lane model (a grey decode per component +
+    the colour stage on the planes) == oracle.  Partly interleaved files stay refused."""
+    n = 0
+    for key, buf in cases_multiscan():
+        g, c = rj.decode(buf, False), rj.decode(buf, True)
+        assert np.array_equal(g, pil_gray(buf)) and np.array_equal(c, pil_rgb(buf)), key
+        with pytest.raises(jpeg.MultiScanJpeg):
+            jpeg.plan(buf)
+        cp = jpeg.plan_components(buf, 64 if n % 2 else 16)
+        assert cp.sampling[0] == key[0] and (cp.width, cp.height) == (key[2], key[1])
+        assert np.array_equal(jpeg_emul.decode_components(cp, False, sweeps=3, order=n % 3), g), key
+        assert np.array_equal(jpeg_emul.decode_components(cp, True, sweeps=3, order=n % 3), c), key
+        n += 1
+    assert n == 60
+    # Y alone, then Cb and Cr interleaved: one SOS with two components -- not taken (the host decoder reads it)
+    buf = jpeg_testenc.encode(synth(24, 24, True, seed=3), (1, 1), per_component=True)
+    i = buf.index(b"\xFF\xDA\x00\x08\x01\x02")
+    bad = buf[:i] + b"\xFF\xDA\x00\x0A\x02\x02\x11\x03\x11\x00\x3F\x00" + buf[i + 10:]
+    with pytest.raises(jpeg.UnsupportedJpeg):
+        jpeg.plan_components(bad)
+    with pytest.raises((jpeg.CorruptJpeg, jpeg.UnsupportedJpeg)):
+        jpeg.plan_components(buf[:i + 40])                                # the file ends inside the second scan
+
+
 def test_thread_order_does_not_change_the_fixed_point():
     buf = encode(synth(480, 640, True, seed=3), quality=90, subsampling=2)
     pl = jpeg.plan(buf)
