@@ -233,22 +233,22 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
     {
     int saw_sos = 0;
     while (p + 4 <= n) {
-        if (buf[p] != 0xFF) return E_FORMAT;
+        if (buf[p] != 0xFF) { rc = E_FORMAT; goto done; }
         while (p < n && buf[p] == 0xFF) ++p;                      /* fill bytes */
-        if (p >= n) return E_FORMAT;
+        if (p >= n) { rc = E_FORMAT; goto done; }
         const int m = buf[p++];
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
-        if (m == 0xD9) return E_FORMAT;
-        if (p + 2 > n) return E_FORMAT;
+        if (m == 0xD9) { rc = E_FORMAT; goto done; }
+        if (p + 2 > n) { rc = E_FORMAT; goto done; }
         const long len = (buf[p] << 8) | buf[p + 1];
-        if (len < 2 || p + len > n) return E_FORMAT;
+        if (len < 2 || p + len > n) { rc = E_FORMAT; goto done; }
         const uint8_t* s = buf + p + 2;
         const long sl = len - 2;
         if (m == 0xDB) {                                          /* DQT */
             long i = 0;
             while (i < sl) {
                 const int pq = s[i] >> 4, tq = s[i] & 15;
-                if (tq > 3) return E_FORMAT;
+                if (tq > 3) { rc = E_FORMAT; goto done; }
                 ++i;
                 for (int k = 0; k < 64; ++k) {
                     int v;
@@ -260,24 +260,24 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
             long i = 0;
             while (i < sl) {
                 const int tc = s[i] >> 4, th = s[i] & 15;
-                if (th > 3 || tc > 1) return E_FORMAT;
+                if (th > 3 || tc > 1) { rc = E_FORMAT; goto done; }
                 Huff* h = tc ? &ac[th] : &dc[th];
                 int cnt = 0;
                 h->bits[0] = 0;
                 for (int l = 1; l <= 16; ++l) { h->bits[l] = s[i + l]; cnt += h->bits[l]; }
-                if (cnt > 256) return E_FORMAT;
+                if (cnt > 256) { rc = E_FORMAT; goto done; }
                 memcpy(h->vals, s + i + 17, cnt);
                 h->present = 1;
                 huff_prepare(h);
                 i += 17 + cnt;
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {         /* SOF0 / SOF1 / SOF2 */
-            if (s[0] != 8) return E_UNSUPPORTED;
+            if (s[0] != 8) { rc = E_UNSUPPORTED; goto done; }
             H = (s[1] << 8) | s[2];
             W = (s[3] << 8) | s[4];
             ncomp = s[5];
             progressive = m == 0xC2;
-            if (ncomp != 1 && ncomp != 3) return E_UNSUPPORTED;
+            if (ncomp != 1 && ncomp != 3) { rc = E_UNSUPPORTED; goto done; }
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].id = s[6 + 3 * c];
                 comp[c].h = s[7 + 3 * c] >> 4;
@@ -286,7 +286,7 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
             }
             have_sof = 1;
         } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            return E_UNSUPPORTED;                                 /* lossless, differential, arithmetic */
+            { rc = E_UNSUPPORTED; goto done; }                                 /* lossless, differential, arithmetic */
         } else if (m == 0xDD) {
             restart = (s[0] << 8) | s[1];
         } else if (m == 0xE0 && sl >= 5 && !memcmp(s, "JFIF", 5)) {
@@ -311,37 +311,37 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
                 }
             }
         } else if (m == 0xDA) {                                   /* SOS */
-            if (!have_sof) return E_FORMAT;
+            if (!have_sof) { rc = E_FORMAT; goto done; }
             if (info) {
                 info[0] = W; info[1] = H; info[2] = ncomp; info[3] = progressive; info[4] = restart;
                 for (int c = 0; c < 3; ++c) { info[5 + 2 * c] = comp[c].h; info[6 + 2 * c] = comp[c].v; }
                 info[11] = orientation;
             }
-            if (progressive) return E_UNSUPPORTED;
+            if (progressive) { rc = E_UNSUPPORTED; goto done; }
             if (s[0] == ncomp) {                                  /* one scan that interleaves every component */
                 for (int c = 0; c < ncomp; ++c) {
-                    if (s[1 + 2 * c] != comp[c].id) return E_UNSUPPORTED;
+                    if (s[1 + 2 * c] != comp[c].id) { rc = E_UNSUPPORTED; goto done; }
                     comp[c].td = s[2 + 2 * c] >> 4;
                     comp[c].ta = s[2 + 2 * c] & 15;
                 }
             } else if (s[0] == 1 && ncomp == 3) {                 /* a non-interleaved scan of one component */
                 for (int c = 0; c < 3; ++c)
                     if (s[1] == comp[c].id) scan_comp = c;
-                if (scan_comp < 0) return E_FORMAT;
+                if (scan_comp < 0) { rc = E_FORMAT; goto done; }
                 comp[scan_comp].td = s[2] >> 4;
                 comp[scan_comp].ta = s[2] & 15;
             } else {
-                return E_UNSUPPORTED;                             /* partial interleaves (Y, then Cb + Cr together) */
+                { rc = E_UNSUPPORTED; goto done; }                             /* partial interleaves (Y, then Cb + Cr together) */
             }
-            if (s[1 + 2 * s[0]] != 0 || s[2 + 2 * s[0]] != 63) return E_UNSUPPORTED;     /* spectral selection = a progressive scan */
+            if (s[1 + 2 * s[0]] != 0 || s[2 + 2 * s[0]] != 63) { rc = E_UNSUPPORTED; goto done; }     /* spectral selection = a progressive scan */
             if (ncomp == 3) {
                 /* colour space as jdapimin.c default_decompress_parms decides it: YCbCr only here */
                 int ycc = 1;
                 if (!jfif && adobe_transform == 0) ycc = 0;
                 if (!jfif && adobe_transform < 0 && comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') ycc = 0;
-                if (!ycc) return E_UNSUPPORTED;
+                if (!ycc) { rc = E_UNSUPPORTED; goto done; }
             }
-            if (!out) return 0;
+            if (!out) { rc = 0; goto done; }
             p += len;
             saw_sos = 1;
             break;
@@ -355,10 +355,10 @@ static int parse_and_decode(const uint8_t* buf, long n, int want_color, uint8_t*
     for (int c = 0; c < ncomp; ++c) { if (comp[c].h > hmax) hmax = comp[c].h; if (comp[c].v > vmax) vmax = comp[c].v; }
     if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }      /* a single-component scan is never interleaved */
     else {
-        if (comp[1].h != 1 || comp[1].v != 1 || comp[2].h != 1 || comp[2].v != 1) return E_UNSUPPORTED;
+        if (comp[1].h != 1 || comp[1].v != 1 || comp[2].h != 1 || comp[2].v != 1) { rc = E_UNSUPPORTED; goto done; }
         if (!((comp[0].h == 1 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 2) ||
               (comp[0].h == 1 && comp[0].v == 2) || (comp[0].h == 4 && comp[0].v == 1)))     /* 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1 */
-            return E_UNSUPPORTED;
+            { rc = E_UNSUPPORTED; goto done; }
     }
     const int fmx = (W + 8 * hmax - 1) / (8 * hmax), fmy = (H + 8 * vmax - 1) / (8 * vmax);
     for (int c = 0; c < ncomp; ++c) {
