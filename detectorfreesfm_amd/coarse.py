@@ -130,6 +130,15 @@ def encoder_layer_split(w: EncoderLayerWeights, xs, src, out_x, out_xs, nhead, x
     return _encoder_layer_unfused(w, xs, src, out_x, out_xs, nhead, x_mask, source_mask, q_group, kv_group, is_self)
 
 
+def encoder_layer_fused128(w: EncoderLayerWeights, x, src, out_xs, x_mask=None, source_mask=None, q_group=1, kv_group=1):
+    """The fused d_model-128 form of ``encoder_layer_split`` on token planes of ANY row stride (``x`` [N,L,C], ``src`` [N,S,C] SplitAct
+    views): what a caller uses whose tokens do not sit in an [x | message] buffer -- the refinement head's first layer reads the
+    backbone's split-plane output directly.  No range-guard shadow pass: callers take ``encoder_layer_split`` while a sweep is open."""
+    state = ops.encoder_kv(src, w.fused, source_mask, kv_group)
+    ops.encoder_apply(x, w.fused, state, src.hi.shape[1], x_mask, q_group, out_split=out_xs)
+    return out_xs
+
+
 def _encoder_layer_unfused(w, xs, src, out_x, out_xs, nhead, x_mask, source_mask, q_group, kv_group, is_self):
     """The five-GEMM + K1 form of ``encoder_layer_split`` (every intermediate reaches memory through a range-checked producer)."""
     N, L, C2 = xs.hi.shape

@@ -1082,7 +1082,7 @@ class PackedDense:
 @_on_device
 def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, out=None, out_split=False):
     """K6/K9.  x: fp32 [N,H,W,Cin] NHWC view, or a SplitAct.  residual: fp32 [.., Cout] view or SplitAct.
-    Returns fp32 [N,Ho,Wo,Cout] (or fills ``out``), or a SplitAct when ``out_split``."""
+    Returns fp32 [N,Ho,Wo,Cout] (or fills ``out``), or a SplitAct when ``out_split`` (True: a new one; a SplitAct: filled)."""
     split_in = isinstance(x, SplitAct)
     xt = x.hi if split_in else x
     _require_cuda(xt)
@@ -1100,7 +1100,14 @@ def conv2d_nhwc(x, pw: PackedDense, stride=1, pad=0, residual=None, relu=False, 
     o32 = oh = ol = None
     ldo = ldo_s = cout_s = 0
     result = None
-    if out_split:
+    if isinstance(out_split, SplitAct):             # fill the caller's split planes (rows of Cout channels, any row stride)
+        result = out_split
+        rows_s, ldo_s = _rows_ld(result.hi, torch.float16)
+        if rows_s != N * Ho * Wo or result.C != pw.Cout or result.hi.shape[-1] != pw.Cout or result.lo.shape != result.hi.shape \
+                or result.lo.stride() != result.hi.stride():
+            raise _lib.DfsfmError("conv2d_nhwc: out_split shape mismatch")
+        oh, ol, cout_s = result.hi, result.lo, pw.Cout
+    elif out_split:
         result = SplitAct.empty(N, Ho, Wo, pw.Cout, dev)
         oh, ol, cout_s, ldo_s = result.hi, result.lo, result.hi.shape[-1], result.hi.shape[-1]
     else:

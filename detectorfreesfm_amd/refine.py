@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F      # _bicubic_rows: PyTorch's own interpolation coefficients, on the host
 
 from . import ops
-from .coarse import EncoderLayerWeights, encoder_layer_split
+from .coarse import EncoderLayerWeights, encoder_layer_fused128, encoder_layer_split
 from .params import ParamModule, multiview_param_spec
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)   # S2DNet.mean / .std, backbone/S2DNet/s2dnet.py:66-67
@@ -51,6 +51,7 @@ class HipMultiviewMatcher(ParamModule):
         # conv1_1 -> conv1_2 -> pool / centre window as ONE launch (ops.s2d_front); False: the three separate layers
         # (tests/test_gpu_kernels.py::test_s2d_front_*, tests/test_gpu_e2e.py::test_refine_fused_front_equals_three_launches)
         self.fused_front = True
+        self.direct_features = True     # r06: the backbone's features go to the transformer as split planes (see forward)
         if not test:
             raise NotImplementedError("training path is out of scope; build with test=True")
         bb = config["backbone"]
@@ -148,7 +149,10 @@ class HipMultiviewMatcher(ParamModule):
             P["bicubic_rows_key"] = key
         up = ops.resample_separable(y1, P["bicubic_rows"], P["bicubic_rows"])     # [m, W*W, od]
         a0 = ops.conv2d_nhwc(f0, H["adap0"][0], 1, 0, **S)                        # [m,W+4,W+4,64]
-        ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out=dst)           # + hypercolumn sum, fused
+        if isinstance(dst, ops.SplitAct):                                          # + hypercolumn sum, fused
+            ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out_split=dst)   # ... as split planes for the transformer
+        else:
+            ops.conv2d_nhwc(a0, H["adap0"][1], 1, 0, residual=up, out=dst)
         return dst
 
     @torch.no_grad()
@@ -212,7 +216,18 @@ class HipMultiviewMatcher(ParamModule):
         M = order.numel()
         r = crop // 2
         boxes = torch.cat([flat_pts - r, flat_pts + r], dim=-1)[order].contiguous()     # fine_preprocess.py:101-104
-        slot = (order % T) * V + order // T                                            # (v t) -> (t v)
+        names = list(mt["layer_names"]) * mt["layer_iter_n"]
+        # r06: when every (track, view) slot is valid and the transformer runs on the fused kernels, the backbone writes its features
+        # as split planes in the order the transformer reads them -- reference views of all tracks first, then (track, view >= 1) --
+        # and the first encoder layer takes them as they are: no fp32 feature tensor, no split_rows pass (0.4 ms of a 2000-track bag)
+        direct = (self.direct_features and n_pad == 0 and len(groups) == 1 and groups[0] == (V, T) and V > 1 and bool(mt["enable"])
+                  and bool(names) and all(w.fused is not None for w in P["layers"]) and mt["nhead"] == 8 and WW >= 32
+                  and not ops.range_check_active())
+        if direct:
+            vv_, tt_ = order // T, order % T
+            slot = torch.where(vv_ == 0, tt_, T + tt_ * (V - 1) + vv_ - 1)
+        else:
+            slot = (order % T) * V + order // T                                        # (v t) -> (t v)
         # patch m of the compact list goes to position rank(slot): the CNN then emits features
         # already in (track, view) order -- no gather afterwards (MultiviewMatcher.py:264-270)
         by_slot = torch.argsort(slot)
@@ -228,9 +243,12 @@ class HipMultiviewMatcher(ParamModule):
                           mean=self._mean, std=self._std, out=patches, channels_last=True)
             start += n
         dense = n_pad == 0                      # every (track, view) slot is valid: write in place
-        feats = torch.empty((T * V, WW, C), dtype=torch.float32, device=dev) if dense else \
-            torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
-        comp = feats if dense else torch.empty((M, WW, C), dtype=torch.float32, device=dev)
+        if direct:
+            feats = comp = ops.SplitAct.empty_rows((T * V, WW), C, dev)
+        else:
+            feats = torch.empty((T * V, WW, C), dtype=torch.float32, device=dev) if dense else \
+                torch.zeros((T * V, WW, C), dtype=torch.float32, device=dev)
+            comp = feats if dense else torch.empty((M, WW, C), dtype=torch.float32, device=dev)
         for s in range(0, M, self.max_backbone_patches):
             e = min(M, s + self.max_backbone_patches)
             self._s2dnet_hip(patches[s:e], P, W, comp[s:e])
@@ -238,7 +256,8 @@ class HipMultiviewMatcher(ParamModule):
             feats.index_copy_(0, slot[by_slot], comp)
             del comp
         del patches
-        feats = feats.view(T, V, WW, C)
+        if not direct:
+            feats = feats.view(T, V, WW, C)
 
         # ---- K10 transformer + K11/K12 fine matching per view-count group ---------------------------
         movable = data["query_movable_mask"][0].contiguous() if "query_movable_mask" in data else None
@@ -247,7 +266,6 @@ class HipMultiviewMatcher(ParamModule):
         q_out = torch.empty((T, 2), dtype=torch.float32, device=dev)
         r_out = torch.zeros((1, V - 1, T, 2), dtype=torch.float32, device=dev)
         s_out = torch.zeros((1, V - 1, T), dtype=torch.float32, device=dev)
-        names = list(mt["layer_names"]) * mt["layer_iter_n"]
         nhead = mt["nhead"]
         i = 0
         for cv, nt in groups:
@@ -262,8 +280,12 @@ class HipMultiviewMatcher(ParamModule):
                 # split planes [., ., 2C] = [x | norm1(message)], ping-pong; the last layer writes dense [., ., C] planes
                 rs = [ops.SplitAct.empty_rows((nt, WW), 2 * C, dev) for _ in range(2)]
                 qs = [ops.SplitAct.empty_rows((nt, Vq * WW), 2 * C, dev) for _ in range(2)]
-                ops.split_rows(feats[sl, 0], None, out_split=rs[0].cols(0, C))            # strided [nt, WW, C] blocks: no copy
-                ops.split_rows(feats[sl, 1:cv].reshape(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
+                if direct:      # the backbone's split planes: [T reference sequences | T query sequences of Vq views]
+                    r_in = ops.SplitAct(feats.hi[:T], feats.lo[:T], C)
+                    q_in = ops.SplitAct(feats.hi[T:].view(T, Vq * WW, C), feats.lo[T:].view(T, Vq * WW, C), C)
+                else:
+                    ops.split_rows(feats[sl, 0], None, out_split=rs[0].cols(0, C))            # strided [nt, WW, C] blocks: no copy
+                    ops.split_rows(feats[sl, 1:cv].reshape(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
                 for li, (w, name) in enumerate(zip(P["layers"], names)):   # matcher_module/transformer.py:158-172
                     last = li == len(names) - 1
                     if last:     # the final features stay split planes (dense [., ., C]): the fine-matching kernel streams them
@@ -271,14 +293,21 @@ class HipMultiviewMatcher(ParamModule):
                         qry = oqs = ops.SplitAct.empty_rows((nt, Vq * WW), C, dev)
                     else:
                         ors, oqs = rs[1].cols(0, C), qs[1].cols(0, C)
-                    if name == "self":
+                    if name not in ("self", "cross"):
+                        raise NotImplementedError(name)
+                    if direct and li == 0:                # x = the backbone's planes (row stride C): the fused kernels directly
+                        if name == "self":
+                            encoder_layer_fused128(w, r_in, r_in, ors)
+                            encoder_layer_fused128(w, q_in, q_in, oqs, qm, qm, WW, WW)
+                        else:
+                            encoder_layer_fused128(w, q_in, r_in, oqs, qm, None, WW, 1)
+                            encoder_layer_fused128(w, r_in, q_in, ors, None, qm, 1, WW)
+                    elif name == "self":
                         encoder_layer_split(w, rs[0], rs[0].cols(0, C), None, ors, nhead, is_self=True)
                         encoder_layer_split(w, qs[0], qs[0].cols(0, C), None, oqs, nhead, qm, qm, WW, WW, is_self=True)
-                    elif name == "cross":                 # both sides from the PRE-update tensors (:163)
+                    else:                                 # cross: both sides from the PRE-update tensors (:163)
                         encoder_layer_split(w, qs[0], rs[0].cols(0, C), None, oqs, nhead, qm, None, WW, 1)
                         encoder_layer_split(w, rs[0], qs[0].cols(0, C), None, ors, nhead, None, qm, 1, WW)
-                    else:
-                        raise NotImplementedError(name)
                     rs.reverse(); qs.reverse()
                 qry = ops.SplitAct(qry.hi.view(nt, Vq, WW, C), qry.lo.view(nt, Vq, WW, C), C)
             else:

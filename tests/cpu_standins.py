@@ -165,6 +165,9 @@ def _conv(x, pw, stride=1, pad=0, residual=None, relu=False, out=None, out_split
         y = torch.nn.functional.leaky_relu(y, 0.01)
     elif relu:
         y = torch.relu(y)
+    if isinstance(out_split, SplitAct):
+        _put_split(out_split, y.reshape(out_split.hi.shape))
+        return out_split
     if out_split:
         return _to_split(y)
     if out is None:

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import parity
-from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, plugin, synth
+from detectorfreesfm_amd import HipLoFTR, HipMultiviewMatcher, ops, plugin, synth
 from detectorfreesfm_amd.config import loftr_coarse_only_config, multiview_refinement_config
 from detectorfreesfm_amd.params import (loftr_param_spec, multiview_param_spec, planted_loftr_state_dict,
                                         random_state_dict)
@@ -332,6 +332,44 @@ def test_refine_fused_front_equals_three_launches(built_lib):
     assert int(same.sum()) >= same.numel() - 2               # a near-tied candidate may flip between two summation orders
     d = (a["reference_points_refined"][-1] - b["reference_points_refined"][-1]).abs().amax(-1)[0][:, same]
     assert float(d.max()) < 1e-3
+
+
+def test_refine_direct_split_features_equal_split_rows_path(built_lib):
+    """r06: on a bag whose every (track, view) slot is valid the backbone writes its features as split planes in the transformer's
+    order and the first encoder layer reads them directly (``model.direct_features``, the default); ``False`` = fp32 features +
+    split_rows as before.  The same values take the same split, so the refined points must be IDENTICAL; a ragged bag takes the old
+    path whatever the flag says, and both meet the oracle."""
+    cfg, sd, m = _refiner(1)
+    alt = HipMultiviewMatcher(cfg, test=True)
+    alt.direct_features = False
+    alt.load_state_dict(sd, strict=True)
+    alt = alt.eval().to(DEV)
+    data = synth.refine_bag(T=96, V=5, H=120, W=160, seed=2311)                       # dense: all five views of every track
+    warm = synth.to_device(synth.refine_bag(T=8, V=5, H=120, W=160, seed=1), DEV)   # closes the first-call range sweep (it takes the old path)
+    m(dict(warm)); alt(dict(warm))
+    a, b = synth.to_device(data, DEV), synth.to_device(data, DEV)
+    calls = []
+    keep = ops.split_rows
+    ops.split_rows = lambda *x, **k: (calls.append(1), keep(*x, **k))[1]
+    try:
+        m(a)
+        n_direct = len(calls)
+        alt(b)
+    finally:
+        ops.split_rows = keep
+    assert n_direct == 0 and len(calls) == 2                   # the direct path has no split_rows launch at all
+    assert torch.equal(a["query_points_refined"], b["query_points_refined"])
+    assert torch.equal(a["reference_points_refined"][-1], b["reference_points_refined"][-1])
+    assert torch.equal(a["std"][-1], b["std"][-1])
+    with torch.no_grad():
+        o = restate.multiview_matcher_forward(sd, cfg, data)
+    assert len(_strict_refine(a, o, data, 7, "direct split-plane features")) <= 2
+    ragged = synth.refine_bag(T=64, V=5, H=120, W=160, seed=2312, variable_lengths=True)
+    c = synth.to_device(ragged, DEV)
+    m(c)
+    with torch.no_grad():
+        o2 = restate.multiview_matcher_forward(sd, cfg, ragged)
+    assert len(_strict_refine(c, o2, ragged, 7, "ragged bag (split_rows path)")) <= 2
 
 
 def test_loftr_features_vs_oracle_640x480(built_lib):
