@@ -220,7 +220,8 @@ class HipMultiviewMatcher(ParamModule):
         # r06: when every (track, view) slot is valid and the transformer runs on the fused kernels, the backbone writes its features
         # as split planes in the order the transformer reads them -- reference views of all tracks first, then (track, view >= 1) --
         # and the first encoder layer takes them as they are: no fp32 feature tensor, no split_rows pass (0.4 ms of a 2000-track bag)
-        direct = (self.direct_features and n_pad == 0 and len(groups) == 1 and groups[0] == (V, T) and V > 1 and bool(mt["enable"])
+        direct = (self.direct_features and n_pad == 0 and all(g_[0] == V for g_ in groups) and sum(g_[1] for g_ in groups) == T
+                  and V > 1 and bool(mt["enable"])
                   and bool(names) and all(w.fused is not None for w in P["layers"]) and mt["nhead"] == 8 and WW >= 32
                   and not ops.range_check_active())
         if direct:
@@ -281,8 +282,8 @@ class HipMultiviewMatcher(ParamModule):
                 rs = [ops.SplitAct.empty_rows((nt, WW), 2 * C, dev) for _ in range(2)]
                 qs = [ops.SplitAct.empty_rows((nt, Vq * WW), 2 * C, dev) for _ in range(2)]
                 if direct:      # the backbone's split planes: [T reference sequences | T query sequences of Vq views]
-                    r_in = ops.SplitAct(feats.hi[:T], feats.lo[:T], C)
-                    q_in = ops.SplitAct(feats.hi[T:].view(T, Vq * WW, C), feats.lo[T:].view(T, Vq * WW, C), C)
+                    r_in = ops.SplitAct(feats.hi[:T][sl], feats.lo[:T][sl], C)
+                    q_in = ops.SplitAct(feats.hi[T:].view(T, Vq * WW, C)[sl], feats.lo[T:].view(T, Vq * WW, C)[sl], C)
                 else:
                     ops.split_rows(feats[sl, 0], None, out_split=rs[0].cols(0, C))            # strided [nt, WW, C] blocks: no copy
                     ops.split_rows(feats[sl, 1:cv].reshape(nt, Vq * WW, C), None, out_split=qs[0].cols(0, C))
