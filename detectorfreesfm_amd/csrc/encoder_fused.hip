@@ -27,8 +27,11 @@
 // conflict-free ds_read_b128.  One wave per SIMD (512-register budget): accumulators + operands of a whole layer stay resident.
 //
 // enc_kv_kernel uses the classic orientation (lane = channel, registers = tokens) so that the contraction over tokens of
-// phi(k)^T v is again an MFMA fed from accumulator registers; a workgroup owns one sequence, its 4 waves take every fourth
-// 32-token block, partial sums are combined in a fixed order (run-to-run deterministic, independent of the batch).
+// phi(k)^T v is again an MFMA fed from accumulator registers; persistent workgroups walk the sequences with the 128 KB of k|v
+// weight fragments RESIDENT in LDS (r06; no ring), the 4 waves take every fourth 32-token block of a sequence, partial sums are
+// combined in a fixed order (run-to-run deterministic, independent of the batch).
+// Build: csrc/Makefile compiles this file with -mllvm -amdgpu-mfma-vgpr-form (MFMA results in the vector register file: every
+// accumulator here is read by VALU epilogues, and a VALU instruction cannot read an AGPR).
 #include "common.h"
 #include "enc_common.h"
 #include <cstdlib>
@@ -51,10 +54,11 @@ constexpr int KV_RED = 16384;             // cross-wave partial sums of one head
 constexpr int KV_KSP = 4096;              // Ksum partials [wave][pair][lane]
 constexpr int SMEM_KV = KV_W_BYTES + KV_RED + KV_KSP;
 constexpr int SMEM_APPLY = SMEM_BYTES + 4 * EC * 4 + 4 * 1024;   // + the LayerNorms' gamma / beta (2 KB) + Ksum of a tile's two sequences per wave
-// This file keeps the SLP vectoriser (packed-fp32 VALU instructions) that csrc/Makefile bans from kernels whose MFMA waves can share a
-// SIMD: its kernels must therefore never be co-resident on a CU.  Registers already cap them at one wave per SIMD; the LDS footprint
-// must as well, whatever a future register diet does.
-static_assert(SMEM_APPLY > 80 * 1024 && SMEM_KV > 80 * 1024, "one workgroup per CU is a correctness premise here (packed fp32 beside MFMAs)");
+// This file keeps the SLP vectoriser and its own packed-fp32 expressions.  The hazard behind the r04 / r05 rule "no packed fp32 beside
+// MFMAs" is the op_sel-on-src1 FORM of such an instruction inside a wave with MFMAs in flight (r06, csrc/Makefile): the build's ISA gate
+// rejects that form in this translation unit, whatever the occupancy.  One workgroup per CU stays a design premise of both kernels
+// (512 registers per wave; enc_kv's resident weights): the LDS footprints say so explicitly.
+static_assert(SMEM_APPLY > 80 * 1024 && SMEM_KV > 80 * 1024, "one workgroup per CU is a design premise of these kernels");
 constexpr int NSLAB_APPLY = 32;          // q 4, merge 4, 4 x (mlp.0 chunk 4 + mlp.2 chunk 2)
 constexpr int KVIMG = 16 * 1024 + 512;   // bytes per sequence: 16 KV^T fragments + Ksum[128]
 
