@@ -1,5 +1,5 @@
 #!/bin/bash
-# r06 session ae: the 7x7 stem on its own kernel: kernel test, timing against the implicit-GEMM kernel, coarse e2e tests, step A/B by module flag
+# r06 session ae: the 7x7 stem on its own kernel (since dropped: tools/studies/stem_conv_r06_not_kept.hip.txt, profiles/r06_encoder_stream_diag.txt section 5) -- kept as the record of what was run
 exec < /dev/null
 tag=${1:-r6ae}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
